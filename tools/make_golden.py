@@ -1,0 +1,523 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors for the score(+grad) hot path from the REFERENCE.
+
+Runs ONLY in the build container (needs /root/reference).  It imports the reference's
+Python modules with the stub recipe of SURVEY.md §8c (fcl/trimesh stubbed, diffco/__init__
+bypassed), evaluates the reference functions on seeded inputs and writes small .npz / .json
+fixtures under tests/golden/.  No reference source or bytecode is copied: fixtures hold
+only inputs and expected outputs.
+
+Every fixture also carries an fp64 "referee" evaluation (reference FK run in float64 +
+direct-difference kernels in float64) because the reference's own fp32 path (torch.cdist
+GEMM form) is ~1e-5 away from the true value.
+
+Usage:  python tools/make_golden.py [--out tests/golden]
+"""
+import argparse
+import importlib
+import json
+import math
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+warnings.filterwarnings("ignore")
+REF = "/root/reference"
+
+
+def import_reference():
+    for n in ("fcl", "trimesh"):
+        sys.modules.setdefault(n, types.ModuleType(n))
+    pkg = types.ModuleType("diffco")
+    pkg.__path__ = [f"{REF}/diffco"]
+    sys.modules["diffco"] = pkg
+    mods = {m: importlib.import_module("diffco." + m)
+            for m in ("kernel", "utils", "kernel_perceptrons", "model", "robot_fkine", "optim")}
+    old = types.ModuleType("olddiffco")
+    old.__path__ = [f"{REF}/diffco/deprecated", f"{REF}/diffco"]
+    sys.modules["olddiffco"] = old
+    for m in ("kernel", "Obstacles", "DiffCo", "MultiDiffCo"):
+        mods["old_" + m] = importlib.import_module("olddiffco." + m)
+    return types.SimpleNamespace(**mods)
+
+
+R = import_reference()
+
+
+class FKKernelRestated:
+    """kernel.py:137-143 behaviour (the reference ctor raises at kernel.py:133)."""
+
+    def __init__(self, fkine, rq_kernel):
+        self.fkine, self.rq_kernel = fkine, rq_kernel
+
+    def __call__(self, xs, x_primes=None):
+        if xs.ndim == 1:
+            xs = xs[None, :]
+        a = self.fkine(xs).reshape(len(xs), -1)
+        b = self.fkine(x_primes).reshape(len(x_primes), -1)
+        return self.rq_kernel(a, b)
+
+
+# ----------------------------------------------------------------------------- robots
+def make_robots():
+    m, rf = R.model, R.robot_fkine
+    robots = {}
+    robots["planar2"] = m.RevolutePlanarRobot(1.0, 0.3, dof=2)
+    robots["planar3"] = m.RevolutePlanarRobot([1.0, 0.7, 0.5], 0.2)
+    robots["planar7"] = m.RevolutePlanarRobot(0.3, 0.1, dof=7)
+    parts = [("box", (0.0, 0.0), (1, 1)), ("box", (1.2, 0.3), (1, 1)), ("box", (-0.8, 0.9), (1, 1))]
+    robots["se2"] = m.RigidPlanarBody(parts)
+    se3 = m.RigidBody.__new__(m.RigidBody)  # ctor needs trimesh; set the fields fkine reads
+    se3.dof = 6
+    se3.limits = torch.FloatTensor([[-10, 10]] * 3 + [[-math.pi, math.pi]] * 3)
+    corners = torch.tensor([[sx * 0.8, sy * 0.5, sz * 0.3] for sx in (-1, 1) for sy in (-1, 1)
+                            for sz in (-1, 1)], dtype=torch.float32).T
+    se3.keypoints = corners / corners.norm(dim=0).max()
+    robots["se3"] = se3
+    robots["baxter_left"] = m.BaxterLeftArmFK()
+    robots["baxter_right"] = m.BaxterRightArmFK()
+    robots["baxter_dual"] = m.BaxterDualArmFK()
+    robots["panda"] = m.PandaFK()
+    robots["panda5"] = rf.PandaFK()
+    robots["dual_panda"] = m.DualPandaFK()
+    return robots
+
+
+def robot_params(name, rob):
+    """Plain-data description of the robot so tests can rebuild it without the reference."""
+    p = {}
+    if name.startswith("planar"):
+        p["link_length"] = rob.link_length.numpy()
+    elif name in ("se2", "se3"):
+        p["keypoints"] = rob.keypoints.numpy()  # [d, M]
+    return p
+
+
+def rand_cfgs(rob, n, gen, dtype=torch.float32):
+    lim = rob.limits
+    u = torch.rand((n, lim.shape[0]), generator=gen)
+    return (u * (lim[:, 1] - lim[:, 0]) + lim[:, 0]).to(dtype)
+
+
+def fk64_fn(rob):
+    """Reference FK evaluated with float64 configurations (params stay fp32-rounded values).
+
+    Three reference classes cannot run in float64 as written (fp32 keypoints / bases, and
+    utils.rot_2d allocates an fp32 result), so for those the fp64 referee casts the fp32
+    parameters up, or (SE(2) only) restates R(theta) @ keypoints + t in float64.
+    """
+    m = R.model
+    if isinstance(rob, m.RigidPlanarBody):
+        kp = rob.keypoints.double()  # [2, M]
+
+        def f(q):
+            q = q.reshape(-1, 3)
+            c, s = q[:, 2].cos(), q[:, 2].sin()
+            x = c[:, None] * kp[0] - s[:, None] * kp[1] + q[:, 0:1]
+            y = s[:, None] * kp[0] + c[:, None] * kp[1] + q[:, 1:2]
+            return torch.stack([x, y], dim=2)
+        return f
+    if isinstance(rob, m.RigidBody):
+        def f(q):
+            k32 = rob.keypoints
+            rob.keypoints = k32.double()
+            try:
+                return rob.fkine(q)
+            finally:
+                rob.keypoints = k32
+        return f
+    if isinstance(rob, m.BaxterDualArmFK):
+        def f(q):
+            b32 = rob.arm_bases
+            rob.arm_bases = b32.double()
+            try:
+                return rob.fkine(q)
+            finally:
+                rob.arm_bases = b32
+        return f
+    if isinstance(rob, m.DualPandaFK):
+        def f(q):
+            b32 = rob.bases
+            rob.bases = b32.double()
+            try:
+                return rob.fkine(q)
+            finally:
+                rob.bases = b32
+        return f
+    return rob.fkine
+
+
+def fk64(rob, q):
+    return fk64_fn(rob)(q.double()).double().clone()
+
+
+def fk32(rob, q):
+    return rob.fkine(q.float()).clone()
+
+
+# ----------------------------------------------------------------------------- fp64 referee kernels
+def k64(kind, params, x, s):
+    x = x.reshape(len(x), -1).double()
+    s = s.reshape(len(s), -1).double()
+    d2 = ((x[:, None, :] - s[None, :, :]) ** 2).sum(-1)
+    if kind == "rq":
+        g, p = params
+        return (1 + g / p * d2) ** (-p)
+    if kind == "poly":
+        k, eps = params
+        # sqrt with a zero (sub)gradient at coincident points, like torch.cdist's backward
+        r = torch.where(d2 > 0, d2.clamp_min(1e-300).sqrt(), torch.zeros_like(d2))
+        if k % 2 == 0:
+            v = r ** k * torch.log(r.clamp_min(1e-300))
+            v = torch.where(r == 0, torch.zeros_like(v), v)
+            return v / eps
+        return r ** k / eps
+    if kind == "mq":
+        (eps,) = params
+        return (d2 / eps ** 2 + 1).sqrt()
+    raise ValueError(kind)
+
+
+def make_kernel(kind, params):
+    if kind == "rq":
+        return R.kernel.RQKernel(*params)
+    if kind == "poly":
+        return R.kernel.Polyharmonic(*params)
+    if kind == "mq":
+        return R.kernel.MultiQuadratic(*params)
+    raise ValueError(kind)
+
+
+# ----------------------------------------------------------------------------- writers
+def save(out, name, **arrs):
+    conv = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        conv[k] = np.asarray(v)
+    np.savez_compressed(os.path.join(out, name + ".npz"), **conv)
+    print(f"  wrote {name}.npz  ({sum(a.nbytes for a in conv.values()) / 1024:.0f} KiB raw)")
+
+
+# ----------------------------------------------------------------------------- A. forward kinematics
+def gen_fk(out, robots):
+    gen = torch.Generator().manual_seed(100)
+    for name, rob in robots.items():
+        q = rand_cfgs(rob, 64, gen)
+        q[0] = 0.0
+        # analytic Jacobian reference: autograd of the reference FK in fp64
+        qd = q.double().requires_grad_(True)
+        X = fk64_fn(rob)(qd)
+        gX = torch.randn(X.shape, generator=gen, dtype=torch.float64)
+        (gq,) = torch.autograd.grad((X * gX).sum(), qd)
+        save(out, f"fk_{name}", q=q, x32=fk32(rob, q), x64=fk64(rob, q), gx=gX.float(), gq64=gq,
+             limits=rob.limits, **robot_params(name, rob))
+
+
+# ----------------------------------------------------------------------------- B. kernels
+KERNELS = [("rq", (10.0, 2)), ("rq", (3.0, 3)), ("poly", (1, 1.0)), ("poly", (3, 2.0)),
+           ("poly", (2, 1.0)), ("mq", (1.0,)), ("mq", (0.5,))]
+
+
+def gen_kernels(out):
+    gen = torch.Generator().manual_seed(200)
+    arrs = {}
+    for D in (4, 12, 21, 6):
+        x = torch.randn((64, D), generator=gen)
+        s = torch.randn((96, D), generator=gen)
+        s[5] = x[7]  # an exact coincidence (r = 0)
+        arrs[f"x_D{D}"], arrs[f"s_D{D}"] = x, s
+        for i, (kind, params) in enumerate(KERNELS):
+            kf = make_kernel(kind, params)
+            arrs[f"k32_D{D}_{i}"] = kf(x, s)
+            arrs[f"k64_D{D}_{i}"] = k64(kind, params, x, s)
+    arrs["kernel_kinds"] = np.array([k for k, _ in KERNELS])
+    arrs["kernel_params"] = np.array([list(p) + [0.0] * (2 - len(p)) for _, p in KERNELS], dtype=np.float64)
+    # known answers
+    a = torch.zeros(1, 1)
+    b = torch.tensor([[1.0], [2.0]])
+    arrs["known_rq10"] = R.kernel.RQKernel(10)(a, b).reshape(-1)
+    arrs["known_poly11"] = R.kernel.Polyharmonic(1, 1)(a, b).reshape(-1)
+    arrs["known_poly32"] = R.kernel.Polyharmonic(3, 2)(a, b).reshape(-1)
+    arrs["known_poly21"] = R.kernel.Polyharmonic(2, 1)(a, b).reshape(-1)
+    save(out, "kernels", **arrs)
+
+
+# ----------------------------------------------------------------------------- C. score + gradient
+def new_diffco(rob, kind, params, sup_q, weights, which):
+    """A reference DiffCo (new API) with its inference state set directly."""
+    dc = R.kernel_perceptrons.DiffCo(kernel_func=make_kernel(kind, params) if which == "score" else "rq",
+                                     transform=None if rob is None else rob.fkine)
+    dc.support_points = sup_q
+    dc.support_transformed = sup_q if rob is None else fk32(rob, sup_q)
+    if which == "score":
+        dc.gains = weights
+    else:
+        dc.rbf_kernel = make_kernel(kind, params)
+        dc.rbf_nodes = weights
+    return dc
+
+
+def score_case(out, name, rob, kind, params, S, B, C, gen, which, zero_frac=0.0, coincide=False):
+    if rob is None:
+        lim = torch.tensor([[-10.0, 10.0]] * 3 + [[-math.pi, math.pi]] * 3)
+        fake = types.SimpleNamespace(limits=lim)
+        q, sup_q = rand_cfgs(fake, B, gen), rand_cfgs(fake, S, gen)
+    else:
+        q, sup_q = rand_cfgs(rob, B, gen), rand_cfgs(rob, S, gen)
+    if coincide:
+        q[3] = sup_q[11]
+    W = torch.randn((S, C), generator=gen)
+    if zero_frac > 0:
+        W = W * (torch.rand((S, C), generator=gen) >= zero_frac)
+    T = (lambda t: t) if rob is None else fk64_fn(rob)
+    sup_x32 = sup_q if rob is None else fk32(rob, sup_q)
+    arrs = dict(q=q, sup_q=sup_q, sup_x32=sup_x32, weights=W, kind=np.array(kind),
+                kparams=np.array(list(params), dtype=np.float64))
+
+    # ---- reference fp32 path, exactly as the reference classes compute it
+    qv = q.clone().requires_grad_(True)
+    if which != "multi":
+        dc = new_diffco(rob, kind, params, sup_q, W[:, 0].clone(), which)
+        s = dc.score(qv) if which == "score" else dc.poly_score(qv)
+        arrs["score32"] = s.detach().clone()
+        (g,) = torch.autograd.grad(s.sum(), qv)
+        arrs["grad32"] = g
+    else:
+        md = R.old_MultiDiffCo.MultiDiffCo.__new__(R.old_MultiDiffCo.MultiDiffCo)
+        md.fkine = None if rob is None else rob.fkine
+        md.support_points = sup_q
+        md.support_fkine = sup_x32.reshape(S, -1)
+        md.rbf_kernel = make_kernel(kind, params)
+        md.rbf_nodes = W
+        md.num_class = C
+        s = md.rbf_score(qv)  # [B, C]
+        arrs["score32"] = s.detach().clone()
+        (g,) = torch.autograd.grad(s.sum(), qv, retain_graph=True)
+        arrs["grad32"] = g
+        up = torch.randn((B, C), generator=gen)
+        (gv,) = torch.autograd.grad((s * up).sum(), qv, retain_graph=True)
+        arrs["upstream"], arrs["vjp32"] = up, gv
+        nj = min(B, 32)
+        jac = torch.stack([torch.autograd.grad(s[:nj, c].sum(), qv, retain_graph=True)[0][:nj]
+                           for c in range(C)], dim=1)
+        arrs["jac32"] = jac  # [nj, C, dof]
+
+    # ---- fp64 referee (direct differences)
+    qd = q.double().requires_grad_(True)
+    Xd = T(qd)
+    Sd = (sup_q.double() if rob is None else fk64(rob, sup_q))
+    K = k64(kind, params, Xd, Sd)
+    s64 = K @ W.double()
+    arrs["score64"] = s64.detach()
+    (g64,) = torch.autograd.grad(s64.sum(), qd, retain_graph=True)
+    arrs["grad64"] = g64
+    if which == "multi":
+        (gv64,) = torch.autograd.grad((s64 * arrs["upstream"].double()).sum(), qd, retain_graph=True)
+        arrs["vjp64"] = gv64
+    save(out, name, **arrs)
+
+
+def gen_scores(out, robots):
+    gen = torch.Generator().manual_seed(300)
+    # BASELINE config #1 (full size): planar 2-DoF, RQ(10) gains, S=200, B=256
+    score_case(out, "cfg1_planar2_rq", robots["planar2"], "rq", (10.0, 2), 200, 256, 1, gen, "score")
+    # config #2: Baxter / Panda, S=1000; B reduced to 512 except the Baxter poly case (full 4096)
+    score_case(out, "cfg2_baxter_poly1", robots["baxter_left"], "poly", (1, 1.0), 1000, 4096, 1, gen, "poly")
+    score_case(out, "cfg2_baxter_rq", robots["baxter_left"], "rq", (10.0, 2), 1000, 512, 1, gen, "score")
+    score_case(out, "cfg2_panda_poly1", robots["panda"], "poly", (1, 1.0), 1000, 512, 1, gen, "poly")
+    score_case(out, "cfg2_panda_rq", robots["panda"], "rq", (10.0, 2), 1000, 512, 1, gen, "score")
+    # headline shape at reduced batch: Baxter, Polyharmonic(1,1), S=2000
+    score_case(out, "headline_baxter_poly1_s2000", robots["baxter_left"], "poly", (1, 1.0), 2000, 512, 1, gen, "poly")
+    # config #3: C=5, S=2000, 40 % zeros per class, B reduced
+    score_case(out, "cfg3_baxter_rq_c5", robots["baxter_left"], "rq", (10.0, 2), 2000, 256, 5, gen, "multi", 0.4)
+    score_case(out, "cfg3_baxter_poly1_c5", robots["baxter_left"], "poly", (1, 1.0), 2000, 256, 5, gen, "multi", 0.4)
+    # config #4: SE(3), RQ(10), S=10k, no FK (D=6) and 8-keypoint variant (D=24); B reduced
+    score_case(out, "cfg4_se3_nofk_rq", None, "rq", (10.0, 2), 10000, 256, 1, gen, "score")
+    score_case(out, "cfg4_se3_keypts_rq", robots["se3"], "rq", (10.0, 2), 2000, 256, 1, gen, "score")
+    # the other FK classes x the other kernels (small)
+    score_case(out, "misc_dualbaxter_poly1", robots["baxter_dual"], "poly", (1, 1.0), 300, 128, 1, gen, "poly")
+    score_case(out, "misc_dualpanda_rq", robots["dual_panda"], "rq", (10.0, 2), 300, 128, 1, gen, "score")
+    score_case(out, "misc_panda5_mq", robots["panda5"], "mq", (1.0,), 300, 128, 1, gen, "multi")
+    score_case(out, "misc_se2_poly3", robots["se2"], "poly", (3, 2.0), 300, 128, 1, gen, "multi")
+    score_case(out, "misc_planar3_poly2", robots["planar3"], "poly", (2, 1.0), 300, 128, 1, gen, "poly")
+    score_case(out, "misc_planar7_rq_p3", robots["planar7"], "rq", (3.0, 3), 300, 128, 1, gen, "score")
+    score_case(out, "misc_baxterR_mq_c2", robots["baxter_right"], "mq", (0.5,), 300, 128, 2, gen, "multi")
+    # edge: query coincides with a support (r = 0) for the kinked kernel
+    score_case(out, "edge_r0_baxter_poly1", robots["baxter_left"], "poly", (1, 1.0), 64, 16, 1, gen, "poly",
+               coincide=True)
+    score_case(out, "edge_r0_planar3_poly2", robots["planar3"], "poly", (2, 1.0), 64, 16, 1, gen, "poly",
+               coincide=True)
+
+
+def gen_edges(out, robots):
+    gen = torch.Generator().manual_seed(400)
+    rob = robots["baxter_left"]
+    sup_q = rand_cfgs(rob, 50, gen)
+    w = torch.randn(50, generator=gen)
+    arrs = dict(sup_q=sup_q, weights=w)
+    # B == 1 : RQKernel squeezes (kernel.py:26-27) -> score is 0-dim; poly_score stays [1,1]
+    q1 = rand_cfgs(rob, 1, gen)[0]
+    dc = new_diffco(rob, "rq", (10.0, 2), sup_q, w, "score")
+    s = dc.score(q1)
+    arrs["q1"], arrs["score_b1"], arrs["score_b1_shape"] = q1, s.reshape(-1), np.array(s.shape, dtype=np.int64)
+    dp = new_diffco(rob, "poly", (1, 1.0), sup_q, w, "poly")
+    s = dp.poly_score(q1)
+    arrs["poly_b1"], arrs["poly_b1_shape"] = s.reshape(-1), np.array(s.shape, dtype=np.int64)
+    # fp64 input to poly_score: cast to fp32 nodes' dtype (kernel_perceptrons.py:313), grad comes back fp64
+    qd = rand_cfgs(rob, 8, gen, torch.float64).requires_grad_(True)
+    s = dp.poly_score(qd)
+    (g,) = torch.autograd.grad(s.sum(), qd)
+    arrs["q_f64"], arrs["poly_f64in"], arrs["grad_f64in"] = qd.detach(), s.detach(), g
+    arrs["poly_f64in_dtype"] = np.array(str(s.dtype))
+    arrs["grad_f64in_dtype"] = np.array(str(g.dtype))
+    # transformed_point bypass (kernel_perceptrons.py:316-317)
+    qb = rand_cfgs(rob, 8, gen)
+    arrs["q_tp"], arrs["poly_tp"] = qb, dp.poly_score(transformed_point=fk32(rob, qb))
+    # zero padding of max_num_supports (rows of zeros with zero weight)
+    sup_pad = torch.cat([sup_q, torch.zeros(14, 7)])
+    w_pad = torch.cat([w, torch.zeros(14)])
+    dz = new_diffco(rob, "poly", (1, 1.0), sup_pad, w_pad, "poly")
+    dz.support_transformed = torch.cat([fk32(rob, sup_q), torch.zeros(14, 4, 3)])
+    arrs["poly_padded"] = dz.poly_score(qb)
+    save(out, "edges", **arrs)
+
+
+# ----------------------------------------------------------------------------- E. trained models
+def synth_labels(rob, X, centers, radius):
+    P = fk32(rob, X)  # [N, m, d]
+    d = (P[:, :, None, :] - centers[None, None]).norm(dim=-1) - radius  # [N, m, n_obs]
+    dist = -d.min(dim=1).values  # [N, n_obs]   > 0 inside
+    return dist
+
+
+def gen_trained(out, robots):
+    gen = torch.Generator().manual_seed(500)
+    rob = robots["baxter_left"]
+    X = rand_cfgs(rob, 3000, gen)
+    centers = torch.tensor([[0.7, 0.3, 0.3], [0.4, -0.5, 0.0]])
+    dist = synth_labels(rob, X, centers, 0.25).max(dim=1).values
+    y = torch.where(dist > 0, 1.0, -1.0)
+    dc = R.kernel_perceptrons.DiffCo(kernel_func=R.kernel.RQKernel(10.0), beta=1.0, transform=rob.fkine)
+    dc.train(X, y, max_iteration=3000, distance=dist)
+    arrs = dict(X=X, y=y, dist=dist, support_points=dc.support_points, support_transformed=dc.support_transformed,
+                gains=dc.gains, hypothesis=dc.hypothesis, kernel_matrix_diag=torch.diag(dc.kernel_matrix),
+                sup_y=dc.y, sup_dist=dc.distance)
+    print(f"  trained Baxter DiffCo: {len(dc.gains)} supports")
+    for tgt in ("label", "hypo", "dist"):
+        dc.fit_poly(R.kernel.Polyharmonic(1, 1.0), target=tgt)
+        arrs[f"rbf_nodes_{tgt}"] = dc.rbf_nodes.clone()
+    dc.fit_poly(R.kernel.Polyharmonic(1, 1.0), target="label")
+    qt = rand_cfgs(rob, 256, gen)
+    qv = qt.clone().requires_grad_(True)
+    s = dc.poly_score(qv)
+    (g,) = torch.autograd.grad(s.sum(), qv)
+    arrs.update(q_test=qt, poly_test=s.detach(), poly_grad_test=g, score_test=dc.score(qt))
+    # active-learning update (jump start): new samples + existing supports, exist_mask marks the last S rows
+    Xn = rand_cfgs(rob, 500, gen)
+    centers2 = centers + torch.tensor([[0.0, 0.1, 0.05], [0.05, 0.0, 0.1]])
+    Xu = torch.cat([Xn, dc.support_points])
+    du = synth_labels(rob, Xu, centers2, 0.25).max(dim=1).values
+    yu = torch.where(du > 0, 1.0, -1.0)
+    mask = torch.zeros(len(Xu), dtype=torch.bool)
+    mask[-len(dc.support_points):] = True
+    dc.train(Xu, yu, update=True, exist_mask=mask, max_iteration=2000, distance=du)
+    arrs.update(Xu=Xu, yu=yu, du=du, exist_mask=mask, upd_support_points=dc.support_points, upd_gains=dc.gains,
+                upd_hypothesis=dc.hypothesis)
+    print(f"  after update: {len(dc.gains)} supports")
+    # max_num_supports variant (zero padded / truncated)
+    dm = R.kernel_perceptrons.DiffCo(kernel_func=R.kernel.RQKernel(10.0), beta=1.0, transform=rob.fkine,
+                                     max_num_supports=300)
+    dm.train(X, y, max_iteration=3000, distance=dist)
+    dm.fit_poly(R.kernel.Polyharmonic(1, 1.0), target="label")
+    arrs.update(mns_support_points=dm.support_points, mns_gains=dm.gains, mns_rbf_nodes=dm.rbf_nodes,
+                mns_valid=np.array(dm.valid_supports), mns_poly_test=dm.poly_score(qt))
+    save(out, "trained_baxter", **arrs)
+
+    # old API: MultiDiffCo, C=2, planar 2-DoF with FKKernel (scripts/active.py:605-672 call pattern)
+    rob2 = robots["planar2"]
+    X2 = rand_cfgs(rob2, 1500, gen)
+    c2 = torch.tensor([[1.2, 0.8], [-0.9, -1.0]])
+    d2 = synth_labels(rob2, X2, c2, 0.45)  # [N, 2]
+    y2 = torch.where(d2 > 0, 1.0, -1.0)
+    fkk = FKKernelRestated(rob2.fkine, R.kernel.RQKernel(10.0))
+    md = R.old_MultiDiffCo.MultiDiffCo(None, kernel_func=fkk, beta=1.0)
+    md.train(X2, y2, max_iteration=1500, distance=d2)
+    md.fit_poly(kernel_func=R.kernel.Polyharmonic(1, 1.0), target="label", fkine=rob2.fkine, reg=0.0)
+    qt2 = rand_cfgs(rob2, 256, gen)
+    qv2 = qt2.clone().requires_grad_(True)
+    s2 = md.rbf_score(qv2)
+    (g2,) = torch.autograd.grad(s2.sum(), qv2)
+    print(f"  trained planar MultiDiffCo: {len(md.gains)} supports")
+    save(out, "trained_multi_planar2", X=X2, y=y2, dist=d2, support_points=md.support_points, gains=md.gains,
+         hypothesis=md.hypothesis, rbf_nodes=md.rbf_nodes, q_test=qt2, rbf_test=s2.detach(), rbf_grad_test=g2,
+         score_test=md.score(qt2))
+    return dc
+
+
+# ----------------------------------------------------------------------------- F. optimiser records
+def gen_optim(out, robots):
+    gen = torch.Generator().manual_seed(600)
+    rob = robots["baxter_left"]
+    sup_q = rand_cfgs(rob, 200, gen)
+    w = torch.randn(200, generator=gen) * 0.05
+    dc = new_diffco(rob, "poly", (1, 1.0), sup_q, w, "poly")
+    start, target = rand_cfgs(rob, 1, gen)[0], rand_cfgs(rob, 1, gen)[0]
+    n_wp = 20
+    t = torch.linspace(0, 1, n_wp)[:, None].double()
+    init = start.double() * (1 - t) + target.double() * t
+    init[1:-1] += 0.05 * torch.randn((n_wp - 2, 7), generator=gen).double()
+    options = {"N_WAYPOINTS": n_wp, "NUM_RE_TRIALS": 1, "MAXITER": 50, "safety_margin": 0.0, "max_speed": 0.3,
+               "seed": 1234, "history": False, "extra_optimizer_options": {"lr": 0.05},
+               "init_solution": init.clone()}
+    # one fused-loss evaluation at the initial path (the quantity the fused Adam step differentiates)
+    p = init.clone().requires_grad_(True)
+    col = torch.clamp(dc.poly_score(p) - 0.0, min=0).sum()
+    cp = rob.fkine(p)
+    mm = torch.clamp((cp[1:] - cp[:-1]).square().sum(dim=2) - 0.3 ** 2, min=0).sum()
+    jl = (torch.clamp(rob.limits[:, 0] - p, min=0) + torch.clamp(p - rob.limits[:, 1], min=0)).sum()
+    diff = (cp[1:] - cp[:-1]).square().sum()
+    loss = diff + 10 * col + 10 * mm + 10 * jl
+    (gl,) = torch.autograd.grad(loss, p)
+    rec = R.optim.adam_traj_optimize(rob, dc.poly_score, start, target, dict(options))
+    save(out, "optim_adam_baxter", sup_q=sup_q, weights=w, start=start, target=target, init=init,
+         loss0=loss.detach(), loss0_terms=torch.stack([diff, col, mm, jl]).detach(), grad0=gl,
+         solution=np.array(rec["solution"]), cost=np.array(rec["cost"]), cnt_check=np.array(rec["cnt_check"]),
+         success=np.array(rec["success"]))
+    with open(os.path.join(out, "optim_adam_baxter_options.json"), "w") as f:
+        json.dump({k: v for k, v in options.items() if k != "init_solution"}, f, indent=1)
+    print(f"  adam record: success={rec['success']} cost={rec['cost']:.6f} cnt_check={rec['cnt_check']}")
+
+    # dense_path (utils.py:87-101) vectors
+    path = rand_cfgs(rob, 6, gen).double()
+    save(out, "dense_path", path=path, dense_0p3=R.utils.dense_path(path, 0.3),
+         dense_2p0=R.utils.dense_path(path, 2.0))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
+    args = ap.parse_args()
+    out = os.path.abspath(args.out)
+    os.makedirs(out, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    robots = make_robots()
+    print("FK");        gen_fk(out, robots)
+    print("kernels");   gen_kernels(out)
+    print("scores");    gen_scores(out, robots)
+    print("edges");     gen_edges(out, robots)
+    print("trained");   gen_trained(out, robots)
+    print("optim");     gen_optim(out, robots)
+    with open(os.path.join(out, "MANIFEST.json"), "w") as f:
+        json.dump({"generator": "tools/make_golden.py", "torch": torch.__version__, "numpy": np.__version__,
+                   "reference": "ucsdarclab/diffco @ /root/reference (2025-03-21)",
+                   "files": sorted(x for x in os.listdir(out) if x.endswith((".npz", ".json")))}, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
