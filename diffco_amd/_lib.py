@@ -1,0 +1,73 @@
+"""Loader for libdcx.so (the HIP implementation) via ctypes.
+
+There is no CPU implementation of the hot path in this package: if the library is missing
+or no GPU is visible, every op raises.  `import torch` happens first on purpose — torch
+bundles its own libamdhip64; loading ours afterwards binds to the already-mapped runtime so
+both share streams and allocations.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede CDLL, see docstring)
+
+from ._fkdesc import FkDesc
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdcx.so")
+
+# every symbol include/dcx.h declares: (restype, argtypes)
+_c_fp = C.c_void_p  # device/host float pointers travel as raw addresses
+SYMBOLS = {
+    "dcx_version": (C.c_int, []),
+    "dcx_last_error": (C.c_char_p, []),
+    "dcx_device_count": (C.c_int, []),
+    "dcx_model_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(FkDesc), C.c_int, C.POINTER(C.c_float),
+                                   _c_fp, _c_fp, C.c_int64, C.c_int32, C.c_int32]),
+    "dcx_model_destroy": (None, [C.c_void_p]),
+    "dcx_model_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                 C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "dcx_score": (C.c_int, [C.c_void_p, _c_fp, C.c_int64, _c_fp, C.c_void_p]),
+    "dcx_score_grad": (C.c_int, [C.c_void_p, _c_fp, C.c_int64, _c_fp, _c_fp, _c_fp, C.c_void_p]),
+    "dcx_score_jac": (C.c_int, [C.c_void_p, _c_fp, C.c_int64, _c_fp, _c_fp, C.c_void_p]),
+    "dcx_fkine": (C.c_int, [C.c_int, C.POINTER(FkDesc), _c_fp, C.c_int64, _c_fp, C.c_void_p]),
+    "dcx_fkine_vjp": (C.c_int, [C.c_int, C.POINTER(FkDesc), _c_fp, _c_fp, C.c_int64, _c_fp, C.c_void_p]),
+    "dcx_kernel_matrix": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_float), _c_fp, C.c_int64, _c_fp, C.c_int64,
+                                    C.c_int32, _c_fp, C.c_void_p]),
+}
+
+_lib = None
+
+
+class DcxError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libdcx.so (once) and bind every declared symbol.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DcxError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C diffco_amd/csrc -j8`.  diffco_amd has no CPU fallback for the score/grad path.")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().dcx_last_error()
+        raise DcxError(f"libdcx error {rc}: {msg.decode() if msg else '?'}")
+
+
+def require_gpu():
+    lib = load()
+    if not torch.cuda.is_available() or lib.dcx_device_count() < 1:
+        raise DcxError("diffco_amd: no MI355X/HIP device visible — the score/grad path is HIP-only "
+                       "(there is deliberately no CPU fallback)")
+    return lib

@@ -1,0 +1,187 @@
+"""torch-facing wrappers of the C ABI (include/dcx.h): device buffers in, device buffers out.
+
+PyTorch is plumbing here (allocation, streams, autograd bookkeeping); all arithmetic of the
+score/grad path happens in libdcx.so.  CPU tensors are moved to the GPU, computed there and
+moved back to the caller's device and dtype, so reference scripts written for CPU tensors run
+unchanged on a GPU box.  Without a GPU every function raises (no CPU fallback).
+"""
+import ctypes as C
+
+import torch
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+from ._fkdesc import DCX_K_MQ, DCX_K_POLY, DCX_K_RQ, FkDesc, none_desc  # noqa: F401
+
+
+def _device(dev=None):
+    _lib.require_gpu()
+    if dev is not None and torch.device(dev).type == "cuda":
+        d = torch.device(dev)
+        return torch.device("cuda", d.index if d.index is not None else torch.cuda.current_device())
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _stream(dev):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _f32(t, dev):
+    return t.detach().to(device=dev, dtype=torch.float32).contiguous()
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else C.c_void_p(0)
+
+
+def _kparams(p0, p1=0.0):
+    return (C.c_float * 2)(float(p0), float(p1))
+
+
+# ----------------------------------------------------------------------------- FK
+class _FkineFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, desc):
+        lib = _lib.require_gpu()
+        dev = _device(q.device)
+        q32 = _f32(q.reshape(-1, desc.dof), dev)
+        B = q32.shape[0]
+        X = torch.empty((B, desc.feature_dim), device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.check(lib.dcx_fkine(dev.index, C.byref(desc), _ptr(q32), B, _ptr(X), _stream(dev)))
+        ctx.desc, ctx.dev, ctx.in_dtype, ctx.in_device, ctx.in_shape = desc, dev, q.dtype, q.device, q.shape
+        ctx.save_for_backward(q32)
+        return X.reshape(B, desc.n_points, desc.point_dim).to(device=q.device, dtype=q.dtype)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gX):
+        lib = _lib.require_gpu()
+        (q32,) = ctx.saved_tensors
+        desc, dev = ctx.desc, ctx.dev
+        B = q32.shape[0]
+        g32 = _f32(gX.reshape(B, -1), dev)
+        gq = torch.empty((B, desc.dof), device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.check(lib.dcx_fkine_vjp(dev.index, C.byref(desc), _ptr(q32), _ptr(g32), B, _ptr(gq), _stream(dev)))
+        return gq.to(device=ctx.in_device, dtype=ctx.in_dtype).reshape(ctx.in_shape), None
+
+
+def fkine(desc: FkDesc, q: torch.Tensor) -> torch.Tensor:
+    """control points [B, m, d] of configurations q [B, dof] (differentiable; HIP forward and vjp)."""
+    return _FkineFn.apply(q, desc)
+
+
+# ----------------------------------------------------------------------------- kernel matrix
+def kernel_matrix(kind, p0, p1, x: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
+    """K[b, j] = K(x_b, s_j) for x [B, D], s [S, D]; result on x's device/dtype (not differentiable)."""
+    lib = _lib.require_gpu()
+    if x.requires_grad or s.requires_grad:
+        raise _lib.DcxError("kernel callables are not differentiable on their own; differentiate through "
+                            "DiffCo.score / poly_score / rbf_score (fused HIP gradient) instead")
+    dev = _device(x.device if x.device.type == "cuda" else s.device)
+    x32, s32 = _f32(x, dev), _f32(s, dev)
+    B, D = x32.shape
+    S = s32.shape[0]
+    if s32.shape[1] != D:
+        raise ValueError(f"kernel: feature widths differ ({D} vs {s32.shape[1]})")
+    K = torch.empty((B, S), device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        _lib.check(lib.dcx_kernel_matrix(dev.index, kind, _kparams(p0, p1), _ptr(x32), B, _ptr(s32), S, D, _ptr(K),
+                                         _stream(dev)))
+    return K.to(device=x.device, dtype=x.dtype)
+
+
+# ----------------------------------------------------------------------------- fused score model
+class ScoreModel:
+    """Owns one ``dcx_model`` (device copy of support rows + FK parameters).  Immutable."""
+
+    def __init__(self, desc, kind, p0, p1, support_feat, weights, device=None):
+        lib = _lib.require_gpu()
+        self.dev = _device(device)
+        self.desc = desc if desc is not None else none_desc(int(support_feat.reshape(len(support_feat), -1).shape[1]))
+        sf = support_feat.detach().reshape(len(support_feat), -1).to(dtype=torch.float32).contiguous()
+        w = weights.detach().to(dtype=torch.float32)
+        w = (w.reshape(-1, 1) if w.ndim == 1 else w).contiguous()
+        if len(sf) != len(w):
+            raise ValueError(f"{len(sf)} supports but {len(w)} weight rows")
+        self.S, self.C, self.dof, self.D = len(sf), int(w.shape[1]), self.desc.dof, self.desc.feature_dim
+        if len(sf) and sf.shape[1] != self.D:
+            raise ValueError(f"supports have {sf.shape[1]} features, the transform produces {self.D}")
+        handle = C.c_void_p()
+        with torch.cuda.device(self.dev):
+            _lib.check(lib.dcx_model_create(C.byref(handle), self.dev.index, C.byref(self.desc), kind,
+                                            _kparams(p0, p1), _ptr(sf), _ptr(w), self.S, self.D, self.C))
+        self._h = handle
+        self._lib = lib
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                self._lib.dcx_model_destroy(h)
+            except Exception:
+                pass
+
+    # raw entry points on fp32 device tensors -------------------------------------------
+    def score_raw(self, q32):
+        B = q32.shape[0]
+        out = torch.empty((B, self.C), device=self.dev, dtype=torch.float32)
+        with torch.cuda.device(self.dev):
+            _lib.check(self._lib.dcx_score(self._h, _ptr(q32), B, _ptr(out), _stream(self.dev)))
+        return out
+
+    def score_grad_raw(self, q32, upstream32=None, want_score=True):
+        B = q32.shape[0]
+        out = torch.empty((B, self.C), device=self.dev, dtype=torch.float32) if want_score else None
+        grad = torch.empty((B, self.dof), device=self.dev, dtype=torch.float32)
+        with torch.cuda.device(self.dev):
+            _lib.check(self._lib.dcx_score_grad(self._h, _ptr(q32), B, _ptr(upstream32), _ptr(out), _ptr(grad),
+                                                _stream(self.dev)))
+        return out, grad
+
+    def score_jac_raw(self, q32):
+        B = q32.shape[0]
+        out = torch.empty((B, self.C), device=self.dev, dtype=torch.float32)
+        jac = torch.empty((B, self.C, self.dof), device=self.dev, dtype=torch.float32)
+        with torch.cuda.device(self.dev):
+            _lib.check(self._lib.dcx_score_jac(self._h, _ptr(q32), B, _ptr(out), _ptr(jac), _stream(self.dev)))
+        return out, jac
+
+    # autograd-aware ------------------------------------------------------------------------
+    def score(self, q: torch.Tensor) -> torch.Tensor:
+        """[B, C] scores for q [B, dof]; differentiable w.r.t. q (gradient from the fused HIP pass)."""
+        return _ScoreFn.apply(q, self)[0]
+
+    def score_and_grad(self, q: torch.Tensor, upstream: torch.Tensor = None):
+        """(score [B, C], d(sum_c upstream*score)/dq [B, dof]) in ONE launch, no autograd graph."""
+        q32 = _f32(q.reshape(-1, self.dof), self.dev)
+        up = None if upstream is None else _f32(upstream.reshape(-1, self.C), self.dev)
+        s, g = self.score_grad_raw(q32, up)
+        return s.to(device=q.device, dtype=q.dtype), g.to(device=q.device, dtype=q.dtype)
+
+
+class _ScoreFn(torch.autograd.Function):
+    """score = model(q).  When q needs a gradient the forward launch also produces the Jacobian
+    (C == 1: the fused score+grad pass; C > 1: one sweep per class), so backward is a tiny torch
+    contraction — which keeps `torch.autograd.functional.jacobian(vectorize=True)` (vmap over the
+    backward, optim.py:211-216 in the reference) working on this op."""
+
+    @staticmethod
+    def forward(ctx, q, model):
+        q32 = _f32(q.reshape(-1, model.dof), model.dev)
+        if ctx.needs_input_grad[0]:
+            s, jac = model.score_jac_raw(q32)
+            jac = jac.to(device=q.device, dtype=q.dtype)
+        else:
+            s, jac = model.score_raw(q32), q.new_zeros(())
+        ctx.save_for_backward(jac)
+        ctx.in_shape = q.shape
+        ctx.mark_non_differentiable(jac)
+        return s.to(device=q.device, dtype=q.dtype), jac
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gs, _gjac):
+        (jac,) = ctx.saved_tensors  # [B, C, dof]
+        return (gs.unsqueeze(-1) * jac).sum(dim=-2).reshape(ctx.in_shape), None

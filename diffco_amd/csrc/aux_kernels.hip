@@ -1,0 +1,135 @@
+// aux_kernels.hip — the pieces of the path that are also callable on their own:
+//   fkine / fkine_vjp  : model.*.fkine and its autograd   (reference model.py:40-48, 90-93, 156-159,
+//                        225-241, 366-383, 430-453, 486-502)
+//   kernel_matrix      : KernelFunc.__call__ -> K[B,S]     (reference kernel.py:17-29, 49-57, 73-79),
+//                        used by the perceptron trainer's row fill and by fit_poly.
+#include "dcx_internal.h"
+
+namespace dcx {
+namespace {
+
+// one wave per block, one lane per configuration; same LDS staging as the fused kernel
+__global__ __launch_bounds__(64) void fkine_kernel(const dcx_fk_desc* fkd, const float* q, int64_t B, float* X,
+                                                   int dof, int d_fk, int frame_floats) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x;
+    const int64_t b0 = (int64_t)blockIdx.x * 64;
+    const int nb = (int)((B - b0) < 64 ? (B - b0) : 64);
+    float* sQ = smem;
+    float* sX = sQ + ((64 * dof + 3) & ~3);
+    float* sF = sX + 64 * d_fk;
+    const fk_cptr fk = as_const(fkd);
+    const float* qsrc = q + b0 * dof;
+    const int n = nb * dof;
+    for (int i = lane; i < 64 * dof; i += 64) sQ[i] = qsrc[i < n ? i : (i % dof) + (nb - 1) * dof];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    fk_forward(fk, sQ + lane * dof, sX + lane, sF + lane);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // [64][d_fk] rows out, coalesced
+    float* dst = X + b0 * d_fk;
+    const int m = nb * d_fk;
+    for (int i = lane; i < m; i += 64) dst[i] = sX[(i % d_fk) * 64 + (i / d_fk)];
+}
+
+__global__ __launch_bounds__(64) void fkine_vjp_kernel(const dcx_fk_desc* fkd, const float* q, const float* gX,
+                                                       int64_t B, float* gq, int dof, int d_fk, int frame_floats) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x;
+    const int64_t b0 = (int64_t)blockIdx.x * 64;
+    const int nb = (int)((B - b0) < 64 ? (B - b0) : 64);
+    float* sQ = smem;
+    float* sX = sQ + ((64 * dof + 3) & ~3);
+    float* sG = sX + 64 * d_fk;
+    float* sF = sG + 64 * d_fk;
+    const fk_cptr fk = as_const(fkd);
+    const float* qsrc = q + b0 * dof;
+    const int n = nb * dof;
+    for (int i = lane; i < 64 * dof; i += 64) sQ[i] = qsrc[i < n ? i : (i % dof) + (nb - 1) * dof];
+    const float* gsrc = gX + b0 * d_fk;
+    const int m = nb * d_fk;
+    for (int i = lane; i < 64 * d_fk; i += 64) {
+        const int ii = i < m ? i : (i % d_fk) + (nb - 1) * d_fk;
+        sG[(i % d_fk) * 64 + (i / d_fk)] = gsrc[ii];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    fk_forward(fk, sQ + lane * dof, sX + lane, sF + lane);
+    fk_vjp(fk, sQ + lane * dof, sX + lane, sF + lane, sG + lane, sQ + lane * dof);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    float* dst = gq + b0 * dof;
+    for (int i = lane; i < n; i += 64) dst[i] = sQ[i];
+}
+
+// K[b, j]: thread = one support column j, loop over a strip of TB configurations.
+// HBM-write bound (4 B per pair); supports are re-read through L1/L2.
+constexpr int KM_TB = 16;
+__global__ __launch_bounds__(256) void kernel_matrix_kernel(ScoreArgs a, const float* x, int64_t B, const float* s,
+                                                            int64_t S, int D, float* K) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t b0 = (int64_t)blockIdx.y * KM_TB;
+    if (j >= S) return;
+    const float* sj = s + j * D;
+    for (int t = 0; t < KM_TB; ++t) {
+        const int64_t b = b0 + t;
+        if (b >= B) break;
+        const float* xb = x + b * D;
+        float d2 = 0.f;
+        for (int k = 0; k < D; ++k) {
+            const float dl = xb[k] - sj[k];
+            d2 = fmaf(dl, dl, d2);
+        }
+        float val, g;
+        if (a.kind == DCX_K_RQ && a.kp1 == 2.0f) {
+            kernel_eval<KF_RQ2>(d2, a, val, g);
+        } else if (a.kind == DCX_K_POLY && a.kp0 == 1.0f) {
+            // exact zero at coincident points, 1/eps applied here (nothing to fold it into)
+            val = (d2 > 0.f ? d2 * __builtin_amdgcn_rsqf(d2) : 0.f) / a.kp1;
+        } else {
+            kernel_eval<KF_GEN>(d2, a, val, g);
+            if (a.kind == DCX_K_POLY && d2 == 0.f) val = 0.f;
+        }
+        K[b * S + j] = val;
+    }
+}
+
+size_t fk_lds_bytes(const dcx_fk_desc& fk, bool with_g) {
+    const int d_fk = fk.n_points * fk.point_dim;
+    return sizeof(float) * (((64 * fk.dof + 3) & ~3) + 64 * d_fk * (with_g ? 2 : 1) + 64 * fk_frame_floats(fk));
+}
+
+}  // namespace
+
+hipError_t launch_fkine(const dcx_fk_desc* fk_dev, const dcx_fk_desc& fk, const float* q, int64_t B, float* X,
+                        hipStream_t st) {
+    if (B == 0) return hipSuccess;
+    const int d_fk = fk.n_points * fk.point_dim;
+    fkine_kernel<<<dim3((unsigned)((B + 63) / 64)), dim3(64), fk_lds_bytes(fk, false), st>>>(
+        fk_dev, q, B, X, fk.dof, d_fk, fk_frame_floats(fk));
+    return hipGetLastError();
+}
+
+hipError_t launch_fkine_vjp(const dcx_fk_desc* fk_dev, const dcx_fk_desc& fk, const float* q, const float* gX,
+                            int64_t B, float* gq, hipStream_t st) {
+    if (B == 0) return hipSuccess;
+    const int d_fk = fk.n_points * fk.point_dim;
+    fkine_vjp_kernel<<<dim3((unsigned)((B + 63) / 64)), dim3(64), fk_lds_bytes(fk, true), st>>>(
+        fk_dev, q, gX, B, gq, fk.dof, d_fk, fk_frame_floats(fk));
+    return hipGetLastError();
+}
+
+hipError_t launch_kernel_matrix(int kind, float kp0, float kp1, const float* x, int64_t B, const float* s, int64_t S,
+                                int D, float* K, hipStream_t st) {
+    if (B == 0 || S == 0) return hipSuccess;
+    ScoreArgs a{};
+    a.kind = kind;
+    a.kp0 = kp0;
+    a.kp1 = kp1;
+    dim3 grid((unsigned)((S + 255) / 256), (unsigned)((B + KM_TB - 1) / KM_TB));
+    kernel_matrix_kernel<<<grid, dim3(256), 0, st>>>(a, x, B, s, S, D, K);
+    return hipGetLastError();
+}
+
+}  // namespace dcx

@@ -1,0 +1,395 @@
+// dcx_api.hip — the C ABI declared in include/dcx.h: model lifetime, argument checking,
+// launch geometry.  No torch types cross this boundary.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "dcx_internal.h"
+
+using namespace dcx;
+
+struct dcx_model {
+    int device = 0;
+    dcx_fk_desc fk{};              // host copy
+    dcx_fk_desc* fk_dev = nullptr; // device copy
+    float* rows_dev = nullptr;     // [S_active][RS]
+    int64_t S_in = 0;
+    int32_t S_active = 0;
+    int32_t D = 0, Dt = 0, C = 0, RS = 0;
+    int32_t kind = 0, kf = 0;
+    float kp0 = 0, kp1 = 0;
+    int32_t frame_floats = 0;
+    launch_fn launch = nullptr;
+    int32_t max_threads = 0;
+    int32_t n_cu = 256;
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+int fail_hip(hipError_t e, const char* what) {
+    return fail(DCX_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define DCX_HIP(call)                                        \
+    do {                                                     \
+        hipError_t e__ = (call);                             \
+        if (e__ != hipSuccess) return fail_hip(e__, #call);  \
+    } while (0)
+
+launch_fn launch_for(int Dt) {
+    switch (Dt) {
+#define DCX_CASE(D) case D: return launch_score_D##D;
+        DCX_CASE(2) DCX_CASE(4) DCX_CASE(6) DCX_CASE(8) DCX_CASE(12) DCX_CASE(16) DCX_CASE(21) DCX_CASE(24)
+        DCX_CASE(32) DCX_CASE(42) DCX_CASE(48) DCX_CASE(64) DCX_CASE(72)
+#undef DCX_CASE
+    default: return nullptr;
+    }
+}
+
+int check_fk(const dcx_fk_desc& fk) {
+    if (fk.dof < 1 || fk.dof > DCX_MAX_DOF) return fail(DCX_ERR_INVALID, "fk.dof out of range");
+    const int D = fk.n_points * fk.point_dim;
+    if (D < 1 || D > DCX_MAX_D) return fail(DCX_ERR_UNSUPPORTED, "fk feature width n_points*point_dim must be in [1, DCX_MAX_D]");
+    switch (fk.kind) {
+    case DCX_FK_NONE:
+        if (fk.n_points * fk.point_dim != fk.dof) return fail(DCX_ERR_INVALID, "DCX_FK_NONE needs n_points*point_dim == dof");
+        break;
+    case DCX_FK_PLANAR:
+        if (fk.point_dim != 2 || fk.n_points != fk.dof) return fail(DCX_ERR_INVALID, "DCX_FK_PLANAR needs point_dim 2, n_points == dof");
+        break;
+    case DCX_FK_DH: {
+        if (fk.point_dim != 3 || fk.n_points > DCX_MAX_POINTS) return fail(DCX_ERR_INVALID, "DCX_FK_DH needs point_dim 3, n_points <= DCX_MAX_POINTS");
+        if (fk.n_chains < 1 || fk.n_chains > DCX_MAX_CHAINS) return fail(DCX_ERR_INVALID, "DCX_FK_DH n_chains out of range");
+        for (int c = 0; c < fk.n_chains; ++c) {
+            if (fk.chain_len[c] < 1 || fk.chain_len[c] > DCX_MAX_JOINTS) return fail(DCX_ERR_INVALID, "DCX_FK_DH chain_len out of range");
+            for (int i = 0; i < fk.chain_len[c]; ++i)
+                if (fk.joint_q[c][i] < 0 || fk.joint_q[c][i] >= fk.dof) return fail(DCX_ERR_INVALID, "DCX_FK_DH joint_q out of range");
+        }
+        for (int k = 0; k < fk.n_points; ++k) {
+            const int c = fk.pt_chain[k];
+            if (c < 0 || c >= fk.n_chains || fk.pt_frame[k] < 0 || fk.pt_frame[k] >= fk.chain_len[c])
+                return fail(DCX_ERR_INVALID, "DCX_FK_DH control point refers to a missing frame");
+        }
+    } break;
+    case DCX_FK_SE2:
+        if (fk.dof != 3 || fk.point_dim != 2 || fk.n_points > DCX_MAX_POINTS) return fail(DCX_ERR_INVALID, "DCX_FK_SE2 needs dof 3, point_dim 2");
+        break;
+    case DCX_FK_SE3:
+        if (fk.dof != 6 || fk.point_dim != 3 || fk.n_points > DCX_MAX_POINTS) return fail(DCX_ERR_INVALID, "DCX_FK_SE3 needs dof 6, point_dim 3");
+        break;
+    default: return fail(DCX_ERR_INVALID, "unknown fk.kind");
+    }
+    return DCX_OK;
+}
+
+int check_kernel(int kind, const float* kp) {
+    if (!kp) return fail(DCX_ERR_INVALID, "kparams is NULL");
+    switch (kind) {
+    case DCX_K_RQ:
+        if (!(kp[1] > 0.f)) return fail(DCX_ERR_INVALID, "RQ kernel needs p > 0");
+        break;
+    case DCX_K_POLY:
+        if (kp[0] < 1.f || kp[0] != std::floor(kp[0]) || kp[0] > 64.f) return fail(DCX_ERR_INVALID, "Polyharmonic needs integer 1 <= k <= 64");
+        if (kp[1] == 0.f) return fail(DCX_ERR_INVALID, "Polyharmonic needs epsilon != 0");
+        break;
+    case DCX_K_MQ:
+        if (kp[0] == 0.f) return fail(DCX_ERR_INVALID, "MultiQuadratic needs epsilon != 0");
+        break;
+    default: return fail(DCX_ERR_INVALID, "unknown kernel_kind");
+    }
+    return DCX_OK;
+}
+
+int set_device(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) return fail(DCX_ERR_NO_DEVICE, "no HIP device visible (libdcx has no CPU path)");
+    if (device < 0 || device >= n) return fail(DCX_ERR_INVALID, "device index out of range");
+    DCX_HIP(hipSetDevice(device));
+    return DCX_OK;
+}
+
+// a tiny cache of device copies of FK descriptions for the stateless fkine entry points
+struct FkCacheEntry {
+    int device;
+    dcx_fk_desc host;
+    dcx_fk_desc* dev;
+};
+thread_local std::vector<FkCacheEntry> g_fk_cache;
+
+int fk_device_copy(int device, const dcx_fk_desc& fk, dcx_fk_desc** out) {
+    for (auto& e : g_fk_cache)
+        if (e.device == device && std::memcmp(&e.host, &fk, sizeof(fk)) == 0) {
+            *out = e.dev;
+            return DCX_OK;
+        }
+    dcx_fk_desc* d = nullptr;
+    DCX_HIP(hipMalloc((void**)&d, sizeof(fk)));
+    DCX_HIP(hipMemcpy(d, &fk, sizeof(fk), hipMemcpyHostToDevice));
+    if (g_fk_cache.size() >= 64) {  // bounded: drop the oldest
+        (void)hipFree(g_fk_cache.front().dev);
+        g_fk_cache.erase(g_fk_cache.begin());
+    }
+    g_fk_cache.push_back({device, fk, d});
+    *out = d;
+    return DCX_OK;
+}
+
+// Waves per block (support slices).  Goal: ~4 waves per SIMD on the whole chip when the batch
+// alone cannot provide them, without slicing below 32 supports per wave or past the LDS budget.
+int pick_nw(const dcx_model* m, int64_t B, int acc_floats) {
+    if (const char* e = std::getenv("DCX_NW")) {
+        const int v = std::atoi(e);
+        if (v >= 1) return std::min(v, m->max_threads / 64);
+    }
+    const int64_t base_waves = (B + 63) / 64;
+    const int64_t target = (int64_t)m->n_cu * 4 * 4;
+    int nw = 1;
+    while (nw * 2 <= m->max_threads / 64 && base_waves * nw < target && m->S_active / (nw * 2) >= 32) nw *= 2;
+    const int d_fk = m->fk.n_points * m->fk.point_dim;
+    while (nw > 1 && lds_plan(m->fk.dof, d_fk, m->frame_floats, nw, acc_floats).total * sizeof(float) > 64 * 1024) nw /= 2;
+    return nw;
+}
+
+int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstream, float* score, float* grad,
+              int mode, int one_hot, int64_t grad_stride, hipStream_t st) {
+    if (B == 0) return DCX_OK;
+    const int d_fk = m->fk.n_points * m->fk.point_dim;
+    const int acc = (mode == MODE_SCORE ? 0 : m->Dt) + m->C;
+    const int nw = pick_nw(m, B, acc);
+    ScoreArgs a{};
+    a.rows = m->rows_dev;
+    a.fk = m->fk_dev;
+    a.q = q;
+    a.upstream = upstream;
+    a.score = score;
+    a.grad = grad;
+    a.B = B;
+    a.S = m->S_active;
+    a.s_chunk = (m->S_active + nw - 1) / nw;
+    a.dof = m->fk.dof;
+    a.d_fk = d_fk;
+    a.frame_floats = m->frame_floats;
+    a.kind = m->kind;
+    a.one_hot = one_hot;
+    a.grad_stride = grad_stride;
+    a.kp0 = m->kp0;
+    a.kp1 = m->kp1;
+    const size_t lds = sizeof(float) * lds_plan(a.dof, d_fk, m->frame_floats, nw, acc).total;
+    const int64_t nblk = (B + 63) / 64;
+    if (nblk > 0x7fffffffLL) return fail(DCX_ERR_UNSUPPORTED, "batch too large for one launch");
+    hipError_t e = m->launch(m->kf, m->C, mode, nw, lds, nblk, a, st);
+    if (e != hipSuccess) return fail_hip(e, "score kernel launch");
+    return DCX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dcx_version(void) { return DCX_VERSION; }
+
+const char* dcx_last_error(void) { return g_err.c_str(); }
+
+int dcx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int dcx_model_create(dcx_model** out, int device, const dcx_fk_desc* fk, int kernel_kind, const float* kparams,
+                     const float* support_feat, const float* weights, int64_t S, int32_t D, int32_t C) {
+    if (!out) return fail(DCX_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (S < 0 || S > 0x7fffffffLL) return fail(DCX_ERR_INVALID, "S out of range");
+    if (S > 0 && (!support_feat || !weights)) return fail(DCX_ERR_INVALID, "support_feat / weights is NULL");
+    if (D < 1 || D > DCX_MAX_D) return fail(DCX_ERR_UNSUPPORTED, "D must be in [1, DCX_MAX_D]");
+    if (C < 1 || C > DCX_MAX_C) return fail(DCX_ERR_UNSUPPORTED, "C must be in [1, DCX_MAX_C]");
+    if (int rc = check_kernel(kernel_kind, kparams)) return rc;
+    dcx_fk_desc desc;
+    std::memset(&desc, 0, sizeof(desc));
+    if (fk && fk->kind != DCX_FK_NONE) {
+        desc = *fk;
+    } else {
+        desc.kind = DCX_FK_NONE;
+        desc.dof = fk ? fk->dof : D;
+        desc.n_points = desc.dof;
+        desc.point_dim = 1;
+    }
+    if (int rc = check_fk(desc)) return rc;
+    if (desc.n_points * desc.point_dim != D) return fail(DCX_ERR_INVALID, "D does not match the transform's feature width");
+    if (int rc = set_device(device)) return rc;
+
+    dcx_model* m = new (std::nothrow) dcx_model();
+    if (!m) return fail(DCX_ERR_INVALID, "out of host memory");
+    m->device = device;
+    m->fk = desc;
+    m->S_in = S;
+    m->D = D;
+    m->Dt = template_d_for(D);
+    m->C = C;
+    m->RS = row_stride(m->Dt, C);
+    m->kind = kernel_kind;
+    m->kp0 = kparams[0];
+    m->kp1 = kparams[1];
+    m->kf = (kernel_kind == DCX_K_RQ && kparams[1] == 2.0f)     ? KF_RQ2
+            : (kernel_kind == DCX_K_POLY && kparams[0] == 1.0f) ? KF_POLY1
+                                                                : KF_GEN;
+    m->frame_floats = fk_frame_floats(desc);
+    m->launch = launch_for(m->Dt);
+    m->max_threads = max_threads_for(m->Dt);
+    if (!m->launch) {
+        delete m;
+        return fail(DCX_ERR_UNSUPPORTED, "no compiled sweep for this feature width");
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) m->n_cu = prop.multiProcessorCount;
+
+    // host staging of the inputs (they may be device pointers)
+    std::vector<float> feat((size_t)S * D), w((size_t)S * C);
+    if (S > 0) {
+        hipError_t e = hipMemcpy(feat.data(), support_feat, feat.size() * sizeof(float), hipMemcpyDefault);
+        if (e == hipSuccess) e = hipMemcpy(w.data(), weights, w.size() * sizeof(float), hipMemcpyDefault);
+        if (e != hipSuccess) {
+            delete m;
+            return fail_hip(e, "copy of supports/weights");
+        }
+    }
+    // support rows: [D coords | zero pad to Dt | C weights | (C>1) row sum | pad]; all-zero-weight rows dropped.
+    // Polyharmonic(k=1): the 1/eps factor is folded into the weights (score and gradient are linear in them).
+    const float fold = (m->kf == KF_POLY1) ? 1.0f / m->kp1 : 1.0f;
+    std::vector<float> rows;
+    rows.reserve((size_t)S * m->RS);
+    int32_t kept = 0;
+    for (int64_t j = 0; j < S; ++j) {
+        bool any = false;
+        for (int c = 0; c < C; ++c) any |= (w[j * C + c] != 0.0f);
+        if (!any) continue;
+        const size_t base = rows.size();
+        rows.resize(base + m->RS, 0.0f);
+        for (int k = 0; k < D; ++k) rows[base + k] = feat[j * D + k];
+        float sum = 0.0f;
+        for (int c = 0; c < C; ++c) {
+            const float v = w[j * C + c] * fold;
+            rows[base + m->Dt + c] = v;
+            sum += v;
+        }
+        if (C > 1) rows[base + m->Dt + C] = sum;
+        ++kept;
+    }
+    m->S_active = kept;
+    hipError_t e = hipMalloc((void**)&m->fk_dev, sizeof(dcx_fk_desc));
+    if (e == hipSuccess) e = hipMemcpy(m->fk_dev, &m->fk, sizeof(dcx_fk_desc), hipMemcpyHostToDevice);
+    if (e == hipSuccess && kept > 0) {
+        e = hipMalloc((void**)&m->rows_dev, rows.size() * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(m->rows_dev, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) {
+        dcx_model_destroy(m);
+        return fail_hip(e, "device allocation of the model");
+    }
+    *out = m;
+    return DCX_OK;
+}
+
+void dcx_model_destroy(dcx_model* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->fk_dev) (void)hipFree(m->fk_dev);
+    if (m->rows_dev) (void)hipFree(m->rows_dev);
+    delete m;
+}
+
+int dcx_model_info(const dcx_model* m, int64_t* S_active, int32_t* D, int32_t* C, int32_t* dof, int32_t* device) {
+    if (!m) return fail(DCX_ERR_INVALID, "model is NULL");
+    if (S_active) *S_active = m->S_active;
+    if (D) *D = m->D;
+    if (C) *C = m->C;
+    if (dof) *dof = m->fk.dof;
+    if (device) *device = m->device;
+    return DCX_OK;
+}
+
+int dcx_score(const dcx_model* m, const float* q, int64_t B, float* score, void* stream) {
+    if (!m) return fail(DCX_ERR_INVALID, "model is NULL");
+    if (B < 0 || (B > 0 && (!q || !score))) return fail(DCX_ERR_INVALID, "q / score is NULL or B < 0");
+    if (int rc = set_device(m->device)) return rc;
+    return run_score(m, q, B, nullptr, score, nullptr, MODE_SCORE, -1, m->fk.dof, (hipStream_t)stream);
+}
+
+int dcx_score_grad(const dcx_model* m, const float* q, int64_t B, const float* upstream, float* score, float* grad,
+                   void* stream) {
+    if (!m) return fail(DCX_ERR_INVALID, "model is NULL");
+    if (B < 0 || (B > 0 && (!q || !grad))) return fail(DCX_ERR_INVALID, "q / grad is NULL or B < 0");
+    if (int rc = set_device(m->device)) return rc;
+    const int mode = (m->C > 1 && upstream) ? MODE_GRAD_UP : MODE_GRAD_ROW;
+    return run_score(m, q, B, upstream, score, grad, mode, -1, m->fk.dof, (hipStream_t)stream);
+}
+
+int dcx_score_jac(const dcx_model* m, const float* q, int64_t B, float* score, float* jac, void* stream) {
+    if (!m) return fail(DCX_ERR_INVALID, "model is NULL");
+    if (B < 0 || (B > 0 && (!q || !jac))) return fail(DCX_ERR_INVALID, "q / jac is NULL or B < 0");
+    if (int rc = set_device(m->device)) return rc;
+    if (m->C == 1) return run_score(m, q, B, nullptr, score, jac, MODE_GRAD_ROW, -1, m->fk.dof, (hipStream_t)stream);
+    // one sweep per class with a one-hot upstream; rows land interleaved in jac[b, c, :]
+    for (int c = 0; c < m->C; ++c) {
+        int rc = run_score(m, q, B, nullptr, c == 0 ? score : nullptr, jac + (int64_t)c * m->fk.dof, MODE_GRAD_UP, c,
+                           (int64_t)m->C * m->fk.dof, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return DCX_OK;
+}
+
+int dcx_fkine(int device, const dcx_fk_desc* fk, const float* q, int64_t B, float* X, void* stream) {
+    if (!fk) return fail(DCX_ERR_INVALID, "fk is NULL");
+    if (B < 0 || (B > 0 && (!q || !X))) return fail(DCX_ERR_INVALID, "q / X is NULL or B < 0");
+    if (int rc = check_fk(*fk)) return rc;
+    if (int rc = set_device(device)) return rc;
+    dcx_fk_desc* dev = nullptr;
+    if (int rc = fk_device_copy(device, *fk, &dev)) return rc;
+    hipError_t e = launch_fkine(dev, *fk, q, B, X, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "fkine launch");
+    return DCX_OK;
+}
+
+int dcx_fkine_vjp(int device, const dcx_fk_desc* fk, const float* q, const float* gX, int64_t B, float* gq,
+                  void* stream) {
+    if (!fk) return fail(DCX_ERR_INVALID, "fk is NULL");
+    if (B < 0 || (B > 0 && (!q || !gX || !gq))) return fail(DCX_ERR_INVALID, "q / gX / gq is NULL or B < 0");
+    if (int rc = check_fk(*fk)) return rc;
+    if (int rc = set_device(device)) return rc;
+    dcx_fk_desc* dev = nullptr;
+    if (int rc = fk_device_copy(device, *fk, &dev)) return rc;
+    hipError_t e = launch_fkine_vjp(dev, *fk, q, gX, B, gq, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "fkine_vjp launch");
+    return DCX_OK;
+}
+
+int dcx_kernel_matrix(int device, int kernel_kind, const float* kparams, const float* x, int64_t B, const float* s,
+                      int64_t S, int32_t D, float* K, void* stream) {
+    if (B < 0 || S < 0 || D < 1) return fail(DCX_ERR_INVALID, "negative size");
+    if (B > 0 && S > 0 && (!x || !s || !K)) return fail(DCX_ERR_INVALID, "x / s / K is NULL");
+    if (int rc = check_kernel(kernel_kind, kparams)) return rc;
+    if (int rc = set_device(device)) return rc;
+    // grid.y carries B/16 strips: split very tall problems
+    const int64_t step = 16LL * 65535;
+    for (int64_t b = 0; b < B; b += step) {
+        const int64_t nb = std::min(step, B - b);
+        hipError_t e = launch_kernel_matrix(kernel_kind, kparams[0], kparams[1], x + b * D, nb, s, S, D, K + b * S,
+                                            (hipStream_t)stream);
+        if (e != hipSuccess) return fail_hip(e, "kernel_matrix launch");
+    }
+    return DCX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,44 @@
+// dcx_internal.h — host-side types shared by the translation units of libdcx.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/dcx.h"
+#include "score_kernel.h"
+
+namespace dcx {
+
+// feature widths the sweep is compiled for; any D <= DCX_MAX_D is zero-padded up to the next one
+static constexpr int kTemplateD[] = {2, 4, 6, 8, 12, 16, 21, 24, 32, 42, 48, 64, 72};
+static constexpr int kNumTemplateD = sizeof(kTemplateD) / sizeof(int);
+
+inline int template_d_for(int D) {
+    for (int i = 0; i < kNumTemplateD; ++i)
+        if (D <= kTemplateD[i]) return kTemplateD[i];
+    return -1;
+}
+// block-size ceiling per compiled width: keeps the VGPR budget (512 / waves-per-SIMD) above
+// the ~3*D live registers of the sweep
+inline int max_threads_for(int Dt) { return Dt <= 16 ? 1024 : (Dt <= 48 ? 512 : 256); }
+
+inline int row_stride(int Dt, int C) { return (Dt + C + (C > 1 ? 1 : 0) + 3) / 4 * 4; }
+
+// one entry point per compiled D (score_inst.hip, built once per width)
+typedef hipError_t (*launch_fn)(int kf, int cc, int mode, int nw, size_t lds_bytes, int64_t n_blocks,
+                                const ScoreArgs& args, hipStream_t stream);
+#define DCX_DECLARE_LAUNCH(D) \
+    hipError_t launch_score_D##D(int, int, int, int, size_t, int64_t, const ScoreArgs&, hipStream_t);
+DCX_DECLARE_LAUNCH(2)  DCX_DECLARE_LAUNCH(4)  DCX_DECLARE_LAUNCH(6)  DCX_DECLARE_LAUNCH(8)
+DCX_DECLARE_LAUNCH(12) DCX_DECLARE_LAUNCH(16) DCX_DECLARE_LAUNCH(21) DCX_DECLARE_LAUNCH(24)
+DCX_DECLARE_LAUNCH(32) DCX_DECLARE_LAUNCH(42) DCX_DECLARE_LAUNCH(48) DCX_DECLARE_LAUNCH(64)
+DCX_DECLARE_LAUNCH(72)
+#undef DCX_DECLARE_LAUNCH
+
+// aux_kernels.hip
+hipError_t launch_fkine(const dcx_fk_desc* fk_dev, const dcx_fk_desc& fk_host, const float* q, int64_t B, float* X,
+                        hipStream_t stream);
+hipError_t launch_fkine_vjp(const dcx_fk_desc* fk_dev, const dcx_fk_desc& fk_host, const float* q, const float* gX,
+                            int64_t B, float* gq, hipStream_t stream);
+hipError_t launch_kernel_matrix(int kind, float kp0, float kp1, const float* x, int64_t B, const float* s, int64_t S,
+                                int D, float* K, hipStream_t stream);
+
+}  // namespace dcx

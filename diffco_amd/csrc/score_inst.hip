@@ -1,0 +1,62 @@
+// score_inst.hip — instantiates the fused sweep for ONE feature width (-DDCX_INST_D=<D>) and
+// every (kernel function, class count, gradient mode) combination, behind a plain dispatcher.
+// Built once per width so the widths compile in parallel (see Makefile).
+#include "dcx_internal.h"
+
+#ifndef DCX_INST_D
+#error "compile with -DDCX_INST_D=<feature width>"
+#endif
+
+namespace dcx {
+namespace {
+
+constexpr int kD = DCX_INST_D;
+constexpr int kMaxT = kD <= 16 ? 1024 : (kD <= 48 ? 512 : 256);
+
+template <int KF, int CC, int MODE>
+hipError_t go(int nw, size_t lds, int64_t nblk, const ScoreArgs& a, hipStream_t st) {
+    score_kernel<kD, KF, CC, MODE, kMaxT><<<dim3((unsigned)nblk), dim3(64 * nw), lds, st>>>(a);
+    return hipGetLastError();
+}
+
+template <int KF, int CC>
+hipError_t by_mode(int mode, int nw, size_t lds, int64_t nblk, const ScoreArgs& a, hipStream_t st) {
+    switch (mode) {
+    case MODE_SCORE: return go<KF, CC, MODE_SCORE>(nw, lds, nblk, a, st);
+    case MODE_GRAD_ROW: return go<KF, CC, MODE_GRAD_ROW>(nw, lds, nblk, a, st);
+    case MODE_GRAD_UP:
+        if constexpr (CC > 1) return go<KF, CC, MODE_GRAD_UP>(nw, lds, nblk, a, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+template <int KF>
+hipError_t by_cc(int cc, int mode, int nw, size_t lds, int64_t nblk, const ScoreArgs& a, hipStream_t st) {
+    switch (cc) {
+    case 1: return by_mode<KF, 1>(mode, nw, lds, nblk, a, st);
+    case 2: return by_mode<KF, 2>(mode, nw, lds, nblk, a, st);
+    case 3: return by_mode<KF, 3>(mode, nw, lds, nblk, a, st);
+    case 4: return by_mode<KF, 4>(mode, nw, lds, nblk, a, st);
+    case 5: return by_mode<KF, 5>(mode, nw, lds, nblk, a, st);
+    case 6: return by_mode<KF, 6>(mode, nw, lds, nblk, a, st);
+    case 7: return by_mode<KF, 7>(mode, nw, lds, nblk, a, st);
+    case 8: return by_mode<KF, 8>(mode, nw, lds, nblk, a, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace
+
+#define DCX_CAT_(a, b) a##b
+#define DCX_CAT(a, b) DCX_CAT_(a, b)
+hipError_t DCX_CAT(launch_score_D, DCX_INST_D)(int kf, int cc, int mode, int nw, size_t lds, int64_t nblk,
+                                               const ScoreArgs& a, hipStream_t st) {
+    switch (kf) {
+    case KF_RQ2: return by_cc<KF_RQ2>(cc, mode, nw, lds, nblk, a, st);
+    case KF_POLY1: return by_cc<KF_POLY1>(cc, mode, nw, lds, nblk, a, st);
+    case KF_GEN: return by_cc<KF_GEN>(cc, mode, nw, lds, nblk, a, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace dcx

@@ -1,0 +1,267 @@
+// score_kernel.h — the fused hot path: FK -> pairwise kernel block -> weight contraction ->
+// analytic gradient -> FK vjp, one launch.
+//
+// Replaces (paths under /root/reference/diffco): DiffCo.score / score_original
+// kernel_perceptrons.py:359-370, DiffCo.poly_score :309-319, MultiDiffCo.score / rbf_score
+// deprecated/MultiDiffCo.py:118-123,156-169, DiffCoBeta.rbf_score deprecated/DiffCoBeta.py:173-181,
+// the kernels kernel.py:17-29,49-57,73-79, and the autograd pass the optimisers run through
+// them (optim.py:101, 211-216).
+//
+// Mapping onto CDNA4
+//   * one lane  = one configuration.  Its D features, D gradient accumulators and C score
+//     accumulators stay in VGPRs for the whole support sweep (K[B,S] is never materialised).
+//   * one wave  = 64 configurations x one contiguous slice of the supports.  The slice is
+//     wave-uniform, so a support row (D coords + C weights [+ row-sum]) is fetched with
+//     scalar loads (s_load_dwordx4/x8/x16 through the constant cache) into SGPRs and used as
+//     the scalar operand of the VALU ops: the sweep issues no vector-memory and no LDS
+//     instruction at all.  The path is fp32-VALU bound, and this layout
+//     spends VALU slots only on the algorithmic sub/fma/rsq work.
+//   * one block = the same 64 configurations x NW waves, each wave on its own support slice
+//     (fills the chip when B is small); partial sums meet in LDS and wave 0 finishes.
+//   * prologue / epilogue (wave 0): q rows staged coalesced through LDS, FK chain evaluated
+//     per lane with frames kept in LDS (fk_device.h), J^T applied to the feature gradient,
+//     gradient rows staged back through LDS for a coalesced store.
+// Distances use direct differences (x - s)^2, never the |x|^2+|s|^2-2x.s GEMM form: that
+// form is what makes the reference's own fp32 result ~1e-5 off.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "fk_device.h"
+
+namespace dcx {
+
+// kernel-function specialisations compiled into the sweep
+enum { KF_RQ2 = 0,   // RQKernel with p == 2 (the reference default, kernel.py:13)
+       KF_POLY1 = 1, // Polyharmonic(k=1) (the reference's inference kernel, collision_checkers.py:206)
+       KF_GEN = 2 }; // everything else, selected by a wave-uniform switch
+
+// gradient modes
+enum { MODE_SCORE = 0,    // score only
+       MODE_GRAD_ROW = 1, // score + grad with the per-row folded weight (C == 1, or upstream == ones)
+       MODE_GRAD_UP = 2 };// score + grad with an explicit upstream[b, :] (C > 1)
+
+struct ScoreArgs {
+    const float* rows;        // [S][RS] support rows: D coords, CC weights, (CC>1: sum of weights), pad
+    const dcx_fk_desc* fk;    // device copy
+    const float* q;           // [B][dof]
+    const float* upstream;    // [B][C] or null
+    float* score;             // [B][C] or null
+    float* grad;              // [B][dof] or null
+    int64_t B;
+    int32_t S;                // active supports
+    int32_t s_chunk;          // supports per wave slice
+    int32_t dof;
+    int32_t d_fk;             // features the FK writes (<= D; the rest are zero padding)
+    int32_t frame_floats;     // per-lane LDS floats for FK frames
+    int32_t kind;             // DCX_K_* (used by KF_GEN)
+    int32_t one_hot;          // MODE_GRAD_UP: >= 0 selects upstream = e_{one_hot} (Jacobian rows); -1 = use upstream[]
+    int64_t grad_stride;      // floats between consecutive configurations' gradient rows (dof, or C*dof for jac)
+    float kp0, kp1;           // kernel parameters
+};
+
+template <int D, int CC>
+struct RowLayout {
+    static constexpr int W_OFF = D;
+    static constexpr int WSUM_OFF = D + CC;  // only present when CC > 1
+    static constexpr int RS = (D + CC + (CC > 1 ? 1 : 0) + 3) / 4 * 4;
+};
+
+typedef const __attribute__((address_space(4))) float* cfloat_ptr;
+
+// value K(d2) and g with dK/dx = g * (x - s)
+template <int KF>
+__device__ __forceinline__ void kernel_eval(float d2, const ScoreArgs& a, float& val, float& g) {
+    if constexpr (KF == KF_RQ2) {
+        // (1 + gamma/2 d2)^-2 ;  dK/dd2 = -gamma (1 + gamma/2 d2)^-3
+        const float t = fmaf(0.5f * a.kp0, d2, 1.0f);
+        const float u = __builtin_amdgcn_rcpf(t);
+        val = u * u;
+        g = (-2.0f * a.kp0) * (val * u);
+    } else if constexpr (KF == KF_POLY1) {
+        // r (1/eps folded into the row weights); sub-gradient 0 at r == 0 because delta == 0 there
+        const float d2c = fmaxf(d2, 1e-30f);
+        const float ri = __builtin_amdgcn_rsqf(d2c);
+        val = d2c * ri;
+        g = ri;
+    } else {
+        if (a.kind == DCX_K_RQ) {
+            const float p = a.kp1;
+            const float t = fmaf(a.kp0 / p, d2, 1.0f);
+            val = powf(t, -p);
+            g = (-2.0f * a.kp0) * val * __builtin_amdgcn_rcpf(t);
+        } else if (a.kind == DCX_K_POLY) {
+            const int k = (int)a.kp0;
+            const float ie = 1.0f / a.kp1;
+            const float d2c = fmaxf(d2, 1e-30f);
+            const float ri = __builtin_amdgcn_rsqf(d2c);
+            const float r = d2c * ri;
+            float rk2 = (k >= 2) ? 1.0f : ri;  // r^(k-2)
+            for (int i = 2; i < k; ++i) rk2 *= r;
+            if (k & 1) {
+                val = rk2 * d2c * ie;
+                g = (float)k * rk2 * ie;
+            } else {
+                const float lg = 0.5f * logf(d2c);
+                val = rk2 * d2c * lg * ie;
+                g = rk2 * fmaf((float)k, lg, 1.0f) * ie;
+            }
+        } else {  // DCX_K_MQ
+            const float ie2 = 1.0f / (a.kp0 * a.kp0);
+            const float v2 = fmaf(d2, ie2, 1.0f);
+            const float rv = __builtin_amdgcn_rsqf(v2);
+            val = v2 * rv;
+            g = rv * ie2;
+        }
+    }
+}
+
+// LDS carve (floats).  Everything per-lane is in column layout [e][64].
+struct LdsPlan {
+    int q, x, g, f, red, total;
+};
+__host__ __device__ inline LdsPlan lds_plan(int dof, int d_fk, int frame_floats, int nw, int acc_floats) {
+    LdsPlan p;
+    p.q = 0;
+    p.x = p.q + ((64 * dof + 3) & ~3);
+    p.g = p.x + 64 * d_fk;
+    p.f = p.g + 64 * d_fk;
+    p.red = p.f + 64 * frame_floats;
+    p.total = p.red + (nw > 1 ? nw * acc_floats * 64 : 0);
+    return p;
+}
+
+template <int D, int KF, int CC, int MODE, int MAXT>
+__global__ __launch_bounds__(MAXT) void score_kernel(const ScoreArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using L = RowLayout<D, CC>;
+    constexpr bool GRAD = (MODE != MODE_SCORE);
+    constexpr int ACC = (GRAD ? D : 0) + CC;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = blockDim.x >> 6;
+    const int64_t b0 = (int64_t)blockIdx.x * 64;
+    const int nb = (int)((a.B - b0) < 64 ? (a.B - b0) : 64);
+    const int dof = a.dof;
+    const LdsPlan lp = lds_plan(dof, a.d_fk, a.frame_floats, nw, ACC);
+    float* sQ = smem + lp.q;
+    float* sX = smem + lp.x;
+    float* sG = smem + lp.g;
+    float* sF = smem + lp.f;
+    float* sRed = smem + lp.red;
+    const fk_cptr fk = as_const(a.fk);
+
+    // ---- prologue: stage q rows (coalesced), FK per lane on wave 0 ----------------------
+    {
+        const float* qsrc = a.q + b0 * dof;
+        const int n = nb * dof;
+        for (int i = threadIdx.x; i < 64 * dof; i += blockDim.x) sQ[i] = qsrc[i < n ? i : (i % dof) + (nb - 1) * dof];
+    }
+    __syncthreads();
+    if (wave == 0) fk_forward(fk, sQ + lane * dof, sX + lane, sF + lane);
+    __syncthreads();
+
+    float x[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) x[k] = (k < a.d_fk) ? sX[k * 64 + lane] : 0.0f;
+
+    float up[CC];
+    if constexpr (MODE == MODE_GRAD_UP) {
+        const int64_t bl = b0 + (lane < nb ? lane : nb - 1);
+#pragma unroll
+        for (int c = 0; c < CC; ++c) up[c] = (a.one_hot >= 0) ? (c == a.one_hot ? 1.0f : 0.0f) : a.upstream[bl * CC + c];
+    }
+
+    // ---- the sweep: this wave's slice of the supports, rows broadcast through SGPRs ---------
+    float sc[CC];
+    float gx[D];
+#pragma unroll
+    for (int c = 0; c < CC; ++c) sc[c] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < D; ++k) gx[k] = 0.0f;
+
+    const int j0 = wave * a.s_chunk;
+    const int j1 = (j0 + a.s_chunk < a.S) ? (j0 + a.s_chunk) : a.S;
+    cfloat_ptr rows = (cfloat_ptr)(uintptr_t)a.rows;
+#pragma unroll 2
+    for (int j = j0; j < j1; ++j) {
+        cfloat_ptr r = rows + (size_t)j * L::RS;
+        float dl[D];
+        float d2 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            dl[k] = x[k] - r[k];
+            d2 = fmaf(dl[k], dl[k], d2);
+        }
+        float val, g;
+        kernel_eval<KF>(d2, a, val, g);
+#pragma unroll
+        for (int c = 0; c < CC; ++c) sc[c] = fmaf(r[L::W_OFF + c], val, sc[c]);
+        if constexpr (GRAD) {
+            float coef;
+            if constexpr (MODE == MODE_GRAD_ROW) {
+                coef = g * r[CC > 1 ? L::WSUM_OFF : L::W_OFF];
+            } else {
+                float wb = 0.0f;
+#pragma unroll
+                for (int c = 0; c < CC; ++c) wb = fmaf(up[c], r[L::W_OFF + c], wb);
+                coef = g * wb;
+            }
+#pragma unroll
+            for (int k = 0; k < D; ++k) gx[k] = fmaf(coef, dl[k], gx[k]);
+        }
+    }
+
+    // ---- meet the NW partial sums in LDS; wave 0 finishes --------------------------------
+    if (nw > 1) {
+        float* mine = sRed + (size_t)wave * ACC * 64 + lane;
+#pragma unroll
+        for (int c = 0; c < CC; ++c) mine[c * 64] = sc[c];
+        if constexpr (GRAD) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) mine[(CC + k) * 64] = gx[k];
+        }
+        __syncthreads();
+        if (wave != 0) return;
+        for (int w = 1; w < nw; ++w) {
+            const float* o = sRed + (size_t)w * ACC * 64 + lane;
+#pragma unroll
+            for (int c = 0; c < CC; ++c) sc[c] += o[c * 64];
+            if constexpr (GRAD) {
+#pragma unroll
+                for (int k = 0; k < D; ++k) gx[k] += o[(CC + k) * 64];
+            }
+        }
+    }
+
+    if (a.score != nullptr && lane < nb) {
+#pragma unroll
+        for (int c = 0; c < CC; ++c) a.score[(b0 + lane) * CC + c] = sc[c];
+    }
+
+    if constexpr (GRAD) {
+        float scale = 1.0f;
+        if constexpr (CC == 1 && MODE == MODE_GRAD_ROW) {
+            if (a.upstream != nullptr) scale = a.upstream[b0 + (lane < nb ? lane : nb - 1)];
+        }
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+            if (k < a.d_fk) sG[k * 64 + lane] = gx[k] * scale;
+        // J^T gX per lane.  The gradient row is built in place of the lane's own q row: every
+        // fk_vjp branch reads what it needs from the q row before its first write to gq.
+        float* gq = smem + lp.q;
+        fk_vjp(fk, sQ + lane * dof, sX + lane, sF + lane, sG + lane, gq + lane * dof);
+        // rows -> HBM, coalesced (LDS ops of one wave complete in order; no other wave is alive)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        float* gdst = a.grad + b0 * a.grad_stride;
+        const int n = nb * dof;
+        if (a.grad_stride == dof) {
+            for (int i = lane; i < n; i += 64) gdst[i] = gq[i];
+        } else {
+            for (int i = lane; i < n; i += 64) gdst[(int64_t)(i / dof) * a.grad_stride + (i % dof)] = gq[i];
+        }
+    }
+}
+
+}  // namespace dcx

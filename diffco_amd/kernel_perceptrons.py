@@ -1,0 +1,271 @@
+"""DiffCo — the kernel-perceptron proxy collision checker (new-API generation).
+
+Drop-in for diffco/kernel_perceptrons.py:31-370 (class DiffCo): same constructor, `train`,
+`fit_poly`, `score` / `score_original`, `poly_score(point=None, transformed_point=None)`,
+`is_collision`, `to` / `cuda`, `device`, `valid_supports`, and the same state attributes
+(`support_points`, `support_transformed`, `gains`, `rbf_nodes`, `hypothesis`, `y`, `distance`,
+`kernel_matrix`).  What differs is where the arithmetic runs:
+
+  * `score` / `poly_score` (+ their gradient) are ONE fused HIP launch (FK -> kernel block ->
+    weight contraction -> analytic gradient), never a materialised K[B,S] and never on the CPU.
+  * `train` keeps the reference's sequential perceptron on the host; kernel rows come from the
+    HIP kernel-matrix kernel.  `fit_poly` solves the S x S system with torch.linalg.solve.
+
+The old-API classes (`DiffCo(obstacles, ...)`, `MultiDiffCo`, `DiffCoBeta`) are in
+diffco_amd/deprecated.py, like the reference keeps them in diffco/deprecated/.
+"""
+from time import time
+
+import torch as th
+
+from . import kernel
+from ._perceptron import FusedScorer, RowFiller, train_perceptron
+
+
+class Perceptron:
+    def __init__(self):
+        self.support_points = None
+
+    def score(self, point):
+        raise NotImplementedError
+
+    def predict(self, point):
+        return self.score(point) > 0
+
+    def __call__(self, *args, **kwargs):
+        return self.predict(*args, **kwargs)
+
+
+class DiffCo(Perceptron):
+    def __init__(self, kernel_func='rq', gamma=1, beta=1, transform=None, max_batch_size=None,
+                 max_num_supports=None):
+        super().__init__()
+        self.train_method = None
+        self.kernel_func = kernel.RQKernel(gamma) if isinstance(kernel_func, str) and kernel_func == 'rq' else kernel_func
+        self.beta = beta
+        self.transform = transform
+        self._cuda = False
+        self.support_transformed = None
+        self.gains = None
+        self.hypothesis = None
+        self.y = None
+        self.distance = None
+        self.kernel_matrix = None
+        self.rbf_nodes = None
+        self.rbf_kernel = None
+        self.max_batch_size = max_batch_size
+        self.max_num_supports = max_num_supports  # fixed-size, zero-padded state when set
+        self._valid_supports = 0
+        self._score_fused, self._poly_fused, self._polyx_fused = FusedScorer(), FusedScorer(), FusedScorer()
+
+    # pickling keeps only the torch/python state; device handles are rebuilt lazily
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st.pop('_score_fused', None)
+        st.pop('_poly_fused', None)
+        st.pop('_polyx_fused', None)
+        return st
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
+        self._score_fused, self._poly_fused, self._polyx_fused = FusedScorer(), FusedScorer(), FusedScorer()
+
+    @property
+    def valid_supports(self):
+        return self._valid_supports
+
+    @property
+    def device(self):
+        return self.support_points.device
+
+    # ------------------------------------------------------------------------------ training
+    def train(self, X, y, update=False, exist_mask=None, max_iteration=1000, method='original', distance=None,
+              verbose=False):
+        if X.device.type == 'cuda':
+            self._cuda = True
+        self.train_method = method
+        self.distance = distance.reshape(-1) if distance is not None else None
+        t0 = time()
+        self.train_perceptron(X, y, update=update, exist_mask=exist_mask, max_iteration=max_iteration, verbose=verbose)
+        if verbose:
+            print(f'DiffCo training done. {time() - t0:.4f} secs cost')
+
+    def _features(self, X):
+        return X if self.transform is None else self.transform(X)
+
+    def initialize(self, X, y):
+        Xt = self._features(X)
+        if len(X) <= 10000:  # small problems train on the host, as the reference does
+            X, Xt, y = X.cpu(), Xt.cpu(), y.cpu()
+        y = y.reshape(-1)
+        assert len(y) == len(X)
+        n = len(X)
+        gains = th.zeros(n, dtype=X.dtype, device=X.device)
+        K = th.zeros((n, n), dtype=X.dtype, device=X.device)
+        hypo = th.zeros(n, dtype=X.dtype, device=X.device)
+        return gains, X, Xt, K, hypo, y
+
+    def jump_start_initialize(self, X, y, exist_mask):
+        """Warm start for active learning: rows flagged in exist_mask are the current supports (same
+        order); the rest are new samples whose hypothesis is the current score."""
+        n = len(X)
+        dev = th.device('cpu') if n <= 10000 else X.device
+        exist_mask = exist_mask.to(th.bool)
+        novel = X[~exist_mask]
+        v = self.valid_supports
+        assert n - len(novel) == v
+        hypo = th.zeros(n, dtype=X.dtype, device=dev)
+        hypo[exist_mask.to(dev)] = self.hypothesis[:v].to(dev)
+        hypo[(~exist_mask).to(dev)] = self.score_original(novel).detach().to(dev).reshape(-1)
+        novel_t = (novel if self.transform is None else self.transform(novel)).detach().to(dev)
+        K = th.zeros((n, n), dtype=X.dtype, device=dev)
+        ei = th.where(exist_mask)[0].to(dev)
+        ni = th.where(~exist_mask)[0].to(dev)
+        K[ei[:, None], ei[None, :]] = self.kernel_matrix[:v, :v].to(dev)
+        if len(ni) and len(ei):
+            cross = self.kernel_func(self.support_transformed[:v].to(dev), novel_t).to(dev)
+            K[ei[:, None], ni[None, :]] = cross.reshape(len(ei), len(ni))
+            K[ni[:, None], ei[None, :]] = cross.reshape(len(ei), len(ni)).T
+        Xt = self.support_transformed.new_zeros((n,) + tuple(novel_t.shape[1:])).to(dev)
+        Xt[exist_mask.to(dev)] = self.support_transformed[:v].to(dev)
+        Xt[(~exist_mask).to(dev)] = novel_t
+        gains = th.zeros(n, dtype=X.dtype, device=dev)
+        gains[exist_mask.to(dev)] = self.gains[:v].to(dev)
+        check = K @ gains
+        assert th.allclose(check, hypo, atol=1e-4), f"diff: {th.abs(check - hypo).max()}"
+        return gains, X.to(dev), Xt, K, hypo, y.to(dev).reshape(-1)
+
+    def train_perceptron(self, X, y, update=False, exist_mask=None, max_iteration=1000, verbose=False):
+        if update:
+            gains, X, Xt, K, hypo, y = self.jump_start_initialize(X, y, exist_mask)
+        else:
+            gains, X, Xt, K, hypo, y = self.initialize(X, y)
+        fill = RowFiller(self.kernel_func, Xt, K.device)
+        t0 = time()
+        progress = None
+        if verbose:
+            from tqdm import tqdm
+            print('DiffCo training...')
+            progress = tqdm(total=max_iteration, ncols=0)
+        it = train_perceptron(y, hypo, gains, K, fill, self.beta, max_iteration, progress)
+        if verbose:
+            progress.close()
+            print(f'Ended at iteration {it}, cost {time() - t0:.4f} secs')
+            print('ACC: {}'.format(th.sum((hypo > 0) == (y > 0)) / float(len(y))))
+
+        keep = gains != 0
+        if keep.sum() < 2:  # always keep at least two supports
+            keep[th.where(~keep)[0][0]] = True
+        idx = th.where(keep)[0]
+        if self.max_num_supports is None:
+            self.support_points = X[keep]
+            self.support_transformed = Xt[keep]
+            self.hypothesis = hypo[keep]
+            self.y = y[keep]
+            self.distance = self.distance.to(keep.device)[keep] if self.distance is not None else None
+            self.gains = gains[keep]
+            self.rbf_nodes = self.gains.new_zeros(len(self.gains))
+            self.kernel_matrix = K[idx[:, None], idx[None, :]]
+            self._valid_supports = len(self.support_points)
+            return
+        # fixed-size state: pad with zeros / truncate to max_num_supports
+        M = self.max_num_supports
+        dist_src = None if self.distance is None else self.distance.to(keep.device).clone()
+        if self.support_points is None or len(self.support_points) != M:
+            self.support_points = th.zeros((M, X.shape[1]), dtype=X.dtype, device=X.device)
+            self.support_transformed = th.zeros((M,) + tuple(Xt.shape[1:]), dtype=Xt.dtype, device=Xt.device)
+            self.hypothesis = th.zeros(M, dtype=hypo.dtype, device=hypo.device)
+            self.y = th.zeros(M, dtype=y.dtype, device=y.device)
+            self.gains = th.zeros(M, dtype=gains.dtype, device=gains.device)
+            self.kernel_matrix = th.zeros((M, M), dtype=K.dtype, device=K.device)
+        if dist_src is not None:
+            self.distance = th.zeros(M, dtype=dist_src.dtype, device=dist_src.device)
+        if len(idx) > M:
+            # (sic) the reference keeps the M entries with the SMALLEST |gain| (kernel_perceptrons.py:174-178)
+            pick = th.topk(gains.abs(), M, largest=False).indices
+            keep.zero_()
+            keep[pick] = True
+            idx = th.where(keep)[0]
+        n = len(idx)
+        for buf, src in ((self.support_points, X), (self.support_transformed, Xt), (self.hypothesis, hypo),
+                         (self.y, y), (self.gains, gains)):
+            buf.zero_()
+            buf[:n] = src[idx]
+        if dist_src is not None:
+            self.distance[:n] = dist_src[idx]
+        self.rbf_nodes = self.gains.new_zeros(len(self.gains))
+        self.kernel_matrix.zero_()
+        self.kernel_matrix[:n, :n] = K[idx[:, None], idx[None, :]]
+        self._valid_supports = n
+        resid = th.abs(self.hypothesis - self.kernel_matrix @ self.gains).max()
+        assert resid <= 1e-4 + 1e-8, f"diff: {resid}"
+
+    def filter_support_points_(self, mask):
+        idx = th.where(mask)[0]
+        self.support_points = self.support_points[mask]
+        self.support_transformed = self.support_points if self.transform is None else self.support_transformed[mask]
+        self.hypothesis = self.hypothesis[mask]
+        self.y = self.y[mask]
+        self.distance = self.distance[mask] if self.distance is not None else None
+        self.gains = self.gains[mask]
+        self.kernel_matrix = self.kernel_matrix[idx[:, None], idx[None, :]]
+
+    def fit_poly(self, kernel_func, target='hypo'):
+        """rbf_nodes = solve(K_rbf(supports, supports), target values)"""
+        if target == 'hypo':
+            t = self.hypothesis
+        elif 'dist' in target:
+            t = self.distance
+        elif 'label' in target:
+            t = self.y
+        else:
+            raise ValueError(f"unknown fit target {target!r}")
+        self.rbf_kernel = kernel_func
+        v = self.valid_supports
+        Xs = self.support_transformed[:v]
+        kmat = self.rbf_kernel(Xs, Xs)
+        self.rbf_nodes.zero_()
+        self.rbf_nodes[:v] = th.linalg.solve(kmat, t[:v, None].to(kmat.dtype)).reshape(-1)
+        if self._cuda:
+            self.cuda()
+
+    # ------------------------------------------------------------------------------ devices
+    def cuda(self):
+        self.to(th.device('cuda'))
+
+    def to(self, device):
+        device = th.device(device)
+        for name in ('support_points', 'support_transformed', 'rbf_nodes', 'gains'):
+            t = getattr(self, name, None)
+            if t is not None:
+                setattr(self, name, t.to(device))
+        self._cuda = device.type == 'cuda'
+
+    # ------------------------------------------------------------------------------ the hot path
+    def is_collision(self, point):
+        return self.score(point) > 0
+
+    def score(self, point):
+        return self.score_original(point)
+
+    def score_original(self, point):
+        """sum_j K(T(q), support_j) gains_j  ->  [N]  (0-dim for a single query under RQ, like the reference)"""
+        single = point.ndim == 1
+        if single:
+            point = point[None, :]
+        s = self._score_fused.score(self.transform, self.kernel_func, self.support_transformed, self.gains, point)
+        s = s.reshape(-1)
+        if s.shape[0] == 1 and isinstance(self.kernel_func, (kernel.RQKernel, kernel.MultiQuadratic)):
+            s = s.reshape(())
+        return s
+
+    def poly_score(self, point=None, transformed_point=None):
+        """sum_j K_rbf(T(q), support_j) rbf_nodes_j  ->  [N, 1]; `transformed_point` skips the FK."""
+        if transformed_point is None:
+            if point.ndim == 1:
+                point = point.unsqueeze(0)
+            point = point.to(device=self.rbf_nodes.device, dtype=self.rbf_nodes.dtype)
+            return self._poly_fused.score(self.transform, self.rbf_kernel, self.support_transformed, self.rbf_nodes,
+                                          point)
+        feats = transformed_point.reshape(len(transformed_point), -1)
+        return self._polyx_fused.score(None, self.rbf_kernel, self.support_transformed, self.rbf_nodes, feats)

@@ -1,0 +1,156 @@
+/*
+ * dcx.h — C ABI of libdcx.so, the MI355X (gfx950) implementation of DiffCo's
+ * score(+gradient) hot path.
+ *
+ * The reference (ucsdarclab/diffco) has no FFI: its boundary for this path is a set of
+ * Python call signatures.  Each entry point below names the reference code it replaces
+ * (paths under /root/reference).  Signatures use only plain pointers and sizes — no torch
+ * types — so any host (ctypes, cgo, JNI, a C++ planner) can bind them; see INTEGRATION.md.
+ *
+ * Conventions
+ *   - All arrays are dense, row-major, fp32.  "dev" = device pointer on the model's GPU,
+ *     "host|dev" = either (copied with hipMemcpyDefault at create time).
+ *   - The caller owns every q/score/grad/jac buffer.  The library owns only the model's
+ *     device copy of the support rows and FK parameters (freed by dcx_model_destroy).
+ *   - Every launch is enqueued on the caller's HIP stream (`stream` = hipStream_t, NULL =
+ *     default stream) and does NOT synchronise.
+ *   - Return value: 0 = DCX_OK, otherwise an error code; text via dcx_last_error()
+ *     (thread-local).  Nothing throws or exits across the ABI.
+ *   - A model handle is immutable after creation: concurrent calls on distinct streams
+ *     are legal.
+ */
+#ifndef DCX_H
+#define DCX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCX_VERSION 100 /* 0.1.0 */
+
+/* ---- status codes ---------------------------------------------------------------- */
+#define DCX_OK 0
+#define DCX_ERR_INVALID 1     /* bad argument (NULL, negative size, inconsistent shapes) */
+#define DCX_ERR_UNSUPPORTED 2 /* shape/kind outside the compiled set (e.g. D > DCX_MAX_D) */
+#define DCX_ERR_HIP 3         /* a HIP runtime call failed (message has hipGetErrorString) */
+#define DCX_ERR_NO_DEVICE 4   /* no gfx950 device visible */
+
+/* ---- pairwise kernel functions (diffco/kernel.py) -------------------------------- */
+/* K(x, s) as a function of d2 = ||x - s||^2, r = sqrt(d2); kparams = {p0, p1}.        */
+#define DCX_K_RQ 0   /* RQKernel       kernel.py:12-29   (1 + p0/p1 * d2)^(-p1); p0=gamma, p1=p */
+#define DCX_K_POLY 1 /* Polyharmonic   kernel.py:59-79   p0=k, p1=eps: k odd r^k/eps; k even r^k log r/eps (0 at r=0) */
+#define DCX_K_MQ 2   /* MultiQuadratic kernel.py:45-57   sqrt(d2/p0^2 + 1); p0=eps */
+
+/* ---- forward-kinematics transforms (diffco/model.py == diffco/robot_fkine.py) ---- */
+#define DCX_FK_NONE 0   /* transform=None: features are the configuration itself (D = dof)      */
+#define DCX_FK_PLANAR 1 /* RevolutePlanarRobot.fkine      model.py:40-48                        */
+#define DCX_FK_DH 2     /* DH chains: Baxter L/R model.py:225-241,283-299; BaxterDual 366-383;
+                           PandaFK 430-453 (robot_fkine.py:428-444); DualPandaFK 486-502;
+                           link transform = utils.DH2mat utils.py:66-75                        */
+#define DCX_FK_SE2 3    /* RigidPlanarBody.fkine          model.py:90-93 (utils.rot_2d)         */
+#define DCX_FK_SE3 4    /* RigidBody.fkine                model.py:156-159 (utils.euler2mat = Rz Ry Rx) */
+
+#define DCX_MAX_JOINTS 16 /* per chain */
+#define DCX_MAX_CHAINS 2
+#define DCX_MAX_POINTS 24
+#define DCX_MAX_DOF 32
+#define DCX_MAX_D 72  /* feature width n_points * point_dim the fused kernels are compiled for */
+#define DCX_MAX_C 8   /* weight columns (classes) the fused kernels are compiled for           */
+
+/*
+ * Plain-data description of one `transform(q[dof]) -> control points [n_points, point_dim]`.
+ * Output feature k*point_dim + j is coordinate j of control point k, i.e. the row-major
+ * flattening the reference kernels apply (kernel.py:20-21, 77).
+ */
+typedef struct dcx_fk_desc {
+    int32_t kind;      /* DCX_FK_*                                                          */
+    int32_t dof;       /* width of a configuration row                                      */
+    int32_t n_points;  /* m (for DCX_FK_NONE: dof)                                          */
+    int32_t point_dim; /* d = 2 or 3 (for DCX_FK_NONE: 1)                                   */
+
+    /* DCX_FK_PLANAR: phi_i = sum_{j<=i} q_j; p_i = sum_{j<=i} l_j (cos phi_j, sin phi_j)   */
+    float link_length[DCX_MAX_DOF];
+
+    /* DCX_FK_DH: n_chains serial chains.  Joint i of chain c reads q[joint_q[c][i]], adds
+     * theta0, and applies T <- T * DH(theta, a, d, sin_alpha, cos_alpha) starting from
+     * base[c] (row-major 3x4 [R|t]).  Control point k is base-frame position of
+     * pt_off[k] expressed in frame pt_frame[k] (0-based joint index, i.e. after joint
+     * pt_frame[k]'s transform) of chain pt_chain[k].                                      */
+    int32_t n_chains;
+    int32_t chain_len[DCX_MAX_CHAINS];
+    int32_t joint_q[DCX_MAX_CHAINS][DCX_MAX_JOINTS];
+    float a[DCX_MAX_CHAINS][DCX_MAX_JOINTS];
+    float d[DCX_MAX_CHAINS][DCX_MAX_JOINTS];
+    float sin_alpha[DCX_MAX_CHAINS][DCX_MAX_JOINTS];
+    float cos_alpha[DCX_MAX_CHAINS][DCX_MAX_JOINTS];
+    float theta0[DCX_MAX_CHAINS][DCX_MAX_JOINTS];
+    float base[DCX_MAX_CHAINS][12];
+    int32_t pt_chain[DCX_MAX_POINTS];
+    int32_t pt_frame[DCX_MAX_POINTS];
+    float pt_off[DCX_MAX_POINTS][3];
+
+    /* DCX_FK_SE2: q = (x, y, theta); p_k = R(theta) keypoints[k][0:2] + (x, y)
+     * DCX_FK_SE3: q = (x, y, z, roll, pitch, yaw); p_k = Rz(yaw) Ry(pitch) Rx(roll) keypoints[k] + (x,y,z) */
+    float keypoints[DCX_MAX_POINTS][3];
+} dcx_fk_desc;
+
+typedef struct dcx_model dcx_model; /* opaque; immutable after create */
+
+/* ---- library ----------------------------------------------------------------------- */
+int dcx_version(void);
+const char* dcx_last_error(void);
+int dcx_device_count(void);
+
+/* ---- model = inference state of a kernel perceptron ------------------------------- */
+/* Replaces the state DiffCo.score/poly_score read: support_transformed[S,m,d] + gains[S]
+ * or rbf_nodes[S] (kernel_perceptrons.py:41-53, 143-196, 282-283); old API support_fkine[S,D]
+ * + rbf_nodes[S,C] (deprecated/MultiDiffCo.py:125-154).
+ *   fk            NULL or kind DCX_FK_NONE => D must equal the configuration width.
+ *   support_feat  [S, D]  transformed supports (already through the FK), host|dev
+ *   weights       [S, C]  gains / rbf_nodes, host|dev; rows whose C weights are all zero
+ *                         are dropped (they contribute nothing; this is what
+ *                         max_num_supports padding produces, kernel_perceptrons.py:159-196)
+ */
+int dcx_model_create(dcx_model** out, int device, const dcx_fk_desc* fk, int kernel_kind,
+                     const float* kparams, const float* support_feat, const float* weights,
+                     int64_t S, int32_t D, int32_t C);
+void dcx_model_destroy(dcx_model* m);
+/* any out pointer may be NULL; S_active = supports kept after dropping all-zero rows */
+int dcx_model_info(const dcx_model* m, int64_t* S_active, int32_t* D, int32_t* C, int32_t* dof,
+                   int32_t* device);
+
+/* ---- the hot path ------------------------------------------------------------------ */
+/* score[b, c] = sum_j K(T(q_b), support_j) * weights[j, c]
+ * Replaces DiffCo.score/score_original kernel_perceptrons.py:359-370, DiffCo.poly_score :309-319,
+ * MultiDiffCo.score / rbf_score deprecated/MultiDiffCo.py:118-123,156-169, DiffCoBeta.rbf_score
+ * deprecated/DiffCoBeta.py:173-181.   q [B, dof] dev -> score [B, C] dev.                 */
+int dcx_score(const dcx_model* m, const float* q, int64_t B, float* score, void* stream);
+
+/* score as above and grad[b, :] = d( sum_c upstream[b,c] * score[b,c] ) / d q_b, in the same
+ * pass (the reference obtains it by autograd: optim.py:101, 211-216).  upstream [B, C] dev or
+ * NULL (= all ones).  score may be NULL.  grad [B, dof] dev.                              */
+int dcx_score_grad(const dcx_model* m, const float* q, int64_t B, const float* upstream,
+                   float* score, float* grad, void* stream);
+
+/* score and the full Jacobian jac[b, c, :] = d score[b,c] / d q_b  ([B, C, dof] dev)
+ * (torch.autograd.functional.jacobian callers, optim.py:211-216).                          */
+int dcx_score_jac(const dcx_model* m, const float* q, int64_t B, float* score, float* jac,
+                  void* stream);
+
+/* ---- pieces of the path exposed on their own ---------------------------------------- */
+/* X[b] = T(q_b): model.*.fkine (see DCX_FK_*).  q [B, dof] dev -> X [B, n_points*point_dim] dev */
+int dcx_fkine(int device, const dcx_fk_desc* fk, const float* q, int64_t B, float* X, void* stream);
+/* gq[b] = J_T(q_b)^T gX[b]  (autograd of fkine).  gX [B, D] dev -> gq [B, dof] dev          */
+int dcx_fkine_vjp(int device, const dcx_fk_desc* fk, const float* q, const float* gX, int64_t B,
+                  float* gq, void* stream);
+/* K[b, j] = K(x_b, s_j): KernelFunc.__call__ kernel.py:17-29, 49-57, 73-79 (used by the trainer's
+ * row fill kernel_perceptrons.py:117-119 and fit_poly :271-287).  x [B, D], s [S, D] dev -> K [B, S] dev */
+int dcx_kernel_matrix(int device, int kernel_kind, const float* kparams, const float* x, int64_t B,
+                      const float* s, int64_t S, int32_t D, float* K, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCX_H */

@@ -1,0 +1,63 @@
+"""Shared by the CPU (oracle) and GPU (parity) tests: golden loading, robot factory, error metric."""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+KIND = {"rq": 0, "poly": 1, "mq": 2}
+
+# which robot each score fixture was generated with (tools/make_golden.py)
+CASE_ROBOT = {
+    "cfg1_planar2_rq": "planar2", "cfg2_baxter_poly1": "baxter_left", "cfg2_baxter_rq": "baxter_left",
+    "cfg2_panda_poly1": "panda", "cfg2_panda_rq": "panda", "headline_baxter_poly1_s2000": "baxter_left",
+    "cfg3_baxter_rq_c5": "baxter_left", "cfg3_baxter_poly1_c5": "baxter_left", "cfg4_se3_nofk_rq": None,
+    "cfg4_se3_keypts_rq": "se3", "misc_dualbaxter_poly1": "baxter_dual", "misc_dualpanda_rq": "dual_panda",
+    "misc_panda5_mq": "panda5", "misc_se2_poly3": "se2", "misc_planar3_poly2": "planar3",
+    "misc_planar7_rq_p3": "planar7", "misc_baxterR_mq_c2": "baxter_right", "edge_r0_baxter_poly1": "baxter_left",
+    "edge_r0_planar3_poly2": "planar3",
+}
+FK_NAMES = ["planar2", "planar3", "planar7", "se2", "se3", "baxter_left", "baxter_right", "baxter_dual", "panda",
+            "panda5", "dual_panda"]
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def make_robot(name):
+    """the diffco_amd.model robot matching a golden fixture's robot (parameters from fk_<name>.npz)"""
+    from diffco_amd import model
+    if name is None:
+        return None
+    if name.startswith("planar"):
+        ll = load("fk_" + name)["link_length"]
+        return model.RevolutePlanarRobot(ll.tolist(), 0.1)
+    if name == "se2":
+        kp = load("fk_se2")["keypoints"]  # [2, M]
+        return model.RigidPlanarBody([("box", tuple(kp[:, i].tolist()), (1, 1)) for i in range(kp.shape[1])])
+    if name == "se3":
+        return model.RigidBody(keypoints=load("fk_se3")["keypoints"])
+    return {"baxter_left": model.BaxterLeftArmFK, "baxter_right": model.BaxterRightArmFK,
+            "baxter_dual": model.BaxterDualArmFK, "panda": model.PandaFK,
+            "panda5": lambda: model.PandaFK(fingers=False), "dual_panda": model.DualPandaFK}[name]()
+
+
+def desc_for(name, dof=None):
+    from diffco_amd import _fkdesc
+    rob = make_robot(name)
+    return _fkdesc.none_desc(dof) if rob is None else rob.fk_desc()
+
+
+def relerr(a, ref):
+    """max|a - ref| / max|ref|  — the parity metric"""
+    a, ref = np.asarray(a, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    den = np.abs(ref).max()
+    return float(np.abs(a - ref).max() / (den if den > 0 else 1.0))
+
+
+def case_kernel(d):
+    kind = str(d["kind"])
+    kp = d["kparams"]
+    return KIND[kind], float(kp[0]), float(kp[1]) if len(kp) > 1 else 0.0

@@ -212,7 +212,7 @@ def gen_fk(out, robots):
         # analytic Jacobian reference: autograd of the reference FK in fp64
         qd = q.double().requires_grad_(True)
         X = fk64_fn(rob)(qd)
-        gX = torch.randn(X.shape, generator=gen, dtype=torch.float64)
+        gX = torch.randn(X.shape, generator=gen, dtype=torch.float32).double()  # fp32-representable
         (gq,) = torch.autograd.grad((X * gX).sum(), qd)
         save(out, f"fk_{name}", q=q, x32=fk32(rob, q), x64=fk64(rob, q), gx=gX.float(), gq64=gq,
              limits=rob.limits, **robot_params(name, rob))
