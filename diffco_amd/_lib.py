@@ -13,7 +13,8 @@ import torch  # noqa: F401  (must precede CDLL, see docstring)
 from ._fkdesc import FkDesc
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdcx.so")
+# DCX_LIB: developer override used by tools/sweep.py to A/B kernel variants; never a CPU path
+LIB_PATH = os.environ.get("DCX_LIB") or os.path.join(_HERE, "libdcx.so")
 
 # every symbol include/dcx.h declares: (restype, argtypes)
 _c_fp = C.c_void_p  # device/host float pointers travel as raw addresses

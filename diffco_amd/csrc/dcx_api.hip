@@ -145,17 +145,19 @@ int fk_device_copy(int device, const dcx_fk_desc& fk, dcx_fk_desc** out) {
     return DCX_OK;
 }
 
-// Waves per block (support slices).  Goal: ~4 waves per SIMD on the whole chip when the batch
-// alone cannot provide them, without slicing below 32 supports per wave or past the LDS budget.
+// Waves per block (support slices).  Measured on MI355X (profiles/r01_sweep_variants.txt, headline
+// D=12): occupancy is what hides the scalar-load latency of the sweep, so even a huge batch wants 4-8 waves
+// per block (B=1M: nw=1 436, nw=4 689 M evals/s) and a small one wants 16 (B=4096: nw=8 120, nw=16 129).
 int pick_nw(const dcx_model* m, int64_t B, int acc_floats) {
+    const int cap = m->max_threads / 64;
     if (const char* e = std::getenv("DCX_NW")) {
         const int v = std::atoi(e);
-        if (v >= 1) return std::min(v, m->max_threads / 64);
+        if (v >= 1) return std::min(v, cap);
     }
-    const int64_t base_waves = (B + 63) / 64;
-    const int64_t target = (int64_t)m->n_cu * 4 * 4;
-    int nw = 1;
-    while (nw * 2 <= m->max_threads / 64 && base_waves * nw < target && m->S_active / (nw * 2) >= 32) nw *= 2;
+    const int64_t tiles = (B + 63) / 64;
+    int nw = (tiles * 16 <= 2 * 1024 * (int64_t)m->n_cu / 256) ? 16 : 8;  // <= 2 waves per SIMD at nw=16 -> 16
+    nw = std::min(nw, cap);
+    while (nw > 1 && m->S_active / nw < 32) nw /= 2;  // keep >= 32 supports per slice
     const int d_fk = m->fk.n_points * m->fk.point_dim;
     while (nw > 1 && lds_plan(m->fk.dof, d_fk, m->frame_floats, nw, acc_floats).total * sizeof(float) > 64 * 1024) nw /= 2;
     return nw;

@@ -4,8 +4,9 @@
 // "column" layout (element e of lane l at base[e*64 + l]: conflict-free, no scratch):
 //   q row    : sQ[l*dof + i]             (staged coalesced from HBM by the caller)
 //   features : sX[k*64 + l]              (control-point coordinates, D = n_points*point_dim)
-//   frames   : sF[(6*j + e)*64 + l]      (DH: axis z_{j-1} (e=0..2) and origin o_{j-1} (e=3..5)
-//                                          of the frame joint j rotates in; planar: cos/sin phi_j)
+//   frames   : sF[e*64 + l]               (DH: sin/cos of every joint angle, then each chain's final
+//                                          rotation (9 floats) — what the reverse sweep of fk_vjp
+//                                          needs; planar: cos/sin phi_j)
 // The FK description is read through the constant address space, so every parameter load
 // is a scalar (s_load) broadcast: all lanes run the same chain.
 //
@@ -31,7 +32,7 @@ __host__ __device__ inline int fk_frame_floats(const dcx_fk_desc& fk) {
     if (fk.kind == DCX_FK_DH) {
         int j = 0;
         for (int c = 0; c < fk.n_chains; ++c) j += fk.chain_len[c];
-        return 6 * j;
+        return 2 * j + 9 * fk.n_chains;
     }
     if (fk.kind == DCX_FK_PLANAR) return 2 * fk.dof;
     return 0;
@@ -60,18 +61,19 @@ __device__ inline void fk_forward(fk_cptr fk, const float* sQrow, float* sXcol, 
         }
     } else if (kind == DCX_FK_DH) {
         const int n_pts = fk->n_points;
-        int jbase = 0;
+        int jbase = 0, jtot = 0;
+        for (int ch = 0; ch < fk->n_chains; ++ch) jtot += fk->chain_len[ch];
         for (int ch = 0; ch < fk->n_chains; ++ch) {
             float r00 = fk->base[ch][0], r01 = fk->base[ch][1], r02 = fk->base[ch][2], t0 = fk->base[ch][3];
             float r10 = fk->base[ch][4], r11 = fk->base[ch][5], r12 = fk->base[ch][6], t1 = fk->base[ch][7];
             float r20 = fk->base[ch][8], r21 = fk->base[ch][9], r22 = fk->base[ch][10], t2 = fk->base[ch][11];
             const int len = fk->chain_len[ch];
             for (int i = 0; i < len; ++i) {
-                float* f = sFcol + (6 * (jbase + i)) * 64;  // frame joint i rotates in
-                f[0] = r02; f[64] = r12; f[128] = r22; f[192] = t0; f[256] = t1; f[320] = t2;
                 const float th = sQrow[fk->joint_q[ch][i]] + fk->theta0[ch][i];
                 float s, c;
                 sincosf(th, &s, &c);
+                sFcol[(2 * (jbase + i)) * 64] = s;
+                sFcol[(2 * (jbase + i) + 1) * 64] = c;
                 const float a = fk->a[ch][i], d = fk->d[ch][i];
                 const float sa = fk->sin_alpha[ch][i], ca = fk->cos_alpha[ch][i];
                 // T <- T * [[c, -s ca,  s sa, a c], [s, c ca, -c sa, a s], [0, sa, ca, d]]
@@ -96,6 +98,9 @@ __device__ inline void fk_forward(fk_cptr fk, const float* sQrow, float* sXcol, 
                     sXcol[(3 * k + 2) * 64] = fmaf(r20, ox, fmaf(r21, oy, fmaf(r22, oz, t2)));
                 }
             }
+            float* fr = sFcol + (2 * jtot + 9 * ch) * 64;  // final rotation of this chain
+            fr[0] = r00; fr[64] = r01; fr[128] = r02; fr[192] = r10; fr[256] = r11; fr[320] = r12;
+            fr[384] = r20; fr[448] = r21; fr[512] = r22;
             jbase += len;
         }
     } else if (kind == DCX_FK_SE2) {
@@ -149,31 +154,74 @@ __device__ inline void fk_vjp(fk_cptr fk, const float* sQrow, const float* sXcol
         }
         return;
     }
-    for (int i = 0; i < dof; ++i) gqRow[i] = 0.f;
+    // NOTE: gqRow may alias sQrow (callers build the gradient row in place of the q row), so every
+    // branch must finish reading sQrow before its first write to gqRow.
     if (kind == DCX_FK_DH) {
+        // Reverse-mode sweep through T_i = T_{i-1} A_i(theta_i), exactly the chain rule autograd applies to
+        // the reference's bmm chain.  Unlike the geometric form z x (p - o) it reproduces STRUCTURAL zeros
+        // exactly (e.g. Baxter's last joint, a = 0 and the control point on the joint axis): an optimiser
+        // such as Adam would otherwise amplify 1e-8 round-off on such a joint into full-size steps.
+        //   GR, Gt : adjoints of the current frame's rotation / translation
+        //   dL/dtheta_i = <R_{i-1}^T GR, dA_R/dtheta> + <R_{i-1}^T Gt, da_t/dtheta>
+        //   GR <- GR A_R^T + Gt a_t^T ;  Gt unchanged ;  R_{i-1} = R_i A_R^T (recomputed, not stored)
+        for (int i = 0; i < dof; ++i) gqRow[i] = 0.f;  // DH reads frames, not q
         const int n_pts = fk->n_points;
+        int jtot = 0;
+        for (int ch = 0; ch < fk->n_chains; ++ch) jtot += fk->chain_len[ch];
         int jbase = 0;
         for (int ch = 0; ch < fk->n_chains; ++ch) {
             const int len = fk->chain_len[ch];
-            // suffix sums over the points hanging at or beyond joint i:
-            //   A = sum p_k x g_k,  G = sum g_k;   gq_i = z_{i-1} . (A - o_{i-1} x G)
-            float A0 = 0.f, A1 = 0.f, A2 = 0.f, G0 = 0.f, G1 = 0.f, G2 = 0.f;
+            const float* fr = sFcol + (2 * jtot + 9 * ch) * 64;
+            float r00 = fr[0], r01 = fr[64], r02 = fr[128], r10 = fr[192], r11 = fr[256], r12 = fr[320];
+            float r20 = fr[384], r21 = fr[448], r22 = fr[512];
+            float G00 = 0.f, G01 = 0.f, G02 = 0.f, G10 = 0.f, G11 = 0.f, G12 = 0.f, G20 = 0.f, G21 = 0.f, G22 = 0.f;
+            float T0 = 0.f, T1 = 0.f, T2 = 0.f;
             for (int i = len - 1; i >= 0; --i) {
                 for (int k = 0; k < n_pts; ++k) {
                     if (fk->pt_chain[k] != ch || fk->pt_frame[k] != i) continue;
-                    const float p0 = sXcol[(3 * k) * 64], p1 = sXcol[(3 * k + 1) * 64], p2 = sXcol[(3 * k + 2) * 64];
                     const float g0 = sGcol[(3 * k) * 64], g1 = sGcol[(3 * k + 1) * 64], g2 = sGcol[(3 * k + 2) * 64];
-                    A0 += p1 * g2 - p2 * g1;
-                    A1 += p2 * g0 - p0 * g2;
-                    A2 += p0 * g1 - p1 * g0;
-                    G0 += g0; G1 += g1; G2 += g2;
+                    const float ox = fk->pt_off[k][0], oy = fk->pt_off[k][1], oz = fk->pt_off[k][2];
+                    T0 += g0; T1 += g1; T2 += g2;
+                    G00 = fmaf(g0, ox, G00); G01 = fmaf(g0, oy, G01); G02 = fmaf(g0, oz, G02);
+                    G10 = fmaf(g1, ox, G10); G11 = fmaf(g1, oy, G11); G12 = fmaf(g1, oz, G12);
+                    G20 = fmaf(g2, ox, G20); G21 = fmaf(g2, oy, G21); G22 = fmaf(g2, oz, G22);
                 }
-                const float* f = sFcol + (6 * (jbase + i)) * 64;
-                const float z0 = f[0], z1 = f[64], z2 = f[128], o0 = f[192], o1 = f[256], o2 = f[320];
-                const float v0 = A0 - (o1 * G2 - o2 * G1);
-                const float v1 = A1 - (o2 * G0 - o0 * G2);
-                const float v2 = A2 - (o0 * G1 - o1 * G0);
-                gqRow[fk->joint_q[ch][i]] += z0 * v0 + z1 * v1 + z2 * v2;
+                const float s = sFcol[(2 * (jbase + i)) * 64], c = sFcol[(2 * (jbase + i) + 1) * 64];
+                const float a = fk->a[ch][i], d = fk->d[ch][i];
+                const float sa = fk->sin_alpha[ch][i], ca = fk->cos_alpha[ch][i];
+                // A_R = [[c, -s ca, s sa], [s, c ca, -c sa], [0, sa, ca]],  a_t = (a c, a s, d)
+                const float a00 = c, a01 = -s * ca, a02 = s * sa, a10 = s, a11 = c * ca, a12 = -c * sa;
+                const float at0 = a * c, at1 = a * s;
+                // R_{i-1} = R_i A_R^T
+                const float p00 = fmaf(r00, a00, fmaf(r01, a01, r02 * a02)), p01 = fmaf(r00, a10, fmaf(r01, a11, r02 * a12)),
+                            p02 = fmaf(r01, sa, r02 * ca);
+                const float p10 = fmaf(r10, a00, fmaf(r11, a01, r12 * a02)), p11 = fmaf(r10, a10, fmaf(r11, a11, r12 * a12)),
+                            p12 = fmaf(r11, sa, r12 * ca);
+                const float p20 = fmaf(r20, a00, fmaf(r21, a01, r22 * a02)), p21 = fmaf(r20, a10, fmaf(r21, a11, r22 * a12)),
+                            p22 = fmaf(r21, sa, r22 * ca);
+                // M = R_{i-1}^T GR (rows 0,1 only: dA_R/dtheta has a zero third row), u = R_{i-1}^T Gt
+                const float M00 = fmaf(p00, G00, fmaf(p10, G10, p20 * G20)), M01 = fmaf(p00, G01, fmaf(p10, G11, p20 * G21)),
+                            M02 = fmaf(p00, G02, fmaf(p10, G12, p20 * G22));
+                const float M10 = fmaf(p01, G00, fmaf(p11, G10, p21 * G20)), M11 = fmaf(p01, G01, fmaf(p11, G11, p21 * G21)),
+                            M12 = fmaf(p01, G02, fmaf(p11, G12, p21 * G22));
+                const float u0 = fmaf(p00, T0, fmaf(p10, T1, p20 * T2)), u1 = fmaf(p01, T0, fmaf(p11, T1, p21 * T2));
+                // dA_R/dtheta = [[-s, -c ca, c sa], [c, -s ca, s sa], [0,0,0]] = [[-a10, -a11, -a12], [a00, a01, a02], 0]
+                // da_t/dtheta = (-a s, a c, 0)
+                const float dth = (M10 * a00 + M11 * a01 + M12 * a02) - (M00 * a10 + M01 * a11 + M02 * a12)
+                                  + (u1 * at0 - u0 * at1);
+                gqRow[fk->joint_q[ch][i]] += dth;
+                // GR <- GR A_R^T + Gt a_t^T
+                const float n00 = fmaf(G00, a00, fmaf(G01, a01, fmaf(G02, a02, T0 * at0)));
+                const float n01 = fmaf(G00, a10, fmaf(G01, a11, fmaf(G02, a12, T0 * at1)));
+                const float n02 = fmaf(G01, sa, fmaf(G02, ca, T0 * d));
+                const float n10 = fmaf(G10, a00, fmaf(G11, a01, fmaf(G12, a02, T1 * at0)));
+                const float n11 = fmaf(G10, a10, fmaf(G11, a11, fmaf(G12, a12, T1 * at1)));
+                const float n12 = fmaf(G11, sa, fmaf(G12, ca, T1 * d));
+                const float n20 = fmaf(G20, a00, fmaf(G21, a01, fmaf(G22, a02, T2 * at0)));
+                const float n21 = fmaf(G20, a10, fmaf(G21, a11, fmaf(G22, a12, T2 * at1)));
+                const float n22 = fmaf(G21, sa, fmaf(G22, ca, T2 * d));
+                G00 = n00; G01 = n01; G02 = n02; G10 = n10; G11 = n11; G12 = n12; G20 = n20; G21 = n21; G22 = n22;
+                r00 = p00; r01 = p01; r02 = p02; r10 = p10; r11 = p11; r12 = p12; r20 = p20; r21 = p21; r22 = p22;
             }
             jbase += len;
         }

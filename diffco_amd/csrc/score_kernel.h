@@ -67,6 +67,16 @@ struct RowLayout {
 };
 
 typedef const __attribute__((address_space(4))) float* cfloat_ptr;
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// Sweep code-generation variants, A/B-measured on MI355X (DESIGN.md "Measured choices"):
+//   bit 0: squared distance accumulated with packed fp32 (v_pk_fma_f32) instead of scalar v_fma_f32
+//   bit 1: scalar loads of the next support row issued before the current row is consumed
+// Measured on MI355X (profiles/r01_sweep_variants.txt): variant 3 is fastest at every batch size
+// (headline B=65536: 551 vs 508 M evals/s for variant 0; B=1M: 689 vs 631).
+#ifndef DCX_SWEEP_VARIANT
+#define DCX_SWEEP_VARIANT 3
+#endif
 
 // value K(d2) and g with dK/dx = g * (x - s)
 template <int KF>
@@ -183,16 +193,37 @@ __global__ __launch_bounds__(MAXT) void score_kernel(const ScoreArgs a) {
     const int j0 = wave * a.s_chunk;
     const int j1 = (j0 + a.s_chunk < a.S) ? (j0 + a.s_chunk) : a.S;
     cfloat_ptr rows = (cfloat_ptr)(uintptr_t)a.rows;
-#pragma unroll 2
-    for (int j = j0; j < j1; ++j) {
-        cfloat_ptr r = rows + (size_t)j * L::RS;
+
+    // one support row against this lane's configuration; `r` is wave-uniform (SGPRs)
+    auto pair = [&](const float (&r)[L::RS]) __attribute__((always_inline)) {
         float dl[D];
-        float d2 = 0.0f;
+        float d2;
+#if DCX_SWEEP_VARIANT & 1
+        {   // squared distance on the packed-fp32 pipe: D/2 v_pk_add + D/2 v_pk_fma
+            v2f acc = {0.0f, 0.0f};
+#pragma unroll
+            for (int k = 0; k + 1 < D; k += 2) {
+                const v2f xv = {x[k], x[k + 1]};
+                const v2f rv = {r[k], r[k + 1]};
+                const v2f d = xv - rv;
+                dl[k] = d.x;
+                dl[k + 1] = d.y;
+                acc = __builtin_elementwise_fma(d, d, acc);
+            }
+            d2 = acc.x + acc.y;
+            if constexpr (D & 1) {
+                dl[D - 1] = x[D - 1] - r[D - 1];
+                d2 = fmaf(dl[D - 1], dl[D - 1], d2);
+            }
+        }
+#else
+        d2 = 0.0f;
 #pragma unroll
         for (int k = 0; k < D; ++k) {
             dl[k] = x[k] - r[k];
             d2 = fmaf(dl[k], dl[k], d2);
         }
+#endif
         float val, g;
         kernel_eval<KF>(d2, a, val, g);
 #pragma unroll
@@ -210,7 +241,36 @@ __global__ __launch_bounds__(MAXT) void score_kernel(const ScoreArgs a) {
 #pragma unroll
             for (int k = 0; k < D; ++k) gx[k] = fmaf(coef, dl[k], gx[k]);
         }
+    };
+    // only the floats a row really carries are loaded (the tail of the padded stride is never touched)
+    constexpr int USED = D + CC + (CC > 1 ? 1 : 0);
+    auto load_row = [&](float (&dst)[L::RS], int j) __attribute__((always_inline)) {
+        cfloat_ptr r = rows + (size_t)j * L::RS;
+#pragma unroll
+        for (int e = 0; e < USED; ++e) dst[e] = r[e];
+    };
+
+#if DCX_SWEEP_VARIANT & 2
+    // software-pipelined: the scalar loads of row j+1 are in flight while row j is consumed
+    if (j0 < j1) {
+        float cur[L::RS], nxt[L::RS];
+        load_row(cur, j0);
+#pragma unroll 2
+        for (int j = j0; j < j1; ++j) {
+            load_row(nxt, (j + 1 < j1) ? j + 1 : j);
+            pair(cur);
+#pragma unroll
+            for (int e = 0; e < USED; ++e) cur[e] = nxt[e];
+        }
     }
+#else
+#pragma unroll 2
+    for (int j = j0; j < j1; ++j) {
+        float cur[L::RS];
+        load_row(cur, j);
+        pair(cur);
+    }
+#endif
 
     // ---- meet the NW partial sums in LDS; wave 0 finishes --------------------------------
     if (nw > 1) {

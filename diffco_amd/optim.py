@@ -1,1 +1,274 @@
-"""placeholder — filled in below"""
+"""Trajectory optimisers that consume a differentiable collision estimate `dist_est(q[N, dof])`.
+
+Same entry points, option keys and result records as the reference's diffco/optim.py
+(`adam_traj_optimize` 13-163, `givengrad_traj_optimize` 166-321, `trustconstr_traj_optimize`
+324-516, `gradient_free_traj_optimize` 519-629); the objective/constraint definitions below restate
+that file's behaviour (weights, margins, validity test, re-trial policy).  These are CALLERS of the
+hot path and stay Python; every `dist_est(p)` / `robot.fkine(p)` they issue lands in the fused HIP
+kernels of libdcx.  `fused_adam_traj_optimize` (diffco_amd/traj.py) is the batched-restart variant.
+
+Differences worth knowing:
+  * the straight-line initial path is built with numpy from array views of the endpoints (the reference's
+    `torch.from_numpy(np.linspace(tensor, tensor))` breaks under numpy 2 / torch 2.10 — SURVEY.md §8c);
+  * trust-constr gets a quasi-Newton (BFGS) constraint Hessian: the exact one needs second derivatives
+    of the score, which the HIP path does not provide (ask with options['exact_hessian'] -> NotImplementedError).
+"""
+import time
+from typing import Dict
+
+import numpy as np
+import torch
+from scipy.optimize import BFGS, NonlinearConstraint, minimize
+
+from . import utils
+
+DIF_WEIGHT = 1           # path-length term; fixed by the reference ("should NOT be changed")
+MAX_MOVE_WEIGHT = 10
+COLLISION_WEIGHT = 10
+JOINT_LIMIT_WEIGHT = 10
+VALID_CONSTRAINT_LOSS = 1e-2
+STATIONARY_GRAD_NORM = 1e-4
+
+
+def _np(x):
+    return x.detach().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
+
+
+def _record(start_cfg, target_cfg, cnt_check, cost, elapsed, success, seed, solution, **extra):
+    rec = {'start_cfg': _np(start_cfg).tolist(), 'target_cfg': _np(target_cfg).tolist(), 'cnt_check': int(cnt_check),
+           'cost': cost.item() if torch.is_tensor(cost) else float(cost), 'time': elapsed, 'success': bool(success), 'seed': seed,
+           'solution': _np(solution).tolist()}
+    rec.update(extra)
+    return rec
+
+
+class _PathProblem:
+    """Waypoint path with fixed endpoints: initialisation policy and the cost / constraint terms."""
+
+    def __init__(self, robot, start_cfg, target_cfg, options):
+        self.robot, self.options = robot, options
+        self.start, self.target = start_cfg, target_cfg
+        self.n_waypoints = options['N_WAYPOINTS']
+        self.max_speed = options['max_speed']
+        self.safety_margin = options.get('safety_margin', 0.0)
+        self.cnt_check = 0
+        self.init_path = None
+
+    def trivial(self):
+        """options['init_solution'] of just two states: nothing to optimise"""
+        init = self.options.get('init_solution')
+        return init is not None and len(init) == 2
+
+    def make_init(self, trial):
+        """trial 0: the given init_solution or the straight line; later trials: uniform random waypoints"""
+        if trial == 0:
+            if 'init_solution' in self.options:
+                init = self.options['init_solution']
+                assert isinstance(init, torch.Tensor) and len(init) >= 2
+                path = init.clone().double()
+            else:
+                line = np.linspace(_np(self.start).astype(np.float64), _np(self.target).astype(np.float64),
+                                   num=self.n_waypoints)
+                path = torch.from_numpy(line).double()
+        else:
+            lim = self.robot.limits.double()
+            path = torch.rand((self.n_waypoints, self.robot.dof)).double() * (lim[:, 1] - lim[:, 0]) + lim[:, 0]
+        path[0] = self.start
+        path[-1] = self.target
+        self.init_path = path
+        return path
+
+    def full(self, inner):
+        """inner waypoints (flat numpy or tensor) -> full path tensor with the fixed endpoints, requires grad"""
+        p = torch.as_tensor(np.asarray(inner), dtype=torch.float64).reshape(-1, self.robot.dof)
+        return torch.cat([self.init_path[:1], p, self.init_path[-1:]], dim=0).requires_grad_(True)
+
+    # -- terms -----------------------------------------------------------------------------
+    def path_length(self, p):
+        cp = self.robot.fkine(p)
+        return (cp[1:] - cp[:-1]).square().sum(), cp
+
+    def joint_limit_violation(self, p):
+        lim = self.robot.limits.to(p.dtype)
+        return (torch.clamp(lim[:, 0] - p, min=0) + torch.clamp(p - lim[:, 1], min=0)).sum()
+
+    def segment_collision(self, p, dist_est, dense_cap=None):
+        """>= 0 when collision-free: per segment, the sum over its densified points of min(0, margin - score)"""
+        dense = utils.dense_path(p, self.max_speed, dense_cap) if dense_cap is not None else \
+            utils.dense_path(p, self.max_speed)
+        self.cnt_check += len(dense)
+        c = torch.clamp(-(dist_est(dense[1:-1]) - self.safety_margin), max=0).reshape(-1)
+        n_seg, n_pt = len(p) - 1, len(dense) - 2
+        per = -(-n_pt // n_seg)
+        if per * n_seg != n_pt:
+            c = torch.cat([c, c.new_zeros(per * n_seg - n_pt)])
+        return c.reshape(n_seg, -1).sum(dim=1)
+
+
+def _trivial_record(prob, robot, seed, t0):
+    init = prob.options['init_solution']
+    cp = robot.fkine(init[1:-1])
+    cost = (cp[1:] - cp[:-1]).square().sum() if len(cp) > 1 else torch.zeros(())
+    return _record(prob.start, prob.target, 0, cost, time.time() - t0, True, seed, init)
+
+
+# ================================================================================ Adam
+def adam_traj_optimize(robot, dist_est, start_cfg, target_cfg, options):
+    """Penalty-method Adam on the waypoints; restarts (sequentially) from random paths until one trial
+    yields a path whose constraint loss is <= 1e-2.  Returns the reference's record dict."""
+    n_trials, max_iter = options['NUM_RE_TRIALS'], options['MAXITER']
+    keep_history = options['history']
+    lr = options.get('extra_optimizer_options', {}).get('lr', 5e-1)
+    print('Adam lr = {}'.format(lr))
+    seed = options['seed']
+    torch.manual_seed(seed)
+    prob = _PathProblem(robot, start_cfg, target_cfg, options)
+    t0 = time.time()
+    if prob.trivial():
+        return _trivial_record(prob, robot, seed, t0)
+
+    lowest = dict(loss=np.inf, obj=np.inf, sol=None, step=None, trial=None)
+    valid = dict(obj=np.inf, sol=None, step=None, trial=None)
+    histories = []
+    found = False
+    for trial in range(n_trials):
+        p = prob.make_init(trial).requires_grad_(True)
+        opt = torch.optim.Adam([p], lr=lr)
+        hist = []
+        for step in range(max_iter):
+            opt.zero_grad()
+            collision = torch.clamp(dist_est(p) - prob.safety_margin, min=0).sum()
+            prob.cnt_check += len(p)
+            objective, cp = prob.path_length(p)
+            max_move = torch.clamp((cp[1:] - cp[:-1]).square().sum(dim=2) - prob.max_speed ** 2, min=0).sum()
+            constraint = (COLLISION_WEIGHT * collision + MAX_MOVE_WEIGHT * max_move
+                          + JOINT_LIMIT_WEIGHT * prob.joint_limit_violation(p))
+            loss = DIF_WEIGHT * objective + constraint
+            loss.backward()
+            p.grad[[0, -1]] = 0.0  # endpoints stay put
+            opt.step()
+            if keep_history:
+                hist.append(p.data.clone())
+            lv, ov, cv = loss.item(), objective.item(), constraint.item()
+            if lv < lowest['loss']:
+                lowest.update(loss=lv, obj=ov, sol=p.data.clone(), step=step, trial=trial)
+            if cv <= VALID_CONSTRAINT_LOSS:
+                if ov < valid['obj']:
+                    valid.update(obj=ov, sol=p.data.clone(), step=step, trial=trial)
+                if float(torch.norm(p.grad)) < STATIONARY_GRAD_NORM:
+                    break
+        histories.append(hist)
+        if valid['sol'] is not None:
+            found = True
+            break
+    chosen = valid if found else lowest
+    return _record(start_cfg, target_cfg, prob.cnt_check, chosen['obj'], time.time() - t0, found, seed, chosen['sol'])
+
+
+# ================================================================================ scipy drivers
+class _ScipyTerms:
+    """cost / constraints as numpy callables with analytic first derivatives from autograd"""
+
+    def __init__(self, prob, dist_est, dense_cap=None):
+        self.prob, self.dist_est, self.dense_cap = prob, dist_est, dense_cap
+
+    def cost(self, x):
+        obj, _ = self.prob.path_length(self.prob.full(x))
+        return obj.item()
+
+    def grad_cost(self, x):
+        p = self.prob.full(x)
+        obj, _ = self.prob.path_length(p)
+        (g,) = torch.autograd.grad(obj, p, allow_unused=True)
+        return np.zeros(len(x)) if g is None else g[1:-1].numpy().reshape(-1)
+
+    def collision(self, x):
+        with torch.no_grad():
+            return self.prob.segment_collision(self.prob.full(x).detach(), self.dist_est, self.dense_cap).numpy()
+
+    def jac_collision(self, x):
+        p = self.prob.full(x)
+        count = self.prob.cnt_check
+        jac = torch.autograd.functional.jacobian(
+            lambda z: self.prob.segment_collision(z, self.dist_est, self.dense_cap), p, create_graph=False,
+            strict=False, vectorize=True, strategy='reverse-mode')
+        self.prob.cnt_check = count  # derivative evaluations are not counted as checks by the reference
+        return jac[:, 1:-1].numpy().reshape(jac.shape[0], -1)
+
+    def joint_limit(self, x):
+        return -self.prob.joint_limit_violation(self.prob.full(x).detach()).item()
+
+    def grad_joint_limit(self, x):
+        p = self.prob.full(x)
+        v = -self.prob.joint_limit_violation(p)
+        (g,) = torch.autograd.grad(v, p, allow_unused=True)
+        return np.zeros(len(x)) if g is None else g[1:-1].numpy().reshape(-1)
+
+
+def _scipy_driver(robot, dist_est, start_cfg, target_cfg, options, run_minimize, dense_cap=None, extra_info=False):
+    n_trials = options['NUM_RE_TRIALS']
+    seed = options['seed']
+    torch.manual_seed(seed)
+    prob = _PathProblem(robot, start_cfg, target_cfg, options)
+    t0 = time.time()
+    if prob.trivial():
+        return _trivial_record(prob, robot, seed, t0)
+    terms = _ScipyTerms(prob, dist_est, dense_cap)
+    best, best_violation, success = None, np.inf, False
+    for trial in range(n_trials):
+        x0 = prob.make_init(trial)[1:-1].reshape(-1).numpy()
+        res = run_minimize(terms, x0)
+        if res.success:
+            best, success = res, True
+            break
+        violation = -(terms.collision(res.x).sum() + terms.joint_limit(res.x))
+        if violation < best_violation:
+            best, best_violation = res, violation
+    elapsed = time.time() - t0
+    sol = prob.full(best.x).detach()
+    extra = {'info': best} if extra_info else {}
+    return _record(start_cfg, target_cfg, prob.cnt_check, best.fun, elapsed, success, seed, sol, **extra)
+
+
+def givengrad_traj_optimize(robot, dist_est, start_cfg, target_cfg, options):
+    """SLSQP with analytic gradients: minimise path length s.t. per-segment collision >= 0, joint limits >= 0"""
+    max_iter = options['MAXITER']
+
+    def run(terms, x0):
+        return minimize(terms.cost, x0, jac=terms.grad_cost, method='slsqp',
+                        constraints=[{'fun': terms.collision, 'type': 'ineq', 'jac': terms.jac_collision},
+                                     {'fun': terms.joint_limit, 'type': 'ineq', 'jac': terms.grad_joint_limit}],
+                        options={'maxiter': max_iter, **options.get('extra_optimizer_options', {})})
+    return _scipy_driver(robot, dist_est, start_cfg, target_cfg, options, run)
+
+
+def trustconstr_traj_optimize(robot, dist_est, start_cfg, target_cfg, options):
+    """trust-constr with analytic first derivatives and a BFGS model of the constraint Hessian"""
+    if options.get('exact_hessian'):
+        raise NotImplementedError("exact constraint Hessians need second derivatives of the score kernel")
+    max_iter = options['MAXITER']
+
+    def run(terms, x0):
+        return minimize(terms.cost, x0, jac=terms.grad_cost, method='trust-constr',
+                        constraints=[NonlinearConstraint(terms.collision, 0, np.inf, jac=terms.jac_collision, hess=BFGS()),
+                                     NonlinearConstraint(terms.joint_limit, 0, np.inf, jac=terms.grad_joint_limit,
+                                                         hess=BFGS())],
+                        options={'maxiter': max_iter, **options.get('extra_optimizer_options', {})})
+    return _scipy_driver(robot, dist_est, start_cfg, target_cfg, options, run, extra_info=True)
+
+
+def gradient_free_traj_optimize(robot, checker, start_cfg, target_cfg, options: Dict = None):
+    """trust-constr with finite-difference derivatives on a (possibly non-differentiable) `checker(q) -> score`"""
+    max_iter = options['MAXITER']
+    cap = options.get('max_dense_waypoints', None)
+    saved_margin = options.get('safety_margin', 0.0)
+    options = dict(options, safety_margin=0.0)  # the reference's gradient-free constraint uses the raw checker output
+
+    def run(terms, x0):
+        return minimize(terms.cost, x0, method='trust-constr',
+                        constraints=[NonlinearConstraint(terms.collision, 0, np.inf),
+                                     NonlinearConstraint(terms.joint_limit, 0, np.inf)],
+                        options={'maxiter': max_iter, **options.get('extra_optimizer_options', {})})
+    rec = _scipy_driver(robot, checker, start_cfg, target_cfg, options, run, dense_cap=cap)
+    options['safety_margin'] = saved_margin
+    return rec

@@ -61,3 +61,61 @@ def case_kernel(d):
     kind = str(d["kind"])
     kp = d["kparams"]
     return KIND[kind], float(kp[0]), float(kp[1]) if len(kp) > 1 else 0.0
+
+
+# ---------------------------------------------------------------------------------------------
+# test-local torch stand-ins (host-logic tests run without a GPU; the product has no CPU path)
+class TorchKernel:
+    """direct-difference torch kernels with the reference call signature — a *foreign* callable as far
+    as diffco_amd is concerned (no dcx_spec), used to drive the host-side trainer on CPU"""
+
+    def __init__(self, kind, p0, p1=0.0):
+        self.kind, self.p0, self.p1 = kind, p0, p1
+
+    def __call__(self, xs, x_primes):
+        import torch
+        if xs.ndim < x_primes.ndim:
+            xs = xs[None]
+        a, b = xs.reshape(len(xs), -1), x_primes.reshape(len(x_primes), -1)
+        d2 = ((a[:, None, :] - b[None, :, :]) ** 2).sum(-1)
+        if self.kind == "rq":
+            k = (1 + self.p0 / self.p1 * d2) ** (-self.p1)
+            return k.squeeze(0) if k.shape[0] == 1 else k
+        if self.kind == "poly1":
+            r = torch.where(d2 > 0, d2.clamp_min(1e-30).sqrt(), torch.zeros_like(d2))
+            return r / self.p1
+        raise ValueError(self.kind)
+
+
+class TorchDHRobot:
+    """differentiable torch FK of a single DH chain built from a diffco_amd robot's description"""
+
+    def __init__(self, rob):
+        import torch
+        d = rob.fk_desc()
+        n = d.chain_len[0]
+        self.dof, self.limits = rob.dof, rob.limits
+        g = lambda arr: torch.tensor([arr[0][i] for i in range(n)], dtype=torch.float64)
+        self.a, self.d, self.sa, self.ca, self.t0 = g(d.a), g(d.d), g(d.sin_alpha), g(d.cos_alpha), g(d.theta0)
+        self.frames = [d.pt_frame[k] for k in range(d.n_points)]
+        self.offs = [[d.pt_off[k][j] for j in range(3)] for k in range(d.n_points)]
+
+    def fkine(self, q, reuse=False):
+        import torch
+        q = q.reshape(-1, self.dof)
+        T = torch.eye(4, dtype=q.dtype).expand(len(q), 4, 4)
+        cum = []
+        for i in range(self.dof):
+            th = q[:, i] + self.t0[i].to(q.dtype)
+            c, s = th.cos(), th.sin()
+            z, o = torch.zeros_like(c), torch.ones_like(c)
+            sa, ca, a, d = (t[i].to(q.dtype) for t in (self.sa, self.ca, self.a, self.d))
+            A = torch.stack([torch.stack([c, -s * ca, s * sa, a * c], -1), torch.stack([s, c * ca, -c * sa, a * s], -1),
+                             torch.stack([z, sa * o, ca * o, d * o], -1), torch.stack([z, z, z, o], -1)], 1)
+            T = T @ A
+            cum.append(T)
+        pts = []
+        for f, off in zip(self.frames, self.offs):
+            v = torch.tensor(off + [1.0], dtype=q.dtype)
+            pts.append((cum[f] @ v)[:, :3])
+        return torch.stack(pts, 1)

@@ -1,0 +1,95 @@
+"""CPU-side checks of the boundary: libdcx.so loads and exports every symbol include/dcx.h declares,
+the ctypes mirror of dcx_fk_desc has the C layout, and the product fails loudly without a GPU.
+No compute calls (there is no GPU here)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "dcx.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dcx_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from diffco_amd import _lib
+    lib = _lib.load()
+    names = declared_symbols()
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(lib, n), f"libdcx.so does not export {n}"
+    assert set(names) == set(_lib.SYMBOLS), "ctypes table and header disagree"
+    assert lib.dcx_version() == 100
+    assert isinstance(lib.dcx_device_count(), int)
+
+
+def test_fk_desc_layout_matches_c(tmp_path):
+    from diffco_amd._fkdesc import FkDesc
+    prog = tmp_path / "sz.c"
+    prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "dcx.h"\n'
+                    'int main(){printf("%zu %zu %zu %zu %zu", sizeof(dcx_fk_desc), offsetof(dcx_fk_desc, n_chains),'
+                    ' offsetof(dcx_fk_desc, base), offsetof(dcx_fk_desc, pt_off), offsetof(dcx_fk_desc, keypoints));}')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
+    assert [int(x) for x in out] == [ctypes.sizeof(FkDesc), FkDesc.n_chains.offset, FkDesc.base.offset,
+                                     FkDesc.pt_off.offset, FkDesc.keypoints.offset]
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_no_gpu_means_loud_failure_not_cpu_fallback():
+    from diffco_amd import _lib, kernel, model
+    from diffco_amd.kernel_perceptrons import DiffCo
+    lib = _lib.load()
+    # the C ABI itself reports the missing device
+    h = ctypes.c_void_p()
+    kp = (ctypes.c_float * 2)(1.0, 1.0)
+    buf = (ctypes.c_float * 12)()
+    rc = lib.dcx_model_create(ctypes.byref(h), 0, None, 1, kp, ctypes.cast(buf, ctypes.c_void_p),
+                              ctypes.cast(buf, ctypes.c_void_p), 1, 12, 1)
+    assert rc == 4 and b"no HIP device" in lib.dcx_last_error()  # DCX_ERR_NO_DEVICE
+    rob = model.BaxterLeftArmFK()
+    with pytest.raises(_lib.DcxError):
+        rob.fkine(torch.zeros(2, 7))
+    with pytest.raises(_lib.DcxError):
+        kernel.RQKernel(10.0)(torch.zeros(2, 3), torch.zeros(4, 3))
+    dc = DiffCo(kernel_func=kernel.RQKernel(10.0), transform=rob.fkine)
+    dc.support_points = torch.zeros(4, 7)
+    dc.support_transformed = torch.zeros(4, 4, 3)
+    dc.gains = torch.ones(4)
+    with pytest.raises(_lib.DcxError):
+        dc.score(torch.zeros(2, 7))
+
+
+def test_argument_errors_before_device_use():
+    from diffco_amd import _lib
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    kp = (ctypes.c_float * 2)(1.0, 1.0)
+    assert lib.dcx_model_create(None, 0, None, 1, kp, None, None, 0, 12, 1) == 1      # out == NULL
+    assert lib.dcx_model_create(ctypes.byref(h), 0, None, 1, kp, None, None, 5, 12, 1) == 1   # NULL supports
+    assert lib.dcx_model_create(ctypes.byref(h), 0, None, 1, kp, None, None, 0, 500, 1) == 2  # D unsupported
+    assert lib.dcx_model_create(ctypes.byref(h), 0, None, 9, kp, None, None, 0, 12, 1) == 1   # kernel kind
+    assert b"kernel_kind" in lib.dcx_last_error()
+    assert lib.dcx_score(None, None, 0, None, None) == 1
+
+
+def test_oracle_is_not_imported_by_the_product():
+    """the shipped package must not reach the oracle (or any CPU path) — static check of its sources"""
+    pkg = os.path.join(ROOT, "diffco_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.lower().replace("no oracle", ""), f"{f} mentions the oracle"
+    code = "import sys; import diffco_amd; assert not any(m.startswith('oracle') for m in sys.modules), 'oracle imported'"
+    subprocess.run([sys.executable, "-c", code], check=True, cwd=ROOT)

@@ -1,0 +1,255 @@
+"""GPU tests of the drop-in Python surface (DiffCo / MultiDiffCo / kernels / robots / optimisers): the
+reference's call signatures and shape/dtype rules, with values checked against the golden vectors
+generated from the reference.  Everything numeric here runs in libdcx.so (HIP)."""
+import json
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, load, make_robot, relerr
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _new_diffco(rob, d, which, device="cpu"):
+    from diffco_amd import kernel
+    from diffco_amd.kernel_perceptrons import DiffCo
+    kinds = {"rq": lambda p: kernel.RQKernel(p[0], int(p[1])), "poly": lambda p: kernel.Polyharmonic(int(p[0]), p[1]),
+             "mq": lambda p: kernel.MultiQuadratic(p[0])}
+    kf = kinds[str(d["kind"])](d["kparams"])
+    dc = DiffCo(kernel_func=kf if which == "score" else "rq", transform=None if rob is None else rob.fkine)
+    dc.support_points = torch.from_numpy(d["sup_q"]).to(device)
+    dc.support_transformed = torch.from_numpy(d["sup_x32"]).to(device)
+    w = torch.from_numpy(d["weights"][:, 0].copy()).to(device)
+    if which == "score":
+        dc.gains = w
+    else:
+        dc.rbf_kernel, dc.rbf_nodes = kf, w
+    return dc
+
+
+@pytest.mark.parametrize("device", ["cpu", "cuda"])
+def test_poly_score_and_autograd_match_reference(device):
+    d = load("cfg2_baxter_poly1")
+    dc = _new_diffco(make_robot("baxter_left"), d, "poly", device)
+    q = torch.from_numpy(d["q"]).to(device).requires_grad_(True)
+    s = dc.poly_score(q)
+    assert s.shape == (4096, 1) and s.device.type == device and s.dtype == torch.float32
+    (g,) = torch.autograd.grad(s.sum(), q)
+    assert g.device.type == device
+    assert relerr(_np(s), d["score64"]) < TOL and relerr(_np(g), d["grad64"]) < TOL
+    assert relerr(_np(s), d["score32"]) < TOL + relerr(d["score32"], d["score64"])
+    # a non-trivial upstream through autograd (clamp + weights), as the optimisers use it
+    wts = torch.linspace(0.5, 2.0, 4096, device=device).reshape(-1, 1)
+    (g2,) = torch.autograd.grad((torch.clamp(dc.poly_score(q) - 0.1, min=0) * wts).sum(), q)
+    mask = (torch.from_numpy(d["score64"]).to(device) - 0.1 > 0).float() * wts
+    assert relerr(_np(g2), _np(mask) * d["grad64"]) < 5e-5  # entries right at the clamp may flip
+    with torch.no_grad():
+        assert torch.allclose(dc.poly_score(q), s, atol=1e-6 * float(s.abs().max()))
+
+
+def test_score_rq_and_is_collision():
+    d = load("cfg2_baxter_rq")
+    dc = _new_diffco(make_robot("baxter_left"), d, "score", "cuda")
+    q = torch.from_numpy(d["q"]).cuda().requires_grad_(True)
+    s = dc.score(q)
+    assert s.shape == (512,)
+    (g,) = torch.autograd.grad(s.sum(), q)
+    assert relerr(_np(s), d["score64"].reshape(-1)) < TOL and relerr(_np(g), d["grad64"]) < TOL
+    assert torch.equal(dc.is_collision(q.detach()), dc.score(q.detach()) > 0)
+    assert torch.equal(dc(q.detach()), dc.score(q.detach()) > 0)
+
+
+def test_planar_config1_on_cpu_tensors():
+    """BASELINE config #1: 2-DoF planar arm, RQ(10), 200 supports, batch 256 — CPU tensors in and out,
+    computed by the HIP path (the reference runs this case on PyTorch CPU)."""
+    d = load("cfg1_planar2_rq")
+    dc = _new_diffco(make_robot("planar2"), d, "score", "cpu")
+    q = torch.from_numpy(d["q"]).requires_grad_(True)
+    s = dc.score(q)
+    (g,) = torch.autograd.grad(s.sum(), q)
+    assert s.device.type == "cpu" and s.shape == (256,)
+    assert relerr(_np(s), d["score64"].reshape(-1)) < TOL and relerr(_np(g), d["grad64"]) < TOL
+    assert relerr(_np(s), d["score32"].reshape(-1)) < TOL + relerr(d["score32"].reshape(-1), d["score64"].reshape(-1))
+
+
+def test_shape_and_dtype_quirks():
+    """single-query squeeze, fp64 input to poly_score, transformed_point, zero padding"""
+    from diffco_amd import kernel
+    from diffco_amd.kernel_perceptrons import DiffCo
+    e = load("edges")
+    rob = make_robot("baxter_left")
+    sup_q, w = torch.from_numpy(e["sup_q"]), torch.from_numpy(e["weights"])
+    dc = DiffCo(kernel_func=kernel.RQKernel(10.0), transform=rob.fkine)
+    dc.support_points, dc.support_transformed, dc.gains = sup_q, rob.fkine(sup_q), w
+    dc.rbf_kernel, dc.rbf_nodes = kernel.Polyharmonic(1, 1.0), w
+    s1 = dc.score(torch.from_numpy(e["q1"]))
+    assert tuple(s1.shape) == tuple(e["score_b1_shape"]) == ()
+    assert relerr(_np(s1).reshape(-1), e["score_b1"]) < 2e-5
+    p1 = dc.poly_score(torch.from_numpy(e["q1"]))
+    assert tuple(p1.shape) == tuple(e["poly_b1_shape"]) == (1, 1)
+    assert relerr(_np(p1).reshape(-1), e["poly_b1"]) < 2e-5
+    qd = torch.from_numpy(e["q_f64"]).requires_grad_(True)
+    s = dc.poly_score(qd)
+    (g,) = torch.autograd.grad(s.sum(), qd)
+    assert str(s.dtype) == str(e["poly_f64in_dtype"]) == "torch.float32"   # cast to the nodes' dtype
+    assert str(g.dtype) == str(e["grad_f64in_dtype"]) == "torch.float64"   # gradient comes back in fp64
+    assert relerr(_np(s), e["poly_f64in"]) < 2e-5 and relerr(_np(g), e["grad_f64in"]) < 2e-5
+    tp = dc.poly_score(transformed_point=rob.fkine(torch.from_numpy(e["q_tp"])))
+    assert tp.shape == (8, 1) and relerr(_np(tp), e["poly_tp"]) < 2e-5
+    # gradient w.r.t. the transformed point flows too (collision_checkers.py:493 differentiates this form)
+    X = rob.fkine(torch.from_numpy(e["q_tp"])).detach().requires_grad_(True)
+    (gx,) = torch.autograd.grad(dc.poly_score(transformed_point=X).sum(), X)
+    assert gx.shape == X.shape and float(gx.abs().max()) > 0
+    # zero padding (max_num_supports)
+    dz = DiffCo(transform=rob.fkine)
+    dz.support_points = torch.cat([sup_q, torch.zeros(14, 7)])
+    dz.support_transformed = torch.cat([rob.fkine(sup_q), torch.zeros(14, 4, 3)])
+    dz.rbf_kernel, dz.rbf_nodes = kernel.Polyharmonic(1, 1.0), torch.cat([w, torch.zeros(14)])
+    assert relerr(_np(dz.poly_score(torch.from_numpy(e["q_tp"]))), e["poly_padded"]) < 2e-5
+
+
+def test_to_cuda_pickle_and_state_updates():
+    d = load("cfg2_baxter_rq")
+    rob = make_robot("baxter_left")
+    dc = _new_diffco(rob, d, "score", "cpu")
+    q = torch.from_numpy(d["q"][:100])
+    s_cpu = dc.score(q)
+    dc.to(torch.device("cuda"))
+    assert dc.gains.device.type == "cuda" and dc.support_transformed.device.type == "cuda"  # gains move too (H3)
+    s_gpu = dc.score(q.cuda())
+    assert torch.allclose(s_gpu.cpu(), s_cpu, atol=1e-6 * float(s_cpu.abs().max()))
+    dc.to("cpu")
+    blob = pickle.dumps(dc)          # no device handle inside
+    dc2 = pickle.loads(blob)
+    assert torch.allclose(dc2.score(q), s_cpu, atol=1e-6 * float(s_cpu.abs().max()))
+    dc2.gains = dc2.gains * 2        # state change -> the cached device model is rebuilt
+    assert torch.allclose(dc2.score(q), 2 * s_cpu, atol=2e-6 * float(s_cpu.abs().max()))
+    dc2.gains.mul_(0.5)              # in-place change is noticed as well
+    assert torch.allclose(dc2.score(q), s_cpu, atol=2e-6 * float(s_cpu.abs().max()))
+
+
+def test_training_on_the_hip_kernel_rows_reproduces_the_reference_model():
+    from diffco_amd import kernel
+    from diffco_amd.kernel_perceptrons import DiffCo
+    d = load("trained_baxter")
+    rob = make_robot("baxter_left")
+    dc = DiffCo(kernel_func=kernel.RQKernel(10.0), beta=1.0, transform=rob.fkine)
+    X, y, dist = (torch.from_numpy(d[k]) for k in ("X", "y", "dist"))
+    dc.train(X, y, max_iteration=3000, distance=dist)
+    np.testing.assert_array_equal(_np(dc.support_points), d["support_points"])
+    assert relerr(_np(dc.gains), d["gains"]) < 1e-3 and relerr(_np(dc.hypothesis), d["hypothesis"]) < 1e-3
+    dc.fit_poly(kernel.Polyharmonic(1, 1.0), target="label")
+    assert relerr(_np(dc.rbf_nodes), d["rbf_nodes_label"]) < 2e-2  # ill-conditioned solve, see test_host_logic
+    qt = torch.from_numpy(d["q_test"]).requires_grad_(True)
+    s = dc.poly_score(qt)
+    (g,) = torch.autograd.grad(s.sum(), qt)
+    assert relerr(_np(s), d["poly_test"]) < 2e-3 and relerr(_np(g), d["poly_grad_test"]) < 5e-3
+    assert relerr(_np(dc.score(qt.detach())), d["score_test"]) < 1e-3
+    # with the reference's own nodes the spline agrees to kernel accuracy
+    dc.rbf_nodes = torch.from_numpy(d["rbf_nodes_label"])
+    dc.support_transformed = torch.from_numpy(d["support_transformed"])
+    assert relerr(_np(dc.poly_score(qt.detach())), d["poly_test"]) < 5e-5
+    # active-learning update with jump start (collision_checkers.py:220-252 call pattern)
+    dc.fit_poly(kernel.Polyharmonic(1, 1.0), target="label")
+    dc.train(torch.from_numpy(d["Xu"]), torch.from_numpy(d["yu"]), update=True,
+             exist_mask=torch.from_numpy(d["exist_mask"]), max_iteration=2000, distance=torch.from_numpy(d["du"]))
+    np.testing.assert_array_equal(_np(dc.support_points), d["upd_support_points"])
+    assert relerr(_np(dc.gains), d["upd_gains"]) < 2e-3
+    # fixed-size variant
+    dm = DiffCo(kernel_func=kernel.RQKernel(10.0), beta=1.0, transform=rob.fkine, max_num_supports=300)
+    dm.train(X, y, max_iteration=3000, distance=dist)
+    dm.fit_poly(kernel.Polyharmonic(1, 1.0), target="label")
+    assert dm.valid_supports == int(d["mns_valid"])
+    assert relerr(_np(dm.poly_score(qt.detach())), d["mns_poly_test"]) < 2e-3
+
+
+def test_old_api_multidiffco():
+    from diffco_amd import MultiDiffCo, kernel
+    d = load("trained_multi_planar2")
+    rob = make_robot("planar2")
+    md = MultiDiffCo(None, kernel_func=kernel.FKKernel(rob.fkine, kernel.RQKernel(10.0)), beta=1.0)
+    md.train(torch.from_numpy(d["X"]), torch.from_numpy(d["y"]), max_iteration=1500, distance=torch.from_numpy(d["dist"]))
+    np.testing.assert_array_equal(_np(md.support_points), d["support_points"])
+    assert relerr(_np(md.gains), d["gains"]) < 1e-3
+    md.fit_poly(kernel_func=kernel.Polyharmonic(1, 1.0), target="label", fkine=rob.fkine, reg=0.0)
+    qt = torch.from_numpy(d["q_test"]).requires_grad_(True)
+    s = md.rbf_score(qt)
+    assert s.shape == (256, 2)
+    (g,) = torch.autograd.grad(s.sum(), qt)
+    assert relerr(_np(s), d["rbf_test"]) < 5e-3 and relerr(_np(g), d["rbf_grad_test"]) < 1e-2
+    assert relerr(_np(md.score(qt.detach())), d["score_test"]) < 1e-3
+    # per-class margins broadcast against [N, C] scores (scripts/active.py:65 call pattern)
+    margin = torch.tensor([0.1, -0.2])
+    loss = torch.clamp(md.rbf_score(qt) - margin, min=0).sum()
+    loss.backward()
+    assert qt.grad is not None and torch.isfinite(qt.grad).all()
+    # exact values with the reference's nodes: C=5 golden case through the old-API attributes
+    c = load("cfg3_baxter_rq_c5")
+    rb = make_robot("baxter_left")
+    m5 = MultiDiffCo(None, kernel_func=kernel.FKKernel(rb.fkine, kernel.RQKernel(10.0)))
+    m5.fkine, m5.support_points = rb.fkine, torch.from_numpy(c["sup_q"])
+    m5.support_fkine = torch.from_numpy(c["sup_x32"]).reshape(2000, -1)
+    m5.rbf_kernel, m5.rbf_nodes, m5.num_class = kernel.RQKernel(10.0), torch.from_numpy(c["weights"]), 5
+    q5 = torch.from_numpy(c["q"]).requires_grad_(True)
+    s5 = m5.rbf_score(q5)
+    (gv,) = torch.autograd.grad((s5 * torch.from_numpy(c["upstream"])).sum(), q5)
+    assert relerr(_np(s5), c["score64"]) < TOL and relerr(_np(gv), c["vjp64"]) < TOL
+
+
+def test_full_jacobian_through_vmap():
+    """torch.autograd.functional.jacobian(vectorize=True) — what SLSQP/trust-constr call (optim.py:211-216)"""
+    d = load("cfg3_baxter_poly1_c5")
+    from diffco_amd import MultiDiffCo, kernel
+    rb = make_robot("baxter_left")
+    m = MultiDiffCo(None)
+    m.fkine, m.support_points = rb.fkine, torch.from_numpy(d["sup_q"])
+    m.support_fkine = torch.from_numpy(d["sup_x32"]).reshape(2000, -1)
+    m.rbf_kernel, m.rbf_nodes, m.num_class = kernel.Polyharmonic(1, 1.0), torch.from_numpy(d["weights"]), 5
+    q = torch.from_numpy(d["q"][:8]).double()
+    jac = torch.autograd.functional.jacobian(lambda x: m.rbf_score(x).sum(0), q, vectorize=True, strategy="reverse-mode")
+    assert jac.shape == (5, 8, 7)
+    assert relerr(_np(jac).transpose(1, 0, 2), d["jac32"][:8]) < 2e-5
+
+
+def test_adam_and_slsqp_on_the_hip_path():
+    from diffco_amd import kernel, optim
+    from diffco_amd.kernel_perceptrons import DiffCo
+    d = load("optim_adam_baxter")
+    options = json.load(open(os.path.join(GOLDEN, "optim_adam_baxter_options.json")))
+    rob = make_robot("baxter_left")
+    dc = DiffCo(transform=rob.fkine)
+    dc.support_points = torch.from_numpy(d["sup_q"])
+    dc.support_transformed = rob.fkine(dc.support_points)
+    dc.rbf_kernel, dc.rbf_nodes = kernel.Polyharmonic(1, 1.0), torch.from_numpy(d["weights"])
+    # one evaluation of the Adam loss at the initial path: value and gradient vs the reference
+    p = torch.from_numpy(d["init"]).clone().requires_grad_(True)
+    col = torch.clamp(dc.poly_score(p), min=0).sum()
+    cp = rob.fkine(p)
+    mm = torch.clamp((cp[1:] - cp[:-1]).square().sum(dim=2) - 0.3 ** 2, min=0).sum()
+    lim = rob.limits.double()
+    jl = (torch.clamp(lim[:, 0] - p, min=0) + torch.clamp(p - lim[:, 1], min=0)).sum()
+    diff = (cp[1:] - cp[:-1]).square().sum()
+    loss = diff + 10 * col + 10 * mm + 10 * jl
+    terms = torch.stack([diff, col, mm, jl]).detach().numpy()
+    assert relerr(terms, d["loss0_terms"]) < 2e-5
+    (g,) = torch.autograd.grad(loss, p)
+    assert relerr(g.numpy(), d["grad0"]) < 2e-5
+    assert float(g[:, 6].abs().max()) == 0.0  # Baxter's last joint moves no control point: EXACT zero, as autograd gives
+    options["init_solution"] = torch.from_numpy(d["init"]).clone()
+    rec = optim.adam_traj_optimize(rob, dc.poly_score, torch.from_numpy(d["start"]), torch.from_numpy(d["target"]),
+                                   dict(options))
+    assert rec["success"] == bool(d["success"]) and rec["cnt_check"] == int(d["cnt_check"])
+    assert abs(rec["cost"] - float(d["cost"])) < 5e-3 * float(d["cost"])
+    assert relerr(np.array(rec["solution"]), d["solution"]) < 5e-3
+    opts = dict(options, MAXITER=8, extra_optimizer_options={})
+    rec2 = optim.givengrad_traj_optimize(rob, dc.poly_score, torch.from_numpy(d["start"]), torch.from_numpy(d["target"]), opts)
+    assert np.isfinite(rec2["cost"]) and len(rec2["solution"]) == 20 and rec2["cnt_check"] > 0

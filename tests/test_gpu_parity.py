@@ -1,0 +1,256 @@
+"""GPU parity: the HIP path (through the C ABI of libdcx.so) against the CPU oracle, the golden
+vectors generated from the reference, and size-independent properties at BASELINE.json's sizes.
+
+Tolerance (BASELINE.json north_star: "within 1e-5 relative fp32"): the metric is
+max|a - ref| / max|ref|.  HIP vs the fp64 referee must be <= 1e-5; HIP vs the reference's own fp32
+output must be <= 1e-5 plus the reference's own distance from the referee (its torch.cdist GEMM
+form is up to ~1e-4 off for large coordinates); HIP vs the fp32 oracle <= 1e-5.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import CASE_ROBOT, FK_NAMES, KIND, case_kernel, desc_for, load, make_robot, relerr
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+TOL_ORACLE = 1e-5  # the fp32 oracle sums S terms sequentially; it is itself ~5e-6 from the referee at S=10k
+
+
+def _t(a):
+    return torch.as_tensor(np.asarray(a), dtype=torch.float32, device="cuda")
+
+
+def _n(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from diffco_amd import _lib, _ops
+    _lib.require_gpu()  # fails loudly if libdcx.so or the GPU is missing
+    return _ops
+
+
+# ----------------------------------------------------------------------------------- FK
+@pytest.mark.parametrize("name", FK_NAMES)
+def test_fkine_and_vjp(ops, name):
+    from oracle import oracle
+    d = load("fk_" + name)
+    desc = desc_for(name)
+    q = _t(d["q"]).requires_grad_(True)
+    X = ops.fkine(desc, q)
+    assert X.shape == d["x64"].shape
+    assert relerr(_n(X), d["x64"]) < 2e-6
+    assert relerr(_n(X), oracle.fkine(desc, d["q"])) < 1e-6
+    (gq,) = torch.autograd.grad((X * _t(d["gx"])).sum(), q)
+    assert relerr(_n(gq), d["gq64"]) < 5e-6
+    # ragged tail and a single configuration
+    for n in (1, 63, 65):
+        Xs = ops.fkine(desc, _t(d["q"][:n] if n <= 64 else np.concatenate([d["q"], d["q"][:1]])))
+        ref = d["x64"][:n] if n <= 64 else np.concatenate([d["x64"], d["x64"][:1]])
+        assert relerr(_n(Xs), ref) < 2e-6
+
+
+def test_robot_classes_known_answers():
+    from diffco_amd import model
+    z = torch.zeros(1, 7, device="cuda")
+    b = model.BaxterLeftArmFK().fkine(z)[0].cpu().numpy()
+    np.testing.assert_allclose(b, [[0.069, 0, 0.27035], [0.43335, 0, 0.20135], [0.80764, 0, 0.19135],
+                                   [1.19499, 0, 0.19135]], atol=2e-6)
+    p = model.PandaFK().fkine(z)[0].cpu().numpy()
+    np.testing.assert_allclose(p[4:], [[.088, 0, .819], [.088, -.107, .819], [.088, .107, .819]], atol=2e-6)
+    pl = model.RevolutePlanarRobot(1.0, 0.1, dof=2).fkine(torch.tensor([[.5, -1.]]))  # CPU tensor in -> CPU out
+    assert pl.device.type == "cpu"
+    np.testing.assert_allclose(pl[0].numpy(), [[0.87758255, 0.47942555], [1.7551651, 0.0]], atol=1e-6)
+
+
+# ----------------------------------------------------------------------------------- kernels
+def test_kernel_matrix(ops):
+    from oracle import oracle
+    d = load("kernels")
+    for D in (4, 12, 21, 6):
+        x, s = d[f"x_D{D}"], d[f"s_D{D}"]
+        for i, (kind, p) in enumerate(zip(d["kernel_kinds"], d["kernel_params"])):
+            K = _n(ops.kernel_matrix(KIND[str(kind)], p[0], p[1], _t(x), _t(s)))
+            assert relerr(K, d[f"k64_D{D}_{i}"]) < 3e-6, (D, i)
+            assert relerr(K, oracle.kernel_matrix(KIND[str(kind)], p[0], p[1], x, s)) < 2e-6, (D, i)
+    from diffco_amd import kernel
+    a, b = torch.zeros(1, 1), torch.tensor([[1.0], [2.0]])
+    np.testing.assert_allclose(kernel.RQKernel(10)(a, b).numpy(), [0.02777778, 0.00226757], rtol=3e-6)
+    assert kernel.RQKernel(10)(a, b).shape == (2,)  # one query row is squeezed (kernel.py:26-27)
+    np.testing.assert_allclose(kernel.Polyharmonic(1, 1)(a, b).numpy(), [[1, 2]], rtol=1e-6)
+    np.testing.assert_allclose(kernel.Polyharmonic(3, 2)(a, b).numpy(), [[0.5, 4]], rtol=1e-6)
+    np.testing.assert_allclose(kernel.Polyharmonic(2, 1)(a, b).numpy(), [[0, 2.7725887]], rtol=2e-6, atol=1e-12)
+
+
+# ----------------------------------------------------------------------------------- fused score + grad
+def _model(ops, name, d, sup=None):
+    kind, p0, p1 = case_kernel(d)
+    desc = desc_for(CASE_ROBOT[name], dof=d["q"].shape[1])
+    if sup is None:
+        sup = ops.fkine(desc, _t(d["sup_q"])) if name.startswith("edge_r0") else _t(d["sup_x32"])
+    return ops.ScoreModel(desc, kind, p0, p1, sup.reshape(len(sup), -1), _t(d["weights"])), desc, (kind, p0, p1)
+
+
+@pytest.mark.parametrize("name", sorted(CASE_ROBOT))
+def test_score_grad_vs_oracle_and_reference(ops, name):
+    from oracle import oracle
+    d = load(name)
+    m, desc, (kind, p0, p1) = _model(ops, name, d)
+    q = _t(d["q"])
+    B, C = len(q), m.C
+    s, g = m.score_grad_raw(q)
+    s, g = _n(s), _n(g)
+    s64, g64 = d["score64"].reshape(B, C), d["grad64"]
+    s32, g32 = d["score32"].reshape(B, C), d["grad32"]
+    assert relerr(s, s64) < TOL and relerr(g, g64) < TOL
+    assert relerr(s, s32) < TOL + relerr(s32, s64) and relerr(g, g32) < TOL + relerr(g32, g64)
+    sup_o = oracle.fkine(desc, d["sup_q"]) if name.startswith("edge_r0") else d["sup_x32"]
+    so, go, jo = oracle.score_grad(desc, kind, p0, p1, sup_o, d["weights"], d["q"], want_jac=True)
+    assert relerr(s, so) < TOL_ORACLE and relerr(g, go) < TOL_ORACLE
+    # score-only entry point == score of the fused pass
+    assert relerr(_n(m.score_raw(q)), s) < 3e-6  # a different instantiation may associate the sums differently
+    # Jacobian entry point
+    sj, jac = m.score_jac_raw(q)
+    assert relerr(_n(sj), s) < 3e-6 and relerr(_n(jac), jo) < TOL_ORACLE
+    if "upstream" in d.files:
+        _, gv = m.score_grad_raw(q, _t(d["upstream"]))
+        assert relerr(_n(gv), d["vjp64"]) < TOL
+        assert relerr(_n(gv), d["vjp32"]) < TOL + relerr(d["vjp32"], d["vjp64"])
+        nj = d["jac32"].shape[0]
+        assert relerr(_n(jac)[:nj], d["jac32"]) < TOL + relerr(g32, g64)
+    elif C == 1:
+        up = torch.linspace(-2, 3, B, device="cuda").reshape(B, 1)
+        _, gv = m.score_grad_raw(q, up)
+        assert relerr(_n(gv), g * _n(up)) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["cfg2_baxter_poly1", "cfg3_baxter_rq_c5", "misc_dualpanda_rq"])
+def test_support_slicing_is_invariant(ops, name, monkeypatch):
+    """every waves-per-block choice (support slices meeting in LDS) gives the same answer"""
+    d = load(name)
+    m, _, _ = _model(ops, name, d)
+    q = _t(d["q"][:200])
+    outs = []
+    for nw in (1, 2, 4, 8, 16):
+        monkeypatch.setenv("DCX_NW", str(nw))
+        s, g = m.score_grad_raw(q)
+        outs.append((_n(s), _n(g)))
+    monkeypatch.delenv("DCX_NW")
+    for s, g in outs[1:]:
+        assert relerr(s, outs[0][0]) < 2e-6 and relerr(g, outs[0][1]) < 2e-6
+
+
+def test_ragged_empty_and_padding(ops, monkeypatch):
+    monkeypatch.setenv("DCX_NW", "4")  # fixed slicing: results are then bit-identical across batch sizes
+    d = load("cfg2_baxter_poly1")
+    m, desc, (kind, p0, p1) = _model(ops, "cfg2_baxter_poly1", d)
+    q = _t(d["q"])
+    s_full, g_full = m.score_grad_raw(q[:300])
+    for n in (1, 2, 63, 64, 65, 127, 257):
+        s, g = m.score_grad_raw(q[:n].contiguous())
+        assert torch.equal(s, s_full[:n]) and torch.equal(g, g_full[:n]), n  # batch-independent, bit-exact
+    s0, g0 = m.score_grad_raw(q[:0])
+    assert s0.shape == (0, 1) and g0.shape == (0, 7)
+    # zero-weight rows (max_num_supports padding, kernel_perceptrons.py:159-196) change nothing ...
+    sup = _t(d["sup_x32"]).reshape(1000, -1)
+    w = _t(d["weights"])
+    mp = ops.ScoreModel(desc, kind, p0, p1, torch.cat([sup, torch.zeros(24, 12, device="cuda")]),
+                        torch.cat([w, torch.zeros(24, 1, device="cuda")]))
+    sp, gp = mp.score_grad_raw(q[:300])
+    assert torch.equal(sp, s_full) and torch.equal(gp, g_full)
+    # ... and a model with no active support scores zero
+    me = ops.ScoreModel(desc, kind, p0, p1, sup[:5], torch.zeros(5, 1))
+    se, ge = me.score_grad_raw(q[:70])
+    assert float(se.abs().max()) == 0.0 and float(ge.abs().max()) == 0.0
+
+
+def test_errors_are_loud(ops):
+    from diffco_amd._lib import DcxError
+    d = load("cfg2_baxter_poly1")
+    desc = desc_for("baxter_left")
+    sup, w = _t(d["sup_x32"]).reshape(1000, -1), _t(d["weights"])
+    with pytest.raises(DcxError):
+        ops.ScoreModel(desc, 7, 1.0, 1.0, sup, w)  # unknown kernel kind
+    with pytest.raises(DcxError):
+        ops.ScoreModel(desc, 1, 1.5, 1.0, sup, w)  # non-integer polyharmonic order
+    with pytest.raises((DcxError, ValueError)):
+        ops.ScoreModel(desc, 1, 1.0, 1.0, sup[:, :9], w)  # feature width mismatch
+    with pytest.raises(DcxError):
+        ops.ScoreModel(desc, 1, 1.0, 1.0, sup, torch.zeros(1000, 9))  # C > DCX_MAX_C
+
+
+# ----------------------------------------------------------------------------------- BASELINE sizes: properties
+def _rand_setup(ops, rob_name, S, C, kind_spec, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    rob = make_robot(rob_name)
+    lim = rob.limits
+    sup_q = torch.rand((S, lim.shape[0]), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]
+    W = torch.randn((S, C), generator=g)
+    desc = rob.fk_desc()
+    sup = ops.fkine(desc, sup_q.cuda()).reshape(S, -1)
+    return rob, desc, sup, W.cuda(), g
+
+
+def _rand_q(rob, B, g):
+    lim = rob.limits
+    return (torch.rand((B, lim.shape[0]), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]).cuda()
+
+
+@pytest.mark.parametrize("B,S,C,kspec", [(65536, 2000, 1, (1, 1.0, 1.0)), (65536, 2000, 5, (0, 10.0, 2.0)),
+                                          (4096, 1000, 1, (0, 10.0, 2.0))])
+def test_full_size_properties(ops, B, S, C, kspec, monkeypatch):
+    """headline / config #2 / config #3 sizes: linearity in the weights, additivity over a support
+    split, invariance to batch order, and an fp64 spot check of 64 random rows."""
+    from oracle import oracle
+    monkeypatch.setenv("DCX_NW", "4")
+    rob, desc, sup, W, g = _rand_setup(ops, "baxter_left", S, C, kspec)
+    q = _rand_q(rob, B, g)
+    m = ops.ScoreModel(desc, *kspec, sup, W)
+    s, gr = m.score_grad_raw(q)
+    scale_s, scale_g = float(s.abs().max()), float(gr.abs().max())
+    # additivity over a support split
+    h = S // 3
+    s1, g1 = ops.ScoreModel(desc, *kspec, sup[:h], W[:h]).score_grad_raw(q)
+    s2, g2 = ops.ScoreModel(desc, *kspec, sup[h:], W[h:]).score_grad_raw(q)
+    assert float((s1 + s2 - s).abs().max()) < 3e-6 * scale_s
+    assert float((g1 + g2 - gr).abs().max()) < 3e-6 * scale_g
+    # linearity in the weights: a power-of-two scale is exact in fp32, so the results are bit-identical
+    s3, g3 = ops.ScoreModel(desc, *kspec, sup, -4.0 * W).score_grad_raw(q)
+    assert torch.equal(s3, -4.0 * s) and torch.equal(g3, -4.0 * gr)
+    s4, g4 = ops.ScoreModel(desc, *kspec, sup, -2.5 * W).score_grad_raw(q)
+    assert float((s4 + 2.5 * s).abs().max()) < 5e-6 * scale_s and float((g4 + 2.5 * gr).abs().max()) < 5e-6 * scale_g
+    # batch order does not matter (each configuration is independent): bit-exact
+    perm = torch.randperm(B, generator=g).cuda()
+    sp, gp = m.score_grad_raw(q[perm].contiguous())
+    assert torch.equal(sp, s[perm]) and torch.equal(gp, gr[perm])
+    # fp64 referee on a random subset of rows
+    idx = torch.randint(0, B, (64,), generator=g)
+    so, go, _ = oracle.score_grad(desc, *kspec, _n(sup).astype(np.float64), _n(W), _n(q[idx.cuda()]), dtype=np.float64)
+    assert relerr(_n(s[idx.cuda()]), so) < TOL and relerr(_n(gr[idx.cuda()]), go) < TOL
+
+
+def test_config4_se3_streaming(ops):
+    """config #4: SE(3) configurations, RQ(10), 10k supports, no FK (D = 6), large batch"""
+    from diffco_amd import _fkdesc
+    from oracle import oracle
+    g = torch.Generator().manual_seed(4)
+    lo = torch.tensor([-10.0] * 3 + [-np.pi] * 3)
+    S, B = 10000, 1 << 18
+    sup = (torch.rand((S, 6), generator=g) * (-2 * lo) + lo).cuda()
+    q = (torch.rand((B, 6), generator=g) * (-2 * lo) + lo).cuda()
+    W = torch.randn((S, 1), generator=g).cuda()
+    desc = _fkdesc.none_desc(6)
+    m = ops.ScoreModel(desc, 0, 10.0, 2.0, sup, W)
+    s, gr = m.score_grad_raw(q)
+    idx = torch.randint(0, B, (64,), generator=g).cuda()
+    so, go, _ = oracle.score_grad(desc, 0, 10.0, 2.0, _n(sup).astype(np.float64), _n(W), _n(q[idx]), dtype=np.float64)
+    assert relerr(_n(s[idx]), so) < TOL and relerr(_n(gr[idx]), go) < TOL
+    half = ops.ScoreModel(desc, 0, 10.0, 2.0, sup[:5000], W[:5000]).score_grad_raw(q)
+    rest = ops.ScoreModel(desc, 0, 10.0, 2.0, sup[5000:], W[5000:]).score_grad_raw(q)
+    assert float((half[0] + rest[0] - s).abs().max()) < 3e-6 * float(s.abs().max())
+    assert float((half[1] + rest[1] - gr).abs().max()) < 3e-6 * float(gr.abs().max())

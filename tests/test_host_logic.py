@@ -1,0 +1,204 @@
+"""Host-side logic that needs no GPU: the sequential perceptron trainer (driven with a test-local torch
+kernel), fit_poly's linear solve, state bookkeeping (max_num_supports padding, pickling, filtering),
+path utilities and the optimisers' plumbing.  Golden data comes from the reference (tools/make_golden.py)."""
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import TorchDHRobot, TorchKernel, desc_for, load, make_robot, relerr
+from oracle import oracle
+
+
+def oracle_transform(desc):
+    return lambda q: torch.from_numpy(oracle.fkine(desc, q.detach().numpy().astype(np.float32)))
+
+
+def test_new_api_trainer_matches_reference_supports():
+    from diffco_amd.kernel_perceptrons import DiffCo
+    d = load("trained_baxter")
+    desc = desc_for("baxter_left")
+    dc = DiffCo(kernel_func=TorchKernel("rq", 10.0, 2.0), beta=1.0, transform=oracle_transform(desc))
+    X, y = torch.from_numpy(d["X"]), torch.from_numpy(d["y"])
+    dc.train(X, y, max_iteration=3000, distance=torch.from_numpy(d["dist"]))
+    assert dc.valid_supports == len(d["gains"]) == len(dc.gains)
+    np.testing.assert_array_equal(dc.support_points.numpy(), d["support_points"])  # same samples, same order
+    assert relerr(dc.gains.numpy(), d["gains"]) < 1e-3
+    assert relerr(dc.hypothesis.numpy(), d["hypothesis"]) < 1e-3
+    np.testing.assert_array_equal(dc.y.numpy(), d["sup_y"])
+    np.testing.assert_allclose(dc.distance.numpy(), d["sup_dist"])
+    assert relerr(dc.support_transformed.numpy(), d["support_transformed"]) < 1e-6
+    # perfect separation of the training supports and K g == hypothesis
+    assert torch.all((dc.hypothesis > 0) == (dc.y > 0))
+    assert torch.allclose(dc.kernel_matrix @ dc.gains, dc.hypothesis, atol=1e-4)
+    # fit_poly for the three targets
+    # (the S x S polyharmonic system is ill-conditioned: the reference's ~1e-5 cdist error in K moves its
+    #  nodes by ~3e-3, so nodes are compared loosely and the interpolation property tightly)
+    pk = TorchKernel("poly1", 1, 1.0)
+    for tgt, vals in (("label", dc.y), ("hypo", dc.hypothesis), ("dist", dc.distance)):
+        dc.fit_poly(pk, target=tgt)
+        assert relerr(dc.rbf_nodes.numpy(), d[f"rbf_nodes_{tgt}"]) < 2e-2, tgt
+        fit = pk(dc.support_transformed, dc.support_transformed) @ dc.rbf_nodes
+        assert float((fit - vals).abs().max()) < 2e-3 * float(vals.abs().max()), tgt
+    # the state pickles without device handles and comes back usable
+    dc2 = pickle.loads(pickle.dumps({k: v for k, v in dc.__getstate__().items() if k != "transform"}))
+    assert torch.equal(dc2["gains"], dc.gains)
+
+
+def test_max_num_supports_padding():
+    from diffco_amd.kernel_perceptrons import DiffCo
+    d = load("trained_baxter")
+    desc = desc_for("baxter_left")
+    dm = DiffCo(kernel_func=TorchKernel("rq", 10.0, 2.0), beta=1.0, transform=oracle_transform(desc),
+                max_num_supports=300)
+    dm.train(torch.from_numpy(d["X"]), torch.from_numpy(d["y"]), max_iteration=3000, distance=torch.from_numpy(d["dist"]))
+    v = int(d["mns_valid"])
+    assert dm.valid_supports == v and len(dm.gains) == 300
+    np.testing.assert_array_equal(dm.support_points.numpy(), d["mns_support_points"])
+    assert relerr(dm.gains.numpy(), d["mns_gains"]) < 1e-3
+    assert float(dm.gains[v:].abs().max()) == 0.0 and float(dm.support_transformed[v:].abs().max()) == 0.0
+    dm.fit_poly(TorchKernel("poly1", 1, 1.0), target="label")
+    assert relerr(dm.rbf_nodes.numpy(), d["mns_rbf_nodes"]) < 2e-2
+    assert float(dm.rbf_nodes[v:].abs().max()) == 0.0
+
+
+def test_old_api_multiclass_trainer_matches_reference():
+    from diffco_amd import deprecated, kernel
+    d = load("trained_multi_planar2")
+    desc = desc_for("planar2")
+    fk = oracle_transform(desc)
+    md = deprecated.MultiDiffCo(None, kernel_func=kernel.FKKernel(fk, TorchKernel("rq", 10.0, 2.0)), beta=1.0)
+    md.train(torch.from_numpy(d["X"]), torch.from_numpy(d["y"]), max_iteration=1500, distance=torch.from_numpy(d["dist"]))
+    assert md.num_class == 2
+    np.testing.assert_array_equal(md.support_points.numpy(), d["support_points"])
+    assert relerr(md.gains.numpy(), d["gains"]) < 1e-3
+    assert relerr(md.hypothesis.numpy(), d["hypothesis"]) < 1e-3
+    md.fit_poly(kernel_func=TorchKernel("poly1", 1, 1.0), target="label", fkine=fk, reg=0.0)
+    assert md.rbf_nodes.shape == d["rbf_nodes"].shape
+    assert relerr(md.rbf_nodes.numpy(), d["rbf_nodes"]) < 2e-2
+    assert torch.all(md.rbf_nodes[md.gains == 0] == 0)  # per-class sparsity (deprecated/MultiDiffCo.py:152-153)
+
+
+def test_score_path_rejects_foreign_kernels_instead_of_falling_back():
+    from diffco_amd.kernel_perceptrons import DiffCo
+    dc = DiffCo(kernel_func=TorchKernel("rq", 10.0, 2.0))
+    dc.support_points = dc.support_transformed = torch.zeros(3, 4)
+    dc.gains = torch.ones(3)
+    with pytest.raises(TypeError, match="HIP-only"):
+        dc.score(torch.zeros(2, 4))
+
+
+def test_dense_path_matches_reference():
+    from diffco_amd import utils
+    d = load("dense_path")
+    p = torch.from_numpy(d["path"])
+    np.testing.assert_allclose(utils.dense_path(p, 0.3).numpy(), d["dense_0p3"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(utils.dense_path(p, 2.0).numpy(), d["dense_2p0"], rtol=0, atol=1e-12)
+    few = utils.dense_path(p, 0.05, max_step_num=20)
+    assert torch.equal(few[0], p[0]) and torch.equal(few[-1], p[-1]) and len(few) <= 20 + len(p)
+
+
+def test_angle_utils():
+    from diffco_amd import utils
+    assert abs(float(utils.wrap2pi(torch.tensor(3 * np.pi / 2))) + np.pi / 2) < 1e-6
+    a = utils.anglin([-0.8 * np.pi], [0.9 * np.pi], 3, endpoint=True)
+    assert a.shape == (3, 1) and abs(float(a[1, 0]) - (-0.95 * np.pi)) < 1e-6  # goes the short way round
+    r = utils.rot_2d(torch.tensor([0.3]))
+    assert torch.allclose(r[0] @ r[0].T, torch.eye(2), atol=1e-6)
+    assert torch.allclose(utils.rotz(torch.tensor([0.3]))[0, :2, :2], r[0])
+    mc = utils.make_continue(torch.tensor([[3.0], [-3.1], [-3.0]]))
+    assert float((mc[1:] - mc[:-1]).abs().max()) < 1.0
+
+
+def test_shard_bounds_cover_exactly():
+    from diffco_amd.sharded import shard_bounds
+    for n in (0, 1, 7, 8, 65536, 65537):
+        for w in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_robot_descriptions():
+    """parameters of the drop-in robot classes (the FK itself is checked against golden FK vectors)"""
+    from diffco_amd import model
+    b = model.BaxterLeftArmFK()
+    assert b.dof == 7 and tuple(b.limits.shape) == (7, 2) and b.fk_desc().feature_dim == 12
+    assert model.BaxterFK is model.BaxterLeftArmFK
+    assert model.BaxterDualArmFK().fk_desc().feature_dim == 24 and model.BaxterDualArmFK().dof == 14
+    assert model.PandaFK().fk_desc().feature_dim == 21 and model.PandaFK(fingers=False).fk_desc().feature_dim == 15
+    dp = model.DualPandaFK()
+    assert dp.dof == 14 and dp.fk_desc().feature_dim == 42 and tuple(dp.limits.shape) == (14, 2)
+    assert float(dp.limits[6, 1]) == pytest.approx(-0.0698) and float(dp.limits[7, 1]) == pytest.approx(-0.0698)
+    pl = model.RevolutePlanarRobot(1.0, 0.3, dof=2)
+    assert pl.fk_desc().feature_dim == 4 and torch.allclose(pl.limits, torch.tensor([[-np.pi, np.pi]] * 2))
+    assert torch.allclose(pl.wrap(torch.tensor([4.0])), torch.tensor([4.0 - 2 * np.pi]))
+    with pytest.raises(ValueError):
+        model.RigidBody()
+
+
+def test_adam_optimizer_plumbing_against_reference_record():
+    """adam_traj_optimize on a torch-only dist_est/robot reproduces the reference's record (same init path,
+    options and support set; the reference's fp32 cdist vs direct fp64 differences explains the tolerance)"""
+    from diffco_amd import optim
+    d = load("optim_adam_baxter")
+    import json, os
+    from helpers import GOLDEN
+    options = json.load(open(os.path.join(GOLDEN, "optim_adam_baxter_options.json")))
+    rob = TorchDHRobot(make_robot("baxter_left"))
+    sup = rob.fkine(torch.from_numpy(d["sup_q"]).double()).reshape(len(d["sup_q"]), -1)
+    w = torch.from_numpy(d["weights"]).double()
+    kern = TorchKernel("poly1", 1, 1.0)
+
+    def dist_est(p):
+        return kern(rob.fkine(p).reshape(len(p), -1), sup) @ w[:, None]
+    # the fused loss at the initial path (what the fused optimiser will have to reproduce too)
+    p = torch.from_numpy(d["init"]).clone().requires_grad_(True)
+    col = torch.clamp(dist_est(p), min=0).sum()
+    cp = rob.fkine(p)
+    mm = torch.clamp((cp[1:] - cp[:-1]).square().sum(dim=2) - 0.3 ** 2, min=0).sum()
+    lim = rob.limits.double()
+    jl = (torch.clamp(lim[:, 0] - p, min=0) + torch.clamp(p - lim[:, 1], min=0)).sum()
+    diff = (cp[1:] - cp[:-1]).square().sum()
+    loss = diff + 10 * col + 10 * mm + 10 * jl
+    assert abs(loss.item() - float(d["loss0"])) < 1e-4 * abs(float(d["loss0"]))
+    (g,) = torch.autograd.grad(loss, p)
+    assert relerr(g.numpy(), d["grad0"]) < 1e-4
+    options["init_solution"] = torch.from_numpy(d["init"]).clone()
+    rec = optim.adam_traj_optimize(rob, dist_est, torch.from_numpy(d["start"]), torch.from_numpy(d["target"]), options)
+    assert rec["success"] == bool(d["success"]) and rec["cnt_check"] == int(d["cnt_check"])
+    assert abs(rec["cost"] - float(d["cost"])) < 2e-3 * float(d["cost"])
+    assert relerr(np.array(rec["solution"]), d["solution"]) < 2e-3
+    assert set(rec) == {"start_cfg", "target_cfg", "cnt_check", "cost", "time", "success", "seed", "solution"}
+
+
+def test_scipy_optimizers_run_on_a_toy_problem():
+    """SLSQP / trust-constr / gradient-free drivers: a 2-DoF point 'robot' steering round a bump"""
+    from diffco_amd import optim
+
+    class Point2D:
+        dof = 2
+        limits = torch.tensor([[-3.0, 3.0], [-3.0, 3.0]])
+
+        def fkine(self, q, reuse=False):
+            return q.reshape(-1, 1, 2)
+
+    def bump(q):  # positive inside a disc of radius 0.7 around the origin
+        return (0.49 - (q.reshape(-1, 2) ** 2).sum(-1)).reshape(-1, 1)
+    opts = {"N_WAYPOINTS": 8, "NUM_RE_TRIALS": 1, "MAXITER": 60, "safety_margin": -0.05, "max_speed": 0.4, "seed": 3,
+            "history": False, "extra_optimizer_options": {}}
+    start, target = torch.tensor([-1.5, 0.1]), torch.tensor([1.5, 0.1])
+    for fn in (optim.givengrad_traj_optimize, optim.trustconstr_traj_optimize):
+        rec = fn(Point2D(), bump, start, target, dict(opts))
+        sol = torch.tensor(rec["solution"], dtype=torch.float64)
+        assert sol.shape == (8, 2) and torch.allclose(sol[0], start.double()) and torch.allclose(sol[-1], target.double())
+        assert float(bump(sol).max()) < 0.0 + 1e-3, fn.__name__  # the path leaves the bump
+        assert rec["cnt_check"] > 0 and np.isfinite(rec["cost"])
+    rec = optim.gradient_free_traj_optimize(Point2D(), bump, start, target, dict(opts, MAXITER=15))
+    assert len(rec["solution"]) == 8 and np.isfinite(rec["cost"])
+    two = dict(opts, init_solution=torch.stack([start, target]).double())
+    rec = optim.adam_traj_optimize(Point2D(), bump, start, target, two)
+    assert rec["success"] and rec["cnt_check"] == 0
