@@ -147,7 +147,8 @@ int fk_device_copy(int device, const dcx_fk_desc& fk, dcx_fk_desc** out) {
 
 // Waves per block (support slices).  Measured on MI355X (profiles/r01_sweep_variants.txt, headline
 // D=12): occupancy is what hides the scalar-load latency of the sweep, so even a huge batch wants 4-8 waves
-// per block (B=1M: nw=1 436, nw=4 689 M evals/s) and a small one wants 16 (B=4096: nw=8 120, nw=16 129).
+// per block (B=1M: nw=1 436, nw=8 687 M evals/s) and a small one wants 16 (B=4096: nw=8 88, nw=16 102;
+// B=65536: 548 vs 555).
 int pick_nw(const dcx_model* m, int64_t B, int acc_floats) {
     const int cap = m->max_threads / 64;
     if (const char* e = std::getenv("DCX_NW")) {
@@ -155,7 +156,7 @@ int pick_nw(const dcx_model* m, int64_t B, int acc_floats) {
         if (v >= 1) return std::min(v, cap);
     }
     const int64_t tiles = (B + 63) / 64;
-    int nw = (tiles * 16 <= 2 * 1024 * (int64_t)m->n_cu / 256) ? 16 : 8;  // <= 2 waves per SIMD at nw=16 -> 16
+    int nw = (tiles <= 4 * (int64_t)m->n_cu) ? 16 : 8;  // up to ~4 tiles per CU: 16 slices; beyond: 8
     nw = std::min(nw, cap);
     while (nw > 1 && m->S_active / nw < 32) nw /= 2;  // keep >= 32 supports per slice
     const int d_fk = m->fk.n_points * m->fk.point_dim;

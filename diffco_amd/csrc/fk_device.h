@@ -27,6 +27,27 @@ typedef const __attribute__((address_space(4))) dcx_fk_desc* fk_cptr;
 
 __device__ __forceinline__ fk_cptr as_const(const dcx_fk_desc* p) { return (fk_cptr)(uintptr_t)p; }
 
+// sin and cos of one angle: Cody-Waite reduction by pi/2 (three fp32 terms, exact products through fma)
+// + the classic degree-7 / degree-8 minimax polynomials on [-pi/4, pi/4].  Max abs error 9e-8 for
+// |x| <= 1e4 rad (tools/: validated against float64), i.e. libm-class accuracy, in ~25 VALU instructions and
+// a handful of registers.  (ocml's sincosf carries a Payne-Hanek path whose register footprint alone would
+// cap the fused kernel at 4 waves per SIMD.)
+__device__ __forceinline__ void sincos_f32(float x, float* sn, float* cs) {
+    const float k = rintf(x * 0.63661977236758134308f);
+    float r = fmaf(k, -1.5707963705062866f, x);
+    r = fmaf(k, 4.371138828673793e-08f, r);
+    r = fmaf(k, 1.7763568394002505e-15f, r);
+    const float r2 = r * r;
+    const float sp = fmaf(r * r2, fmaf(r2, fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), r);
+    const float cp = fmaf(r2 * r2, fmaf(r2, fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f),
+                          fmaf(-0.5f, r2, 1.0f));
+    const int q = (int)k & 3;
+    const float s0 = (q & 1) ? cp : sp;
+    const float c0 = (q & 1) ? sp : cp;
+    *sn = (q & 2) ? -s0 : s0;
+    *cs = ((q + 1) & 2) ? -c0 : c0;
+}
+
 // LDS floats per lane the FK needs for its frames.
 __host__ __device__ inline int fk_frame_floats(const dcx_fk_desc& fk) {
     if (fk.kind == DCX_FK_DH) {
@@ -50,7 +71,7 @@ __device__ inline void fk_forward(fk_cptr fk, const float* sQrow, float* sXcol, 
         for (int i = 0; i < dof; ++i) {
             phi += sQrow[i];
             float s, c;
-            sincosf(phi, &s, &c);
+            sincos_f32(phi, &s, &c);
             const float l = fk->link_length[i];
             x = fmaf(l, c, x);
             y = fmaf(l, s, y);
@@ -71,7 +92,7 @@ __device__ inline void fk_forward(fk_cptr fk, const float* sQrow, float* sXcol, 
             for (int i = 0; i < len; ++i) {
                 const float th = sQrow[fk->joint_q[ch][i]] + fk->theta0[ch][i];
                 float s, c;
-                sincosf(th, &s, &c);
+                sincos_f32(th, &s, &c);
                 sFcol[(2 * (jbase + i)) * 64] = s;
                 sFcol[(2 * (jbase + i) + 1) * 64] = c;
                 const float a = fk->a[ch][i], d = fk->d[ch][i];
@@ -106,7 +127,7 @@ __device__ inline void fk_forward(fk_cptr fk, const float* sQrow, float* sXcol, 
     } else if (kind == DCX_FK_SE2) {
         const float x = sQrow[0], y = sQrow[1];
         float s, c;
-        sincosf(sQrow[2], &s, &c);
+        sincos_f32(sQrow[2], &s, &c);
         const int n_pts = fk->n_points;
         for (int k = 0; k < n_pts; ++k) {
             const float kx = fk->keypoints[k][0], ky = fk->keypoints[k][1];
@@ -115,9 +136,9 @@ __device__ inline void fk_forward(fk_cptr fk, const float* sQrow, float* sXcol, 
         }
     } else if (kind == DCX_FK_SE3) {
         float sx, cx, sy, cy, sz, cz;
-        sincosf(sQrow[3], &sx, &cx);
-        sincosf(sQrow[4], &sy, &cy);
-        sincosf(sQrow[5], &sz, &cz);
+        sincos_f32(sQrow[3], &sx, &cx);
+        sincos_f32(sQrow[4], &sy, &cy);
+        sincos_f32(sQrow[5], &sz, &cz);
         // R = Rz(yaw) Ry(pitch) Rx(roll)
         const float r00 = cz * cy, r01 = cz * sy * sx - sz * cx, r02 = cz * sy * cx + sz * sx;
         const float r10 = sz * cy, r11 = sz * sy * sx + cz * cx, r12 = sz * sy * cx - cz * sx;
@@ -227,7 +248,7 @@ __device__ inline void fk_vjp(fk_cptr fk, const float* sQrow, const float* sXcol
         }
     } else if (kind == DCX_FK_SE2) {
         float s, c;
-        sincosf(sQrow[2], &s, &c);
+        sincos_f32(sQrow[2], &s, &c);
         float gx = 0.f, gy = 0.f, gt = 0.f;
         const int n_pts = fk->n_points;
         for (int k = 0; k < n_pts; ++k) {
@@ -240,9 +261,9 @@ __device__ inline void fk_vjp(fk_cptr fk, const float* sQrow, const float* sXcol
         gqRow[0] = gx; gqRow[1] = gy; gqRow[2] = gt;
     } else if (kind == DCX_FK_SE3) {
         float sx, cx, sy, cy, sz, cz;
-        sincosf(sQrow[3], &sx, &cx);
-        sincosf(sQrow[4], &sy, &cy);
-        sincosf(sQrow[5], &sz, &cz);
+        sincos_f32(sQrow[3], &sx, &cx);
+        sincos_f32(sQrow[4], &sy, &cy);
+        sincos_f32(sQrow[5], &sz, &cz);
         // M = sum_k g_k k_k^T (3x3); d/dangle = <dR/dangle, M>
         float m00 = 0, m01 = 0, m02 = 0, m10 = 0, m11 = 0, m12 = 0, m20 = 0, m21 = 0, m22 = 0;
         float g0s = 0, g1s = 0, g2s = 0;

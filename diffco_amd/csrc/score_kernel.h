@@ -72,10 +72,11 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // Sweep code-generation variants, A/B-measured on MI355X (DESIGN.md "Measured choices"):
 //   bit 0: squared distance accumulated with packed fp32 (v_pk_fma_f32) instead of scalar v_fma_f32
 //   bit 1: scalar loads of the next support row issued before the current row is consumed
-// Measured on MI355X (profiles/r01_sweep_variants.txt): variant 3 is fastest at every batch size
-// (headline B=65536: 551 vs 508 M evals/s for variant 0; B=1M: 689 vs 631).
+//   bit 2: explicit two-buffer software pipeline (overrides bit 1)
+// Measured on MI355X (profiles/r01_sweep_variants.txt): packed d2 + the explicit two-buffer pipeline (5) is
+// fastest at every batch size (headline B=65536: 555 vs 485 (variant 3) vs ~470 (variant 0) M evals/s).
 #ifndef DCX_SWEEP_VARIANT
-#define DCX_SWEEP_VARIANT 3
+#define DCX_SWEEP_VARIANT 5
 #endif
 
 // value K(d2) and g with dK/dx = g * (x - s)
@@ -140,8 +141,19 @@ __host__ __device__ inline LdsPlan lds_plan(int dof, int d_fk, int frame_floats,
     return p;
 }
 
+// waves per SIMD the register allocator is asked to make room for (gfx950: 512 VGPRs per lane per SIMD, 8-register
+// granules: <=64 -> 8 waves, 72 -> 7, 80 -> 6, 96 -> 5, 128 -> 4, 168 -> 3, 256 -> 2).  The sweep keeps about
+// 3*D + 2*C + 16 values live; asking for more waves than that allows would spill inside the hot loop.
+#ifndef DCX_MINW_SLACK
+#define DCX_MINW_SLACK 0
+#endif
+constexpr int sweep_min_waves(int D, int CC, int KF) {
+    const int need = 3 * D + 2 * CC + 16 + DCX_MINW_SLACK + (KF == 2 ? 40 : 0);  // KF_GEN calls powf/logf
+    return need <= 64 ? 8 : need <= 72 ? 7 : need <= 80 ? 6 : need <= 96 ? 5 : need <= 128 ? 4 : need <= 168 ? 3 : need <= 256 ? 2 : 1;
+}
+
 template <int D, int KF, int CC, int MODE, int MAXT>
-__global__ __launch_bounds__(MAXT) void score_kernel(const ScoreArgs a) {
+__global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel(const ScoreArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using L = RowLayout<D, CC>;
     constexpr bool GRAD = (MODE != MODE_SCORE);
@@ -168,7 +180,11 @@ __global__ __launch_bounds__(MAXT) void score_kernel(const ScoreArgs a) {
         for (int i = threadIdx.x; i < 64 * dof; i += blockDim.x) sQ[i] = qsrc[i < n ? i : (i % dof) + (nb - 1) * dof];
     }
     __syncthreads();
+#if defined(DCX_ABLATE) && (DCX_ABLATE & 2)  // timing ablation only (wrong results): no FK
+    if (wave == 0) for (int k = 0; k < a.d_fk; ++k) sX[k * 64 + lane] = sQ[lane * dof + (k % dof)];
+#else
     if (wave == 0) fk_forward(fk, sQ + lane * dof, sX + lane, sF + lane);
+#endif
     __syncthreads();
 
     float x[D];
@@ -250,7 +266,32 @@ __global__ __launch_bounds__(MAXT) void score_kernel(const ScoreArgs a) {
         for (int e = 0; e < USED; ++e) dst[e] = r[e];
     };
 
-#if DCX_SWEEP_VARIANT & 2
+#if DCX_SWEEP_VARIANT & 4
+    // Explicit two-buffer software pipeline.  Scalar loads return out of order, so the only wait the
+    // hardware offers is "all of them" (lgkmcnt(0)); it is therefore placed BEFORE the next row's loads are
+    // issued: at that point only the previous prefetch (issued one whole VALU body earlier) is in flight.
+    //   wait -> issue B -> body(A) -> wait -> issue A' -> body(B) -> ...
+    if (j0 < j1) {
+        float rowA[L::RS], rowB[L::RS];
+        load_row(rowA, j0);
+        int j = j0;
+        for (; j + 1 < j1; j += 2) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): rowA has landed
+            __builtin_amdgcn_sched_barrier(0);
+            load_row(rowB, j + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            pair(rowA);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // rowB has landed (issued a full body ago)
+            __builtin_amdgcn_sched_barrier(0);
+            load_row(rowA, (j + 2 < j1) ? j + 2 : j + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            pair(rowB);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (j < j1) pair(rowA);
+    }
+#elif DCX_SWEEP_VARIANT & 2
     // software-pipelined: the scalar loads of row j+1 are in flight while row j is consumed
     if (j0 < j1) {
         float cur[L::RS], nxt[L::RS];
@@ -310,7 +351,11 @@ __global__ __launch_bounds__(MAXT) void score_kernel(const ScoreArgs a) {
         // J^T gX per lane.  The gradient row is built in place of the lane's own q row: every
         // fk_vjp branch reads what it needs from the q row before its first write to gq.
         float* gq = smem + lp.q;
+#if defined(DCX_ABLATE) && (DCX_ABLATE & 1)  // timing ablation only (wrong results): no J^T
+        for (int i = 0; i < dof; ++i) gq[lane * dof + i] = sG[(i % a.d_fk) * 64 + lane];
+#else
         fk_vjp(fk, sQ + lane * dof, sX + lane, sF + lane, sG + lane, gq + lane * dof);
+#endif
         // rows -> HBM, coalesced (LDS ops of one wave complete in order; no other wave is alive)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();

@@ -223,7 +223,7 @@ def test_full_size_properties(ops, B, S, C, kspec, monkeypatch):
     s3, g3 = ops.ScoreModel(desc, *kspec, sup, -4.0 * W).score_grad_raw(q)
     assert torch.equal(s3, -4.0 * s) and torch.equal(g3, -4.0 * gr)
     s4, g4 = ops.ScoreModel(desc, *kspec, sup, -2.5 * W).score_grad_raw(q)
-    assert float((s4 + 2.5 * s).abs().max()) < 5e-6 * scale_s and float((g4 + 2.5 * gr).abs().max()) < 5e-6 * scale_g
+    assert float((s4 + 2.5 * s).abs().max()) < 2e-5 * scale_s and float((g4 + 2.5 * gr).abs().max()) < 2e-5 * scale_g  # -2.5*w rounds
     # batch order does not matter (each configuration is independent): bit-exact
     perm = torch.randperm(B, generator=g).cuda()
     sp, gp = m.score_grad_raw(q[perm].contiguous())
