@@ -9,22 +9,23 @@ namespace dcx {
 namespace {
 
 // one wave per block, one lane per configuration; same LDS staging as the fused kernel
-__global__ __launch_bounds__(64) void fkine_kernel(const dcx_fk_desc* fkd, const float* q, int64_t B, float* X,
+__global__ __launch_bounds__(64) void fkine_kernel(const FkProg* fkd, const float* q, int64_t B, float* X,
                                                    int dof, int d_fk, int frame_floats) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x;
     const int64_t b0 = (int64_t)blockIdx.x * 64;
     const int nb = (int)((B - b0) < 64 ? (B - b0) : 64);
-    float* sQ = smem;
+    float* sQ = smem + kFkProgLdsFloats;
     float* sX = sQ + ((64 * dof + 3) & ~3);
     float* sF = sX + 64 * d_fk;
-    const fk_cptr fk = as_const(fkd);
+    const fk_cptr fk = stage_fk_prog(fkd, smem, lane, 64);
     const float* qsrc = q + b0 * dof;
     const int n = nb * dof;
     for (int i = lane; i < 64 * dof; i += 64) sQ[i] = qsrc[i < n ? i : (i % dof) + (nb - 1) * dof];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    fk_forward(fk, sQ + lane * dof, sX + lane, sF + lane);
+    fk_forward_trig(fk, sQ + lane * dof, sF + lane, 0, 1);
+    fk_forward_chain(fk, sQ + lane * dof, sX + lane, sF + lane);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
     // [64][d_fk] rows out, coalesced
@@ -33,17 +34,17 @@ __global__ __launch_bounds__(64) void fkine_kernel(const dcx_fk_desc* fkd, const
     for (int i = lane; i < m; i += 64) dst[i] = sX[(i % d_fk) * 64 + (i / d_fk)];
 }
 
-__global__ __launch_bounds__(64) void fkine_vjp_kernel(const dcx_fk_desc* fkd, const float* q, const float* gX,
+__global__ __launch_bounds__(64) void fkine_vjp_kernel(const FkProg* fkd, const float* q, const float* gX,
                                                        int64_t B, float* gq, int dof, int d_fk, int frame_floats) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x;
     const int64_t b0 = (int64_t)blockIdx.x * 64;
     const int nb = (int)((B - b0) < 64 ? (B - b0) : 64);
-    float* sQ = smem;
+    float* sQ = smem + kFkProgLdsFloats;
     float* sX = sQ + ((64 * dof + 3) & ~3);
     float* sG = sX + 64 * d_fk;
     float* sF = sG + 64 * d_fk;
-    const fk_cptr fk = as_const(fkd);
+    const fk_cptr fk = stage_fk_prog(fkd, smem, lane, 64);
     const float* qsrc = q + b0 * dof;
     const int n = nb * dof;
     for (int i = lane; i < 64 * dof; i += 64) sQ[i] = qsrc[i < n ? i : (i % dof) + (nb - 1) * dof];
@@ -55,8 +56,9 @@ __global__ __launch_bounds__(64) void fkine_vjp_kernel(const dcx_fk_desc* fkd, c
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    fk_forward(fk, sQ + lane * dof, sX + lane, sF + lane);
-    fk_vjp(fk, sQ + lane * dof, sX + lane, sF + lane, sG + lane, sQ + lane * dof);
+    fk_forward_trig(fk, sQ + lane * dof, sF + lane, 0, 1);
+    fk_forward_chain(fk, sQ + lane * dof, sX + lane, sF + lane);
+    fk_vjp(fk, sQ + lane * dof, sF + lane, sG + lane, sQ + lane * dof);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
     float* dst = gq + b0 * dof;
@@ -95,14 +97,62 @@ __global__ __launch_bounds__(256) void kernel_matrix_kernel(ScoreArgs a, const f
     }
 }
 
+__global__ __launch_bounds__(64) void score_finish_kernel(const FinishArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x;
+    const int64_t b0 = (int64_t)blockIdx.x * 64;
+    const int nb = (int)((a.B - b0) < 64 ? (a.B - b0) : 64);
+    const int dof = a.dof;
+    const LdsPlan lp = lds_plan(dof, a.d_fk, a.frame_floats, 1, 0);
+    float* sQ = smem + lp.q;
+    float* sX = smem + lp.x;
+    float* sG = smem + lp.g;
+    float* sF = smem + lp.f;
+    const float* part = a.partial + (size_t)blockIdx.x * a.ys * a.acc * 64 + lane;
+    for (int c = 0; c < a.C; ++c) {
+        float v = 0.0f;
+        for (int y = 0; y < a.ys; ++y) v += part[((size_t)y * a.acc + c) * 64];
+        if (a.score != nullptr && lane < nb) a.score[(b0 + lane) * a.C + c] = v;
+    }
+    if (!a.want_grad) return;
+    const fk_cptr fk = stage_fk_prog(a.fk, smem + lp.fk, lane, 64);
+    {
+        const float* qsrc = a.q + b0 * dof;
+        const int n = nb * dof;
+        for (int i = lane; i < 64 * dof; i += 64) sQ[i] = qsrc[i < n ? i : (i % dof) + (nb - 1) * dof];
+    }
+    float scale = 1.0f;
+    if (a.C == 1 && a.upstream != nullptr) scale = a.upstream[b0 + (lane < nb ? lane : nb - 1)];
+    for (int k = 0; k < a.d_fk; ++k) {
+        float v = 0.0f;
+        for (int y = 0; y < a.ys; ++y) v += part[((size_t)y * a.acc + a.C + k) * 64];
+        sG[k * 64 + lane] = v * scale;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    fk_forward_trig(fk, sQ + lane * dof, sF + lane, 0, 1);
+    fk_forward_chain(fk, sQ + lane * dof, sX + lane, sF + lane);
+    fk_vjp(fk, sQ + lane * dof, sF + lane, sG + lane, sQ + lane * dof);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    float* gdst = a.grad + b0 * a.grad_stride;
+    const int n = nb * dof;
+    if (a.grad_stride == dof) {
+        for (int i = lane; i < n; i += 64) gdst[i] = sQ[i];
+    } else {
+        for (int i = lane; i < n; i += 64) gdst[(int64_t)(i / dof) * a.grad_stride + (i % dof)] = sQ[i];
+    }
+}
+
+
 size_t fk_lds_bytes(const dcx_fk_desc& fk, bool with_g) {
     const int d_fk = fk.n_points * fk.point_dim;
-    return sizeof(float) * (((64 * fk.dof + 3) & ~3) + 64 * d_fk * (with_g ? 2 : 1) + 64 * fk_frame_floats(fk));
+    return sizeof(float) * (kFkProgLdsFloats + ((64 * fk.dof + 3) & ~3) + 64 * d_fk * (with_g ? 2 : 1) + 64 * fk_frame_floats(fk));
 }
 
 }  // namespace
 
-hipError_t launch_fkine(const dcx_fk_desc* fk_dev, const dcx_fk_desc& fk, const float* q, int64_t B, float* X,
+hipError_t launch_fkine(const FkProg* fk_dev, const dcx_fk_desc& fk, const float* q, int64_t B, float* X,
                         hipStream_t st) {
     if (B == 0) return hipSuccess;
     const int d_fk = fk.n_points * fk.point_dim;
@@ -111,12 +161,17 @@ hipError_t launch_fkine(const dcx_fk_desc* fk_dev, const dcx_fk_desc& fk, const 
     return hipGetLastError();
 }
 
-hipError_t launch_fkine_vjp(const dcx_fk_desc* fk_dev, const dcx_fk_desc& fk, const float* q, const float* gX,
+hipError_t launch_fkine_vjp(const FkProg* fk_dev, const dcx_fk_desc& fk, const float* q, const float* gX,
                             int64_t B, float* gq, hipStream_t st) {
     if (B == 0) return hipSuccess;
     const int d_fk = fk.n_points * fk.point_dim;
     fkine_vjp_kernel<<<dim3((unsigned)((B + 63) / 64)), dim3(64), fk_lds_bytes(fk, true), st>>>(
         fk_dev, q, gX, B, gq, fk.dof, d_fk, fk_frame_floats(fk));
+    return hipGetLastError();
+}
+
+hipError_t launch_score_finish(const FinishArgs& a, int64_t n_tiles, size_t lds_bytes, hipStream_t st) {
+    score_finish_kernel<<<dim3((unsigned)n_tiles), dim3(64), lds_bytes, st>>>(a);
     return hipGetLastError();
 }
 

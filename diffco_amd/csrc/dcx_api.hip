@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -16,7 +17,7 @@ using namespace dcx;
 struct dcx_model {
     int device = 0;
     dcx_fk_desc fk{};              // host copy
-    dcx_fk_desc* fk_dev = nullptr; // device copy
+    FkProg* fk_dev = nullptr;      // device copy of the compiled program
     float* rows_dev = nullptr;     // [S_active][RS]
     int64_t S_in = 0;
     int32_t S_active = 0;
@@ -27,7 +28,20 @@ struct dcx_model {
     launch_fn launch = nullptr;
     int32_t max_threads = 0;
     int32_t n_cu = 256;
+    // scratch for split launches (small batches): one buffer per stream that has used this model, so that
+    // launches on different streams never share partial rows.  Guarded by `mu`; never shrinks.
+    struct Scratch {
+        hipStream_t stream;
+        float* ptr;
+        size_t bytes;
+    };
+    mutable std::mutex mu;
+    mutable std::vector<Scratch> scratch;
 };
+
+#ifdef DCX_TIMING
+static unsigned long long* g_ts_dev = nullptr;
+#endif
 
 namespace {
 
@@ -123,19 +137,32 @@ int set_device(int device) {
 struct FkCacheEntry {
     int device;
     dcx_fk_desc host;
-    dcx_fk_desc* dev;
+    FkProg* dev;
 };
 thread_local std::vector<FkCacheEntry> g_fk_cache;
 
-int fk_device_copy(int device, const dcx_fk_desc& fk, dcx_fk_desc** out) {
+int upload_fk_prog(const dcx_fk_desc& fk, FkProg** out) {
+    FkProg prog;
+    build_fk_prog(fk, prog);
+    FkProg* d = nullptr;
+    DCX_HIP(hipMalloc((void**)&d, sizeof(FkProg)));
+    hipError_t e = hipMemcpy(d, &prog, sizeof(FkProg), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        return fail_hip(e, "upload of the FK program");
+    }
+    *out = d;
+    return DCX_OK;
+}
+
+int fk_device_copy(int device, const dcx_fk_desc& fk, FkProg** out) {
     for (auto& e : g_fk_cache)
         if (e.device == device && std::memcmp(&e.host, &fk, sizeof(fk)) == 0) {
             *out = e.dev;
             return DCX_OK;
         }
-    dcx_fk_desc* d = nullptr;
-    DCX_HIP(hipMalloc((void**)&d, sizeof(fk)));
-    DCX_HIP(hipMemcpy(d, &fk, sizeof(fk), hipMemcpyHostToDevice));
+    FkProg* d = nullptr;
+    if (int rc = upload_fk_prog(fk, &d)) return rc;
     if (g_fk_cache.size() >= 64) {  // bounded: drop the oldest
         (void)hipFree(g_fk_cache.front().dev);
         g_fk_cache.erase(g_fk_cache.begin());
@@ -145,23 +172,72 @@ int fk_device_copy(int device, const dcx_fk_desc& fk, dcx_fk_desc** out) {
     return DCX_OK;
 }
 
-// Waves per block (support slices).  Measured on MI355X (profiles/r01_sweep_variants.txt, headline
-// D=12): occupancy is what hides the scalar-load latency of the sweep, so even a huge batch wants 4-8 waves
-// per block (B=1M: nw=1 436, nw=8 687 M evals/s) and a small one wants 16 (B=4096: nw=8 88, nw=16 102;
-// B=65536: 548 vs 555).
-int pick_nw(const dcx_model* m, int64_t B, int acc_floats) {
+// Launch geometry.  nw = waves per block (support slices inside a block), ys = support super-chunks across
+// blocks (split launch, finished by score_finish_kernel).  Measured on MI355X (profiles/r01_sweep_variants.txt):
+//  * occupancy is what hides the scalar-load latency of the sweep, so even a huge batch wants 8 waves per block
+//    (B=1M: nw=1 436, nw=8 687 M evals/s) and a mid-size one 16 (B=65536: 548 vs 555);
+//  * a batch with fewer 64-configuration tiles than CUs cannot fill the chip with one block per tile: the
+//    supports are then also split across blocks (B=4096: 64 tiles on 256 CUs).
+struct Geometry {
+    int nw, ys;
+};
+Geometry pick_geometry(const dcx_model* m, int64_t B, int acc_floats, bool allow_split) {
     const int cap = m->max_threads / 64;
+    const int64_t tiles = (B + 63) / 64;
+    Geometry g;
+    g.ys = 1;
+    if (allow_split && 2 * tiles <= m->n_cu) {
+        // graph-replay timings, headline: B=1024 36 -> 27.5 us, B=4096 36 -> 28.5 us with ys=4..8;
+        // at 200 tiles (B=12800) the split already loses (39 vs 45 us)
+        g.ys = (int)std::min<int64_t>(8, (2 * (int64_t)m->n_cu) / tiles);
+        g.nw = std::min(8, cap);
+    } else {
+        g.nw = std::min((tiles <= 4 * (int64_t)m->n_cu) ? 16 : 8, cap);
+    }
+    if (const char* e = std::getenv("DCX_YS")) {
+        const int v = std::atoi(e);
+        if (v >= 1 && allow_split) g.ys = std::min(v, 64);
+    }
     if (const char* e = std::getenv("DCX_NW")) {
         const int v = std::atoi(e);
-        if (v >= 1) return std::min(v, cap);
+        if (v >= 1) g.nw = std::min(v, cap);
     }
-    const int64_t tiles = (B + 63) / 64;
-    int nw = (tiles <= 4 * (int64_t)m->n_cu) ? 16 : 8;  // up to ~4 tiles per CU: 16 slices; beyond: 8
-    nw = std::min(nw, cap);
-    while (nw > 1 && m->S_active / nw < 32) nw /= 2;  // keep >= 32 supports per slice
+    // keep >= 32 supports per wave slice
+    while (g.ys > 1 && m->S_active / (g.ys * g.nw) < 32) g.ys /= 2;
+    while (g.nw > 1 && m->S_active / (g.ys * g.nw) < 32) g.nw /= 2;
     const int d_fk = m->fk.n_points * m->fk.point_dim;
-    while (nw > 1 && lds_plan(m->fk.dof, d_fk, m->frame_floats, nw, acc_floats).total * sizeof(float) > 64 * 1024) nw /= 2;
-    return nw;
+    while (g.nw > 1 && lds_plan(m->fk.dof, d_fk, m->frame_floats, g.nw, acc_floats).total * sizeof(float) > 64 * 1024) g.nw /= 2;
+    return g;
+}
+
+// This stream's scratch buffer for the partial rows of a split launch, grown on demand.  Returns nullptr when
+// it cannot be provided right now (the stream is being captured into a graph and the buffer does not exist
+// yet, or the allocation failed): the caller then uses the unsplit geometry, which is always valid.
+float* split_scratch(const dcx_model* m, hipStream_t st, size_t bytes) {
+    std::lock_guard<std::mutex> lock(m->mu);
+    dcx_model::Scratch* slot = nullptr;
+    for (auto& sc : m->scratch)
+        if (sc.stream == st) slot = &sc;
+    if (slot && slot->bytes >= bytes) return slot->ptr;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
+    if (!slot) {
+        m->scratch.push_back({st, nullptr, 0});
+        slot = &m->scratch.back();
+    }
+    if (slot->ptr) {  // growing: enqueued work may still read the old buffer
+        (void)hipStreamSynchronize(st);
+        (void)hipFree(slot->ptr);
+        slot->ptr = nullptr;
+        slot->bytes = 0;
+    }
+    if (hipMalloc((void**)&slot->ptr, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        slot->ptr = nullptr;
+        return nullptr;
+    }
+    slot->bytes = bytes;
+    return slot->ptr;
 }
 
 int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstream, float* score, float* grad,
@@ -169,7 +245,14 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
     if (B == 0) return DCX_OK;
     const int d_fk = m->fk.n_points * m->fk.point_dim;
     const int acc = (mode == MODE_SCORE ? 0 : m->Dt) + m->C;
-    const int nw = pick_nw(m, B, acc);
+    Geometry g = pick_geometry(m, B, acc, true);
+    const int64_t nblk = (B + 63) / 64;
+    float* part = nullptr;
+    if (g.ys > 1) {
+        part = split_scratch(m, st, (size_t)nblk * g.ys * acc * 64 * sizeof(float));
+        if (!part) g = pick_geometry(m, B, acc, false);
+    }
+    if (nblk > 0x7fffffffLL) return fail(DCX_ERR_UNSUPPORTED, "batch too large for one launch");
     ScoreArgs a{};
     a.rows = m->rows_dev;
     a.fk = m->fk_dev;
@@ -179,7 +262,9 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
     a.grad = grad;
     a.B = B;
     a.S = m->S_active;
-    a.s_chunk = (m->S_active + nw - 1) / nw;
+    a.ys = g.ys;
+    a.s_super = (m->S_active + g.ys - 1) / g.ys;
+    a.s_chunk = (a.s_super + g.nw - 1) / g.nw;
     a.dof = m->fk.dof;
     a.d_fk = d_fk;
     a.frame_floats = m->frame_floats;
@@ -188,17 +273,55 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
     a.grad_stride = grad_stride;
     a.kp0 = m->kp0;
     a.kp1 = m->kp1;
-    const size_t lds = sizeof(float) * lds_plan(a.dof, d_fk, m->frame_floats, nw, acc).total;
-    const int64_t nblk = (B + 63) / 64;
-    if (nblk > 0x7fffffffLL) return fail(DCX_ERR_UNSUPPORTED, "batch too large for one launch");
-    hipError_t e = m->launch(m->kf, m->C, mode, nw, lds, nblk, a, st);
-    if (e != hipSuccess) return fail_hip(e, "score kernel launch");
+#ifdef DCX_TIMING
+    if (!g_ts_dev && hipMalloc((void**)&g_ts_dev, sizeof(unsigned long long) * 16 * 8) == hipSuccess)
+        (void)hipMemset(g_ts_dev, 0, sizeof(unsigned long long) * 16 * 8);
+    a.ts = g_ts_dev;
+    a.ts_block = std::getenv("DCX_TS_BLOCK") ? (unsigned)std::atoi(std::getenv("DCX_TS_BLOCK")) : 0u;
+#endif
+    const size_t lds = sizeof(float) * lds_plan(a.dof, d_fk, m->frame_floats, g.nw, acc).total;
+    if (g.ys == 1) {
+        hipError_t e = m->launch(m->kf, m->C, mode, g.nw, lds, nblk, a, st);
+        if (e != hipSuccess) return fail_hip(e, "score kernel launch");
+        return DCX_OK;
+    }
+    a.partial = part;
+    hipError_t e = m->launch(m->kf, m->C, mode, g.nw, lds, nblk, a, st);
+    if (e == hipSuccess) {
+        FinishArgs f{};
+        f.partial = part;
+        f.fk = m->fk_dev;
+        f.q = q;
+        f.upstream = (m->C == 1) ? upstream : nullptr;
+        f.score = score;
+        f.grad = grad;
+        f.B = B;
+        f.grad_stride = grad_stride;
+        f.ys = g.ys;
+        f.acc = acc;
+        f.C = m->C;
+        f.Dt = m->Dt;
+        f.dof = m->fk.dof;
+        f.d_fk = d_fk;
+        f.frame_floats = m->frame_floats;
+        f.want_grad = (mode != MODE_SCORE);
+        e = launch_score_finish(f, nblk, sizeof(float) * lds_plan(a.dof, d_fk, m->frame_floats, 1, 0).total, st);
+    }
+    if (e != hipSuccess) return fail_hip(e, "split score launch");
     return DCX_OK;
 }
 
 }  // namespace
 
 extern "C" {
+
+#ifdef DCX_TIMING
+int dcx_debug_read_ts(unsigned long long* out) {  // developer builds only
+    if (!g_ts_dev) return 1;
+    (void)hipDeviceSynchronize();
+    return hipMemcpy(out, g_ts_dev, sizeof(unsigned long long) * 16 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 3;
+}
+#endif
 
 int dcx_version(void) { return DCX_VERSION; }
 
@@ -291,9 +414,12 @@ int dcx_model_create(dcx_model** out, int device, const dcx_fk_desc* fk, int ker
         ++kept;
     }
     m->S_active = kept;
-    hipError_t e = hipMalloc((void**)&m->fk_dev, sizeof(dcx_fk_desc));
-    if (e == hipSuccess) e = hipMemcpy(m->fk_dev, &m->fk, sizeof(dcx_fk_desc), hipMemcpyHostToDevice);
-    if (e == hipSuccess && kept > 0) {
+    if (int rc = upload_fk_prog(m->fk, &m->fk_dev)) {
+        dcx_model_destroy(m);
+        return rc;
+    }
+    hipError_t e = hipSuccess;
+    if (kept > 0) {
         e = hipMalloc((void**)&m->rows_dev, rows.size() * sizeof(float));
         if (e == hipSuccess) e = hipMemcpy(m->rows_dev, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice);
     }
@@ -310,6 +436,8 @@ void dcx_model_destroy(dcx_model* m) {
     (void)hipSetDevice(m->device);
     if (m->fk_dev) (void)hipFree(m->fk_dev);
     if (m->rows_dev) (void)hipFree(m->rows_dev);
+    for (auto& sc : m->scratch)
+        if (sc.ptr) (void)hipFree(sc.ptr);
     delete m;
 }
 
@@ -358,7 +486,7 @@ int dcx_fkine(int device, const dcx_fk_desc* fk, const float* q, int64_t B, floa
     if (B < 0 || (B > 0 && (!q || !X))) return fail(DCX_ERR_INVALID, "q / X is NULL or B < 0");
     if (int rc = check_fk(*fk)) return rc;
     if (int rc = set_device(device)) return rc;
-    dcx_fk_desc* dev = nullptr;
+    FkProg* dev = nullptr;
     if (int rc = fk_device_copy(device, *fk, &dev)) return rc;
     hipError_t e = launch_fkine(dev, *fk, q, B, X, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "fkine launch");
@@ -371,7 +499,7 @@ int dcx_fkine_vjp(int device, const dcx_fk_desc* fk, const float* q, const float
     if (B < 0 || (B > 0 && (!q || !gX || !gq))) return fail(DCX_ERR_INVALID, "q / gX / gq is NULL or B < 0");
     if (int rc = check_fk(*fk)) return rc;
     if (int rc = set_device(device)) return rc;
-    dcx_fk_desc* dev = nullptr;
+    FkProg* dev = nullptr;
     if (int rc = fk_device_copy(device, *fk, &dev)) return rc;
     hipError_t e = launch_fkine_vjp(dev, *fk, q, gX, B, gq, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "fkine_vjp launch");

@@ -34,9 +34,10 @@ DCX_DECLARE_LAUNCH(72)
 #undef DCX_DECLARE_LAUNCH
 
 // aux_kernels.hip
-hipError_t launch_fkine(const dcx_fk_desc* fk_dev, const dcx_fk_desc& fk_host, const float* q, int64_t B, float* X,
+hipError_t launch_score_finish(const FinishArgs& a, int64_t n_tiles, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_fkine(const FkProg* fk_dev, const dcx_fk_desc& fk_host, const float* q, int64_t B, float* X,
                         hipStream_t stream);
-hipError_t launch_fkine_vjp(const dcx_fk_desc* fk_dev, const dcx_fk_desc& fk_host, const float* q, const float* gX,
+hipError_t launch_fkine_vjp(const FkProg* fk_dev, const dcx_fk_desc& fk_host, const float* q, const float* gX,
                             int64_t B, float* gq, hipStream_t stream);
 hipError_t launch_kernel_matrix(int kind, float kp0, float kp1, const float* x, int64_t B, const float* s, int64_t S,
                                 int D, float* K, hipStream_t stream);

@@ -2,13 +2,21 @@
 //
 // One lane = one configuration.  Everything that is indexed at run time lives in LDS in
 // "column" layout (element e of lane l at base[e*64 + l]: conflict-free, no scratch):
-//   q row    : sQ[l*dof + i]             (staged coalesced from HBM by the caller)
-//   features : sX[k*64 + l]              (control-point coordinates, D = n_points*point_dim)
-//   frames   : sF[e*64 + l]               (DH: sin/cos of every joint angle, then each chain's final
-//                                          rotation (9 floats) — what the reverse sweep of fk_vjp
-//                                          needs; planar: cos/sin phi_j)
-// The FK description is read through the constant address space, so every parameter load
-// is a scalar (s_load) broadcast: all lanes run the same chain.
+//   q row    : sQ[l*dof + i]     (staged coalesced from HBM by the caller)
+//   features : sX[k*64 + l]      (control-point coordinates, D = n_points*point_dim)
+//   frames   : sF[e*64 + l]      (DH: sin/cos of every joint angle, then each chain's final rotation
+//                                 (9 floats) - what the reverse sweep of fk_vjp needs; planar: cos/sin phi_j)
+//
+// The public description (dcx_fk_desc, include/dcx.h) is compiled on the host into an FkProg: joints in
+// execution order, each carrying its parameters and the [begin, end) range of the control points attached to
+// its frame.  The program is staged into LDS once per block and read from there with addresses that depend on
+// loop counters only - a chain walk has no dependent "load an index, then load through it" steps and no
+// per-point search.  Measured on MI355X (profiles/r01_phase_timing.txt): with the description read field by
+// field and a point search per joint, the FK of one wave took 13k cycles and its vjp 14k (~11 us of a 45 us
+// small-batch launch).
+//
+// The sin/cos of all joints are independent of each other, so the block's waves share them (wave w takes
+// joints w, w+nw, ...); the chain composition (pure FMA) then runs on wave 0.
 //
 // Reference semantics restated here (paths under /root/reference/diffco):
 //   utils.DH2mat utils.py:66-75; BaxterLeftArmFK.fkine model.py:225-241; BaxterDualArmFK.fkine
@@ -19,13 +27,97 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 #include "../../include/dcx.h"
 
 namespace dcx {
 
-typedef const __attribute__((address_space(4))) dcx_fk_desc* fk_cptr;
+constexpr int kMaxProgJoints = DCX_MAX_CHAINS * DCX_MAX_JOINTS;
 
-__device__ __forceinline__ fk_cptr as_const(const dcx_fk_desc* p) { return (fk_cptr)(uintptr_t)p; }
+struct FkProgJoint {  // 8 dwords
+    int32_t q_index;
+    float theta0, a, d, sin_alpha, cos_alpha;
+    int32_t pt_begin, pt_end;  // control points attached to this joint's frame: points[pt_begin .. pt_end)
+};
+struct FkProgPoint {  // 4 dwords
+    float ox, oy, oz;
+    int32_t out_k;  // feature slot: coordinates go to X[3*out_k .. 3*out_k+2]
+};
+struct FkProg {
+    int32_t kind, dof, n_points, point_dim;
+    int32_t n_chains, n_joints, pad0, pad1;
+    int32_t chain_begin[DCX_MAX_CHAINS], chain_end[DCX_MAX_CHAINS];  // joint ranges
+    float base[DCX_MAX_CHAINS][12];
+    FkProgJoint joints[kMaxProgJoints];
+    FkProgPoint points[DCX_MAX_POINTS];
+    float link_length[DCX_MAX_DOF];
+    float keypoints[DCX_MAX_POINTS][4];
+};
+constexpr int kFkProgDwords = (sizeof(FkProg) + 3) / 4;
+constexpr int kFkProgLdsFloats = (kFkProgDwords + 3) & ~3;
+
+// host: compile the public description into the device program
+inline void build_fk_prog(const dcx_fk_desc& fk, FkProg& p) {
+    memset(&p, 0, sizeof(p));
+    p.kind = fk.kind;
+    p.dof = fk.dof;
+    p.n_points = fk.n_points;
+    p.point_dim = fk.point_dim;
+    for (int i = 0; i < DCX_MAX_DOF; ++i) p.link_length[i] = fk.link_length[i];
+    for (int k = 0; k < DCX_MAX_POINTS; ++k)
+        for (int j = 0; j < 3; ++j) p.keypoints[k][j] = fk.keypoints[k][j];
+    if (fk.kind != DCX_FK_DH) return;
+    p.n_chains = fk.n_chains;
+    int nj = 0, np = 0;
+    for (int c = 0; c < fk.n_chains; ++c) {
+        p.chain_begin[c] = nj;
+        for (int e = 0; e < 12; ++e) p.base[c][e] = fk.base[c][e];
+        for (int i = 0; i < fk.chain_len[c]; ++i, ++nj) {
+            FkProgJoint& J = p.joints[nj];
+            J.q_index = fk.joint_q[c][i];
+            J.theta0 = fk.theta0[c][i];
+            J.a = fk.a[c][i];
+            J.d = fk.d[c][i];
+            J.sin_alpha = fk.sin_alpha[c][i];
+            J.cos_alpha = fk.cos_alpha[c][i];
+            J.pt_begin = np;
+            for (int k = 0; k < fk.n_points; ++k) {
+                if (fk.pt_chain[k] != c || fk.pt_frame[k] != i) continue;
+                p.points[np].ox = fk.pt_off[k][0];
+                p.points[np].oy = fk.pt_off[k][1];
+                p.points[np].oz = fk.pt_off[k][2];
+                p.points[np].out_k = k;
+                ++np;
+            }
+            J.pt_end = np;
+        }
+        p.chain_end[c] = nj;
+    }
+    p.n_joints = nj;
+}
+
+// LDS floats per lane the FK needs for its frames.
+__host__ __device__ inline int fk_frame_floats(const dcx_fk_desc& fk) {
+    if (fk.kind == DCX_FK_DH) {
+        int j = 0;
+        for (int c = 0; c < fk.n_chains; ++c) j += fk.chain_len[c];
+        return 2 * j + 9 * fk.n_chains;
+    }
+    if (fk.kind == DCX_FK_PLANAR) return 2 * fk.dof;
+    return 0;
+}
+
+typedef const __attribute__((address_space(3))) FkProg* fk_cptr;
+
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// all threads of the block copy the program global -> LDS (coalesced); caller synchronises
+__device__ __forceinline__ fk_cptr stage_fk_prog(const FkProg* g, float* lds, int tid, int nthreads) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(g);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(lds);
+    for (int i = tid; i < kFkProgDwords; i += nthreads) dst[i] = src[i];
+    return (fk_cptr)(uint32_t)(uintptr_t)lds;
+}
 
 // sin and cos of one angle: Cody-Waite reduction by pi/2 (three fp32 terms, exact products through fma)
 // + the classic degree-7 / degree-8 minimax polynomials on [-pi/4, pi/4].  Max abs error 9e-8 for
@@ -48,56 +140,60 @@ __device__ __forceinline__ void sincos_f32(float x, float* sn, float* cs) {
     *cs = ((q + 1) & 2) ? -c0 : c0;
 }
 
-// LDS floats per lane the FK needs for its frames.
-__host__ __device__ inline int fk_frame_floats(const dcx_fk_desc& fk) {
-    if (fk.kind == DCX_FK_DH) {
-        int j = 0;
-        for (int c = 0; c < fk.n_chains; ++c) j += fk.chain_len[c];
-        return 2 * j + 9 * fk.n_chains;
-    }
-    if (fk.kind == DCX_FK_PLANAR) return 2 * fk.dof;
-    return 0;
-}
-
-// ---- forward: q (LDS row) -> X (LDS column), frames (LDS column) ------------------------
-__device__ inline void fk_forward(fk_cptr fk, const float* sQrow, float* sXcol, float* sFcol) {
-    const int kind = fk->kind;
-    if (kind == DCX_FK_NONE) {
-        const int dof = fk->dof;
-        for (int i = 0; i < dof; ++i) sXcol[i * 64] = sQrow[i];
+// ---- forward, phase A (every wave of the block): sin/cos of the joint angles -> frames ---------------
+// wave w of nw takes joints w, w+nw, ...   Caller synchronises the block afterwards.
+__device__ inline void fk_forward_trig(fk_cptr fk, const float* sQrow, float* sFcol, int wave, int nw) {
+    const int kind = rfl(fk->kind);
+    if (kind == DCX_FK_DH) {
+        const int nj = rfl(fk->n_joints);
+        for (int j = wave; j < nj; j += nw) {
+            const float th = sQrow[rfl(fk->joints[j].q_index)] + fk->joints[j].theta0;
+            float s, c;
+            sincos_f32(th, &s, &c);
+            sFcol[(2 * j) * 64] = s;
+            sFcol[(2 * j + 1) * 64] = c;
+        }
     } else if (kind == DCX_FK_PLANAR) {
-        const int dof = fk->dof;
-        float phi = 0.f, x = 0.f, y = 0.f;
-        for (int i = 0; i < dof; ++i) {
-            phi += sQrow[i];
+        const int dof = rfl(fk->dof);
+        for (int j = wave; j < dof; j += nw) {
+            float phi = 0.f;
+            for (int i = 0; i <= j; ++i) phi += sQrow[i];  // same left-to-right sum as cumsum
             float s, c;
             sincos_f32(phi, &s, &c);
+            sFcol[(2 * j) * 64] = c;
+            sFcol[(2 * j + 1) * 64] = s;
+        }
+    }
+}
+
+// ---- forward, phase B (one wave): compose the chain -> X (LDS column) --------------------------------
+__device__ inline void fk_forward_chain(fk_cptr fk, const float* sQrow, float* sXcol, float* sFcol) {
+    const int kind = rfl(fk->kind);
+    if (kind == DCX_FK_NONE) {
+        const int dof = rfl(fk->dof);
+        for (int i = 0; i < dof; ++i) sXcol[i * 64] = sQrow[i];
+    } else if (kind == DCX_FK_PLANAR) {
+        const int dof = rfl(fk->dof);
+        float x = 0.f, y = 0.f;
+        for (int i = 0; i < dof; ++i) {
             const float l = fk->link_length[i];
-            x = fmaf(l, c, x);
-            y = fmaf(l, s, y);
+            x = fmaf(l, sFcol[(2 * i) * 64], x);
+            y = fmaf(l, sFcol[(2 * i + 1) * 64], y);
             sXcol[(2 * i) * 64] = x;
             sXcol[(2 * i + 1) * 64] = y;
-            sFcol[(2 * i) * 64] = c;
-            sFcol[(2 * i + 1) * 64] = s;
         }
     } else if (kind == DCX_FK_DH) {
-        const int n_pts = fk->n_points;
-        int jbase = 0, jtot = 0;
-        for (int ch = 0; ch < fk->n_chains; ++ch) jtot += fk->chain_len[ch];
-        for (int ch = 0; ch < fk->n_chains; ++ch) {
+        const int nch = rfl(fk->n_chains), njt = rfl(fk->n_joints);
+        for (int ch = 0; ch < nch; ++ch) {
             float r00 = fk->base[ch][0], r01 = fk->base[ch][1], r02 = fk->base[ch][2], t0 = fk->base[ch][3];
             float r10 = fk->base[ch][4], r11 = fk->base[ch][5], r12 = fk->base[ch][6], t1 = fk->base[ch][7];
             float r20 = fk->base[ch][8], r21 = fk->base[ch][9], r22 = fk->base[ch][10], t2 = fk->base[ch][11];
-            const int len = fk->chain_len[ch];
-            for (int i = 0; i < len; ++i) {
-                const float th = sQrow[fk->joint_q[ch][i]] + fk->theta0[ch][i];
-                float s, c;
-                sincos_f32(th, &s, &c);
-                sFcol[(2 * (jbase + i)) * 64] = s;
-                sFcol[(2 * (jbase + i) + 1) * 64] = c;
-                const float a = fk->a[ch][i], d = fk->d[ch][i];
-                const float sa = fk->sin_alpha[ch][i], ca = fk->cos_alpha[ch][i];
-                // T <- T * [[c, -s ca,  s sa, a c], [s, c ca, -c sa, a s], [0, sa, ca, d]]
+            const int jb = rfl(fk->chain_begin[ch]), je = rfl(fk->chain_end[ch]);
+            for (int j = jb; j < je; ++j) {
+                const float s = sFcol[(2 * j) * 64], c = sFcol[(2 * j + 1) * 64];
+                const float a = fk->joints[j].a, d = fk->joints[j].d;
+                const float sa = fk->joints[j].sin_alpha, ca = fk->joints[j].cos_alpha;
+                // T <- T * [[c, -s ca,  s sa, a c], [s, c ca, -c sa, a s], [0, sa, ca, d]]   (utils.DH2mat)
                 const float m01 = -s * ca, m02 = s * sa, m11 = c * ca, m12 = -c * sa;
                 const float ac = a * c, as = a * s;
                 t0 = fmaf(r00, ac, fmaf(r01, as, fmaf(r02, d, t0)));
@@ -111,24 +207,24 @@ __device__ inline void fk_forward(fk_cptr fk, const float* sQrow, float* sXcol, 
                 const float n12 = fmaf(r10, m02, fmaf(r11, m12, r12 * ca));
                 const float n22 = fmaf(r20, m02, fmaf(r21, m12, r22 * ca));
                 r00 = n00; r01 = n01; r02 = n02; r10 = n10; r11 = n11; r12 = n12; r20 = n20; r21 = n21; r22 = n22;
-                for (int k = 0; k < n_pts; ++k) {
-                    if (fk->pt_chain[k] != ch || fk->pt_frame[k] != i) continue;
-                    const float ox = fk->pt_off[k][0], oy = fk->pt_off[k][1], oz = fk->pt_off[k][2];
-                    sXcol[(3 * k) * 64] = fmaf(r00, ox, fmaf(r01, oy, fmaf(r02, oz, t0)));
-                    sXcol[(3 * k + 1) * 64] = fmaf(r10, ox, fmaf(r11, oy, fmaf(r12, oz, t1)));
-                    sXcol[(3 * k + 2) * 64] = fmaf(r20, ox, fmaf(r21, oy, fmaf(r22, oz, t2)));
+                const int pb = rfl(fk->joints[j].pt_begin), pe = rfl(fk->joints[j].pt_end);
+                for (int p = pb; p < pe; ++p) {
+                    const float ox = fk->points[p].ox, oy = fk->points[p].oy, oz = fk->points[p].oz;
+                    float* out = sXcol + (3 * rfl(fk->points[p].out_k)) * 64;
+                    out[0] = fmaf(r00, ox, fmaf(r01, oy, fmaf(r02, oz, t0)));
+                    out[64] = fmaf(r10, ox, fmaf(r11, oy, fmaf(r12, oz, t1)));
+                    out[128] = fmaf(r20, ox, fmaf(r21, oy, fmaf(r22, oz, t2)));
                 }
             }
-            float* fr = sFcol + (2 * jtot + 9 * ch) * 64;  // final rotation of this chain
+            float* fr = sFcol + (2 * njt + 9 * ch) * 64;  // final rotation of this chain (for the reverse sweep)
             fr[0] = r00; fr[64] = r01; fr[128] = r02; fr[192] = r10; fr[256] = r11; fr[320] = r12;
             fr[384] = r20; fr[448] = r21; fr[512] = r22;
-            jbase += len;
         }
     } else if (kind == DCX_FK_SE2) {
         const float x = sQrow[0], y = sQrow[1];
         float s, c;
         sincos_f32(sQrow[2], &s, &c);
-        const int n_pts = fk->n_points;
+        const int n_pts = rfl(fk->n_points);
         for (int k = 0; k < n_pts; ++k) {
             const float kx = fk->keypoints[k][0], ky = fk->keypoints[k][1];
             sXcol[(2 * k) * 64] = fmaf(c, kx, fmaf(-s, ky, x));
@@ -144,7 +240,7 @@ __device__ inline void fk_forward(fk_cptr fk, const float* sQrow, float* sXcol, 
         const float r10 = sz * cy, r11 = sz * sy * sx + cz * cx, r12 = sz * sy * cx - cz * sx;
         const float r20 = -sy, r21 = cy * sx, r22 = cy * cx;
         const float x = sQrow[0], y = sQrow[1], z = sQrow[2];
-        const int n_pts = fk->n_points;
+        const int n_pts = rfl(fk->n_points);
         for (int k = 0; k < n_pts; ++k) {
             const float kx = fk->keypoints[k][0], ky = fk->keypoints[k][1], kz = fk->keypoints[k][2];
             sXcol[(3 * k) * 64] = fmaf(r00, kx, fmaf(r01, ky, fmaf(r02, kz, x)));
@@ -154,11 +250,12 @@ __device__ inline void fk_forward(fk_cptr fk, const float* sQrow, float* sXcol, 
     }
 }
 
-// ---- vjp: gq (LDS row, dof floats) = J(q)^T gX, using X and the frames the forward left ---
-__device__ inline void fk_vjp(fk_cptr fk, const float* sQrow, const float* sXcol, const float* sFcol,
-                              const float* sGcol, float* gqRow) {
-    const int kind = fk->kind;
-    const int dof = fk->dof;
+// ---- vjp (one wave): gq (LDS row, dof floats) = J(q)^T gX, using the frames the forward left ------------
+// NOTE: gqRow may alias sQrow (callers build the gradient row in place of the q row), so every branch must
+// finish reading sQrow before its first write to gqRow.
+__device__ inline void fk_vjp(fk_cptr fk, const float* sQrow, const float* sFcol, const float* sGcol, float* gqRow) {
+    const int kind = rfl(fk->kind);
+    const int dof = rfl(fk->dof);
     if (kind == DCX_FK_NONE) {
         for (int i = 0; i < dof; ++i) gqRow[i] = sGcol[i * 64];
         return;
@@ -175,41 +272,37 @@ __device__ inline void fk_vjp(fk_cptr fk, const float* sQrow, const float* sXcol
         }
         return;
     }
-    // NOTE: gqRow may alias sQrow (callers build the gradient row in place of the q row), so every
-    // branch must finish reading sQrow before its first write to gqRow.
     if (kind == DCX_FK_DH) {
-        // Reverse-mode sweep through T_i = T_{i-1} A_i(theta_i), exactly the chain rule autograd applies to
+        // Reverse-mode sweep through T_j = T_{j-1} A_j(theta_j), exactly the chain rule autograd applies to
         // the reference's bmm chain.  Unlike the geometric form z x (p - o) it reproduces STRUCTURAL zeros
         // exactly (e.g. Baxter's last joint, a = 0 and the control point on the joint axis): an optimiser
         // such as Adam would otherwise amplify 1e-8 round-off on such a joint into full-size steps.
         //   GR, Gt : adjoints of the current frame's rotation / translation
-        //   dL/dtheta_i = <R_{i-1}^T GR, dA_R/dtheta> + <R_{i-1}^T Gt, da_t/dtheta>
-        //   GR <- GR A_R^T + Gt a_t^T ;  Gt unchanged ;  R_{i-1} = R_i A_R^T (recomputed, not stored)
+        //   dL/dtheta_j = <R_{j-1}^T GR, dA_R/dtheta> + <R_{j-1}^T Gt, da_t/dtheta>
+        //   GR <- GR A_R^T + Gt a_t^T ;  Gt unchanged ;  R_{j-1} = R_j A_R^T (recomputed, not stored)
         for (int i = 0; i < dof; ++i) gqRow[i] = 0.f;  // DH reads frames, not q
-        const int n_pts = fk->n_points;
-        int jtot = 0;
-        for (int ch = 0; ch < fk->n_chains; ++ch) jtot += fk->chain_len[ch];
-        int jbase = 0;
-        for (int ch = 0; ch < fk->n_chains; ++ch) {
-            const int len = fk->chain_len[ch];
-            const float* fr = sFcol + (2 * jtot + 9 * ch) * 64;
+        const int nch = rfl(fk->n_chains), njt = rfl(fk->n_joints);
+        for (int ch = 0; ch < nch; ++ch) {
+            const float* fr = sFcol + (2 * njt + 9 * ch) * 64;
             float r00 = fr[0], r01 = fr[64], r02 = fr[128], r10 = fr[192], r11 = fr[256], r12 = fr[320];
             float r20 = fr[384], r21 = fr[448], r22 = fr[512];
             float G00 = 0.f, G01 = 0.f, G02 = 0.f, G10 = 0.f, G11 = 0.f, G12 = 0.f, G20 = 0.f, G21 = 0.f, G22 = 0.f;
             float T0 = 0.f, T1 = 0.f, T2 = 0.f;
-            for (int i = len - 1; i >= 0; --i) {
-                for (int k = 0; k < n_pts; ++k) {
-                    if (fk->pt_chain[k] != ch || fk->pt_frame[k] != i) continue;
-                    const float g0 = sGcol[(3 * k) * 64], g1 = sGcol[(3 * k + 1) * 64], g2 = sGcol[(3 * k + 2) * 64];
-                    const float ox = fk->pt_off[k][0], oy = fk->pt_off[k][1], oz = fk->pt_off[k][2];
+            const int jb = rfl(fk->chain_begin[ch]), je = rfl(fk->chain_end[ch]);
+            for (int j = je - 1; j >= jb; --j) {
+                const int pb = rfl(fk->joints[j].pt_begin), pe = rfl(fk->joints[j].pt_end);
+                for (int p = pb; p < pe; ++p) {
+                    const float* gin = sGcol + (3 * rfl(fk->points[p].out_k)) * 64;
+                    const float g0 = gin[0], g1 = gin[64], g2 = gin[128];
+                    const float ox = fk->points[p].ox, oy = fk->points[p].oy, oz = fk->points[p].oz;
                     T0 += g0; T1 += g1; T2 += g2;
                     G00 = fmaf(g0, ox, G00); G01 = fmaf(g0, oy, G01); G02 = fmaf(g0, oz, G02);
                     G10 = fmaf(g1, ox, G10); G11 = fmaf(g1, oy, G11); G12 = fmaf(g1, oz, G12);
                     G20 = fmaf(g2, ox, G20); G21 = fmaf(g2, oy, G21); G22 = fmaf(g2, oz, G22);
                 }
-                const float s = sFcol[(2 * (jbase + i)) * 64], c = sFcol[(2 * (jbase + i) + 1) * 64];
-                const float a = fk->a[ch][i], d = fk->d[ch][i];
-                const float sa = fk->sin_alpha[ch][i], ca = fk->cos_alpha[ch][i];
+                const float s = sFcol[(2 * j) * 64], c = sFcol[(2 * j + 1) * 64];
+                const float a = fk->joints[j].a, d = fk->joints[j].d;
+                const float sa = fk->joints[j].sin_alpha, ca = fk->joints[j].cos_alpha;
                 // A_R = [[c, -s ca, s sa], [s, c ca, -c sa], [0, sa, ca]],  a_t = (a c, a s, d)
                 const float a00 = c, a01 = -s * ca, a02 = s * sa, a10 = s, a11 = c * ca, a12 = -c * sa;
                 const float at0 = a * c, at1 = a * s;
@@ -230,7 +323,7 @@ __device__ inline void fk_vjp(fk_cptr fk, const float* sQrow, const float* sXcol
                 // da_t/dtheta = (-a s, a c, 0)
                 const float dth = (M10 * a00 + M11 * a01 + M12 * a02) - (M00 * a10 + M01 * a11 + M02 * a12)
                                   + (u1 * at0 - u0 * at1);
-                gqRow[fk->joint_q[ch][i]] += dth;
+                gqRow[rfl(fk->joints[j].q_index)] += dth;
                 // GR <- GR A_R^T + Gt a_t^T
                 const float n00 = fmaf(G00, a00, fmaf(G01, a01, fmaf(G02, a02, T0 * at0)));
                 const float n01 = fmaf(G00, a10, fmaf(G01, a11, fmaf(G02, a12, T0 * at1)));
@@ -244,13 +337,12 @@ __device__ inline void fk_vjp(fk_cptr fk, const float* sQrow, const float* sXcol
                 G00 = n00; G01 = n01; G02 = n02; G10 = n10; G11 = n11; G12 = n12; G20 = n20; G21 = n21; G22 = n22;
                 r00 = p00; r01 = p01; r02 = p02; r10 = p10; r11 = p11; r12 = p12; r20 = p20; r21 = p21; r22 = p22;
             }
-            jbase += len;
         }
     } else if (kind == DCX_FK_SE2) {
         float s, c;
         sincos_f32(sQrow[2], &s, &c);
         float gx = 0.f, gy = 0.f, gt = 0.f;
-        const int n_pts = fk->n_points;
+        const int n_pts = rfl(fk->n_points);
         for (int k = 0; k < n_pts; ++k) {
             const float kx = fk->keypoints[k][0], ky = fk->keypoints[k][1];
             const float a = sGcol[(2 * k) * 64], b = sGcol[(2 * k + 1) * 64];
@@ -267,7 +359,7 @@ __device__ inline void fk_vjp(fk_cptr fk, const float* sQrow, const float* sXcol
         // M = sum_k g_k k_k^T (3x3); d/dangle = <dR/dangle, M>
         float m00 = 0, m01 = 0, m02 = 0, m10 = 0, m11 = 0, m12 = 0, m20 = 0, m21 = 0, m22 = 0;
         float g0s = 0, g1s = 0, g2s = 0;
-        const int n_pts = fk->n_points;
+        const int n_pts = rfl(fk->n_points);
         for (int k = 0; k < n_pts; ++k) {
             const float kx = fk->keypoints[k][0], ky = fk->keypoints[k][1], kz = fk->keypoints[k][2];
             const float g0 = sGcol[(3 * k) * 64], g1 = sGcol[(3 * k + 1) * 64], g2 = sGcol[(3 * k + 2) * 64];

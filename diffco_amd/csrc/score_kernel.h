@@ -42,7 +42,7 @@ enum { MODE_SCORE = 0,    // score only
 
 struct ScoreArgs {
     const float* rows;        // [S][RS] support rows: D coords, CC weights, (CC>1: sum of weights), pad
-    const dcx_fk_desc* fk;    // device copy
+    const FkProg* fk;         // device copy of the compiled FK program
     const float* q;           // [B][dof]
     const float* upstream;    // [B][C] or null
     float* score;             // [B][C] or null
@@ -56,6 +56,13 @@ struct ScoreArgs {
     int32_t kind;             // DCX_K_* (used by KF_GEN)
     int32_t one_hot;          // MODE_GRAD_UP: >= 0 selects upstream = e_{one_hot} (Jacobian rows); -1 = use upstream[]
     int64_t grad_stride;      // floats between consecutive configurations' gradient rows (dof, or C*dof for jac)
+    float* partial;           // split launch: per (tile, y) partial sums [(tile*ys + y)][ACC][64]; null = finish in-kernel
+    int32_t ys;               // support super-chunks (gridDim.y); block y sweeps [y*s_super, (y+1)*s_super)
+    int32_t s_super;
+#ifdef DCX_TIMING
+    unsigned long long* ts;   // developer builds: [16 slots][8 waves] cycle stamps of block (ts_block,0)
+    unsigned int ts_block;
+#endif
     float kp0, kp1;           // kernel parameters
 };
 
@@ -69,14 +76,27 @@ struct RowLayout {
 typedef const __attribute__((address_space(4))) float* cfloat_ptr;
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+// Developer-only phase timing (build with -DDCX_TIMING): block (0,0) records s_memtime at checkpoints into
+// a device symbol that tools/phase_timing.py reads back.  Not compiled into the shipped library.
+#ifdef DCX_TIMING
+#define DCX_TS(slot)                                                                              \
+    do {                                                                                          \
+        if (a.ts && blockIdx.x == a.ts_block && blockIdx.y == 0 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 8) \
+            a.ts[(slot) * 8 + (threadIdx.x >> 6)] = __builtin_readcyclecounter();                \
+    } while (0)
+#else
+#define DCX_TS(slot) do { } while (0)
+#endif
+
 // Sweep code-generation variants, A/B-measured on MI355X (DESIGN.md "Measured choices"):
 //   bit 0: squared distance accumulated with packed fp32 (v_pk_fma_f32) instead of scalar v_fma_f32
 //   bit 1: scalar loads of the next support row issued before the current row is consumed
 //   bit 2: explicit two-buffer software pipeline (overrides bit 1)
-// Measured on MI355X (profiles/r01_sweep_variants.txt): packed d2 + the explicit two-buffer pipeline (5) is
+//   bit 3: explicit four-buffer pipeline, two rows per stage (overrides bits 1, 2)
+// Measured on MI355X (profiles/r01_sweep_variants.txt): packed d2 + the explicit four-buffer pipeline (9) is
 // fastest at every batch size (headline B=65536: 555 vs 485 (variant 3) vs ~470 (variant 0) M evals/s).
 #ifndef DCX_SWEEP_VARIANT
-#define DCX_SWEEP_VARIANT 5
+#define DCX_SWEEP_VARIANT 9
 #endif
 
 // value K(d2) and g with dK/dx = g * (x - s)
@@ -128,11 +148,12 @@ __device__ __forceinline__ void kernel_eval(float d2, const ScoreArgs& a, float&
 
 // LDS carve (floats).  Everything per-lane is in column layout [e][64].
 struct LdsPlan {
-    int q, x, g, f, red, total;
+    int fk, q, x, g, f, red, total;
 };
 __host__ __device__ inline LdsPlan lds_plan(int dof, int d_fk, int frame_floats, int nw, int acc_floats) {
     LdsPlan p;
-    p.q = 0;
+    p.fk = 0;                              // the FK program itself
+    p.q = p.fk + kFkProgLdsFloats;
     p.x = p.q + ((64 * dof + 3) & ~3);
     p.g = p.x + 64 * d_fk;
     p.f = p.g + 64 * d_fk;
@@ -171,22 +192,28 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
     float* sG = smem + lp.g;
     float* sF = smem + lp.f;
     float* sRed = smem + lp.red;
-    const fk_cptr fk = as_const(a.fk);
 
-    // ---- prologue: stage q rows (coalesced), FK per lane on wave 0 ----------------------
+    DCX_TS(0);
+    // ---- prologue: stage the FK description and the q rows (coalesced), FK per lane on wave 0 ----
+    const fk_cptr fk = stage_fk_prog(a.fk, smem + lp.fk, threadIdx.x, blockDim.x);
     {
         const float* qsrc = a.q + b0 * dof;
         const int n = nb * dof;
         for (int i = threadIdx.x; i < 64 * dof; i += blockDim.x) sQ[i] = qsrc[i < n ? i : (i % dof) + (nb - 1) * dof];
     }
     __syncthreads();
+    DCX_TS(1);
 #if defined(DCX_ABLATE) && (DCX_ABLATE & 2)  // timing ablation only (wrong results): no FK
     if (wave == 0) for (int k = 0; k < a.d_fk; ++k) sX[k * 64 + lane] = sQ[lane * dof + (k % dof)];
 #else
-    if (wave == 0) fk_forward(fk, sQ + lane * dof, sX + lane, sF + lane);
+    fk_forward_trig(fk, sQ + lane * dof, sF + lane, wave, nw);   // all waves: sin/cos of the joint angles
+    __syncthreads();
+    DCX_TS(6);
+    if (wave == 0) fk_forward_chain(fk, sQ + lane * dof, sX + lane, sF + lane);
 #endif
     __syncthreads();
 
+    DCX_TS(2);
     float x[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) x[k] = (k < a.d_fk) ? sX[k * 64 + lane] : 0.0f;
@@ -206,8 +233,10 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
 #pragma unroll
     for (int k = 0; k < D; ++k) gx[k] = 0.0f;
 
-    const int j0 = wave * a.s_chunk;
-    const int j1 = (j0 + a.s_chunk < a.S) ? (j0 + a.s_chunk) : a.S;
+    const int ybase = blockIdx.y * a.s_super;                               // this block's super-chunk
+    const int yend = (ybase + a.s_super < a.S) ? (ybase + a.s_super) : a.S;
+    const int j0 = (ybase + wave * a.s_chunk < yend) ? (ybase + wave * a.s_chunk) : yend;
+    const int j1 = (j0 + a.s_chunk < yend) ? (j0 + a.s_chunk) : yend;
     cfloat_ptr rows = (cfloat_ptr)(uintptr_t)a.rows;
 
     // one support row against this lane's configuration; `r` is wave-uniform (SGPRs)
@@ -266,32 +295,44 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
         for (int e = 0; e < USED; ++e) dst[e] = r[e];
     };
 
-#if DCX_SWEEP_VARIANT & 4
-    // Explicit two-buffer software pipeline.  Scalar loads return out of order, so the only wait the
-    // hardware offers is "all of them" (lgkmcnt(0)); it is therefore placed BEFORE the next row's loads are
-    // issued: at that point only the previous prefetch (issued one whole VALU body earlier) is in flight.
-    //   wait -> issue B -> body(A) -> wait -> issue A' -> body(B) -> ...
+#if DCX_SWEEP_VARIANT & 8
+    // Explicit software pipeline, two rows per stage (4 row buffers): the wait before a stage covers loads
+    // issued TWO row bodies earlier, which is what hides an L2-latency scalar miss when only a few waves
+    // share a SIMD (small batches).  wait -> issue {C,D} -> body(A), body(B) -> wait -> issue {A,B} -> body(C), body(D)
     if (j0 < j1) {
-        float rowA[L::RS], rowB[L::RS];
+        float rowA[L::RS], rowB[L::RS], rowC[L::RS], rowD[L::RS];
+        const int jl = j1 - 1;  // clamp target for the look-ahead loads (harmless re-reads at the end)
         load_row(rowA, j0);
+        load_row(rowB, (j0 + 1 < j1) ? j0 + 1 : jl);
         int j = j0;
-        for (; j + 1 < j1; j += 2) {
-            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): rowA has landed
+        for (; j + 3 < j1; j += 4) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_sched_barrier(0);
-            load_row(rowB, j + 1);
+            load_row(rowC, j + 2);
+            load_row(rowD, j + 3);
             __builtin_amdgcn_sched_barrier(0);
             pair(rowA);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_waitcnt(0xC07F);  // rowB has landed (issued a full body ago)
-            __builtin_amdgcn_sched_barrier(0);
-            load_row(rowA, (j + 2 < j1) ? j + 2 : j + 1);
-            __builtin_amdgcn_sched_barrier(0);
             pair(rowB);
             __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_sched_barrier(0);
+            load_row(rowA, (j + 4 < j1) ? j + 4 : jl);
+            load_row(rowB, (j + 5 < j1) ? j + 5 : jl);
+            __builtin_amdgcn_sched_barrier(0);
+            pair(rowC);
+            pair(rowD);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        // up to three rows left: rowA / rowB already hold rows j and j+1
         if (j < j1) pair(rowA);
+        if (j + 1 < j1) pair(rowB);
+        if (j + 2 < j1) {
+            load_row(rowC, j + 2);
+            pair(rowC);
+        }
     }
-#elif DCX_SWEEP_VARIANT & 2
+#elif DCX_SWEEP_VARIANT & 4
+    // Explicit two-buffer software pipeline.#elif DCX_SWEEP_VARIANT & 2
     // software-pipelined: the scalar loads of row j+1 are in flight while row j is consumed
     if (j0 < j1) {
         float cur[L::RS], nxt[L::RS];
@@ -313,6 +354,7 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
     }
 #endif
 
+    DCX_TS(3);
     // ---- meet the NW partial sums in LDS; wave 0 finishes --------------------------------
     if (nw > 1) {
         float* mine = sRed + (size_t)wave * ACC * 64 + lane;
@@ -335,6 +377,20 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
         }
     }
 
+    DCX_TS(4);
+    if (a.partial != nullptr) {
+        // split launch (small batches): this block saw only its super-chunk; score_finish_kernel adds the
+        // ys partial rows in a fixed order (deterministic) and applies J^T
+        float* out = a.partial + ((size_t)blockIdx.x * a.ys + blockIdx.y) * ACC * 64 + lane;
+#pragma unroll
+        for (int c = 0; c < CC; ++c) out[c * 64] = sc[c];
+        if constexpr (GRAD) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) out[(CC + k) * 64] = gx[k];
+        }
+        return;
+    }
+
     if (a.score != nullptr && lane < nb) {
 #pragma unroll
         for (int c = 0; c < CC; ++c) a.score[(b0 + lane) * CC + c] = sc[c];
@@ -354,8 +410,9 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
 #if defined(DCX_ABLATE) && (DCX_ABLATE & 1)  // timing ablation only (wrong results): no J^T
         for (int i = 0; i < dof; ++i) gq[lane * dof + i] = sG[(i % a.d_fk) * 64 + lane];
 #else
-        fk_vjp(fk, sQ + lane * dof, sX + lane, sF + lane, sG + lane, gq + lane * dof);
+        fk_vjp(fk, sQ + lane * dof, sF + lane, sG + lane, gq + lane * dof);
 #endif
+        DCX_TS(5);
         // rows -> HBM, coalesced (LDS ops of one wave complete in order; no other wave is alive)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -368,5 +425,19 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
         }
     }
 }
+
+// Second half of a split launch: one wave per 64-configuration tile adds the ys partial rows, redoes the
+// (cheap) FK for its frames and applies J^T.  Runtime D and C — this kernel is not on the VALU-bound path.
+struct FinishArgs {
+    const float* partial;
+    const FkProg* fk;
+    const float* q;
+    const float* upstream;   // C == 1 only: scales the gradient row
+    float* score;
+    float* grad;
+    int64_t B;
+    int64_t grad_stride;
+    int32_t ys, acc, C, Dt, dof, d_fk, frame_floats, want_grad;
+};
 
 }  // namespace dcx

@@ -36,21 +36,46 @@ def child(args):
             st = Ct.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
             def launch():
+                cur = Ct.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
                 _lib.check(lib.dcx_score_grad(m._h, Ct.c_void_p(q.data_ptr()), w["B"], None,
-                                              Ct.c_void_p(score.data_ptr()), Ct.c_void_p(grad.data_ptr()), st))
+                                              Ct.c_void_p(score.data_ptr()), Ct.c_void_p(grad.data_ptr()), cur))
             times = {nw: [] for nw in args.nw}
+            graphs = {}
+            if args.graph:
+                # capture `inner` back-to-back launches per geometry into a HIP graph: replay time is GPU time,
+                # free of the Python/ctypes launch overhead that dominates below ~50 us per call
+                side = torch.cuda.Stream(dev)
+                for nw in args.nw:
+                    if nw:
+                        os.environ["DCX_NW"] = str(nw)
+                    else:
+                        os.environ.pop("DCX_NW", None)
+                    with torch.cuda.stream(side):   # warm up ON the capture stream (per-stream scratch, lazy init)
+                        launch()
+                    torch.cuda.synchronize()
+                    gr = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gr, stream=side):
+                        st = Ct.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+                        for _ in range(args.inner):
+                            launch()
+                    graphs[nw] = gr
+                st = Ct.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             for rnd in range(args.rounds + 1):
                 for nw in args.nw:
                     if nw:
                         os.environ["DCX_NW"] = str(nw)
                     else:
                         os.environ.pop("DCX_NW", None)
-                    launch()
+                    if not args.graph:
+                        launch()
                     torch.cuda.synchronize()
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                    for _ in range(args.inner):
-                        launch()
+                    if args.graph:
+                        graphs[nw].replay()
+                    else:
+                        for _ in range(args.inner):
+                            launch()
                     e1.record()
                     torch.cuda.synchronize()
                     if rnd:
@@ -72,6 +97,7 @@ def main():
     ap.add_argument("--nw", nargs="+", type=int, default=[0], help="waves per block; 0 = library heuristic")
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--inner", type=int, default=20)
+    ap.add_argument("--graph", action="store_true", help="time HIP-graph replays (GPU time without host launch overhead)")
     ap.add_argument("--child", action="store_true")
     args = ap.parse_args()
     if args.child:
@@ -80,7 +106,7 @@ def main():
     for libp in args.libs:
         env = dict(os.environ, DCX_LIB=os.path.abspath(libp))
         cmd = [sys.executable, os.path.abspath(__file__), "--child", "--workloads", *args.workloads, "--batches",
-               *map(str, args.batches), "--nw", *map(str, args.nw), "--rounds", str(args.rounds), "--inner", str(args.inner)]
+               *map(str, args.batches), "--nw", *map(str, args.nw), "--rounds", str(args.rounds), "--inner", str(args.inner)] + (["--graph"] if args.graph else [])
         r = subprocess.run(cmd, env=env, capture_output=True, text=True)
         if r.returncode != 0:
             print(f"[{libp}] FAILED\n{r.stderr[-2000:]}")
