@@ -155,6 +155,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather of scores")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="exercise the N>1 code path (process group + overlapped all-gather) even with one rank")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -168,9 +170,12 @@ def main():
     _lib.require_gpu()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     w = make_workload(args.workload, args.batch, dev, seed=rank)
     m, q, B, C, dof = w["model"], w["q"], w["B"], w["C"], w["dof"]
@@ -178,20 +183,20 @@ def main():
     lib = _lib.load()
     score = torch.empty((B, C), device=dev, dtype=torch.float32)
     grad = torch.empty((B, dof), device=dev, dtype=torch.float32)
-    gathered = [torch.empty((world * B, C), device=dev, dtype=torch.float32) for _ in range(2)] if world > 1 else None
+    gathered = [torch.empty((world * B, C), device=dev, dtype=torch.float32) for _ in range(2)] if multi else None
     score2 = [torch.empty_like(score) for _ in range(2)]
-    comm_stream = torch.cuda.Stream(dev) if world > 1 else None
+    comm_stream = torch.cuda.Stream(dev) if multi else None
     qp, gp = Ct.c_void_p(q.data_ptr()), Ct.c_void_p(grad.data_ptr())
 
     def step(i, pending):
-        out = score2[i & 1] if world > 1 else score
-        if world > 1 and pending[i & 1] is not None:
+        out = score2[i & 1] if multi else score
+        if multi and pending[i & 1] is not None:
             pending[i & 1].wait()  # this buffer pair's gather (two steps ago) must be done before it is rewritten
             pending[i & 1] = None
         # ONE launch of the hot path on torch's current stream
         st = Ct.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(lib.dcx_score_grad(m._h, qp, B, None, Ct.c_void_p(out.data_ptr()), gp, st))
-        if world > 1 and not args.no_gather:
+        if multi and not args.no_gather:
             # all-gather of this step's scores on a side stream, overlapped with the next step's sweep
             ev = torch.cuda.Event()
             ev.record()
@@ -210,7 +215,7 @@ def main():
     for i in range(args.warmup):
         step(i, pending)
     drain(pending)
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize(dev)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -221,13 +226,13 @@ def main():
         step(i, pending)
     e1.record()      # closes the sweep kernels on the launch stream (HIP events, same stream as the launches)
     drain(pending)
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize(dev)
     wall = time.perf_counter() - t0
     kern_ms = e0.elapsed_time(e1) / args.steps  # average launch-to-launch duration of the sweep kernel
 
-    if world > 1:
+    if multi:
         tt = torch.tensor([wall], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall = float(tt.item())
@@ -270,7 +275,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
