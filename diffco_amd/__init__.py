@@ -12,5 +12,7 @@ from .deprecated import MultiDiffCo, DiffCoBeta  # noqa: F401
 from . import deprecated  # noqa: F401
 from . import optim  # noqa: F401
 from . import sharded  # noqa: F401
+from . import traj  # noqa: F401
+from .traj import fused_adam_traj_optimize  # noqa: F401
 
-__all__ = ["kernel", "model", "utils", "optim", "sharded", "deprecated", "DiffCo", "MultiDiffCo", "DiffCoBeta"]
+__all__ = ["kernel", "model", "utils", "optim", "sharded", "traj", "fused_adam_traj_optimize", "deprecated", "DiffCo", "MultiDiffCo", "DiffCoBeta"]

@@ -30,11 +30,29 @@ SYMBOLS = {
     "dcx_score": (C.c_int, [C.c_void_p, _c_fp, C.c_int64, _c_fp, C.c_void_p]),
     "dcx_score_grad": (C.c_int, [C.c_void_p, _c_fp, C.c_int64, _c_fp, _c_fp, _c_fp, C.c_void_p]),
     "dcx_score_jac": (C.c_int, [C.c_void_p, _c_fp, C.c_int64, _c_fp, _c_fp, C.c_void_p]),
+    "dcx_score_hinge_grad": (C.c_int, [C.c_void_p, _c_fp, C.c_int64, C.c_float, C.c_float, _c_fp, _c_fp, C.c_void_p]),
+    "dcx_traj_adam_step": (C.c_int, [C.c_int, C.POINTER(FkDesc), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "dcx_traj_adam_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "dcx_fkine": (C.c_int, [C.c_int, C.POINTER(FkDesc), _c_fp, C.c_int64, _c_fp, C.c_void_p]),
     "dcx_fkine_vjp": (C.c_int, [C.c_int, C.POINTER(FkDesc), _c_fp, _c_fp, C.c_int64, _c_fp, C.c_void_p]),
     "dcx_kernel_matrix": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_float), _c_fp, C.c_int64, _c_fp, C.c_int64,
                                     C.c_int32, _c_fp, C.c_void_p]),
 }
+
+
+
+class TrajState(C.Structure):
+    """ctypes mirror of dcx_traj_state (include/dcx.h)"""
+    _fields_ = [("n_paths", C.c_int32), ("n_waypoints", C.c_int32)] + [
+        (n, C.c_void_p) for n in ("path", "adam_m", "adam_v", "limits", "col_score", "col_grad", "stats", "lowest_loss",
+                                  "lowest_obj", "lowest_path", "best_valid_obj", "best_valid_path", "done", "steps")]
+
+
+class TrajOpts(C.Structure):
+    """ctypes mirror of dcx_traj_opts (include/dcx.h)"""
+    _fields_ = [(n, C.c_float) for n in ("lr", "beta1", "beta2", "eps", "w_diff", "w_collision", "w_max_move",
+                                         "w_joint_limit", "safety_margin", "max_speed", "valid_tol", "grad_tol")]
+
 
 _lib = None
 

@@ -148,6 +148,16 @@ class ScoreModel:
             _lib.check(self._lib.dcx_score_jac(self._h, _ptr(q32), B, _ptr(out), _ptr(jac), _stream(self.dev)))
         return out, jac
 
+    def score_hinge_grad_raw(self, q32, margin, weight):
+        """(score [B,1], weight * 1[score > margin] * dscore/dq [B,dof]) — the optimisers' collision term, one launch"""
+        B = q32.shape[0]
+        out = torch.empty((B, self.C), device=self.dev, dtype=torch.float32)
+        grad = torch.empty((B, self.dof), device=self.dev, dtype=torch.float32)
+        with torch.cuda.device(self.dev):
+            _lib.check(self._lib.dcx_score_hinge_grad(self._h, _ptr(q32), B, float(margin), float(weight), _ptr(out),
+                                                      _ptr(grad), _stream(self.dev)))
+        return out, grad
+
     # autograd-aware ------------------------------------------------------------------------
     def score(self, q: torch.Tensor) -> torch.Tensor:
         """[B, C] scores for q [B, dof]; differentiable w.r.t. q (gradient from the fused HIP pass)."""

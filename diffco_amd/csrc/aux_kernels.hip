@@ -109,9 +109,11 @@ __global__ __launch_bounds__(64) void score_finish_kernel(const FinishArgs a) {
     float* sG = smem + lp.g;
     float* sF = smem + lp.f;
     const float* part = a.partial + (size_t)blockIdx.x * a.ys * a.acc * 64 + lane;
+    float score0 = 0.0f;
     for (int c = 0; c < a.C; ++c) {
         float v = 0.0f;
         for (int y = 0; y < a.ys; ++y) v += part[((size_t)y * a.acc + c) * 64];
+        if (c == 0) score0 = v;
         if (a.score != nullptr && lane < nb) a.score[(b0 + lane) * a.C + c] = v;
     }
     if (!a.want_grad) return;
@@ -123,6 +125,7 @@ __global__ __launch_bounds__(64) void score_finish_kernel(const FinishArgs a) {
     }
     float scale = 1.0f;
     if (a.C == 1 && a.upstream != nullptr) scale = a.upstream[b0 + (lane < nb ? lane : nb - 1)];
+    if (a.C == 1 && a.hinge) scale = (score0 - a.hinge_margin > 0.0f) ? a.hinge_weight : 0.0f;
     for (int k = 0; k < a.d_fk; ++k) {
         float v = 0.0f;
         for (int y = 0; y < a.ys; ++y) v += part[((size_t)y * a.acc + a.C + k) * 64];

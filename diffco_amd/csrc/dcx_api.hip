@@ -240,8 +240,13 @@ float* split_scratch(const dcx_model* m, hipStream_t st, size_t bytes) {
     return slot->ptr;
 }
 
+struct Hinge {
+    int on = 0;
+    float margin = 0.f, weight = 0.f;
+};
+
 int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstream, float* score, float* grad,
-              int mode, int one_hot, int64_t grad_stride, hipStream_t st) {
+              int mode, int one_hot, int64_t grad_stride, hipStream_t st, Hinge hinge = Hinge()) {
     if (B == 0) return DCX_OK;
     const int d_fk = m->fk.n_points * m->fk.point_dim;
     const int acc = (mode == MODE_SCORE ? 0 : m->Dt) + m->C;
@@ -273,6 +278,9 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
     a.grad_stride = grad_stride;
     a.kp0 = m->kp0;
     a.kp1 = m->kp1;
+    a.hinge = hinge.on;
+    a.hinge_margin = hinge.margin;
+    a.hinge_weight = hinge.weight;
 #ifdef DCX_TIMING
     if (!g_ts_dev && hipMalloc((void**)&g_ts_dev, sizeof(unsigned long long) * 16 * 8) == hipSuccess)
         (void)hipMemset(g_ts_dev, 0, sizeof(unsigned long long) * 16 * 8);
@@ -305,6 +313,9 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
         f.d_fk = d_fk;
         f.frame_floats = m->frame_floats;
         f.want_grad = (mode != MODE_SCORE);
+        f.hinge = hinge.on;
+        f.hinge_margin = hinge.margin;
+        f.hinge_weight = hinge.weight;
         e = launch_score_finish(f, nblk, sizeof(float) * lds_plan(a.dof, d_fk, m->frame_floats, 1, 0).total, st);
     }
     if (e != hipSuccess) return fail_hip(e, "split score launch");
@@ -467,6 +478,19 @@ int dcx_score_grad(const dcx_model* m, const float* q, int64_t B, const float* u
     return run_score(m, q, B, upstream, score, grad, mode, -1, m->fk.dof, (hipStream_t)stream);
 }
 
+int dcx_score_hinge_grad(const dcx_model* m, const float* q, int64_t B, float margin, float weight, float* score,
+                         float* grad, void* stream) {
+    if (!m) return fail(DCX_ERR_INVALID, "model is NULL");
+    if (m->C != 1) return fail(DCX_ERR_UNSUPPORTED, "dcx_score_hinge_grad needs a C == 1 model");
+    if (B < 0 || (B > 0 && (!q || !grad))) return fail(DCX_ERR_INVALID, "q / grad is NULL or B < 0");
+    if (int rc = set_device(m->device)) return rc;
+    Hinge h;
+    h.on = 1;
+    h.margin = margin;
+    h.weight = weight;
+    return run_score(m, q, B, nullptr, score, grad, MODE_GRAD_ROW, -1, m->fk.dof, (hipStream_t)stream, h);
+}
+
 int dcx_score_jac(const dcx_model* m, const float* q, int64_t B, float* score, float* jac, void* stream) {
     if (!m) return fail(DCX_ERR_INVALID, "model is NULL");
     if (B < 0 || (B > 0 && (!q || !jac))) return fail(DCX_ERR_INVALID, "q / jac is NULL or B < 0");
@@ -477,6 +501,56 @@ int dcx_score_jac(const dcx_model* m, const float* q, int64_t B, float* score, f
         int rc = run_score(m, q, B, nullptr, c == 0 ? score : nullptr, jac + (int64_t)c * m->fk.dof, MODE_GRAD_UP, c,
                            (int64_t)m->C * m->fk.dof, (hipStream_t)stream);
         if (rc) return rc;
+    }
+    return DCX_OK;
+}
+
+static int check_traj(const dcx_traj_state* st, const dcx_traj_opts* opt, int dof) {
+    if (!st || !opt) return fail(DCX_ERR_INVALID, "traj state / opts is NULL");
+    if (st->n_paths < 0 || st->n_waypoints < 2 || st->n_waypoints > 1024)
+        return fail(DCX_ERR_UNSUPPORTED, "trajectory step needs 2 <= n_waypoints <= 1024 and n_paths >= 0");
+    if (st->n_paths > 0 && (!st->path || !st->adam_m || !st->adam_v || !st->limits || !st->col_score || !st->col_grad ||
+                            !st->stats || !st->lowest_loss || !st->lowest_obj || !st->lowest_path || !st->best_valid_obj ||
+                            !st->best_valid_path || !st->done || !st->steps))
+        return fail(DCX_ERR_INVALID, "a trajectory state pointer is NULL");
+    if (!(opt->lr > 0.f) || !(opt->beta1 >= 0.f && opt->beta1 < 1.f) || !(opt->beta2 >= 0.f && opt->beta2 < 1.f))
+        return fail(DCX_ERR_INVALID, "Adam options out of range");
+    (void)dof;
+    return DCX_OK;
+}
+
+int dcx_traj_adam_step(int device, const dcx_fk_desc* fk, const dcx_traj_state* st, const dcx_traj_opts* opt,
+                       int32_t step, void* stream) {
+    if (!fk) return fail(DCX_ERR_INVALID, "fk is NULL");
+    if (step < 1) return fail(DCX_ERR_INVALID, "step is 1-based");
+    if (int rc = check_fk(*fk)) return rc;
+    if (int rc = check_traj(st, opt, fk->dof)) return rc;
+    if (int rc = set_device(device)) return rc;
+    FkProg* dev = nullptr;
+    if (int rc = fk_device_copy(device, *fk, &dev)) return rc;
+    hipError_t e = launch_traj_adam_step(dev, *fk, *st, *opt, step, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "trajectory step launch");
+    return DCX_OK;
+}
+
+int dcx_traj_adam_run(const dcx_model* m, const dcx_traj_state* st, const dcx_traj_opts* opt, int32_t first_step,
+                      int32_t n_iters, void* stream) {
+    if (!m) return fail(DCX_ERR_INVALID, "model is NULL");
+    if (m->C != 1) return fail(DCX_ERR_UNSUPPORTED, "dcx_traj_adam_run needs a C == 1 model");
+    if (first_step < 1 || n_iters < 0) return fail(DCX_ERR_INVALID, "first_step is 1-based, n_iters >= 0");
+    if (int rc = check_traj(st, opt, m->fk.dof)) return rc;
+    if (int rc = set_device(m->device)) return rc;
+    const int64_t B = (int64_t)st->n_paths * st->n_waypoints;
+    Hinge h;
+    h.on = 1;
+    h.margin = opt->safety_margin;
+    h.weight = opt->w_collision;
+    for (int it = 0; it < n_iters; ++it) {
+        int rc = run_score(m, st->path, B, nullptr, const_cast<float*>(st->col_score), const_cast<float*>(st->col_grad),
+                           MODE_GRAD_ROW, -1, m->fk.dof, (hipStream_t)stream, h);
+        if (rc) return rc;
+        hipError_t e = launch_traj_adam_step(m->fk_dev, m->fk, *st, *opt, first_step + it, (hipStream_t)stream);
+        if (e != hipSuccess) return fail_hip(e, "trajectory step launch");
     }
     return DCX_OK;
 }

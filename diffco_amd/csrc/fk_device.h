@@ -116,7 +116,7 @@ __device__ __forceinline__ fk_cptr stage_fk_prog(const FkProg* g, float* lds, in
     const uint32_t* src = reinterpret_cast<const uint32_t*>(g);
     uint32_t* dst = reinterpret_cast<uint32_t*>(lds);
     for (int i = tid; i < kFkProgDwords; i += nthreads) dst[i] = src[i];
-    return (fk_cptr)(uint32_t)(uintptr_t)lds;
+    return (fk_cptr)(uintptr_t)(uint32_t)(uintptr_t)lds;  // generic -> LDS: the low 32 bits are the LDS offset
 }
 
 // sin and cos of one angle: Cody-Waite reduction by pi/2 (three fp32 terms, exact products through fma)

@@ -64,6 +64,8 @@ struct ScoreArgs {
     unsigned int ts_block;
 #endif
     float kp0, kp1;           // kernel parameters
+    int32_t hinge;            // C == 1: gradient of weight * clamp(score - margin, 0) instead of the score's
+    float hinge_margin, hinge_weight;
 };
 
 template <int D, int CC>
@@ -400,6 +402,7 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
         float scale = 1.0f;
         if constexpr (CC == 1 && MODE == MODE_GRAD_ROW) {
             if (a.upstream != nullptr) scale = a.upstream[b0 + (lane < nb ? lane : nb - 1)];
+            if (a.hinge) scale = (sc[0] - a.hinge_margin > 0.0f) ? a.hinge_weight : 0.0f;
         }
 #pragma unroll
         for (int k = 0; k < D; ++k)
@@ -438,6 +441,8 @@ struct FinishArgs {
     int64_t B;
     int64_t grad_stride;
     int32_t ys, acc, C, Dt, dof, d_fk, frame_floats, want_grad;
+    int32_t hinge;
+    float hinge_margin, hinge_weight;
 };
 
 }  // namespace dcx

@@ -1,0 +1,203 @@
+// traj_kernels.hip — one fused Adam step on R waypoint paths.
+//
+// Batched restatement of the loop body of the reference's adam_traj_optimize (optim.py:86-127): the collision
+// term (score and hinge gradient) comes from the fused score kernel; everything else of the step — the FK of
+// the waypoints, the path-length and max-move terms that couple neighbouring waypoints, the joint-limit term,
+// J^T, endpoint masking, the Adam update and the best-so-far bookkeeping — happens here, in one launch, with
+// no host synchronisation (the reference syncs every iteration through .data.numpy(), optim.py:107-118).
+//
+// Mapping: one block per path, one lane per waypoint (W <= 1024); a wave owns 64 consecutive waypoints and
+// keeps their control points in its own LDS slab, so a waypoint reads its neighbours' control points from LDS.
+#include <cmath>
+
+#include "dcx_internal.h"
+
+namespace dcx {
+namespace {
+
+struct TrajArgs {
+    const FkProg* fk;
+    dcx_traj_state st;
+    dcx_traj_opts opt;
+    int32_t step;
+    int32_t dof, d_fk, n_points, point_dim, frame_floats;
+    float bias1, bias2_sqrt;  // 1 - beta1^t, sqrt(1 - beta2^t)
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(1024) void traj_adam_step_kernel(const TrajArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int r = blockIdx.x;
+    if (a.st.done[r]) return;  // frozen path
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const int W = a.st.n_waypoints, dof = a.dof, D = a.d_fk;
+    const int w = tid;                       // this lane's waypoint
+    const bool live = w < W;
+
+    // LDS carve: program | q rows [nw*64][dof] | gq rows | per-wave slabs X, G, F | reduction scratch
+    float* sP = smem;
+    float* sQ = sP + kFkProgLdsFloats;
+    float* sGQ = sQ + nw * 64 * dof;
+    float* sX = sGQ + nw * 64 * dof;
+    float* sG = sX + nw * 64 * D;
+    float* sF = sG + nw * 64 * D;
+    float* sR = sF + nw * 64 * a.frame_floats;  // [6][16] partial sums + flags
+
+    const fk_cptr fk = stage_fk_prog(a.fk, sP, tid, blockDim.x);
+    const float* path = a.st.path + (size_t)r * W * dof;
+    for (int i = tid; i < nw * 64 * dof; i += blockDim.x) sQ[i] = path[i < W * dof ? i : (i % dof) + (W - 1) * dof];
+    __syncthreads();
+
+    float* myQ = sQ + (wave * 64 + lane) * dof;
+    float* myX = sX + wave * 64 * D + lane;
+    float* myG = sG + wave * 64 * D + lane;
+    float* myF = sF + wave * 64 * a.frame_floats + lane;
+    fk_forward_trig(fk, myQ, myF, 0, 1);
+    fk_forward_chain(fk, myQ, myX, myF);
+    __syncthreads();
+
+    // control point coordinate k of waypoint v
+    auto X = [&](int k, int v) { return sX[(v >> 6) * 64 * D + k * 64 + (v & 63)]; };
+
+    // ---- path-length and max-move terms: gradient w.r.t. this waypoint's control points ---------------
+    const float v2 = a.opt.max_speed * a.opt.max_speed;
+    float obj = 0.f, mmv = 0.f;
+    const int pd = a.point_dim;
+    for (int p = 0; p < a.n_points; ++p) {
+        float dn[3] = {0.f, 0.f, 0.f}, dp[3] = {0.f, 0.f, 0.f};
+        float n2n = 0.f, n2p = 0.f;
+        for (int c = 0; c < pd; ++c) {
+            const int k = p * pd + c;
+            const float xc = live ? X(k, w) : 0.f;
+            if (live && w + 1 < W) { dn[c] = X(k, w + 1) - xc; n2n = fmaf(dn[c], dn[c], n2n); }
+            if (live && w >= 1)    { dp[c] = xc - X(k, w - 1); n2p = fmaf(dp[c], dp[c], n2p); }
+        }
+        const float mn = n2n - v2, mp = n2p - v2;
+        if (live && w + 1 < W) {   // each segment is counted once, by its left waypoint
+            obj += n2n;
+            if (mn > 0.f) mmv += mn;
+        }
+        const float cn = 2.f * (a.opt.w_diff + (mn > 0.f ? a.opt.w_max_move : 0.f));
+        const float cp = 2.f * (a.opt.w_diff + (mp > 0.f ? a.opt.w_max_move : 0.f));
+        for (int c = 0; c < pd; ++c) myG[(p * pd + c) * 64] = cp * dp[c] - cn * dn[c];
+    }
+    // J^T of that gradient (per lane; frames of this lane are in its slab)
+    float* myGQ = sGQ + (wave * 64 + lane) * dof;
+    fk_vjp(fk, myQ, myF, myG, myGQ);
+
+    // ---- joint limits, collision gradient, endpoint mask, Adam ----------------------------------------
+    float jl = 0.f, gn2 = 0.f, col = 0.f;
+    if (live) {
+        const size_t base = ((size_t)r * W + w) * dof;
+        const bool endpoint = (w == 0) || (w == W - 1);
+        const float sc = a.st.col_score[(size_t)r * W + w] - a.opt.safety_margin;
+        if (sc > 0.f) col = sc;
+        for (int i = 0; i < dof; ++i) {
+            const float q = myQ[i];
+            const float lo = a.st.limits[2 * i], hi = a.st.limits[2 * i + 1];
+            float g = myGQ[i] + a.st.col_grad[base + i];
+            if (q < lo) { jl += lo - q; g -= a.opt.w_joint_limit; }
+            if (q > hi) { jl += q - hi; g += a.opt.w_joint_limit; }
+            if (endpoint) g = 0.f;  // p.grad[[0, -1]] = 0 (optim.py:102)
+            gn2 = fmaf(g, g, gn2);
+            float m = a.st.adam_m[base + i], v = a.st.adam_v[base + i];
+            m = fmaf(a.opt.beta1, m, (1.f - a.opt.beta1) * g);
+            v = fmaf(a.opt.beta2, v, (1.f - a.opt.beta2) * g * g);
+            const float denom = sqrtf(v) / a.bias2_sqrt + a.opt.eps;
+            const float qn = q - (a.opt.lr / a.bias1) * (m / denom);
+            a.st.adam_m[base + i] = m;
+            a.st.adam_v[base + i] = v;
+            a.st.path[base + i] = qn;
+            myQ[i] = qn;  // keep the new row for the bookkeeping copies below
+        }
+    }
+
+    // ---- block sums -> loss terms ------------------------------------------------------------------------
+    float part[5] = {obj, mmv, jl, col, gn2};
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const float s = wave_sum(part[t]);
+        if (lane == 0) sR[t * 16 + wave] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float tot[5];
+        for (int t = 0; t < 5; ++t) {
+            float s = 0.f;
+            for (int k = 0; k < nw; ++k) s += sR[t * 16 + k];
+            tot[t] = s;
+        }
+        const float objective = a.opt.w_diff * tot[0];
+        const float constraint = a.opt.w_collision * tot[3] + a.opt.w_max_move * tot[1] + a.opt.w_joint_limit * tot[2];
+        const float loss = objective + constraint;
+        const float gnorm = sqrtf(tot[4]);
+        float* st = a.st.stats + (size_t)r * 8;
+        st[0] = loss; st[1] = objective; st[2] = constraint; st[3] = gnorm; st[4] = tot[3]; st[5] = tot[1]; st[6] = tot[2];
+        st[7] = 0.f;
+        int flags = 0;
+        if (loss < a.st.lowest_loss[r]) {  // optim.py:107-112 (solution = p AFTER the step)
+            a.st.lowest_loss[r] = loss;
+            a.st.lowest_obj[r] = objective;
+            flags |= 1;
+        }
+        if (constraint <= a.opt.valid_tol) {  // optim.py:113-118
+            if (objective < a.st.best_valid_obj[r]) {
+                a.st.best_valid_obj[r] = objective;
+                flags |= 2;
+            }
+            if (gnorm < a.opt.grad_tol) a.st.done[r] = 1;  // optim.py:126-127
+        }
+        a.st.steps[r] += 1;
+        sR[96] = __int_as_float(flags);
+    }
+    __syncthreads();
+    const int flags = __float_as_int(sR[96]);
+    if (flags) {
+        float* lo = a.st.lowest_path + (size_t)r * W * dof;
+        float* bv = a.st.best_valid_path + (size_t)r * W * dof;
+        for (int i = tid; i < W * dof; i += blockDim.x) {
+            const float v = sQ[i];
+            if (flags & 1) lo[i] = v;
+            if (flags & 2) bv[i] = v;
+        }
+    }
+}
+
+}  // namespace
+
+size_t traj_lds_bytes(const dcx_fk_desc& fk, int nw) {
+    const int d_fk = fk.n_points * fk.point_dim;
+    return sizeof(float) * (kFkProgLdsFloats + 2 * nw * 64 * fk.dof + 2 * nw * 64 * d_fk + nw * 64 * fk_frame_floats(fk) + 128);
+}
+
+hipError_t launch_traj_adam_step(const FkProg* fk_dev, const dcx_fk_desc& fk, const dcx_traj_state& st,
+                                 const dcx_traj_opts& opt, int step, hipStream_t stream) {
+    if (st.n_paths == 0) return hipSuccess;
+    TrajArgs a;
+    a.fk = fk_dev;
+    a.st = st;
+    a.opt = opt;
+    a.step = step;
+    a.dof = fk.dof;
+    a.d_fk = fk.n_points * fk.point_dim;
+    a.n_points = fk.n_points;
+    a.point_dim = fk.point_dim;
+    a.frame_floats = fk_frame_floats(fk);
+    a.bias1 = (float)(1.0 - pow((double)opt.beta1, (double)step));
+    a.bias2_sqrt = (float)sqrt(1.0 - pow((double)opt.beta2, (double)step));
+    const int nw = (st.n_waypoints + 63) / 64;
+    const size_t lds = traj_lds_bytes(fk, nw);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)traj_adam_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    traj_adam_step_kernel<<<dim3((unsigned)st.n_paths), dim3(64 * nw), lds, stream>>>(a);
+    return hipGetLastError();
+}
+
+}  // namespace dcx

@@ -16,8 +16,8 @@
  *     default stream) and does NOT synchronise.
  *   - Return value: 0 = DCX_OK, otherwise an error code; text via dcx_last_error()
  *     (thread-local).  Nothing throws or exits across the ABI.
- *   - A model handle is immutable after creation: concurrent calls on distinct streams
- *     are legal.
+ *   - A model handle's numerical state is immutable after creation: concurrent calls on distinct
+ *     streams are legal (small-batch launches keep one internal scratch buffer per stream).
  */
 #ifndef DCX_H
 #define DCX_H
@@ -138,6 +138,57 @@ int dcx_score_grad(const dcx_model* m, const float* q, int64_t B, const float* u
  * (torch.autograd.functional.jacobian callers, optim.py:211-216).                          */
 int dcx_score_jac(const dcx_model* m, const float* q, int64_t B, float* score, float* jac,
                   void* stream);
+
+/* score as above (C == 1 models only) and the gradient of the hinge penalty the optimisers build on it:
+ *   grad[b, :] = weight * 1[score_b - margin > 0] * d score_b / d q_b
+ * i.e. d/dq of  weight * clamp(dist_est(q) - safety_margin, min=0).sum()  (optim.py:88-89, 97-101) in the
+ * same pass that produces the score.  score may be NULL.                                                */
+int dcx_score_hinge_grad(const dcx_model* m, const float* q, int64_t B, float margin, float weight,
+                         float* score, float* grad, void* stream);
+
+/* ---- fused Adam trajectory step (caller of the path) ------------------------------- */
+/* Batched restatement of the loop body of adam_traj_optimize (optim.py:86-127): R independent paths of W
+ * waypoints are advanced by ONE Adam step on
+ *   loss = w_diff * sum |cp[w+1]-cp[w]|^2 + w_collision * sum clamp(score - margin, 0)
+ *        + w_max_move * sum_{segments, points} clamp(|cp[w+1]-cp[w]|^2 - max_speed^2, 0)
+ *        + w_joint_limit * sum (clamp(lo - q, 0) + clamp(q - hi, 0))
+ * with the endpoints' gradient zeroed, plus the reference's bookkeeping (lowest-loss path, best valid path,
+ * per-path stop when constraint <= valid_tol and |grad| < grad_tol).  All pointers are device memory owned by
+ * the caller; every array is dense fp32 unless noted.                                                    */
+typedef struct dcx_traj_state {
+    int32_t n_paths, n_waypoints;      /* R, W (W <= 1024)                                              */
+    float* path;                       /* [R, W, dof]  in/out                                            */
+    float* adam_m;                     /* [R, W, dof]  first moment  (zero before step 1)                */
+    float* adam_v;                     /* [R, W, dof]  second moment (zero before step 1)                */
+    const float* limits;               /* [dof, 2]     joint limits (lo, hi)                             */
+    const float* col_score;            /* [R*W]        dist_est(path) of THIS step (dcx_score*)          */
+    const float* col_grad;             /* [R*W, dof]   hinge gradient of this step (dcx_score_hinge_grad)*/
+    float* stats;                      /* [R, 8] out: loss, objective, constraint, |grad|, collision, max_move, joint_limit, 0 */
+    float* lowest_loss;                /* [R] in/out (+inf before step 1)                                */
+    float* lowest_obj;                 /* [R] out: objective at the lowest-loss step                     */
+    float* lowest_path;                /* [R, W, dof] out: path AFTER the lowest-loss step               */
+    float* best_valid_obj;             /* [R] in/out (+inf before step 1)                                */
+    float* best_valid_path;            /* [R, W, dof] out: path AFTER the best valid step                */
+    int32_t* done;                     /* [R] in/out: 1 = path stopped (frozen); 0 before step 1         */
+    int32_t* steps;                    /* [R] in/out: steps actually taken                               */
+} dcx_traj_state;
+
+typedef struct dcx_traj_opts {
+    float lr, beta1, beta2, eps;       /* torch.optim.Adam defaults: beta 0.9 / 0.999, eps 1e-8          */
+    float w_diff, w_collision, w_max_move, w_joint_limit; /* 1, 10, 10, 10 in the reference (optim.py:19-22) */
+    float safety_margin, max_speed;
+    float valid_tol, grad_tol;         /* 1e-2, 1e-4 (optim.py:114, 126)                                  */
+} dcx_traj_opts;
+
+/* one Adam step; `step` is 1-based (bias correction).  col_score / col_grad must already hold this step's
+ * collision term for the CURRENT path.                                                                   */
+int dcx_traj_adam_step(int device, const dcx_fk_desc* fk, const dcx_traj_state* st, const dcx_traj_opts* opt,
+                       int32_t step, void* stream);
+/* n_iters iterations of {dcx_score_hinge_grad(model, path) -> dcx_traj_adam_step} enqueued back to back from
+ * native code, starting at 1-based step `first_step`; `model` must be a C == 1 model whose transform is the
+ * robot's FK.  st->col_score / st->col_grad are used as scratch ([R*W], [R*W, dof], non-const here).      */
+int dcx_traj_adam_run(const dcx_model* model, const dcx_traj_state* st, const dcx_traj_opts* opt,
+                      int32_t first_step, int32_t n_iters, void* stream);
 
 /* ---- pieces of the path exposed on their own ---------------------------------------- */
 /* X[b] = T(q_b): model.*.fkine (see DCX_FK_*).  q [B, dof] dev -> X [B, n_points*point_dim] dev */

@@ -45,6 +45,20 @@ def test_fk_desc_layout_matches_c(tmp_path):
                                      FkDesc.pt_off.offset, FkDesc.keypoints.offset]
 
 
+def test_traj_struct_layouts_match_c(tmp_path):
+    from diffco_amd._lib import TrajOpts, TrajState
+    prog = tmp_path / "sz2.c"
+    prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "dcx.h"\n'
+                    'int main(){printf("%zu %zu %zu %zu %zu %zu", sizeof(dcx_traj_state), offsetof(dcx_traj_state, path),'
+                    ' offsetof(dcx_traj_state, col_score), offsetof(dcx_traj_state, steps), sizeof(dcx_traj_opts),'
+                    ' offsetof(dcx_traj_opts, valid_tol));}')
+    exe = tmp_path / "sz2"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)], check=True)
+    out = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    assert out == [ctypes.sizeof(TrajState), TrajState.path.offset, TrajState.col_score.offset, TrajState.steps.offset,
+                   ctypes.sizeof(TrajOpts), TrajOpts.valid_tol.offset]
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
 def test_no_gpu_means_loud_failure_not_cpu_fallback():
     from diffco_amd import _lib, kernel, model

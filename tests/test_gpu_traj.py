@@ -1,0 +1,152 @@
+"""GPU tests of the hinge-gradient entry point and the fused Adam trajectory step, against a
+float64 torch restatement of the reference's loop body (optim.py:86-127) and the golden Adam record."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, TorchDHRobot, TorchKernel, load, make_robot, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup():
+    from diffco_amd import kernel
+    from diffco_amd.kernel_perceptrons import DiffCo
+    d = load("optim_adam_baxter")
+    rob = make_robot("baxter_left")
+    dc = DiffCo(transform=rob.fkine)
+    dc.support_points = torch.from_numpy(d["sup_q"])
+    dc.support_transformed = rob.fkine(dc.support_points)
+    dc.rbf_kernel, dc.rbf_nodes = kernel.Polyharmonic(1, 1.0), torch.from_numpy(d["weights"])
+    return d, rob, dc
+
+
+def test_hinge_gradient_equals_masked_gradient():
+    from diffco_amd import traj
+    d, rob, dc = _setup()
+    m = traj._resolve_model(dc.poly_score)
+    g = torch.Generator().manual_seed(5)
+    lim = rob.limits
+    q = (torch.rand((777, 7), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]).cuda()
+    s, gr = m.score_grad_raw(q)
+    for margin, weight in ((0.0, 10.0), (float(s.median()), 2.5)):
+        sh, gh = m.score_hinge_grad_raw(q, margin, weight)
+        assert torch.equal(sh, s)
+        mask = ((s - margin) > 0).float() * weight
+        assert torch.equal(gh, gr * mask)
+    # both launch geometries (split / unsplit) agree
+    sh2, gh2 = m.score_hinge_grad_raw(q[:100].contiguous(), 0.0, 10.0)
+    assert relerr(gh2.cpu().numpy(), (gr * ((s > 0).float() * 10.0))[:100].cpu().numpy()) < 3e-6
+
+
+def _torch_step(rob64, dist_est, p, m, v, t, lr, margin, max_speed):
+    """one iteration of optim.py:86-103 in float64 torch; returns new p, m, v and the loss terms"""
+    p = p.clone().requires_grad_(True)
+    col = torch.clamp(dist_est(p) - margin, min=0).sum()
+    cp = rob64.fkine(p)
+    mm = torch.clamp((cp[1:] - cp[:-1]).square().sum(dim=2) - max_speed ** 2, min=0).sum()
+    lim = rob64.limits.double()
+    jl = (torch.clamp(lim[:, 0] - p, min=0) + torch.clamp(p - lim[:, 1], min=0)).sum()
+    diff = (cp[1:] - cp[:-1]).square().sum()
+    loss = diff + 10 * col + 10 * mm + 10 * jl
+    (g,) = torch.autograd.grad(loss, p)
+    g[[0, -1]] = 0.0
+    m = 0.9 * m + 0.1 * g
+    v = 0.999 * v + 0.001 * g * g
+    denom = v.sqrt() / np.sqrt(1 - 0.999 ** t) + 1e-8
+    pn = p.detach() - lr / (1 - 0.9 ** t) * m / denom
+    return pn, m, v, torch.stack([loss, diff, 10 * col + 10 * mm + 10 * jl, g.norm(), col, mm, jl]).detach()
+
+
+def test_single_adam_step_matches_float64_restatement():
+    import ctypes as C
+    from diffco_amd import _lib, traj
+    d, rob, dc = _setup()
+    model = traj._resolve_model(dc.poly_score)
+    lib = _lib.require_gpu()
+    rob64 = TorchDHRobot(rob)
+    sup = rob64.fkine(torch.from_numpy(d["sup_q"]).double()).reshape(len(d["sup_q"]), -1)
+    w = torch.from_numpy(d["weights"]).double()
+    kern = TorchKernel("poly1", 1, 1.0)
+    dist_est = lambda p: kern(rob64.fkine(p).reshape(len(p), -1), sup) @ w[:, None]
+    # three paths: the golden init, a perturbed copy pushed outside the joint limits, and a long-stride one
+    g = torch.Generator().manual_seed(9)
+    init = torch.from_numpy(d["init"])
+    p1 = init.clone()
+    p1[5:9] += 2.0 * torch.randn((4, 7), generator=g).double()
+    p2 = init + 0.4 * torch.randn(init.shape, generator=g).double()
+    paths64 = torch.stack([init, p1, p2])
+    R, W, dof = paths64.shape
+    lr, margin, ms = 0.05, 0.02, 0.3
+    dev = model.dev
+    f32 = dict(device=dev, dtype=torch.float32)
+    path = paths64.to(**f32).contiguous()
+    am, av = torch.zeros_like(path), torch.zeros_like(path)
+    bufs = dict(limits=rob.limits.to(**f32).contiguous(), col_score=torch.empty(R * W, **f32),
+                col_grad=torch.empty((R * W, dof), **f32), stats=torch.zeros((R, 8), **f32),
+                lowest_loss=torch.full((R,), float("inf"), **f32), lowest_obj=torch.full((R,), float("inf"), **f32),
+                lowest_path=path.clone(), best_valid_obj=torch.full((R,), float("inf"), **f32),
+                best_valid_path=path.clone(), done=torch.zeros(R, device=dev, dtype=torch.int32),
+                steps=torch.zeros(R, device=dev, dtype=torch.int32))
+    st = _lib.TrajState(R, W, *(C.c_void_p(t.data_ptr()) for t in (
+        path, am, av, bufs["limits"], bufs["col_score"], bufs["col_grad"], bufs["stats"], bufs["lowest_loss"],
+        bufs["lowest_obj"], bufs["lowest_path"], bufs["best_valid_obj"], bufs["best_valid_path"], bufs["done"],
+        bufs["steps"])))
+    opt = _lib.TrajOpts(lr, 0.9, 0.999, 1e-8, 1, 10, 10, 10, margin, ms, 1e-2, 1e-4)
+    ref_p = [paths64[r].clone() for r in range(R)]
+    ref_m = [torch.zeros(W, dof, dtype=torch.float64) for _ in range(R)]
+    ref_v = [torch.zeros(W, dof, dtype=torch.float64) for _ in range(R)]
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    for t in (1, 2, 3):
+        _lib.check(lib.dcx_traj_adam_run(model._h, C.byref(st), C.byref(opt), t, 1, stream))
+        torch.cuda.synchronize()
+        for r in range(R):
+            ref_p[r], ref_m[r], ref_v[r], terms = _torch_step(rob64, dist_est, ref_p[r], ref_m[r], ref_v[r], t, lr, margin, ms)
+            got = bufs["stats"][r, :7].cpu().double()
+            assert relerr(got.numpy(), terms.numpy()) < 5e-5, (t, r, got, terms)
+            assert relerr(path[r].cpu().numpy(), ref_p[r].numpy()) < 2e-5, (t, r)
+            assert torch.equal(path[r, 0].cpu(), paths64[r, 0].float()) and torch.equal(path[r, -1].cpu(), paths64[r, -1].float())
+    assert bufs["steps"].tolist() == [3, 3, 3]
+    assert torch.isfinite(bufs["lowest_loss"]).all()
+
+
+def test_fused_optimizer_reproduces_the_reference_record():
+    from diffco_amd import fused_adam_traj_optimize, optim
+    d, rob, dc = _setup()
+    options = json.load(open(os.path.join(GOLDEN, "optim_adam_baxter_options.json")))
+    options["init_solution"] = torch.from_numpy(d["init"]).clone()
+    start, target = torch.from_numpy(d["start"]), torch.from_numpy(d["target"])
+    rec = fused_adam_traj_optimize(rob, dc.poly_score, start, target, dict(options))
+    assert rec["success"] == bool(d["success"]) and rec["cnt_check"] == int(d["cnt_check"])
+    assert abs(rec["cost"] - float(d["cost"])) < 5e-3 * float(d["cost"])
+    assert relerr(np.array(rec["solution"]), d["solution"]) < 5e-3
+    # and agrees with the un-fused optimiser on the same HIP path
+    rec2 = optim.adam_traj_optimize(rob, dc.poly_score, start, target, dict(options))
+    assert relerr(np.array(rec["solution"]), np.array(rec2["solution"])) < 2e-3
+    assert {"start_cfg", "target_cfg", "cnt_check", "cost", "time", "success", "seed", "solution"} <= set(rec)
+
+
+def test_batched_restarts_follow_the_reference_policy():
+    from diffco_amd import fused_adam_traj_optimize, optim
+    d, rob, dc = _setup()
+    start, target = torch.from_numpy(d["start"]), torch.from_numpy(d["target"])
+    base = {"N_WAYPOINTS": 20, "NUM_RE_TRIALS": 6, "MAXITER": 60, "max_speed": 0.3, "seed": 77, "history": False,
+            "extra_optimizer_options": {"lr": 0.05}}
+    # an unreachable margin: no trial is ever valid -> the lowest loss over ALL trials is returned
+    hard = dict(base, safety_margin=-1e3)
+    a = fused_adam_traj_optimize(rob, dc.poly_score, start, target, dict(hard))
+    b = optim.adam_traj_optimize(rob, dc.poly_score, start, target, dict(hard))
+    assert not a["success"] and not b["success"]
+    assert a["cnt_check"] == b["cnt_check"] == 6 * 60 * 20
+    assert abs(a["cost"] - b["cost"]) < 2e-2 * abs(b["cost"]) and relerr(np.array(a["solution"]), np.array(b["solution"])) < 2e-2
+    # a feasible margin: the first trial that becomes valid wins, like the sequential reference
+    easy = dict(base, safety_margin=0.0)
+    a = fused_adam_traj_optimize(rob, dc.poly_score, start, target, dict(easy))
+    b = optim.adam_traj_optimize(rob, dc.poly_score, start, target, dict(easy))
+    assert a["success"] == b["success"]
+    if a["success"]:
+        assert a["cnt_check"] == b["cnt_check"]
+        assert abs(a["cost"] - b["cost"]) < 1e-2 * abs(b["cost"])
