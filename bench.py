@@ -38,6 +38,10 @@ WORKLOADS = {
     "cfg2_panda": ("panda", (1, 1.0, 1.0), 1000, 1, 4096, "config #2 with PandaFK (D=21)"),
     "cfg3": ("baxter", (0, 10.0, 2.0), 2000, 5, 8192, "BASELINE config #3: MultiDiffCo C=5, RQ(10), S=2000, 8192 per GPU"),
     "cfg4": (None, (0, 10.0, 2.0), 10000, 1, 1 << 20, "BASELINE config #4: SE(3) no-FK (D=6), RQ(10), S=10k, 1M configs"),
+    # config #5: a "step" is ONE fused Adam iteration over 256 restarts x 50 waypoints (= 12800 score+grad evals)
+    "cfg5": ("baxter", (1, 1.0, 1.0), 2000, 1, 256 * 50,
+             "BASELINE config #5: fused Adam trajopt, 7-DoF, 50 waypoints x 256 restarts per GPU, S=2000 "
+             "(step = 1 iteration: score+hinge-grad sweep + fused Adam step)"),
 }
 
 
@@ -72,7 +76,7 @@ def make_workload(name, batch, dev, seed=0):
     sup = _ops.fkine(desc, sup_q.to(dev)).reshape(S, -1)
     m = _ops.ScoreModel(desc, *kspec, sup, W.to(dev), device=dev)
     return dict(name=name, text=desc_txt, model=m, desc=desc, kspec=kspec, S=S, C=C, B=B, D=desc.feature_dim,
-                dof=desc.dof, q=q.to(dev).contiguous(), sup=sup, W=W, q_cpu=q, rob_name=rob_name)
+                dof=desc.dof, q=q.to(dev).contiguous(), sup=sup, W=W, q_cpu=q, rob_name=rob_name, lo=lo, hi=hi)
 
 
 def cpu_baseline(w, budget_s=12.0):
@@ -188,7 +192,26 @@ def main():
     comm_stream = torch.cuda.Stream(dev) if multi else None
     qp, gp = Ct.c_void_p(q.data_ptr()), Ct.c_void_p(grad.data_ptr())
 
+    traj = None
+    if w["name"] == "cfg5":
+        # trajectory state: R restarts of W waypoints in joint limits; grad_tol = 0 so no path ever freezes
+        R, Wp = B // 50, 50
+        f32 = dict(device=dev, dtype=torch.float32)
+        path = q.reshape(R, Wp, dof).clone()
+        bufs = [path, torch.zeros_like(path), torch.zeros_like(path),
+                torch.stack([w["lo"], w["hi"]], dim=1).to(**f32).contiguous(), torch.empty(B, **f32),
+                torch.empty((B, dof), **f32), torch.zeros((R, 8), **f32), torch.full((R,), float("inf"), **f32),
+                torch.full((R,), float("inf"), **f32), path.clone(), torch.full((R,), float("inf"), **f32), path.clone(),
+                torch.zeros(R, device=dev, dtype=torch.int32), torch.zeros(R, device=dev, dtype=torch.int32)]
+        tst = _lib.TrajState(R, Wp, *(Ct.c_void_p(t.data_ptr()) for t in bufs))
+        topt = _lib.TrajOpts(0.05, 0.9, 0.999, 1e-8, 1, 10, 10, 10, 0.0, 0.3, 1e-2, 0.0)
+        traj = (tst, topt, bufs)
+
     def step(i, pending):
+        if traj is not None:
+            st = Ct.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(lib.dcx_traj_adam_run(m._h, Ct.byref(traj[0]), Ct.byref(traj[1]), i + 1, 1, st))
+            return
         out = score2[i & 1] if multi else score
         if multi and pending[i & 1] is not None:
             pending[i & 1].wait()  # this buffer pair's gather (two steps ago) must be done before it is rewritten
@@ -256,7 +279,7 @@ def main():
                        "parallelism": f"batch-sharded x{world}, model replicated" +
                                       ("" if world == 1 else (", no gather" if args.no_gather else
                                                               ", RCCL all-gather of scores overlapped")),
-                       "launches_per_step": 1},
+                       "launches_per_step": 2 if traj is not None else 1},
             "roofline": {"bound": "valu", "achieved": round(ach_tf, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach_tf / PEAK_FP32_TFLOPS, 4), "traffic": load_pmc_traffic(w["name"]),
                          "kernel": "dcx::score_kernel<D,KF,C,MODE>", "kernel_ms": round(kern_ms, 5),

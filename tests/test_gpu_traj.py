@@ -36,7 +36,10 @@ def test_hinge_gradient_equals_masked_gradient():
         sh, gh = m.score_hinge_grad_raw(q, margin, weight)
         assert torch.equal(sh, s)
         mask = ((s - margin) > 0).float() * weight
-        assert torch.equal(gh, gr * mask)
+        # the weight scales the feature gradient BEFORE J^T here and the joint gradient AFTER it there: equal up
+        # to fp32 rounding, and exactly zero wherever the hinge is inactive
+        assert relerr(gh.cpu().numpy(), (gr * mask).cpu().numpy()) < 1e-6
+        assert float(gh[(mask == 0).reshape(-1)].abs().max()) == 0.0
     # both launch geometries (split / unsplit) agree
     sh2, gh2 = m.score_hinge_grad_raw(q[:100].contiguous(), 0.0, 10.0)
     assert relerr(gh2.cpu().numpy(), (gr * ((s > 0).float() * 10.0))[:100].cpu().numpy()) < 3e-6
