@@ -92,6 +92,29 @@ def kernel_matrix(kind, p0, p1, x: torch.Tensor, s: torch.Tensor) -> torch.Tenso
     return K.to(device=x.device, dtype=x.dtype)
 
 
+# ----------------------------------------------------------------------------- perceptron trainer
+def train_perceptron_device(kind, p0, p1, beta, feats, y, gains, hypo, K, max_iteration):
+    """The whole perceptron loop in one persistent launch (dcx_train_perceptron).  feats [N, D], y / gains / hypo
+    [N] or [N, C], K [N, N] or None (cold start: allocated as zeros on the device).  Returns device tensors
+    (gains, hypo, K) in fp32 with y's shape, and (iterations, converged)."""
+    lib = _lib.require_gpu()
+    dev = _device(feats.device)
+    f = _f32(feats.reshape(len(feats), -1), dev)
+    N, D = f.shape
+    shape = tuple(y.shape)
+    yy = _f32(y.reshape(N, -1), dev)
+    Cn = yy.shape[1]
+    g = _f32(gains.reshape(N, -1), dev).clone()
+    h = _f32(hypo.reshape(N, -1), dev).clone()
+    Kd = torch.zeros((N, N), device=dev, dtype=torch.float32) if K is None else _f32(K, dev).clone()
+    info = torch.zeros(2, device=dev, dtype=torch.int32)
+    with torch.cuda.device(dev):
+        _lib.check(lib.dcx_train_perceptron(dev.index, kind, _kparams(p0, p1), float(beta), _ptr(f), N, D, _ptr(yy), Cn,
+                                            _ptr(g), _ptr(h), _ptr(Kd), int(max_iteration), _ptr(info), _stream(dev)))
+    it, conv = (int(v) for v in info.tolist())
+    return g.reshape(shape), h.reshape(shape), Kd, it, bool(conv)
+
+
 # ----------------------------------------------------------------------------- fused score model
 class ScoreModel:
     """Owns one ``dcx_model`` (device copy of support rows + FK parameters).  Immutable."""

@@ -1,12 +1,11 @@
-"""Host logic shared by the checkers: the sequential kernel-perceptron trainer and the glue that
-turns a checker's state (transform, kernel, supports, weights) into a fused HIP score model.
+"""Logic shared by the checkers: the kernel-perceptron trainer and the glue that turns a checker's
+state (transform, kernel, supports, weights) into a fused HIP score model.
 
-The trainer is inherently sequential (one argmin per iteration) and stays on the host as in the
-reference; its only heavy step, filling one kernel row K(x_i, X) per
-iteration, is delegated to the kernel callable — for diffco_amd kernels that is the HIP
-kernel-matrix kernel with the sample features kept resident on the GPU.
-Behaviour restated from the reference: DiffCo.train_perceptron kernel_perceptrons.py:98-137 and
-MultiDiffCo.train_perceptron deprecated/MultiDiffCo.py:50-83.
+The trainer is inherently sequential (one argmin per iteration).  For diffco_amd kernels the whole loop runs
+in ONE persistent launch on the GPU (`dcx_train_perceptron`, csrc/train_kernels.hip — SURVEY.md §8f-1); for a
+foreign kernel callable the same algorithm runs as a host loop below, filling kernel rows by calling it like
+the reference does.  Behaviour restated from the reference: DiffCo.train_perceptron
+kernel_perceptrons.py:98-137 and MultiDiffCo.train_perceptron deprecated/MultiDiffCo.py:50-83.
 """
 import torch
 
@@ -91,6 +90,44 @@ def train_perceptron(y, hypo, gains, K, fill, beta, max_iteration, progress=None
         if bool(done.all()):
             break
     return it
+
+
+def device_trainer_spec(kernel_func):
+    """(kind, p0, p1) when the training kernel can run inside the persistent device trainer, else None.
+    DCX_HOST_TRAINER=1 forces the host loop (A/B and debugging)."""
+    import os
+    if os.environ.get("DCX_HOST_TRAINER") == "1":
+        return None
+    if isinstance(kernel_func, KernelFunc) and not isinstance(kernel_func, FKKernel):
+        return kernel_func.dcx_spec()
+    return None
+
+
+def run_trainer(kernel_func, feats, y, gains, hypo, K, beta, max_iteration, progress=None, cold=False):
+    """Train in place semantics, wherever it is fastest: the persistent device kernel for diffco_amd kernels
+    (one launch for the whole loop), the host loop otherwise.  K may be None for a cold start (the N x N matrix is
+    then created where the trainer runs).  Returns (gains, hypo, K, iterations)."""
+    spec = device_trainer_spec(kernel_func)
+    if K is None and (spec is None or not cold):
+        K = torch.zeros((len(y), len(y)), dtype=gains.dtype, device=gains.device)  # lazily filled
+    if spec is None:
+        fill = RowFiller(kernel_func, feats, K.device)
+        it = train_perceptron(y, hypo, gains, K, fill, beta, max_iteration, progress)
+        return gains, hypo, K, it
+    out_dev, out_dtype = gains.device, gains.dtype
+    g, h, Kd, it, _ = _ops.train_perceptron_device(spec[0], spec[1], spec[2], beta, feats, y, gains, hypo,
+                                                   None if cold else K, max_iteration)
+    if progress is not None:
+        progress.update(it)
+    # gains / hypothesis go back to where the caller keeps them; the N x N kernel matrix stays on the GPU (callers
+    # only ever take the support sub-block of it: see sub_block)
+    return g.to(device=out_dev, dtype=out_dtype), h.to(device=out_dev, dtype=out_dtype), Kd, it
+
+
+def sub_block(K, idx, device, dtype):
+    """K[idx][:, idx] gathered where K lives, then moved to (device, dtype)"""
+    i = idx.to(K.device)
+    return K[i[:, None], i[None, :]].to(device=device, dtype=dtype)
 
 
 # ----------------------------------------------------------------------------- fused-model glue

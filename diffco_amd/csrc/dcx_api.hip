@@ -555,6 +555,20 @@ int dcx_traj_adam_run(const dcx_model* m, const dcx_traj_state* st, const dcx_tr
     return DCX_OK;
 }
 
+int dcx_train_perceptron(int device, int kernel_kind, const float* kparams, float beta, const float* feats, int64_t N,
+                         int32_t D, const float* y, int32_t C, float* gains, float* hypothesis, float* kernel_matrix,
+                         int32_t max_iteration, int32_t* info, void* stream) {
+    if (N < 1 || N > 0x7fffffffLL || D < 1 || C < 1 || C > 31 || max_iteration < 0)
+        return fail(DCX_ERR_INVALID, "perceptron trainer: N >= 1, D >= 1, 1 <= C <= 31, max_iteration >= 0");
+    if (!feats || !y || !gains || !hypothesis || !kernel_matrix || !info) return fail(DCX_ERR_INVALID, "a trainer pointer is NULL");
+    if (int rc = check_kernel(kernel_kind, kparams)) return rc;
+    if (int rc = set_device(device)) return rc;
+    hipError_t e = launch_perceptron(kernel_kind, kparams[0], kparams[1], beta, feats, y, gains, hypothesis, kernel_matrix,
+                                     info, (int)N, D, C, max_iteration, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "perceptron trainer launch");
+    return DCX_OK;
+}
+
 int dcx_fkine(int device, const dcx_fk_desc* fk, const float* q, int64_t B, float* X, void* stream) {
     if (!fk) return fail(DCX_ERR_INVALID, "fk is NULL");
     if (B < 0 || (B > 0 && (!q || !X))) return fail(DCX_ERR_INVALID, "q / X is NULL or B < 0");

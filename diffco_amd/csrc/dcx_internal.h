@@ -42,6 +42,10 @@ hipError_t launch_fkine_vjp(const FkProg* fk_dev, const dcx_fk_desc& fk_host, co
 hipError_t launch_kernel_matrix(int kind, float kp0, float kp1, const float* x, int64_t B, const float* s, int64_t S,
                                 int D, float* K, hipStream_t stream);
 
+// train_kernels.hip
+hipError_t launch_perceptron(int kind, float kp0, float kp1, float beta, const float* feats, const float* y, float* gains,
+                             float* hypo, float* K, int32_t* info, int N, int D, int C, int max_iter, hipStream_t st);
+
 // traj_kernels.hip
 hipError_t launch_traj_adam_step(const FkProg* fk_dev, const dcx_fk_desc& fk, const dcx_traj_state& st,
                                  const dcx_traj_opts& opt, int step, hipStream_t stream);

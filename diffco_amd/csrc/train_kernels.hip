@@ -1,0 +1,332 @@
+// train_kernels.hip — the kernel-perceptron trainer as ONE persistent workgroup.
+//
+// Restates DiffCo.train_perceptron (kernel_perceptrons.py:98-137) and the multi-class variant
+// (deprecated/MultiDiffCo.py:50-83): an inherently sequential loop — one argmin per iteration — whose body is
+// tiny (N-element reductions, one lazily filled kernel row K(x_i, X), an axpy on the hypothesis).  The reference
+// runs it as ~10 torch ops per iteration on the host (848 iterations = 0.38 s in its notebook).  Here the whole
+// loop runs inside one launch: 1024 threads of one workgroup stride over the N samples, the state (y, gains,
+// hypothesis, the lazily filled N x N kernel matrix) stays in HBM/L2, and nothing returns to the host until the
+// loop ends.  With 288 GB of HBM the dense N x N matrix is affordable far beyond the reference's 10 000-sample
+// "move it to the CPU to save VRAM" threshold (kernel_perceptrons.py:90-94, 151-155).
+//
+// Arithmetic mirrors the torch expressions (separate multiply and add where torch has two ops) so that the
+// sequence of argmin choices, and therefore the support set, matches the reference's.
+#include "dcx_internal.h"
+
+namespace dcx {
+namespace {
+
+struct TrainArgs {
+    const float* feats;  // [N, D] transformed samples
+    const float* y;      // [N, C]  +-1 labels
+    float* gains;        // [N, C]  in/out
+    float* hypo;         // [N, C]  in/out
+    float* K;            // [N, N]  in/out; a row is filled when first needed; K[i,i] == 0 means "not filled"
+    int32_t* info;       // [2] out: iterations used, converged flag
+    int32_t N, D, C, max_iter;
+    int32_t kind;
+    float kp0, kp1, beta;
+};
+
+struct Best {
+    float v;
+    int i;
+};
+__device__ __forceinline__ Best better_min(Best a, Best b) { return (b.v < a.v || (b.v == a.v && b.i < a.i)) ? b : a; }
+__device__ __forceinline__ Best better_max(Best a, Best b) { return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a; }
+
+template <bool IS_MIN>
+__device__ Best block_best(Best mine, Best* sB, int tid) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        Best other{__shfl_xor(mine.v, o, 64), __shfl_xor(mine.i, o, 64)};
+        mine = IS_MIN ? better_min(mine, other) : better_max(mine, other);
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) sB[tid >> 6] = mine;
+    __syncthreads();
+    Best r = sB[0];
+    const int nw = blockDim.x >> 6;
+    for (int w = 1; w < nw; ++w) r = IS_MIN ? better_min(r, sB[w]) : better_max(r, sB[w]);
+    return r;  // every thread computes the same result
+}
+
+__device__ float kernel_value(const TrainArgs& a, float d2) {
+    ScoreArgs k{};
+    k.kind = a.kind;
+    k.kp0 = a.kp0;
+    k.kp1 = a.kp1;
+    float val, g;
+    if (a.kind == DCX_K_RQ && a.kp1 == 2.0f) {
+        kernel_eval<KF_RQ2>(d2, k, val, g);
+    } else if (a.kind == DCX_K_POLY && a.kp0 == 1.0f) {
+        val = (d2 > 0.f ? d2 * __builtin_amdgcn_rsqf(d2) : 0.f) / a.kp1;
+    } else {
+        kernel_eval<KF_GEN>(d2, k, val, g);
+        if (a.kind == DCX_K_POLY && d2 == 0.f) val = 0.f;
+    }
+    return val;
+}
+
+// one perceptron step for label column c; returns true when the column has converged
+__device__ bool class_step(const TrainArgs& a, int c, float* sX, Best* sB, int* sCnt) {
+    const int tid = threadIdx.x, NT = blockDim.x, N = a.N, C = a.C;
+    // 1. the worst margin (first index on ties, like torch.min)
+    Best mine{INFINITY, 0x7fffffff};
+    for (int j = tid; j < N; j += NT) {
+        const float m = a.y[(size_t)j * C + c] * a.hypo[(size_t)j * C + c];
+        mine = better_min(mine, Best{m, j});
+    }
+    const Best worst = block_best<true>(mine, sB, tid);
+    const int i = worst.i;
+    float* Ki = a.K + (size_t)i * N;
+    // 2. fill row i of the kernel matrix on first use (k(x, x) != 0 marks a filled row)
+    if (Ki[i] == 0.0f) {
+        for (int k = tid; k < a.D; k += NT) sX[k] = a.feats[(size_t)i * a.D + k];
+        __syncthreads();
+        for (int j = tid; j < N; j += NT) {
+            const float* xj = a.feats + (size_t)j * a.D;
+            float d2 = 0.f;
+            for (int k = 0; k < a.D; ++k) {
+                const float dl = sX[k] - xj[k];
+                d2 = fmaf(dl, dl, d2);
+            }
+            Ki[j] = kernel_value(a, d2);
+        }
+        __syncthreads();
+    }
+    const float kii = Ki[i];
+    if (worst.v <= 0.0f) {
+        // 3. margin violated: move sample i onto its target (beta scales the positive target)
+        const float yi = a.y[(size_t)i * C + c], hi = a.hypo[(size_t)i * C + c];
+        const float target = (yi > 0.f ? a.beta : 1.0f) * yi;  // beta^((1+y)/2) * y
+        const float step = __fdiv_rn(__fsub_rn(target, hi), kii);
+        __syncthreads();  // everyone has read hypo[i] before it changes
+        for (int j = tid; j < N; j += NT) {
+            const size_t o = (size_t)j * C + c;
+            a.hypo[o] = __fadd_rn(a.hypo[o], __fmul_rn(step, Ki[j]));
+        }
+        if (tid == 0) a.gains[(size_t)i * C + c] = __fadd_rn(a.gains[(size_t)i * C + c], step);
+        __syncthreads();
+        return false;
+    }
+    // 4. all margins positive: retire a support that is classified correctly without its own contribution
+    Best cand{-INFINITY, 0x7fffffff};
+    int nnz = 0;
+    for (int j = tid; j < N; j += NT) {
+        const size_t o = (size_t)j * C + c;
+        const float g = a.gains[o];
+        float mm = 0.0f;
+        if (g != 0.0f) {
+            ++nnz;
+            mm = __fmul_rn(a.y[o], __fsub_rn(a.hypo[o], __fmul_rn(g, a.K[(size_t)j * N + j])));
+        }
+        cand = better_max(cand, Best{mm, j});
+    }
+    const Best top = block_best<false>(cand, sB, tid);
+    // count of active supports
+    for (int o = 32; o > 0; o >>= 1) nnz += __shfl_xor(nnz, o, 64);
+    __syncthreads();
+    if ((tid & 63) == 0) sCnt[tid >> 6] = nnz;
+    __syncthreads();
+    int total = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) total += sCnt[w];
+    if (top.v > 0.0f && total > 1) {
+        const int jx = top.i;
+        const float gj = a.gains[(size_t)jx * C + c];
+        const float* Kj = a.K + (size_t)jx * N;
+        __syncthreads();
+        for (int j = tid; j < N; j += NT) {
+            const size_t o = (size_t)j * C + c;
+            a.hypo[o] = __fsub_rn(a.hypo[o], __fmul_rn(gj, Kj[j]));
+        }
+        if (tid == 0) a.gains[(size_t)jx * C + c] = 0.0f;
+        __syncthreads();
+        return false;
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(1024) void perceptron_kernel(const TrainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sX = smem;                                         // [D]
+    Best* sB = reinterpret_cast<Best*>(sX + ((a.D + 3) & ~3));  // [16]
+    int* sCnt = reinterpret_cast<int*>(sB + 16);              // [16]
+    int it = 0;
+    bool converged = false;
+    if (a.C == 1) {
+        for (; it < a.max_iter; ++it) {
+            if (class_step(a, 0, sX, sB, sCnt)) { converged = true; break; }
+        }
+    } else {
+        unsigned done_mask = 0;  // a column that converged once stays flagged (deprecated/MultiDiffCo.py:52, 75-80)
+        for (; it < a.max_iter; ++it) {
+            for (int c = 0; c < a.C; ++c)
+                if (class_step(a, c, sX, sB, sCnt)) done_mask |= 1u << c;
+            if (done_mask == (1u << a.C) - 1u) { converged = true; break; }
+        }
+    }
+    if (threadIdx.x == 0) {
+        a.info[0] = it;
+        a.info[1] = converged ? 1 : 0;
+    }
+}
+
+// ---- register-resident variant (single class, N <= 1024 * EPT) ---------------------------------------------
+// Each thread owns EPT samples (j = tid + e*NT) and keeps their margin, signed gain and kernel diagonal in
+// registers for the whole training run; per iteration only the selected kernel row crosses memory (computed and
+// stored on first use, re-loaded from the N x N matrix afterwards).  Everything else is register arithmetic plus
+// two block reductions, so an iteration costs a few microseconds instead of several passes over global arrays.
+template <int EPT, int NT>
+__global__ __launch_bounds__(NT) void perceptron_reg_kernel(const TrainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sX = smem;                                         // [D]
+    Best* sB = reinterpret_cast<Best*>(sX + ((a.D + 3) & ~3));  // [16]
+    int* sCnt = reinterpret_cast<int*>(sB + 16);              // [16]
+    float* sS = reinterpret_cast<float*>(sCnt + 16);          // [4] broadcast slots
+    const int tid = threadIdx.x, N = a.N;
+    // Per-sample state in "margin form": m = y*h and yg = y*g.  With y in {-1,+1} every update below is the
+    // reference's update multiplied by an exact sign, so the roundings (and the argmin sequence) are identical,
+    // and the label itself shrinks to one bit.
+    float m[EPT], yg[EPT], dg[EPT];
+    unsigned ypos = 0;  // bit e set <=> y_j > 0
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int j = tid + e * NT;
+        const bool in = j < N;
+        const float yj = in ? a.y[j] : 1.0f;
+        if (yj > 0.f) ypos |= 1u << e;
+        m[e] = in ? yj * a.hypo[j] : INFINITY;
+        yg[e] = in ? yj * a.gains[j] : 0.0f;
+        dg[e] = in ? a.K[(size_t)j * N + j] : 0.0f;
+    }
+    auto ysign = [&](int e) { return (ypos >> e) & 1u ? 1.0f : -1.0f; };
+    int it = 0;
+    bool converged = false;
+    for (; it < a.max_iter; ++it) {
+        // 1. worst margin (first index on ties)
+        Best mine{INFINITY, 0x7fffffff};
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int j = tid + e * NT;
+            if (j < N) mine = better_min(mine, Best{m[e], j});
+        }
+        const Best worst = block_best<true>(mine, sB, tid);
+        const int i = worst.i;
+        // owner broadcasts y_i and K_ii (h_i = y_i * m_i)
+#pragma unroll
+        for (int e = 0; e < EPT; ++e)
+            if (tid + e * NT == i) { sS[1] = ysign(e); sS[2] = dg[e]; }
+        __syncthreads();
+        const float yi = sS[1], hi = yi * worst.v;
+        float kii = sS[2];
+        float* Ki = a.K + (size_t)i * N;
+        const bool violated = worst.v <= 0.0f;
+        if (kii == 0.0f) {
+            // 2. first use of row i: compute it once (rolled loop: the kernel function may be a powf/logf body)
+            //    and store it in the N x N matrix
+            for (int k = tid; k < a.D; k += NT) sX[k] = a.feats[(size_t)i * a.D + k];
+            __syncthreads();
+#pragma unroll 1
+            for (int j = tid; j < N; j += NT) {
+                const float* xj = a.feats + (size_t)j * a.D;
+                float d2 = 0.f;
+                for (int k = 0; k < a.D; ++k) {
+                    const float dl = sX[k] - xj[k];
+                    d2 = fmaf(dl, dl, d2);
+                }
+                const float kv = kernel_value(a, d2);
+                Ki[j] = kv;
+                if (j == i) sS[3] = kv;
+            }
+            __syncthreads();
+            kii = sS[3];
+#pragma unroll
+            for (int e = 0; e < EPT; ++e)
+                if (tid + e * NT == i) dg[e] = kii;
+        }
+        if (violated) {
+            // 3. margin violated: move sample i onto its target:  h += step * K_i,  g_i += step
+            const float target = (yi > 0.f ? a.beta : 1.0f) * yi;
+            const float step = __fdiv_rn(__fsub_rn(target, hi), kii);
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                const int j = tid + e * NT;
+                if (j < N) m[e] = __fadd_rn(m[e], ysign(e) * __fmul_rn(step, Ki[j]));
+                if (j == i) yg[e] = __fadd_rn(yg[e], ysign(e) * step);
+            }
+            __syncthreads();  // sS is rewritten next iteration
+            continue;
+        }
+        // 4. all margins positive: retire a support that is classified correctly without its own contribution
+        Best cand{-INFINITY, 0x7fffffff};
+        int nnz = 0;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int j = tid + e * NT;
+            if (j < N) {
+                float mm = 0.0f;
+                if (yg[e] != 0.0f) {
+                    ++nnz;
+                    mm = __fsub_rn(m[e], __fmul_rn(yg[e], dg[e]));
+                }
+                cand = better_max(cand, Best{mm, j});
+            }
+        }
+        const Best top = block_best<false>(cand, sB, tid);
+        for (int o = 32; o > 0; o >>= 1) nnz += __shfl_xor(nnz, o, 64);
+        __syncthreads();
+        if ((tid & 63) == 0) sCnt[tid >> 6] = nnz;
+        __syncthreads();
+        int total = 0;
+        for (int w = 0; w < NT / 64; ++w) total += sCnt[w];
+        if (top.v > 0.0f && total > 1) {
+            const int jx = top.i;
+#pragma unroll
+            for (int e = 0; e < EPT; ++e)
+                if (tid + e * NT == jx) sS[0] = ysign(e) * yg[e];   // g_jx
+            __syncthreads();
+            const float gj = sS[0];
+            const float* Kj = a.K + (size_t)jx * N;
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                const int j = tid + e * NT;
+                if (j < N) m[e] = __fsub_rn(m[e], ysign(e) * __fmul_rn(gj, Kj[j]));
+                if (j == jx) yg[e] = 0.0f;
+            }
+            __syncthreads();
+            continue;
+        }
+        converged = true;
+        break;
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int j = tid + e * NT;
+        if (j < N) { a.hypo[j] = ysign(e) * m[e]; a.gains[j] = ysign(e) * yg[e]; }
+    }
+    if (tid == 0) {
+        a.info[0] = it;
+        a.info[1] = converged ? 1 : 0;
+    }
+}
+
+}  // namespace
+
+hipError_t launch_perceptron(int kind, float kp0, float kp1, float beta, const float* feats, const float* y, float* gains,
+                             float* hypo, float* K, int32_t* info, int N, int D, int C, int max_iter, hipStream_t st) {
+    TrainArgs a;
+    a.feats = feats; a.y = y; a.gains = gains; a.hypo = hypo; a.K = K; a.info = info;
+    a.N = N; a.D = D; a.C = C; a.max_iter = max_iter; a.kind = kind; a.kp0 = kp0; a.kp1 = kp1; a.beta = beta;
+    const size_t lds = sizeof(float) * ((D + 3) & ~3) + 16 * sizeof(Best) + 16 * sizeof(int) + 4 * sizeof(float);
+    if (C == 1 && N <= 1024 * 4) {
+        perceptron_reg_kernel<4, 1024><<<dim3(1), dim3(1024), lds, st>>>(a);
+    } else if (C == 1 && N <= 512 * 20) {   // 8 waves = 2 per SIMD: 256 VGPRs per lane hold 20 samples' state
+        perceptron_reg_kernel<20, 512><<<dim3(1), dim3(512), lds, st>>>(a);
+    } else {
+        perceptron_kernel<<<dim3(1), dim3(1024), lds, st>>>(a);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace dcx

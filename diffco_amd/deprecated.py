@@ -13,7 +13,7 @@ from time import time
 import torch
 
 from . import kernel
-from ._perceptron import FusedScorer, RowFiller, train_perceptron
+from ._perceptron import FusedScorer, run_trainer, sub_block
 
 
 class CollisionChecker:
@@ -66,18 +66,24 @@ class DiffCo(CollisionChecker):
         assert len(self.y) == len(X)
         n = len(X)
         self.gains = torch.zeros(n, dtype=X.dtype)
-        self.kernel_matrix = torch.zeros((n, n), dtype=X.dtype)
+        self.kernel_matrix = None  # created where the trainer runs
         self.hypothesis = torch.zeros(n, dtype=X.dtype)
 
-    def _row_filler(self):
+    def _train_inputs(self):
+        """(point kernel, features of all samples under the training kernel's transform)"""
         tf, point_kernel = _split_kernel(self.kernel_func)
         feats = self.support_points if tf is None else tf(self.support_points).reshape(len(self.support_points), -1)
-        return RowFiller(point_kernel, feats.detach(), self.kernel_matrix.device)
+        return point_kernel, feats.detach()
+
+    def _run_trainer(self, max_iteration, cold):
+        pk, feats = self._train_inputs()
+        self.gains, self.hypothesis, self.kernel_matrix, it = run_trainer(
+            pk, feats, self.y, self.gains, self.hypothesis, self.kernel_matrix, self.beta, max_iteration, cold=cold)
+        return it
 
     def train_perceptron(self, X, y, max_iteration=1000):
         self.initialize(X, y)
-        it = train_perceptron(self.y, self.hypothesis, self.gains, self.kernel_matrix, self._row_filler(), self.beta,
-                              max_iteration)
+        it = self._run_trainer(max_iteration, cold=True)
         print('Ended at iteration {}'.format(it))
         print('ACC: {}'.format(torch.sum((self.hypothesis > 0) == (self.y > 0)) / float(self.y.numel())))
 
@@ -99,7 +105,7 @@ class DiffCo(CollisionChecker):
         self.y = self.y[mask]
         self.distance = self.distance[mask] if self.distance is not None else None
         self.gains = self.gains[mask]
-        self.kernel_matrix = self.kernel_matrix[idx[:, None], idx[None, :]]
+        self.kernel_matrix = sub_block(self.kernel_matrix, idx, self.gains.device, self.gains.dtype)
         self._score_feats = None
 
     # ------------------------------------------------------------------------------ spline fit
@@ -202,7 +208,7 @@ class MultiDiffCo(DiffCo):
         if not any(given):
             self.gains = torch.zeros((n, self.num_class), dtype=X.dtype)
             self.hypothesis = torch.zeros((n, self.num_class), dtype=X.dtype)
-            self.kernel_matrix = torch.zeros((n, n), dtype=X.dtype)
+            self.kernel_matrix = None  # created where the trainer runs
         elif not all(given):
             raise ValueError('DiffCo: you passed in some existing parameters but not all three of gains, '
                              'hypothesis, and kernel_matrix')
@@ -212,8 +218,7 @@ class MultiDiffCo(DiffCo):
     def train_perceptron(self, X, y, max_iteration=1000, gains=None, hypothesis=None, kernel_matrix=None):
         self.initialize(X, y, gains=gains, hypothesis=hypothesis, kernel_matrix=kernel_matrix)
         print('MultiDiffCo training...')
-        it = train_perceptron(self.y, self.hypothesis, self.gains, self.kernel_matrix, self._row_filler(), self.beta,
-                              max_iteration)
+        it = self._run_trainer(max_iteration, cold=(gains is None))
         print('Ended at iteration {}'.format(it))
         print('ACC: {}'.format(torch.sum((self.hypothesis > 0) == (self.y > 0)) / float(self.y.numel())))
 

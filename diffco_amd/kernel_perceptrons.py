@@ -19,7 +19,7 @@ from time import time
 import torch as th
 
 from . import kernel
-from ._perceptron import FusedScorer, RowFiller, train_perceptron
+from ._perceptron import FusedScorer, run_trainer, sub_block
 
 
 class Perceptron:
@@ -101,9 +101,8 @@ class DiffCo(Perceptron):
         assert len(y) == len(X)
         n = len(X)
         gains = th.zeros(n, dtype=X.dtype, device=X.device)
-        K = th.zeros((n, n), dtype=X.dtype, device=X.device)
         hypo = th.zeros(n, dtype=X.dtype, device=X.device)
-        return gains, X, Xt, K, hypo, y
+        return gains, X, Xt, None, hypo, y  # the n x n kernel matrix is created where the trainer runs
 
     def jump_start_initialize(self, X, y, exist_mask):
         """Warm start for active learning: rows flagged in exist_mask are the current supports (same
@@ -140,14 +139,15 @@ class DiffCo(Perceptron):
             gains, X, Xt, K, hypo, y = self.jump_start_initialize(X, y, exist_mask)
         else:
             gains, X, Xt, K, hypo, y = self.initialize(X, y)
-        fill = RowFiller(self.kernel_func, Xt, K.device)
         t0 = time()
         progress = None
         if verbose:
             from tqdm import tqdm
             print('DiffCo training...')
             progress = tqdm(total=max_iteration, ncols=0)
-        it = train_perceptron(y, hypo, gains, K, fill, self.beta, max_iteration, progress)
+        # persistent device trainer for diffco_amd kernels (one launch for the whole loop), host loop otherwise
+        gains, hypo, K, it = run_trainer(self.kernel_func, Xt, y, gains, hypo, K, self.beta, max_iteration, progress,
+                                         cold=not update)
         if verbose:
             progress.close()
             print(f'Ended at iteration {it}, cost {time() - t0:.4f} secs')
@@ -165,7 +165,7 @@ class DiffCo(Perceptron):
             self.distance = self.distance.to(keep.device)[keep] if self.distance is not None else None
             self.gains = gains[keep]
             self.rbf_nodes = self.gains.new_zeros(len(self.gains))
-            self.kernel_matrix = K[idx[:, None], idx[None, :]]
+            self.kernel_matrix = sub_block(K, idx, gains.device, gains.dtype)
             self._valid_supports = len(self.support_points)
             return
         # fixed-size state: pad with zeros / truncate to max_num_supports
@@ -177,7 +177,7 @@ class DiffCo(Perceptron):
             self.hypothesis = th.zeros(M, dtype=hypo.dtype, device=hypo.device)
             self.y = th.zeros(M, dtype=y.dtype, device=y.device)
             self.gains = th.zeros(M, dtype=gains.dtype, device=gains.device)
-            self.kernel_matrix = th.zeros((M, M), dtype=K.dtype, device=K.device)
+            self.kernel_matrix = th.zeros((M, M), dtype=gains.dtype, device=gains.device)
         if dist_src is not None:
             self.distance = th.zeros(M, dtype=dist_src.dtype, device=dist_src.device)
         if len(idx) > M:
@@ -195,7 +195,7 @@ class DiffCo(Perceptron):
             self.distance[:n] = dist_src[idx]
         self.rbf_nodes = self.gains.new_zeros(len(self.gains))
         self.kernel_matrix.zero_()
-        self.kernel_matrix[:n, :n] = K[idx[:, None], idx[None, :]]
+        self.kernel_matrix[:n, :n] = sub_block(K, idx, gains.device, gains.dtype)
         self._valid_supports = n
         resid = th.abs(self.hypothesis - self.kernel_matrix @ self.gains).max()
         assert resid <= 1e-4 + 1e-8, f"diff: {resid}"

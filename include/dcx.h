@@ -190,6 +190,19 @@ int dcx_traj_adam_step(int device, const dcx_fk_desc* fk, const dcx_traj_state* 
 int dcx_traj_adam_run(const dcx_model* model, const dcx_traj_state* st, const dcx_traj_opts* opt,
                       int32_t first_step, int32_t n_iters, void* stream);
 
+/* ---- kernel-perceptron trainer (producer of the path's state) ----------------------- */
+/* DiffCo.train_perceptron kernel_perceptrons.py:98-137 and MultiDiffCo.train_perceptron
+ * deprecated/MultiDiffCo.py:50-83 as one persistent launch: worst-margin search, lazily filled kernel rows,
+ * margin fix / support retirement, until convergence or max_iteration.
+ *   feats [N, D] dev   transformed samples          y [N, C] dev   labels in {-1, +1}
+ *   gains, hypothesis [N, C] dev in/out (zeros for a cold start, previous state for a jump start)
+ *   kernel_matrix [N, N] dev in/out: zeros = "row not computed yet"; rows are filled on first use
+ *                 (only rows, not columns: K is symmetric and the trainer reads rows and the diagonal)
+ *   info [2] dev out: iterations used, 1 if converged                                                    */
+int dcx_train_perceptron(int device, int kernel_kind, const float* kparams, float beta, const float* feats, int64_t N,
+                         int32_t D, const float* y, int32_t C, float* gains, float* hypothesis, float* kernel_matrix,
+                         int32_t max_iteration, int32_t* info, void* stream);
+
 /* ---- pieces of the path exposed on their own ---------------------------------------- */
 /* X[b] = T(q_b): model.*.fkine (see DCX_FK_*).  q [B, dof] dev -> X [B, n_points*point_dim] dev */
 int dcx_fkine(int device, const dcx_fk_desc* fk, const float* q, int64_t B, float* X, void* stream);

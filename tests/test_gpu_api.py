@@ -253,3 +253,50 @@ def test_adam_and_slsqp_on_the_hip_path():
     opts = dict(options, MAXITER=8, extra_optimizer_options={})
     rec2 = optim.givengrad_traj_optimize(rob, dc.poly_score, torch.from_numpy(d["start"]), torch.from_numpy(d["target"]), opts)
     assert np.isfinite(rec2["cost"]) and len(rec2["solution"]) == 20 and rec2["cnt_check"] > 0
+
+
+def test_device_trainer_equals_host_trainer_and_reference(monkeypatch):
+    """f1: the persistent-workgroup trainer (dcx_train_perceptron) walks the same sequence as the host loop — same
+    supports in the same order as the reference's model — for the single- and the multi-class perceptron."""
+    import time
+    from diffco_amd import MultiDiffCo, kernel
+    from diffco_amd.kernel_perceptrons import DiffCo
+    d = load("trained_baxter")
+    rob = make_robot("baxter_left")
+    X, y, dist = (torch.from_numpy(d[k]) for k in ("X", "y", "dist"))
+    runs = {}
+    for mode in ("device", "host"):
+        if mode == "host":
+            monkeypatch.setenv("DCX_HOST_TRAINER", "1")
+        dc = DiffCo(kernel_func=kernel.RQKernel(10.0), beta=1.0, transform=rob.fkine)
+        t0 = time.perf_counter()
+        dc.train(X, y, max_iteration=3000, distance=dist)
+        runs[mode] = (dc, time.perf_counter() - t0)
+    monkeypatch.delenv("DCX_HOST_TRAINER")
+    dev, host = runs["device"][0], runs["host"][0]
+    np.testing.assert_array_equal(_np(dev.support_points), d["support_points"])
+    np.testing.assert_array_equal(_np(dev.support_points), _np(host.support_points))
+    assert relerr(_np(dev.gains), _np(host.gains)) < 1e-4 and relerr(_np(dev.gains), d["gains"]) < 1e-3
+    assert relerr(_np(dev.kernel_matrix), _np(host.kernel_matrix)) < 1e-6
+    assert torch.allclose(dev.kernel_matrix @ dev.gains, dev.hypothesis, atol=1e-4)
+    print(f"trainer: device {runs['device'][1] * 1e3:.1f} ms, host loop {runs['host'][1] * 1e3:.1f} ms")
+    # multi-class, old API
+    m = load("trained_multi_planar2")
+    r2 = make_robot("planar2")
+    md = MultiDiffCo(None, kernel_func=kernel.FKKernel(r2.fkine, kernel.RQKernel(10.0)), beta=1.0)
+    md.train(torch.from_numpy(m["X"]), torch.from_numpy(m["y"]), max_iteration=1500, distance=torch.from_numpy(m["dist"]))
+    np.testing.assert_array_equal(_np(md.support_points), m["support_points"])
+    assert relerr(_np(md.gains), m["gains"]) < 1e-3 and relerr(_np(md.hypothesis), m["hypothesis"]) < 1e-3
+    # max_iteration is honoured and a 20k-sample problem (beyond the reference's CPU threshold) trains on the device
+    g = torch.Generator().manual_seed(1)
+    lim = rob.limits
+    Xb = torch.rand((20000, 7), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]
+    P = rob.fkine(Xb)
+    yb = torch.where(((P - torch.tensor([0.7, 0.3, 0.3])).norm(dim=-1) < 0.3).any(dim=1), 1.0, -1.0)
+    big = DiffCo(kernel_func=kernel.RQKernel(10.0), beta=1.0, transform=rob.fkine)
+    t0 = time.perf_counter()
+    big.train(Xb, yb, max_iteration=20000)
+    print(f"trainer: 20000 samples -> {big.valid_supports} supports in {(time.perf_counter() - t0) * 1e3:.0f} ms")
+    assert torch.all((big.hypothesis > 0) == (big.y > 0)) and 10 < big.valid_supports < 20000
+    s = big.score(Xb[:4096])
+    assert float(((s > 0) == (yb[:4096] > 0)).float().mean()) > 0.99
