@@ -48,6 +48,19 @@ def _resolve_model(dist_est, device=None):
     raise TypeError(f"cannot fuse {dist_est!r}")
 
 
+def select_trial(best_valid_obj, lowest_loss, lowest_obj, steps, n_waypoints):
+    """The reference's selection policy over per-trial summaries (1-D tensors over trials, in trial order):
+    the first trial that found a valid path wins (optim.py:129-131, sequential trials stop there), otherwise the
+    lowest loss seen in any trial (optim.py:134-141).  Returns (trial, found, cost, cnt_check) with cnt_check =
+    what the sequential reference would have evaluated."""
+    valid = torch.isfinite(best_valid_obj)
+    if bool(valid.any()):
+        t = int(torch.nonzero(valid)[0])
+        return t, True, float(best_valid_obj[t]), int(steps[:t + 1].sum().item()) * n_waypoints
+    t = int(torch.argmin(lowest_loss))
+    return t, False, float(lowest_obj[t]), int(steps.sum().item()) * n_waypoints
+
+
 def fused_adam_traj_optimize(robot, dist_est, start_cfg, target_cfg, options, group=None):
     """Drop-in for `optim.adam_traj_optimize` with all restarts batched on the GPU.  With an initialised
     torch.distributed `group` (or the default group when options['distributed'] is true) the restarts are sharded
@@ -122,15 +135,8 @@ def fused_adam_traj_optimize(robot, dist_est, start_cfg, target_cfg, options, gr
         lowest_path = all_gather_rows(lowest_path, n_trials, group)
     summ = summ.cpu()
     bvo, lol, loo, nst = summ[:, 0], summ[:, 1], summ[:, 2], summ[:, 3]
-    valid = torch.isfinite(bvo)
-    if bool(valid.any()):
-        t_win = int(torch.nonzero(valid)[0])          # first trial (in order) with a valid path
-        solution, cost, found = best_valid_path[t_win], float(bvo[t_win]), True
-        cnt = int(nst[:t_win + 1].sum().item()) * W   # what the sequential reference would have evaluated
-    else:
-        t_win = int(torch.argmin(lol))
-        solution, cost, found = lowest_path[t_win], float(loo[t_win]), False
-        cnt = int(nst.sum().item()) * W
+    t_win, found, cost, cnt = select_trial(bvo, lol, loo, nst, W)
+    solution = (best_valid_path if found else lowest_path)[t_win]
     return {'start_cfg': _np(start_cfg).tolist(), 'target_cfg': _np(target_cfg).tolist(), 'cnt_check': cnt,
             'cost': cost, 'time': time.time() - t0, 'success': found, 'seed': seed,
             'solution': solution.double().cpu().numpy().tolist(),

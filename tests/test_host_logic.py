@@ -202,3 +202,17 @@ def test_scipy_optimizers_run_on_a_toy_problem():
     two = dict(opts, init_solution=torch.stack([start, target]).double())
     rec = optim.adam_traj_optimize(Point2D(), bump, start, target, two)
     assert rec["success"] and rec["cnt_check"] == 0
+
+
+def test_fused_optimizer_selection_policy():
+    from diffco_amd.traj import select_trial
+    inf = float("inf")
+    steps = torch.tensor([200., 200., 57., 200.])
+    # trial 2 is the first valid one: it wins even though trial 3 has a better objective; checks stop there
+    t, ok, cost, cnt = select_trial(torch.tensor([inf, inf, 0.9, 0.4]), torch.tensor([5., 3., 1., .5]),
+                                    torch.tensor([4., 2., .9, .4]), steps, 20)
+    assert (t, ok, cost, cnt) == (2, True, pytest.approx(0.9), (200 + 200 + 57) * 20)
+    # nothing valid: lowest loss over all trials, every step counted
+    t, ok, cost, cnt = select_trial(torch.full((4,), inf), torch.tensor([5., 3., 7., 4.]), torch.tensor([4., 2., 6., 3.]),
+                                    steps, 20)
+    assert (t, ok, cost, cnt) == (1, False, pytest.approx(2.0), 657 * 20)
