@@ -153,3 +153,66 @@ def test_batched_restarts_follow_the_reference_policy():
     if a["success"]:
         assert a["cnt_check"] == b["cnt_check"]
         assert abs(a["cost"] - b["cost"]) < 1e-2 * abs(b["cost"])
+
+
+@pytest.mark.parametrize("robot_name,W", [("baxter_left", 130), ("planar3", 70), ("se3", 33)])
+def test_adam_step_multi_wave_paths_and_other_transforms(robot_name, W):
+    """paths longer than one wave (waypoints spread over several LDS slabs) and non-DH transforms: one step of the
+    fused kernel against float64 autograd of the same loss built from torch ops on the HIP FK"""
+    import ctypes as C
+    from diffco_amd import _lib, _ops, kernel
+    rob = make_robot(robot_name)
+    lib = _lib.require_gpu()
+    g = torch.Generator().manual_seed(W)
+    lim = rob.limits
+    dof = rob.dof
+    S = 150
+    sup_q = torch.rand((S, dof), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]
+    w = 0.05 * torch.randn(S, generator=g)
+    desc = rob.fk_desc()
+    sup = _ops.fkine(desc, sup_q.cuda()).reshape(S, -1)
+    model = _ops.ScoreModel(desc, 1, 1.0, 1.0, sup, w.cuda())
+    R = 3
+    t = torch.linspace(0, 1, W)[None, :, None]
+    a = torch.rand((R, 1, dof), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]
+    b = torch.rand((R, 1, dof), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]
+    paths = (a * (1 - t) + b * t + 0.05 * torch.randn((R, W, dof), generator=g)).float()
+    paths[:, 3] = lim[:, 1] + 0.2   # one waypoint outside the joint limits
+    dev = model.dev
+    f32 = dict(device=dev, dtype=torch.float32)
+    path = paths.to(**f32).contiguous()
+    am, av = torch.zeros_like(path), torch.zeros_like(path)
+    bufs = [rob.limits.to(**f32).contiguous(), torch.empty(R * W, **f32), torch.empty((R * W, dof), **f32),
+            torch.zeros((R, 8), **f32), torch.full((R,), float("inf"), **f32), torch.full((R,), float("inf"), **f32),
+            path.clone(), torch.full((R,), float("inf"), **f32), path.clone(),
+            torch.zeros(R, device=dev, dtype=torch.int32), torch.zeros(R, device=dev, dtype=torch.int32)]
+    st = _lib.TrajState(R, W, *(C.c_void_p(x.data_ptr()) for x in [path, am, av] + bufs))
+    lr, margin, ms = 0.02, 0.01, 0.15
+    opt = _lib.TrajOpts(lr, 0.9, 0.999, 1e-8, 1, 10, 10, 10, margin, ms, 1e-2, 1e-4)
+    # float64 reference of the same step: torch ops on top of the (already verified) HIP FK and score ops
+    p64 = paths.double().clone().requires_grad_(True)
+    flat = p64.reshape(R * W, dof)
+    col = torch.clamp(model.score(flat).reshape(R, W) - margin, min=0).sum(dim=1)
+    cp = rob.fkine(flat).reshape(R, W, desc.n_points, desc.point_dim)
+    seg = (cp[:, 1:] - cp[:, :-1]).square().sum(dim=3)
+    mm = torch.clamp(seg - ms ** 2, min=0).sum(dim=(1, 2))
+    l64 = rob.limits.double()
+    jl = (torch.clamp(l64[:, 0] - p64, min=0) + torch.clamp(p64 - l64[:, 1], min=0)).sum(dim=(1, 2))
+    diff = seg.sum(dim=(1, 2))
+    loss = diff + 10 * col + 10 * mm + 10 * jl
+    (gr,) = torch.autograd.grad(loss.sum(), p64)
+    gr[:, 0] = 0
+    gr[:, -1] = 0
+    m1 = 0.1 * gr
+    v1 = 0.001 * gr * gr
+    ref = paths.double() - lr / 0.1 * m1 / (v1.sqrt() / np.sqrt(0.001) + 1e-8)
+    _lib.check(lib.dcx_traj_adam_run(model._h, C.byref(st), C.byref(opt), 1, 1, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    torch.cuda.synchronize()
+    stats = bufs[3].cpu().double()
+    assert relerr(stats[:, 0].numpy(), loss.detach().numpy()) < 5e-5
+    assert relerr(stats[:, 1].numpy(), diff.detach().numpy()) < 5e-5
+    assert relerr(stats[:, 6].numpy(), jl.detach().numpy()) < 5e-5 and float(jl.detach().min()) > 0
+    # Adam's first step is lr * sign(g) wherever |g| >> eps: compare where the gradient is not tiny
+    big = gr.abs() > 1e-4 * gr.abs().max()
+    assert float((path.cpu().double() - ref)[big].abs().max()) < 1e-5
+    assert torch.equal(path[:, 0].cpu(), paths[:, 0]) and torch.equal(path[:, -1].cpu(), paths[:, -1])
