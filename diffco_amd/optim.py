@@ -186,7 +186,27 @@ class _ScipyTerms:
         with torch.no_grad():
             return self.prob.segment_collision(self.prob.full(x).detach(), self.dist_est, self.dense_cap).numpy()
 
+    def _fused_model(self):
+        """the ScoreModel behind dist_est when it is a diffco_amd checker method with one output, else None"""
+        if not hasattr(self, "_model"):
+            self._model = None
+            try:
+                from .traj import _resolve_model
+                m = _resolve_model(self.dist_est)
+                if m.C == 1 and m.desc.key() == self.prob.robot.fk_desc().key():
+                    self._model = m
+            except Exception:
+                self._model = None
+        return self._model
+
     def jac_collision(self, x):
+        """[n_segments, (W-2)*dof] Jacobian of `collision`.  With a fusable dist_est it is assembled analytically
+        from ONE score+hinge-gradient launch over the densified path: d c_r / d dense_n =
+        -1[score_n > margin] * dscore_n/dq, chained through dense_n = p_i + k * max_step * unit(p_{i+1} - p_i).
+        Otherwise: autograd's vectorised Jacobian through dist_est, as the reference does (optim.py:209-218)."""
+        m = self._fused_model()
+        if m is not None and self.dense_cap is None:
+            return self._jac_collision_fused(x, m)
         p = self.prob.full(x)
         count = self.prob.cnt_check
         jac = torch.autograd.functional.jacobian(
@@ -194,6 +214,31 @@ class _ScipyTerms:
             strict=False, vectorize=True, strategy='reverse-mode')
         self.prob.cnt_check = count  # derivative evaluations are not counted as checks by the reference
         return jac[:, 1:-1].numpy().reshape(jac.shape[0], -1)
+
+    def _jac_collision_fused(self, x, model):
+        prob = self.prob
+        p = prob.full(x).detach()
+        W, dof = p.shape
+        ms = prob.max_speed
+        dense, seg, step = utils.dense_path_indexed(p, ms)
+        pts, seg, step = dense[1:-1], seg[1:-1], step[1:-1]
+        n_seg, n_pt = W - 1, len(pts)
+        per = -(-n_pt // n_seg) if n_pt else 0
+        J = torch.zeros((n_seg, W, dof), dtype=torch.float64)
+        if n_pt:
+            q32 = pts.to(device=model.dev, dtype=torch.float32).contiguous()
+            _, h = model.score_hinge_grad_raw(q32, prob.safety_margin, -1.0)  # h_n = d c_n / d dense_n
+            h = h.double().cpu()
+            delta = p[1:] - p[:-1]
+            length = delta.norm(dim=1)
+            unit = delta / length[:, None]
+            u = unit[seg]                                                   # [n_pt, dof]
+            scale = (step * ms / length[seg])[:, None]
+            a = scale * (h - u * (u * h).sum(dim=1, keepdim=True))          # part carried by p_{i+1}
+            row = torch.arange(n_pt) // per
+            J.index_put_((row, seg), h - a, accumulate=True)
+            J.index_put_((row, seg + 1), a, accumulate=True)
+        return J[:, 1:-1].numpy().reshape(n_seg, -1)
 
     def joint_limit(self, x):
         return -self.prob.joint_limit_violation(self.prob.full(x).detach()).item()

@@ -66,3 +66,22 @@ def dense_path(q, max_step=2.0, max_step_num=None):
     out = torch.cat(pieces)
     assert torch.all(out[0] == q[0]) and torch.all(out[-1] == q[-1])
     return out
+
+
+def dense_path_indexed(q, max_step=2.0):
+    """`dense_path(q, max_step)` plus, for every dense point, the segment it lies on and its step index:
+    dense[n] = q[seg[n]] + step[n] * max_step * unit(q[seg[n]+1] - q[seg[n]]); the final point q[-1] is reported
+    with seg = len(q) - 1, step = 0.  Used to build the constraint Jacobian analytically."""
+    pieces, segs, steps = [], [], []
+    for i in range(len(q) - 1):
+        seg = q[i + 1] - q[i]
+        length = seg.norm()
+        n = int(torch.ceil(length / max_step).item())
+        idx = torch.arange(n, device=q.device, dtype=q.dtype).reshape(-1, 1)
+        pieces.append(q[i] + idx * (seg * (max_step / length)))
+        segs += [i] * n
+        steps += list(range(n))
+    pieces.append(q[-1:])
+    segs.append(len(q) - 1)
+    steps.append(0)
+    return torch.cat(pieces), torch.tensor(segs, dtype=torch.long), torch.tensor(steps, dtype=q.dtype)

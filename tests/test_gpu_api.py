@@ -250,6 +250,17 @@ def test_adam_and_slsqp_on_the_hip_path():
     assert rec["success"] == bool(d["success"]) and rec["cnt_check"] == int(d["cnt_check"])
     assert abs(rec["cost"] - float(d["cost"])) < 5e-3 * float(d["cost"])
     assert relerr(np.array(rec["solution"]), d["solution"]) < 5e-3
+    # f4: the fused analytic constraint Jacobian (one hinge-gradient launch) equals autograd's vectorised Jacobian
+    prob = optim._PathProblem(rob, torch.from_numpy(d["start"]), torch.from_numpy(d["target"]), dict(options, safety_margin=-50.0))
+    prob.init_path = torch.from_numpy(d["init"]).clone()
+    terms = optim._ScipyTerms(prob, dc.poly_score)
+    x = prob.init_path[1:-1].reshape(-1).numpy()
+    assert terms._fused_model() is not None
+    Ja = terms.jac_collision(x)
+    terms._model = None
+    Jb = terms.jac_collision(x)
+    assert Ja.shape == Jb.shape == (19, 18 * 7) and np.abs(Jb).max() > 0
+    assert relerr(Ja, Jb) < 2e-5
     opts = dict(options, MAXITER=8, extra_optimizer_options={})
     rec2 = optim.givengrad_traj_optimize(rob, dc.poly_score, torch.from_numpy(d["start"]), torch.from_numpy(d["target"]), opts)
     assert np.isfinite(rec2["cost"]) and len(rec2["solution"]) == 20 and rec2["cnt_check"] > 0
