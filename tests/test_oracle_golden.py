@@ -114,3 +114,15 @@ def test_r0_subgradient_is_zero():
     W[11] = 0  # drop the coincident support entirely
     _, g_wo, _ = oracle.score_grad(desc, kind, p0, p1, sup, W, d["q"][3:4])
     assert relerr(g_all, g_wo) < 1e-6
+
+
+def test_oracle_is_sanitizer_clean():
+    """ASan + UBSan pass over every oracle entry point (all FK kinds x all kernel kinds, r = 0 pair included)"""
+    import os
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["make", "-C", os.path.join(root, "oracle"), "sanitize"], capture_output=True, text=True)
+    assert r.returncode == 0 and "oracle sanitize run ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
