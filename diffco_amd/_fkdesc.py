@@ -12,9 +12,11 @@ import math
 import numpy as np
 import torch
 
-DCX_FK_NONE, DCX_FK_PLANAR, DCX_FK_DH, DCX_FK_SE2, DCX_FK_SE3 = range(5)
+DCX_FK_NONE, DCX_FK_PLANAR, DCX_FK_DH, DCX_FK_SE2, DCX_FK_SE3, DCX_FK_TREE = range(6)
+DCX_J_FIXED, DCX_J_REV_X, DCX_J_REV_Y, DCX_J_REV_Z, DCX_J_PRISMATIC = range(5)
 DCX_K_RQ, DCX_K_POLY, DCX_K_MQ = range(3)
 MAX_JOINTS, MAX_CHAINS, MAX_POINTS, MAX_DOF, MAX_D, MAX_C = 16, 2, 24, 32, 72, 8
+MAX_TREE_CHAINS, MAX_TREE_JOINTS = 8, 64
 
 
 class FkDesc(C.Structure):
@@ -32,11 +34,25 @@ class FkDesc(C.Structure):
         ("pt_chain", C.c_int32 * MAX_POINTS), ("pt_frame", C.c_int32 * MAX_POINTS),
         ("pt_off", (C.c_float * 3) * MAX_POINTS),
         ("keypoints", (C.c_float * 3) * MAX_POINTS),
+        ("t_n_chains", C.c_int32), ("t_coord_major", C.c_int32),
+        ("t_chain_len", C.c_int32 * MAX_TREE_CHAINS),
+        ("t_base", (C.c_float * 12) * MAX_TREE_CHAINS),
+        ("t_type", C.c_int32 * MAX_TREE_JOINTS), ("t_q", C.c_int32 * MAX_TREE_JOINTS),
+        ("t_scale", C.c_float * MAX_TREE_JOINTS), ("t_offset", C.c_float * MAX_TREE_JOINTS),
+        ("t_fixed", (C.c_float * 12) * MAX_TREE_JOINTS),
+        ("t_axis", (C.c_float * 3) * MAX_TREE_JOINTS),
     ]
 
     @property
     def feature_dim(self):
         return self.n_points * self.point_dim
+
+    @property
+    def feature_shape(self):
+        """shape of one configuration's feature block as the reference lays it out"""
+        if self.kind == DCX_FK_TREE and self.t_coord_major:
+            return (self.point_dim, self.n_points)
+        return (self.n_points, self.point_dim)
 
     def key(self):
         return bytes(self)
@@ -112,3 +128,46 @@ def rotz_base(angle, t):
     c, s = math.cos(angle), math.sin(angle)
     # fp32 rounding of the entries happens when they are stored in the struct
     return [c, -s, 0, t[0], s, c, 0, t[1], 0, 0, 1, t[2]]
+
+
+def tree_desc(dof, chains, points, coord_major=True):
+    """DCX_FK_TREE description.
+
+    chains: list of dict(base=[12 floats] (optional), joints=[dict(type=DCX_J_*, q=int, scale=float, offset=float,
+            fixed=[12 floats, row-major 3x4], axis=(x, y, z))]) — one entry per root-to-leaf path;
+    points: list of (chain, frame, (ox, oy, oz)) in feature order."""
+    n_j = sum(len(ch["joints"]) for ch in chains)
+    if (len(chains) > MAX_TREE_CHAINS or n_j > MAX_TREE_JOINTS or len(points) > MAX_POINTS or dof > MAX_DOF
+            or 3 * len(points) > MAX_D):
+        raise ValueError(
+            f"kinematic tree exceeds the compiled limits: {len(chains)} chains (max {MAX_TREE_CHAINS}), {n_j} joints "
+            f"over all root-to-leaf paths (max {MAX_TREE_JOINTS}), {len(points)} control points (max {MAX_POINTS}), "
+            f"dof {dof} (max {MAX_DOF})")
+    d = FkDesc()
+    d.kind, d.dof, d.n_points, d.point_dim = DCX_FK_TREE, dof, len(points), 3
+    d.t_n_chains, d.t_coord_major = len(chains), int(bool(coord_major))
+    j = 0
+    for c, ch in enumerate(chains):
+        d.t_chain_len[c] = len(ch["joints"])
+        for e, v in enumerate(ch.get("base", IDENTITY_BASE)):
+            d.t_base[c][e] = float(v)
+        for jt in ch["joints"]:
+            d.t_type[j] = int(jt["type"])
+            movable = jt["type"] != DCX_J_FIXED
+            if movable and not 0 <= int(jt["q"]) < dof:
+                raise ValueError("joint reads a configuration entry outside [0, dof)")
+            d.t_q[j] = int(jt["q"]) if movable else 0
+            d.t_scale[j] = float(jt.get("scale", 1.0)) if movable else 0.0
+            d.t_offset[j] = float(jt.get("offset", 0.0)) if movable else 0.0
+            for e, v in enumerate(jt.get("fixed", IDENTITY_BASE)):
+                d.t_fixed[j][e] = float(v)
+            for e, v in enumerate(jt.get("axis", (0.0, 0.0, 0.0))):
+                d.t_axis[j][e] = float(v)
+            j += 1
+    for k, (c, f, off) in enumerate(points):
+        if not (0 <= c < len(chains) and 0 <= f < len(chains[c]["joints"])):
+            raise ValueError("control point attached to a frame that does not exist")
+        d.pt_chain[k], d.pt_frame[k] = int(c), int(f)
+        for e in range(3):
+            d.pt_off[k][e] = float(off[e])
+    return d

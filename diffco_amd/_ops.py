@@ -51,7 +51,7 @@ class _FkineFn(torch.autograd.Function):
             _lib.check(lib.dcx_fkine(dev.index, C.byref(desc), _ptr(q32), B, _ptr(X), _stream(dev)))
         ctx.desc, ctx.dev, ctx.in_dtype, ctx.in_device, ctx.in_shape = desc, dev, q.dtype, q.device, q.shape
         ctx.save_for_backward(q32)
-        return X.reshape(B, desc.n_points, desc.point_dim).to(device=q.device, dtype=q.dtype)
+        return X.reshape(B, *desc.feature_shape).to(device=q.device, dtype=q.dtype)
 
     @staticmethod
     @once_differentiable

@@ -15,10 +15,10 @@ __global__ __launch_bounds__(64) void fkine_kernel(const FkProg* fkd, const floa
     const int lane = threadIdx.x;
     const int64_t b0 = (int64_t)blockIdx.x * 64;
     const int nb = (int)((B - b0) < 64 ? (B - b0) : 64);
-    float* sQ = smem + kFkProgLdsFloats;
+    float* sQ = smem;
     float* sX = sQ + ((64 * dof + 3) & ~3);
     float* sF = sX + 64 * d_fk;
-    const fk_cptr fk = stage_fk_prog(fkd, smem, lane, 64);
+    const fk_cptr fk = stage_fk_prog(fkd, sF + 64 * frame_floats, lane, 64);  // program last (variable size)
     const float* qsrc = q + b0 * dof;
     const int n = nb * dof;
     for (int i = lane; i < 64 * dof; i += 64) sQ[i] = qsrc[i < n ? i : (i % dof) + (nb - 1) * dof];
@@ -40,11 +40,11 @@ __global__ __launch_bounds__(64) void fkine_vjp_kernel(const FkProg* fkd, const 
     const int lane = threadIdx.x;
     const int64_t b0 = (int64_t)blockIdx.x * 64;
     const int nb = (int)((B - b0) < 64 ? (B - b0) : 64);
-    float* sQ = smem + kFkProgLdsFloats;
+    float* sQ = smem;
     float* sX = sQ + ((64 * dof + 3) & ~3);
     float* sG = sX + 64 * d_fk;
     float* sF = sG + 64 * d_fk;
-    const fk_cptr fk = stage_fk_prog(fkd, smem, lane, 64);
+    const fk_cptr fk = stage_fk_prog(fkd, sF + 64 * frame_floats, lane, 64);  // program last (variable size)
     const float* qsrc = q + b0 * dof;
     const int n = nb * dof;
     for (int i = lane; i < 64 * dof; i += 64) sQ[i] = qsrc[i < n ? i : (i % dof) + (nb - 1) * dof];
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(64) void score_finish_kernel(const FinishArgs a) {
 
 size_t fk_lds_bytes(const dcx_fk_desc& fk, bool with_g) {
     const int d_fk = fk.n_points * fk.point_dim;
-    return sizeof(float) * (kFkProgLdsFloats + ((64 * fk.dof + 3) & ~3) + 64 * d_fk * (with_g ? 2 : 1) + 64 * fk_frame_floats(fk));
+    return sizeof(float) * (fk_prog_floats(fk) + ((64 * fk.dof + 3) & ~3) + 64 * d_fk * (with_g ? 2 : 1) + 64 * fk_frame_floats(fk));
 }
 
 }  // namespace

@@ -25,6 +25,7 @@ struct dcx_model {
     int32_t kind = 0, kf = 0;
     float kp0 = 0, kp1 = 0;
     int32_t frame_floats = 0;
+    int32_t prog_floats = 0;       // LDS floats of the staged FK program
     launch_fn launch = nullptr;
     int32_t max_threads = 0;
     int32_t n_cu = 256;
@@ -93,6 +94,25 @@ int check_fk(const dcx_fk_desc& fk) {
             const int c = fk.pt_chain[k];
             if (c < 0 || c >= fk.n_chains || fk.pt_frame[k] < 0 || fk.pt_frame[k] >= fk.chain_len[c])
                 return fail(DCX_ERR_INVALID, "DCX_FK_DH control point refers to a missing frame");
+        }
+    } break;
+    case DCX_FK_TREE: {
+        if (fk.point_dim != 3 || fk.n_points > DCX_MAX_POINTS) return fail(DCX_ERR_INVALID, "DCX_FK_TREE needs point_dim 3, n_points <= DCX_MAX_POINTS");
+        if (fk.t_n_chains < 1 || fk.t_n_chains > DCX_MAX_TREE_CHAINS) return fail(DCX_ERR_UNSUPPORTED, "DCX_FK_TREE t_n_chains must be in [1, DCX_MAX_TREE_CHAINS]");
+        int total = 0;
+        for (int c = 0; c < fk.t_n_chains; ++c) {
+            if (fk.t_chain_len[c] < 1) return fail(DCX_ERR_INVALID, "DCX_FK_TREE empty chain");
+            total += fk.t_chain_len[c];
+            if (total > DCX_MAX_TREE_JOINTS) return fail(DCX_ERR_UNSUPPORTED, "DCX_FK_TREE more than DCX_MAX_TREE_JOINTS joints over all chains");
+        }
+        for (int j = 0; j < total; ++j) {
+            if (fk.t_type[j] < DCX_J_FIXED || fk.t_type[j] > DCX_J_PRISMATIC) return fail(DCX_ERR_INVALID, "DCX_FK_TREE unknown joint type");
+            if (fk.t_type[j] != DCX_J_FIXED && (fk.t_q[j] < 0 || fk.t_q[j] >= fk.dof)) return fail(DCX_ERR_INVALID, "DCX_FK_TREE t_q out of range");
+        }
+        for (int k = 0; k < fk.n_points; ++k) {
+            const int c = fk.pt_chain[k];
+            if (c < 0 || c >= fk.t_n_chains || fk.pt_frame[k] < 0 || fk.pt_frame[k] >= fk.t_chain_len[c])
+                return fail(DCX_ERR_INVALID, "DCX_FK_TREE control point refers to a missing frame");
         }
     } break;
     case DCX_FK_SE2:
@@ -206,7 +226,7 @@ Geometry pick_geometry(const dcx_model* m, int64_t B, int acc_floats, bool allow
     while (g.ys > 1 && m->S_active / (g.ys * g.nw) < 32) g.ys /= 2;
     while (g.nw > 1 && m->S_active / (g.ys * g.nw) < 32) g.nw /= 2;
     const int d_fk = m->fk.n_points * m->fk.point_dim;
-    while (g.nw > 1 && lds_plan(m->fk.dof, d_fk, m->frame_floats, g.nw, acc_floats).total * sizeof(float) > 64 * 1024) g.nw /= 2;
+    while (g.nw > 1 && (lds_plan(m->fk.dof, d_fk, m->frame_floats, g.nw, acc_floats).total + m->prog_floats) * sizeof(float) > 64 * 1024) g.nw /= 2;
     return g;
 }
 
@@ -287,7 +307,7 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
     a.ts = g_ts_dev;
     a.ts_block = std::getenv("DCX_TS_BLOCK") ? (unsigned)std::atoi(std::getenv("DCX_TS_BLOCK")) : 0u;
 #endif
-    const size_t lds = sizeof(float) * lds_plan(a.dof, d_fk, m->frame_floats, g.nw, acc).total;
+    const size_t lds = sizeof(float) * (lds_plan(a.dof, d_fk, m->frame_floats, g.nw, acc).total + m->prog_floats);
     if (g.ys == 1) {
         hipError_t e = m->launch(m->kf, m->C, mode, g.nw, lds, nblk, a, st);
         if (e != hipSuccess) return fail_hip(e, "score kernel launch");
@@ -316,7 +336,7 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
         f.hinge = hinge.on;
         f.hinge_margin = hinge.margin;
         f.hinge_weight = hinge.weight;
-        e = launch_score_finish(f, nblk, sizeof(float) * lds_plan(a.dof, d_fk, m->frame_floats, 1, 0).total, st);
+        e = launch_score_finish(f, nblk, sizeof(float) * (lds_plan(a.dof, d_fk, m->frame_floats, 1, 0).total + m->prog_floats), st);
     }
     if (e != hipSuccess) return fail_hip(e, "split score launch");
     return DCX_OK;
@@ -383,6 +403,7 @@ int dcx_model_create(dcx_model** out, int device, const dcx_fk_desc* fk, int ker
             : (kernel_kind == DCX_K_POLY && kparams[0] == 1.0f) ? KF_POLY1
                                                                 : KF_GEN;
     m->frame_floats = fk_frame_floats(desc);
+    m->prog_floats = fk_prog_floats(desc);
     m->launch = launch_for(m->Dt);
     m->max_threads = max_threads_for(m->Dt);
     if (!m->launch) {

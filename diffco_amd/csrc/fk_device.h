@@ -33,28 +33,130 @@
 namespace dcx {
 
 constexpr int kMaxProgJoints = DCX_MAX_CHAINS * DCX_MAX_JOINTS;
+constexpr int kMaxProgChains = DCX_MAX_TREE_CHAINS > DCX_MAX_CHAINS ? DCX_MAX_TREE_CHAINS : DCX_MAX_CHAINS;
 
-struct FkProgJoint {  // 8 dwords
+struct FkProgJoint {  // DCX_FK_DH, 8 dwords
     int32_t q_index;
     float theta0, a, d, sin_alpha, cos_alpha;
     int32_t pt_begin, pt_end;  // control points attached to this joint's frame: points[pt_begin .. pt_end)
 };
+// DCX_FK_TREE joint, 24 dwords:  T <- T * [F] * Motion.  The host has already conjugated x/y revolute axes onto z
+// (a signed permutation, exact in fp32), so the device knows one rotation: Rz(v).
+enum { TJ_FIXED = 0, TJ_REV = 1, TJ_PRISM = 2 };
+struct FkProgTreeJoint {
+    int32_t type, q_index;
+    float scale, offset;       // joint variable v = scale * q[q_index] + offset
+    int32_t slot, slot_owner;  // frames slot of (sin v, cos v) or (v, -); owner = first joint that uses the slot
+    int32_t pt_begin, pt_end;
+    float ax, ay, az, pad;     // prismatic direction
+    float F[12];               // row-major 3x4 constant transform applied before the motion
+};
 struct FkProgPoint {  // 4 dwords
     float ox, oy, oz;
-    int32_t out_k;  // feature slot: coordinates go to X[3*out_k .. 3*out_k+2]
+    int32_t out_k;  // feature slot: coordinate r goes to X[out_k + r * out_stride]
 };
 struct FkProg {
     int32_t kind, dof, n_points, point_dim;
-    int32_t n_chains, n_joints, pad0, pad1;
-    int32_t chain_begin[DCX_MAX_CHAINS], chain_end[DCX_MAX_CHAINS];  // joint ranges
-    float base[DCX_MAX_CHAINS][12];
-    FkProgJoint joints[kMaxProgJoints];
+    int32_t n_chains, n_joints, out_stride, n_dwords;  // n_dwords: how much of this struct the kind uses
+    int32_t chain_begin[kMaxProgChains], chain_end[kMaxProgChains];  // joint ranges
+    float base[kMaxProgChains][12];
     FkProgPoint points[DCX_MAX_POINTS];
     float link_length[DCX_MAX_DOF];
     float keypoints[DCX_MAX_POINTS][4];
+    union {  // last member: only the used prefix is staged into LDS
+        FkProgJoint joints[kMaxProgJoints];
+        FkProgTreeJoint tj[DCX_MAX_TREE_JOINTS];
+    };
 };
-constexpr int kFkProgDwords = (sizeof(FkProg) + 3) / 4;
-constexpr int kFkProgLdsFloats = (kFkProgDwords + 3) & ~3;
+constexpr int kFkProgHeadDwords = (int)(offsetof(FkProg, joints) / 4);
+
+// joints a description executes (DH / TREE), 0 otherwise
+__host__ __device__ inline int fk_joint_count(const dcx_fk_desc& fk) {
+    int j = 0;
+    if (fk.kind == DCX_FK_DH)
+        for (int c = 0; c < fk.n_chains; ++c) j += fk.chain_len[c];
+    if (fk.kind == DCX_FK_TREE)
+        for (int c = 0; c < fk.t_n_chains; ++c) j += fk.t_chain_len[c];
+    return j;
+}
+// LDS floats the staged program of this description occupies
+__host__ __device__ inline int fk_prog_floats(const dcx_fk_desc& fk) {
+    const int per = fk.kind == DCX_FK_DH ? (int)(sizeof(FkProgJoint) / 4) : fk.kind == DCX_FK_TREE ? (int)(sizeof(FkProgTreeJoint) / 4) : 0;
+    return (kFkProgHeadDwords + per * fk_joint_count(fk) + 3) & ~3;
+}
+
+// DCX_FK_TREE: joints that read the same joint variable (a shared prefix repeated in several chains, or mimic
+// joints with equal multiplier/offset) share one frames slot.  Returns the number of slots.
+inline int tree_slots(const dcx_fk_desc& fk, int* slot_of, int* owner) {
+    const int n = fk_joint_count(fk);
+    int n_slots = 0;
+    for (int j = 0; j < n; ++j) {
+        slot_of[j] = -1;
+        owner[j] = 0;
+        if (fk.t_type[j] == DCX_J_FIXED) continue;
+        const bool prism = fk.t_type[j] == DCX_J_PRISMATIC;
+        for (int i = 0; i < j && slot_of[j] < 0; ++i)
+            if (fk.t_type[i] != DCX_J_FIXED && (fk.t_type[i] == DCX_J_PRISMATIC) == prism && fk.t_q[i] == fk.t_q[j] &&
+                fk.t_scale[i] == fk.t_scale[j] && fk.t_offset[i] == fk.t_offset[j])
+                slot_of[j] = slot_of[i];
+        if (slot_of[j] < 0) {
+            slot_of[j] = n_slots++;
+            owner[j] = 1;
+        }
+    }
+    return n_slots;
+}
+
+// host: DCX_FK_TREE -> program.  Revolute joints about x / y are rewritten as rotations about z:
+//   Rx(v) = P Rz(v) P^T,  P = [e_y e_z e_x];   Ry(v) = P' Rz(v) P'^T,  P' = P P = [e_z e_x e_y]
+// with the permutation folded into the neighbouring constants (F_j <- P_{j-1}^T F_j P_j, control-point offsets
+// o <- P_j^T o).  Permuting entries does not round, so the chain computes exactly the values the x/y forms would.
+inline void build_tree_prog(const dcx_fk_desc& fk, FkProg& p) {
+    int slot_of[DCX_MAX_TREE_JOINTS], owner[DCX_MAX_TREE_JOINTS];
+    tree_slots(fk, slot_of, owner);
+    p.n_chains = fk.t_n_chains;
+    p.out_stride = fk.t_coord_major ? fk.n_points : 1;
+    static const int perm_of[3][3] = {{1, 2, 0}, {2, 0, 1}, {0, 1, 2}};  // column c of P is e_{perm[c]}: REV_X, REV_Y, identity
+    int nj = 0, np = 0;
+    for (int c = 0; c < fk.t_n_chains; ++c) {
+        p.chain_begin[c] = nj;
+        for (int e = 0; e < 12; ++e) p.base[c][e] = fk.t_base[c][e];
+        const int* prev = perm_of[2];
+        for (int i = 0; i < fk.t_chain_len[c]; ++i, ++nj) {
+            FkProgTreeJoint& J = p.tj[nj];
+            const int t = fk.t_type[nj];
+            const int* cur = t == DCX_J_REV_X ? perm_of[0] : t == DCX_J_REV_Y ? perm_of[1] : perm_of[2];
+            J.type = (t == DCX_J_FIXED) ? TJ_FIXED : (t == DCX_J_PRISMATIC) ? TJ_PRISM : TJ_REV;
+            J.q_index = fk.t_q[nj];
+            J.scale = fk.t_scale[nj];
+            J.offset = fk.t_offset[nj];
+            J.slot = slot_of[nj] < 0 ? 0 : slot_of[nj];
+            J.slot_owner = owner[nj];
+            J.ax = fk.t_axis[nj][0];
+            J.ay = fk.t_axis[nj][1];
+            J.az = fk.t_axis[nj][2];
+            // (P_prev^T F P_cur): row r of the result is row prev[r] of F; column k of its rotation is column cur[k]
+            for (int r = 0; r < 3; ++r) {
+                for (int k = 0; k < 3; ++k) J.F[r * 4 + k] = fk.t_fixed[nj][prev[r] * 4 + cur[k]];
+                J.F[r * 4 + 3] = fk.t_fixed[nj][prev[r] * 4 + 3];
+            }
+            J.pt_begin = np;
+            for (int k = 0; k < fk.n_points; ++k) {
+                if (fk.pt_chain[k] != c || fk.pt_frame[k] != i) continue;
+                const float* o = fk.pt_off[k];
+                p.points[np].ox = o[cur[0]];  // P_cur^T o
+                p.points[np].oy = o[cur[1]];
+                p.points[np].oz = o[cur[2]];
+                p.points[np].out_k = fk.t_coord_major ? k : 3 * k;
+                ++np;
+            }
+            J.pt_end = np;
+            prev = cur;
+        }
+        p.chain_end[c] = nj;
+    }
+    p.n_joints = nj;
+}
 
 // host: compile the public description into the device program
 inline void build_fk_prog(const dcx_fk_desc& fk, FkProg& p) {
@@ -63,9 +165,15 @@ inline void build_fk_prog(const dcx_fk_desc& fk, FkProg& p) {
     p.dof = fk.dof;
     p.n_points = fk.n_points;
     p.point_dim = fk.point_dim;
+    p.out_stride = 1;
+    p.n_dwords = fk_prog_floats(fk);
     for (int i = 0; i < DCX_MAX_DOF; ++i) p.link_length[i] = fk.link_length[i];
     for (int k = 0; k < DCX_MAX_POINTS; ++k)
         for (int j = 0; j < 3; ++j) p.keypoints[k][j] = fk.keypoints[k][j];
+    if (fk.kind == DCX_FK_TREE) {
+        build_tree_prog(fk, p);
+        return;
+    }
     if (fk.kind != DCX_FK_DH) return;
     p.n_chains = fk.n_chains;
     int nj = 0, np = 0;
@@ -86,7 +194,7 @@ inline void build_fk_prog(const dcx_fk_desc& fk, FkProg& p) {
                 p.points[np].ox = fk.pt_off[k][0];
                 p.points[np].oy = fk.pt_off[k][1];
                 p.points[np].oz = fk.pt_off[k][2];
-                p.points[np].out_k = k;
+                p.points[np].out_k = 3 * k;
                 ++np;
             }
             J.pt_end = np;
@@ -97,13 +205,17 @@ inline void build_fk_prog(const dcx_fk_desc& fk, FkProg& p) {
 }
 
 // LDS floats per lane the FK needs for its frames.
-__host__ __device__ inline int fk_frame_floats(const dcx_fk_desc& fk) {
+inline int fk_frame_floats(const dcx_fk_desc& fk) {
     if (fk.kind == DCX_FK_DH) {
         int j = 0;
         for (int c = 0; c < fk.n_chains; ++c) j += fk.chain_len[c];
         return 2 * j + 9 * fk.n_chains;
     }
     if (fk.kind == DCX_FK_PLANAR) return 2 * fk.dof;
+    if (fk.kind == DCX_FK_TREE) {
+        int slot_of[DCX_MAX_TREE_JOINTS], owner[DCX_MAX_TREE_JOINTS];
+        return 2 * tree_slots(fk, slot_of, owner) + 9 * fk.t_n_chains;
+    }
     return 0;
 }
 
@@ -115,7 +227,8 @@ __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlan
 __device__ __forceinline__ fk_cptr stage_fk_prog(const FkProg* g, float* lds, int tid, int nthreads) {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(g);
     uint32_t* dst = reinterpret_cast<uint32_t*>(lds);
-    for (int i = tid; i < kFkProgDwords; i += nthreads) dst[i] = src[i];
+    const int n = rfl(g->n_dwords);
+    for (int i = tid; i < n; i += nthreads) dst[i] = src[i];
     return (fk_cptr)(uintptr_t)(uint32_t)(uintptr_t)lds;  // generic -> LDS: the low 32 bits are the LDS offset
 }
 
@@ -152,6 +265,22 @@ __device__ inline void fk_forward_trig(fk_cptr fk, const float* sQrow, float* sF
             sincos_f32(th, &s, &c);
             sFcol[(2 * j) * 64] = s;
             sFcol[(2 * j + 1) * 64] = c;
+        }
+    } else if (kind == DCX_FK_TREE) {
+        const int nj = rfl(fk->n_joints);
+        for (int j = wave; j < nj; j += nw) {
+            const int type = rfl(fk->tj[j].type);
+            if (type == TJ_FIXED || !rfl(fk->tj[j].slot_owner)) continue;
+            const float v = fmaf(fk->tj[j].scale, sQrow[rfl(fk->tj[j].q_index)], fk->tj[j].offset);
+            const int slot = rfl(fk->tj[j].slot);
+            if (type == TJ_REV) {
+                float s, c;
+                sincos_f32(v, &s, &c);
+                sFcol[(2 * slot) * 64] = s;
+                sFcol[(2 * slot + 1) * 64] = c;
+            } else {
+                sFcol[(2 * slot) * 64] = v;  // prismatic: the reverse sweep needs v after q has been overwritten
+            }
         }
     } else if (kind == DCX_FK_PLANAR) {
         const int dof = rfl(fk->dof);
@@ -210,13 +339,72 @@ __device__ inline void fk_forward_chain(fk_cptr fk, const float* sQrow, float* s
                 const int pb = rfl(fk->joints[j].pt_begin), pe = rfl(fk->joints[j].pt_end);
                 for (int p = pb; p < pe; ++p) {
                     const float ox = fk->points[p].ox, oy = fk->points[p].oy, oz = fk->points[p].oz;
-                    float* out = sXcol + (3 * rfl(fk->points[p].out_k)) * 64;
+                    float* out = sXcol + rfl(fk->points[p].out_k) * 64;
                     out[0] = fmaf(r00, ox, fmaf(r01, oy, fmaf(r02, oz, t0)));
                     out[64] = fmaf(r10, ox, fmaf(r11, oy, fmaf(r12, oz, t1)));
                     out[128] = fmaf(r20, ox, fmaf(r21, oy, fmaf(r22, oz, t2)));
                 }
             }
             float* fr = sFcol + (2 * njt + 9 * ch) * 64;  // final rotation of this chain (for the reverse sweep)
+            fr[0] = r00; fr[64] = r01; fr[128] = r02; fr[192] = r10; fr[256] = r11; fr[320] = r12;
+            fr[384] = r20; fr[448] = r21; fr[512] = r22;
+        }
+    } else if (kind == DCX_FK_TREE) {
+        // T <- T * F * Motion along every root-to-leaf chain (reference: RigidBody.forward_kinematics,
+        // collision_interfaces/rigid_body.py:82-140, unrolled); features = frame origins (+ constant offsets for
+        // links behind fixed joints), collision_checkers.py:386-393
+        const int nch = rfl(fk->n_chains), stride = rfl(fk->out_stride) * 64;
+        int n_slots2 = 0;
+        {
+            const int njt = rfl(fk->n_joints);
+            for (int j = 0; j < njt; ++j) n_slots2 += 2 * rfl(fk->tj[j].slot_owner);
+        }
+        for (int ch = 0; ch < nch; ++ch) {
+            float r00 = fk->base[ch][0], r01 = fk->base[ch][1], r02 = fk->base[ch][2], t0 = fk->base[ch][3];
+            float r10 = fk->base[ch][4], r11 = fk->base[ch][5], r12 = fk->base[ch][6], t1 = fk->base[ch][7];
+            float r20 = fk->base[ch][8], r21 = fk->base[ch][9], r22 = fk->base[ch][10], t2 = fk->base[ch][11];
+            const int jb = rfl(fk->chain_begin[ch]), je = rfl(fk->chain_end[ch]);
+            for (int j = jb; j < je; ++j) {
+                const auto* F = fk->tj[j].F;
+                // N = T * F
+                const float f00 = F[0], f01 = F[1], f02 = F[2], f03 = F[3], f10 = F[4], f11 = F[5], f12 = F[6], f13 = F[7];
+                const float f20 = F[8], f21 = F[9], f22 = F[10], f23 = F[11];
+                t0 = fmaf(r00, f03, fmaf(r01, f13, fmaf(r02, f23, t0)));
+                t1 = fmaf(r10, f03, fmaf(r11, f13, fmaf(r12, f23, t1)));
+                t2 = fmaf(r20, f03, fmaf(r21, f13, fmaf(r22, f23, t2)));
+                float n00 = fmaf(r00, f00, fmaf(r01, f10, r02 * f20)), n01 = fmaf(r00, f01, fmaf(r01, f11, r02 * f21)),
+                      n02 = fmaf(r00, f02, fmaf(r01, f12, r02 * f22));
+                float n10 = fmaf(r10, f00, fmaf(r11, f10, r12 * f20)), n11 = fmaf(r10, f01, fmaf(r11, f11, r12 * f21)),
+                      n12 = fmaf(r10, f02, fmaf(r11, f12, r12 * f22));
+                float n20 = fmaf(r20, f00, fmaf(r21, f10, r22 * f20)), n21 = fmaf(r20, f01, fmaf(r21, f11, r22 * f21)),
+                      n22 = fmaf(r20, f02, fmaf(r21, f12, r22 * f22));
+                const int type = rfl(fk->tj[j].type), slot = rfl(fk->tj[j].slot);
+                if (type == TJ_REV) {
+                    // R <- N * Rz(v): columns 0, 1 rotate
+                    const float s = sFcol[(2 * slot) * 64], c = sFcol[(2 * slot + 1) * 64];
+                    r00 = fmaf(n00, c, n01 * s); r01 = fmaf(n01, c, -n00 * s); r02 = n02;
+                    r10 = fmaf(n10, c, n11 * s); r11 = fmaf(n11, c, -n10 * s); r12 = n12;
+                    r20 = fmaf(n20, c, n21 * s); r21 = fmaf(n21, c, -n20 * s); r22 = n22;
+                } else {
+                    r00 = n00; r01 = n01; r02 = n02; r10 = n10; r11 = n11; r12 = n12; r20 = n20; r21 = n21; r22 = n22;
+                    if (type == TJ_PRISM) {
+                        const float v = sFcol[(2 * slot) * 64];
+                        const float dx = fk->tj[j].ax * v, dy = fk->tj[j].ay * v, dz = fk->tj[j].az * v;
+                        t0 = fmaf(r00, dx, fmaf(r01, dy, fmaf(r02, dz, t0)));
+                        t1 = fmaf(r10, dx, fmaf(r11, dy, fmaf(r12, dz, t1)));
+                        t2 = fmaf(r20, dx, fmaf(r21, dy, fmaf(r22, dz, t2)));
+                    }
+                }
+                const int pb = rfl(fk->tj[j].pt_begin), pe = rfl(fk->tj[j].pt_end);
+                for (int p = pb; p < pe; ++p) {
+                    const float ox = fk->points[p].ox, oy = fk->points[p].oy, oz = fk->points[p].oz;
+                    float* out = sXcol + rfl(fk->points[p].out_k) * 64;
+                    out[0] = fmaf(r00, ox, fmaf(r01, oy, fmaf(r02, oz, t0)));
+                    out[stride] = fmaf(r10, ox, fmaf(r11, oy, fmaf(r12, oz, t1)));
+                    out[2 * stride] = fmaf(r20, ox, fmaf(r21, oy, fmaf(r22, oz, t2)));
+                }
+            }
+            float* fr = sFcol + (n_slots2 + 9 * ch) * 64;  // final rotation of this chain (for the reverse sweep)
             fr[0] = r00; fr[64] = r01; fr[128] = r02; fr[192] = r10; fr[256] = r11; fr[320] = r12;
             fr[384] = r20; fr[448] = r21; fr[512] = r22;
         }
@@ -292,7 +480,7 @@ __device__ inline void fk_vjp(fk_cptr fk, const float* sQrow, const float* sFcol
             for (int j = je - 1; j >= jb; --j) {
                 const int pb = rfl(fk->joints[j].pt_begin), pe = rfl(fk->joints[j].pt_end);
                 for (int p = pb; p < pe; ++p) {
-                    const float* gin = sGcol + (3 * rfl(fk->points[p].out_k)) * 64;
+                    const float* gin = sGcol + rfl(fk->points[p].out_k) * 64;
                     const float g0 = gin[0], g1 = gin[64], g2 = gin[128];
                     const float ox = fk->points[p].ox, oy = fk->points[p].oy, oz = fk->points[p].oz;
                     T0 += g0; T1 += g1; T2 += g2;
@@ -336,6 +524,89 @@ __device__ inline void fk_vjp(fk_cptr fk, const float* sQrow, const float* sFcol
                 const float n22 = fmaf(G21, sa, fmaf(G22, ca, T2 * d));
                 G00 = n00; G01 = n01; G02 = n02; G10 = n10; G11 = n11; G12 = n12; G20 = n20; G21 = n21; G22 = n22;
                 r00 = p00; r01 = p01; r02 = p02; r10 = p10; r11 = p11; r12 = p12; r20 = p20; r21 = p21; r22 = p22;
+            }
+        }
+    } else if (kind == DCX_FK_TREE) {
+        // Reverse-mode sweep through T_j = T_{j-1} F_j M_j(v_j), chain by chain; a joint repeated on several chains
+        // (shared prefix) or driven by the same q (mimic) simply accumulates.  With N = T_{j-1} F_j:
+        //   revolute : R_j = R_N Rz(v), t_j = t_N   ->  dL/dv = <R_N^T GR, dRz/dv>,  G_RN = GR Rz^T
+        //   prismatic: R_j = R_N, t_j = t_N + R_N a v -> dL/dv = Gt . (R_N a),        G_RN = GR + Gt (a v)^T
+        //   through F: G_R(j-1) = G_RN F_R^T + Gt F_t^T,  R_(j-1) = R_N F_R^T,  Gt unchanged
+        for (int i = 0; i < dof; ++i) gqRow[i] = 0.f;  // the sweep reads frames, not q
+        const int nch = rfl(fk->n_chains), stride = rfl(fk->out_stride) * 64;
+        int n_slots2 = 0;
+        {
+            const int njt = rfl(fk->n_joints);
+            for (int j = 0; j < njt; ++j) n_slots2 += 2 * rfl(fk->tj[j].slot_owner);
+        }
+        for (int ch = 0; ch < nch; ++ch) {
+            const float* fr = sFcol + (n_slots2 + 9 * ch) * 64;
+            float r00 = fr[0], r01 = fr[64], r02 = fr[128], r10 = fr[192], r11 = fr[256], r12 = fr[320];
+            float r20 = fr[384], r21 = fr[448], r22 = fr[512];
+            float G00 = 0.f, G01 = 0.f, G02 = 0.f, G10 = 0.f, G11 = 0.f, G12 = 0.f, G20 = 0.f, G21 = 0.f, G22 = 0.f;
+            float T0 = 0.f, T1 = 0.f, T2 = 0.f;
+            const int jb = rfl(fk->chain_begin[ch]), je = rfl(fk->chain_end[ch]);
+            for (int j = je - 1; j >= jb; --j) {
+                const int pb = rfl(fk->tj[j].pt_begin), pe = rfl(fk->tj[j].pt_end);
+                for (int p = pb; p < pe; ++p) {
+                    const float* gin = sGcol + rfl(fk->points[p].out_k) * 64;
+                    const float g0 = gin[0], g1 = gin[stride], g2 = gin[2 * stride];
+                    const float ox = fk->points[p].ox, oy = fk->points[p].oy, oz = fk->points[p].oz;
+                    T0 += g0; T1 += g1; T2 += g2;
+                    G00 = fmaf(g0, ox, G00); G01 = fmaf(g0, oy, G01); G02 = fmaf(g0, oz, G02);
+                    G10 = fmaf(g1, ox, G10); G11 = fmaf(g1, oy, G11); G12 = fmaf(g1, oz, G12);
+                    G20 = fmaf(g2, ox, G20); G21 = fmaf(g2, oy, G21); G22 = fmaf(g2, oz, G22);
+                }
+                const int type = rfl(fk->tj[j].type), slot = rfl(fk->tj[j].slot);
+                if (type == TJ_REV) {
+                    const float s = sFcol[(2 * slot) * 64], c = sFcol[(2 * slot + 1) * 64];
+                    // R_N = R_j Rz^T: columns 0, 1 rotate back
+                    const float p00 = fmaf(r00, c, -r01 * s), p01 = fmaf(r01, c, r00 * s);
+                    const float p10 = fmaf(r10, c, -r11 * s), p11 = fmaf(r11, c, r10 * s);
+                    const float p20 = fmaf(r20, c, -r21 * s), p21 = fmaf(r21, c, r20 * s);
+                    // A = R_N^T GR, rows 0 and 1, columns 0 and 1 (dRz/dv = [[-s, -c, 0], [c, -s, 0], [0, 0, 0]])
+                    const float A00 = fmaf(p00, G00, fmaf(p10, G10, p20 * G20)), A01 = fmaf(p00, G01, fmaf(p10, G11, p20 * G21));
+                    const float A10 = fmaf(p01, G00, fmaf(p11, G10, p21 * G20)), A11 = fmaf(p01, G01, fmaf(p11, G11, p21 * G21));
+                    const float dv = (c * A10 - s * A11) - (s * A00 + c * A01);
+                    gqRow[rfl(fk->tj[j].q_index)] += fk->tj[j].scale * dv;
+                    // G_RN = GR Rz^T
+                    const float h00 = fmaf(G00, c, -G01 * s), h01 = fmaf(G01, c, G00 * s);
+                    const float h10 = fmaf(G10, c, -G11 * s), h11 = fmaf(G11, c, G10 * s);
+                    const float h20 = fmaf(G20, c, -G21 * s), h21 = fmaf(G21, c, G20 * s);
+                    G00 = h00; G01 = h01; G10 = h10; G11 = h11; G20 = h20; G21 = h21;
+                    r00 = p00; r01 = p01; r10 = p10; r11 = p11; r20 = p20; r21 = p21;
+                } else if (type == TJ_PRISM) {
+                    const float v = sFcol[(2 * slot) * 64];
+                    const float ax = fk->tj[j].ax, ay = fk->tj[j].ay, az = fk->tj[j].az;
+                    const float w0 = fmaf(r00, ax, fmaf(r01, ay, r02 * az)), w1 = fmaf(r10, ax, fmaf(r11, ay, r12 * az)),
+                                w2 = fmaf(r20, ax, fmaf(r21, ay, r22 * az));
+                    gqRow[rfl(fk->tj[j].q_index)] += fk->tj[j].scale * fmaf(T0, w0, fmaf(T1, w1, T2 * w2));
+                    const float dx = ax * v, dy = ay * v, dz = az * v;
+                    G00 = fmaf(T0, dx, G00); G01 = fmaf(T0, dy, G01); G02 = fmaf(T0, dz, G02);
+                    G10 = fmaf(T1, dx, G10); G11 = fmaf(T1, dy, G11); G12 = fmaf(T1, dz, G12);
+                    G20 = fmaf(T2, dx, G20); G21 = fmaf(T2, dy, G21); G22 = fmaf(T2, dz, G22);
+                }
+                // back through the constant transform F
+                const auto* F = fk->tj[j].F;
+                const float f00 = F[0], f01 = F[1], f02 = F[2], f03 = F[3], f10 = F[4], f11 = F[5], f12 = F[6], f13 = F[7];
+                const float f20 = F[8], f21 = F[9], f22 = F[10], f23 = F[11];
+                const float n00 = fmaf(G00, f00, fmaf(G01, f01, fmaf(G02, f02, T0 * f03)));
+                const float n01 = fmaf(G00, f10, fmaf(G01, f11, fmaf(G02, f12, T0 * f13)));
+                const float n02 = fmaf(G00, f20, fmaf(G01, f21, fmaf(G02, f22, T0 * f23)));
+                const float n10 = fmaf(G10, f00, fmaf(G11, f01, fmaf(G12, f02, T1 * f03)));
+                const float n11 = fmaf(G10, f10, fmaf(G11, f11, fmaf(G12, f12, T1 * f13)));
+                const float n12 = fmaf(G10, f20, fmaf(G11, f21, fmaf(G12, f22, T1 * f23)));
+                const float n20 = fmaf(G20, f00, fmaf(G21, f01, fmaf(G22, f02, T2 * f03)));
+                const float n21 = fmaf(G20, f10, fmaf(G21, f11, fmaf(G22, f12, T2 * f13)));
+                const float n22 = fmaf(G20, f20, fmaf(G21, f21, fmaf(G22, f22, T2 * f23)));
+                G00 = n00; G01 = n01; G02 = n02; G10 = n10; G11 = n11; G12 = n12; G20 = n20; G21 = n21; G22 = n22;
+                const float q00 = fmaf(r00, f00, fmaf(r01, f01, r02 * f02)), q01 = fmaf(r00, f10, fmaf(r01, f11, r02 * f12)),
+                            q02 = fmaf(r00, f20, fmaf(r01, f21, r02 * f22));
+                const float q10 = fmaf(r10, f00, fmaf(r11, f01, r12 * f02)), q11 = fmaf(r10, f10, fmaf(r11, f11, r12 * f12)),
+                            q12 = fmaf(r10, f20, fmaf(r11, f21, r12 * f22));
+                const float q20 = fmaf(r20, f00, fmaf(r21, f01, r22 * f02)), q21 = fmaf(r20, f10, fmaf(r21, f11, r22 * f12)),
+                            q22 = fmaf(r20, f20, fmaf(r21, f21, r22 * f22));
+                r00 = q00; r01 = q01; r02 = q02; r10 = q10; r11 = q11; r12 = q12; r20 = q20; r21 = q21; r22 = q22;
             }
         }
     } else if (kind == DCX_FK_SE2) {

@@ -154,13 +154,13 @@ struct LdsPlan {
 };
 __host__ __device__ inline LdsPlan lds_plan(int dof, int d_fk, int frame_floats, int nw, int acc_floats) {
     LdsPlan p;
-    p.fk = 0;                              // the FK program itself
-    p.q = p.fk + kFkProgLdsFloats;
+    p.q = 0;
     p.x = p.q + ((64 * dof + 3) & ~3);
     p.g = p.x + 64 * d_fk;
     p.f = p.g + 64 * d_fk;
     p.red = p.f + 64 * frame_floats;
-    p.total = p.red + (nw > 1 ? nw * acc_floats * 64 : 0);
+    p.fk = p.red + (nw > 1 ? nw * acc_floats * 64 : 0);  // the FK program comes last: its size varies with the
+    p.total = p.fk;                                      // robot and only the host needs it (+ fk_prog_floats)
     return p;
 }
 

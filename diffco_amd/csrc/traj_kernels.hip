@@ -21,6 +21,7 @@ struct TrajArgs {
     dcx_traj_opts opt;
     int32_t step;
     int32_t dof, d_fk, n_points, point_dim, frame_floats;
+    int32_t coord_major;  // features laid out [point_dim][n_points] (DCX_FK_TREE, t_coord_major) instead of [n_points][point_dim]
     float bias1, bias2_sqrt;  // 1 - beta1^t, sqrt(1 - beta2^t)
 };
 
@@ -39,14 +40,14 @@ __global__ __launch_bounds__(1024) void traj_adam_step_kernel(const TrajArgs a) 
     const int w = tid;                       // this lane's waypoint
     const bool live = w < W;
 
-    // LDS carve: program | q rows [nw*64][dof] | gq rows | per-wave slabs X, G, F | reduction scratch
-    float* sP = smem;
-    float* sQ = sP + kFkProgLdsFloats;
+    // LDS carve: q rows [nw*64][dof] | gq rows | per-wave slabs X, G, F | reduction scratch | program (variable size)
+    float* sQ = smem;
     float* sGQ = sQ + nw * 64 * dof;
     float* sX = sGQ + nw * 64 * dof;
     float* sG = sX + nw * 64 * D;
     float* sF = sG + nw * 64 * D;
     float* sR = sF + nw * 64 * a.frame_floats;  // [6][16] partial sums + flags
+    float* sP = sR + 128;
 
     const fk_cptr fk = stage_fk_prog(a.fk, sP, tid, blockDim.x);
     const float* path = a.st.path + (size_t)r * W * dof;
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(1024) void traj_adam_step_kernel(const TrajArgs a) 
         float dn[3] = {0.f, 0.f, 0.f}, dp[3] = {0.f, 0.f, 0.f};
         float n2n = 0.f, n2p = 0.f;
         for (int c = 0; c < pd; ++c) {
-            const int k = p * pd + c;
+            const int k = a.coord_major ? c * a.n_points + p : p * pd + c;
             const float xc = live ? X(k, w) : 0.f;
             if (live && w + 1 < W) { dn[c] = X(k, w + 1) - xc; n2n = fmaf(dn[c], dn[c], n2n); }
             if (live && w >= 1)    { dp[c] = xc - X(k, w - 1); n2p = fmaf(dp[c], dp[c], n2p); }
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(1024) void traj_adam_step_kernel(const TrajArgs a) 
         }
         const float cn = 2.f * (a.opt.w_diff + (mn > 0.f ? a.opt.w_max_move : 0.f));
         const float cp = 2.f * (a.opt.w_diff + (mp > 0.f ? a.opt.w_max_move : 0.f));
-        for (int c = 0; c < pd; ++c) myG[(p * pd + c) * 64] = cp * dp[c] - cn * dn[c];
+        for (int c = 0; c < pd; ++c) myG[(a.coord_major ? c * a.n_points + p : p * pd + c) * 64] = cp * dp[c] - cn * dn[c];
     }
     // J^T of that gradient (per lane; frames of this lane are in its slab)
     float* myGQ = sGQ + (wave * 64 + lane) * dof;
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(1024) void traj_adam_step_kernel(const TrajArgs a) 
 
 size_t traj_lds_bytes(const dcx_fk_desc& fk, int nw) {
     const int d_fk = fk.n_points * fk.point_dim;
-    return sizeof(float) * (kFkProgLdsFloats + 2 * nw * 64 * fk.dof + 2 * nw * 64 * d_fk + nw * 64 * fk_frame_floats(fk) + 128);
+    return sizeof(float) * (fk_prog_floats(fk) + 2 * nw * 64 * fk.dof + 2 * nw * 64 * d_fk + nw * 64 * fk_frame_floats(fk) + 128);
 }
 
 hipError_t launch_traj_adam_step(const FkProg* fk_dev, const dcx_fk_desc& fk, const dcx_traj_state& st,
@@ -187,6 +188,7 @@ hipError_t launch_traj_adam_step(const FkProg* fk_dev, const dcx_fk_desc& fk, co
     a.d_fk = fk.n_points * fk.point_dim;
     a.n_points = fk.n_points;
     a.point_dim = fk.point_dim;
+    a.coord_major = (fk.kind == DCX_FK_TREE && fk.t_coord_major) ? 1 : 0;
     a.frame_floats = fk_frame_floats(fk);
     a.bias1 = (float)(1.0 - pow((double)opt.beta1, (double)step));
     a.bias2_sqrt = (float)sqrt(1.0 - pow((double)opt.beta2, (double)step));

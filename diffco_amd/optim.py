@@ -34,6 +34,14 @@ def _np(x):
     return x.detach().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
 
 
+def _coord_axis(robot):
+    """axis of `robot.fkine(p)` that runs over a control point's coordinates: 2 for the [W, m, d] layout of the
+    reference's model.* robots (optim.py:93 sums dim=2), 1 for a URDF robot's [W, 3, L] link-origin stack"""
+    fk = getattr(robot, "fk_desc", None)
+    desc = fk() if callable(fk) else None
+    return 1 if desc is not None and desc.feature_shape[0] == desc.point_dim and desc.kind == 5 and desc.t_coord_major else 2
+
+
 def _record(start_cfg, target_cfg, cnt_check, cost, elapsed, success, seed, solution, **extra):
     rec = {'start_cfg': _np(start_cfg).tolist(), 'target_cfg': _np(target_cfg).tolist(), 'cnt_check': int(cnt_check),
            'cost': cost.item() if torch.is_tensor(cost) else float(cost), 'time': elapsed, 'success': bool(success), 'seed': seed,
@@ -140,7 +148,7 @@ def adam_traj_optimize(robot, dist_est, start_cfg, target_cfg, options):
             collision = torch.clamp(dist_est(p) - prob.safety_margin, min=0).sum()
             prob.cnt_check += len(p)
             objective, cp = prob.path_length(p)
-            max_move = torch.clamp((cp[1:] - cp[:-1]).square().sum(dim=2) - prob.max_speed ** 2, min=0).sum()
+            max_move = torch.clamp((cp[1:] - cp[:-1]).square().sum(dim=_coord_axis(robot)) - prob.max_speed ** 2, min=0).sum()
             constraint = (COLLISION_WEIGHT * collision + MAX_MOVE_WEIGHT * max_move
                           + JOINT_LIMIT_WEIGHT * prob.joint_limit_violation(p))
             loss = DIF_WEIGHT * objective + constraint

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DCX_VERSION 100 /* 0.1.0 */
+#define DCX_VERSION 101 /* 0.1.1: dcx_fk_desc grew the DCX_FK_TREE section (appended; older offsets unchanged) */
 
 /* ---- status codes ---------------------------------------------------------------- */
 #define DCX_OK 0
@@ -51,6 +51,17 @@ extern "C" {
                            link transform = utils.DH2mat utils.py:66-75                        */
 #define DCX_FK_SE2 3    /* RigidPlanarBody.fkine          model.py:90-93 (utils.rot_2d)         */
 #define DCX_FK_SE3 4    /* RigidBody.fkine                model.py:156-159 (utils.euler2mat = Rz Ry Rx) */
+#define DCX_FK_TREE 5   /* URDF kinematic tree, flattened into root-to-leaf chains: link-origin features of
+                           RobotDiffCo.tensorized_fkine_single_robot collision_checkers.py:385-393 over
+                           URDFRobot.compute_forward_kinematics_all_links urdf_interface.py:516-553 and
+                           RigidBody.forward_kinematics collision_interfaces/rigid_body.py:82-140      */
+
+/* joint motions of DCX_FK_TREE (rigid_body.py:100-126); the joint variable is v = t_scale * q + t_offset */
+#define DCX_J_FIXED 0     /* no motion (fixed joints that were not merged into their successor)        */
+#define DCX_J_REV_X 1     /* x_rot(v)  spatial_vector_algebra.py x_rot                                  */
+#define DCX_J_REV_Y 2     /* y_rot(v)                                                                    */
+#define DCX_J_REV_Z 3     /* z_rot(v)                                                                    */
+#define DCX_J_PRISMATIC 4 /* translation t_axis * v along the joint's own (post-fixed-transform) axes   */
 
 #define DCX_MAX_JOINTS 16 /* per chain */
 #define DCX_MAX_CHAINS 2
@@ -58,6 +69,8 @@ extern "C" {
 #define DCX_MAX_DOF 32
 #define DCX_MAX_D 72  /* feature width n_points * point_dim the fused kernels are compiled for */
 #define DCX_MAX_C 8   /* weight columns (classes) the fused kernels are compiled for           */
+#define DCX_MAX_TREE_CHAINS 8  /* root-to-leaf paths of a DCX_FK_TREE                           */
+#define DCX_MAX_TREE_JOINTS 64 /* joints summed over all paths (shared prefixes count per path) */
 
 /*
  * Plain-data description of one `transform(q[dof]) -> control points [n_points, point_dim]`.
@@ -94,6 +107,27 @@ typedef struct dcx_fk_desc {
     /* DCX_FK_SE2: q = (x, y, theta); p_k = R(theta) keypoints[k][0:2] + (x, y)
      * DCX_FK_SE3: q = (x, y, z, roll, pitch, yaw); p_k = Rz(yaw) Ry(pitch) Rx(roll) keypoints[k] + (x,y,z) */
     float keypoints[DCX_MAX_POINTS][3];
+
+    /* DCX_FK_TREE: t_n_chains serial chains stored back to back in the t_* joint arrays (chain c owns the
+     * next t_chain_len[c] entries).  A chain starts from t_base[c] (row-major 3x4) and every joint applies
+     *     T <- T * [t_fixed | as 3x4] * Motion(t_type, t_scale * q[t_q] + t_offset)
+     * i.e. the joint's <origin> followed by its motion, as rigid_body.py:100-126 composes them.  A URDF
+     * tree becomes one chain per leaf; joints on a shared prefix are simply repeated (their gradient
+     * contributions add up).  Mimic joints use the driver's t_q with the mimic multiplier/offset
+     * (rigid_body.py:93-94); an axis of -1 is a negative t_scale (rigid_body.py:103-108).
+     * Control point k is pt_off[k] in the frame after joint pt_frame[k] (index within its chain) of chain
+     * pt_chain[k].  t_coord_major != 0 lays the features out as [3][n_points] (feature j*n_points + k), the
+     * torch.stack(..., dim=-1) layout of collision_checkers.py:390; 0 keeps [n_points][3].               */
+    int32_t t_n_chains;
+    int32_t t_coord_major;
+    int32_t t_chain_len[DCX_MAX_TREE_CHAINS];
+    float t_base[DCX_MAX_TREE_CHAINS][12];
+    int32_t t_type[DCX_MAX_TREE_JOINTS];
+    int32_t t_q[DCX_MAX_TREE_JOINTS];
+    float t_scale[DCX_MAX_TREE_JOINTS];
+    float t_offset[DCX_MAX_TREE_JOINTS];
+    float t_fixed[DCX_MAX_TREE_JOINTS][12];
+    float t_axis[DCX_MAX_TREE_JOINTS][3];
 } dcx_fk_desc;
 
 typedef struct dcx_model dcx_model; /* opaque; immutable after create */

@@ -59,6 +59,42 @@ static void FN(euler_zyx)(REAL roll, REAL pitch, REAL yaw, REAL* Rm, REAL* dRoll
     }
 }
 
+/* joint_pose of one URDF joint — rigid_body.py:100-126: rot = fixed_rotation @ {x,y,z}_rot(v) and
+ * trans = fixed_translation for revolute/continuous (spatial_vector_algebra.py x_rot/y_rot/z_rot),
+ * rot = fixed_rotation and trans = fixed_translation + fixed_rotation @ (axis * v) for prismatic; a joint
+ * without a q entry keeps joint_pose = [fixed_rotation | fixed_translation] (rigid_body.py:150-176).
+ * dA (optional) = d joint_pose / d v. */
+static void FN(tree_joint)(const dcx_fk_desc* fk, int j, REAL v, REAL* A, REAL* dA) {
+    const float* F = fk->t_fixed[j];
+    REAL M[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}, dM[12] = {0};
+    REAL c = MATH(cos)(v), s = MATH(sin)(v);
+    switch (fk->t_type[j]) {
+    case DCX_J_REV_X: M[5] = c; M[6] = -s; M[9] = s; M[10] = c; dM[5] = -s; dM[6] = -c; dM[9] = c; dM[10] = -s; break;
+    case DCX_J_REV_Y: M[0] = c; M[2] = s; M[8] = -s; M[10] = c; dM[0] = -s; dM[2] = c; dM[8] = -c; dM[10] = -s; break;
+    case DCX_J_REV_Z: M[0] = c; M[1] = -s; M[4] = s; M[5] = c; dM[0] = -s; dM[1] = -c; dM[4] = c; dM[5] = -s; break;
+    case DCX_J_PRISMATIC:
+        for (int r = 0; r < 3; ++r) { M[r * 4 + 3] = (REAL)fk->t_axis[j][r] * v; dM[r * 4 + 3] = (REAL)fk->t_axis[j][r]; }
+        break;
+    default: break;
+    }
+    REAL Fr[12];
+    for (int e = 0; e < 12; ++e) Fr[e] = (REAL)F[e];
+    FN(m34_mul)(Fr, M, A);
+    if (dA) {
+        /* derivative of a product with a constant left factor: the homogeneous "1" of M does not vary */
+        for (int r = 0; r < 3; ++r)
+            for (int cc = 0; cc < 4; ++cc) {
+                REAL acc = 0;
+                for (int k = 0; k < 3; ++k) acc += Fr[r * 4 + k] * dM[k * 4 + cc];
+                dA[r * 4 + cc] = acc;
+            }
+    }
+}
+
+static int FN(tree_slot)(const dcx_fk_desc* fk, int k, int r) {
+    return fk->t_coord_major ? r * fk->n_points + k : 3 * k + r;
+}
+
 /* ---- forward kinematics of ONE configuration ---------------------------------------- */
 /* X: [n_points*point_dim].  frames (optional, DH only): [n_chains][chain_len+1][12], entry 0 = base,
  * entry i+1 = cumulative transform after joint i. */
@@ -120,6 +156,31 @@ static void FN(fk_one)(const dcx_fk_desc* fk, const REAL* q, REAL* X, REAL* fram
                 X[3 * k + r] = Rm[r * 3 + 0] * (REAL)fk->keypoints[k][0] + Rm[r * 3 + 1] * (REAL)fk->keypoints[k][1] +
                                Rm[r * 3 + 2] * (REAL)fk->keypoints[k][2] + q[r];
     } break;
+    case DCX_FK_TREE: {
+        /* RigidBody.forward_kinematics rigid_body.py:82-140 unrolled along each root-to-leaf path; features =
+         * link-origin translations, collision_checkers.py:385-393 */
+        int j0 = 0;
+        for (int c = 0; c < fk->t_n_chains; ++c) {
+            REAL T[12], A[12], N[12];
+            for (int e = 0; e < 12; ++e) T[e] = (REAL)fk->t_base[c][e];
+            for (int i = 0; i < fk->t_chain_len[c]; ++i) {
+                int j = j0 + i;
+                REAL v = (fk->t_type[j] == DCX_J_FIXED) ? (REAL)0
+                                                        : (REAL)fk->t_scale[j] * q[fk->t_q[j]] + (REAL)fk->t_offset[j];
+                FN(tree_joint)(fk, j, v, A, 0);
+                FN(m34_mul)(T, A, N);
+                for (int e = 0; e < 12; ++e) T[e] = N[e];
+                for (int k = 0; k < fk->n_points; ++k) {
+                    if (fk->pt_chain[k] != c || fk->pt_frame[k] != i) continue;
+                    for (int r = 0; r < 3; ++r)
+                        X[FN(tree_slot)(fk, k, r)] = T[r * 4 + 3] + T[r * 4 + 0] * (REAL)fk->pt_off[k][0] +
+                                                     T[r * 4 + 1] * (REAL)fk->pt_off[k][1] +
+                                                     T[r * 4 + 2] * (REAL)fk->pt_off[k][2];
+                }
+            }
+            j0 += fk->t_chain_len[c];
+        }
+    } break;
     default: break;
     }
 }
@@ -154,6 +215,56 @@ static void FN(fk_vjp_one)(const dcx_fk_desc* fk, const REAL* q, const REAL* gX,
                 REAL v[3] = {z[1] * r[2] - z[2] * r[1], z[2] * r[0] - z[0] * r[2], z[0] * r[1] - z[1] * r[0]};
                 gq[fk->joint_q[c][i]] += v[0] * gX[3 * k] + v[1] * gX[3 * k + 1] + v[2] * gX[3 * k + 2];
             }
+        }
+    } break;
+    case DCX_FK_TREE: {
+        /* product rule, one joint at a time: dT/dv_m = A_0 .. A_{m-1} (dA_m/dv) A_{m+1} .. ; the chain rule
+         * through v = scale*q + offset adds the factor scale.  O(n^2) per chain, deliberately naive. */
+        int j0 = 0;
+        for (int c = 0; c < fk->t_n_chains; ++c) {
+            int n = fk->t_chain_len[c];
+            for (int m = 0; m < n; ++m) {
+                if (fk->t_type[j0 + m] == DCX_J_FIXED) continue;
+                REAL T[12], A[12], dA[12], N[12];
+                for (int e = 0; e < 12; ++e) T[e] = (REAL)fk->t_base[c][e];
+                for (int i = 0; i < n; ++i) {
+                    int j = j0 + i;
+                    REAL v = (fk->t_type[j] == DCX_J_FIXED) ? (REAL)0
+                                                            : (REAL)fk->t_scale[j] * q[fk->t_q[j]] + (REAL)fk->t_offset[j];
+                    FN(tree_joint)(fk, j, v, A, dA);
+                    if (i == m) {
+                        /* T (3x4, implicit last row 0 0 0 1) times dA (last row 0 0 0 0) */
+                        for (int r = 0; r < 3; ++r)
+                            for (int cc = 0; cc < 4; ++cc) {
+                                REAL acc = 0;
+                                for (int k = 0; k < 3; ++k) acc += T[r * 4 + k] * dA[k * 4 + cc];
+                                N[r * 4 + cc] = acc;
+                            }
+                    } else if (i > m) {
+                        /* derivative transform [dR | dt] (homogeneous row 0) times a rigid transform [R | t; 0 0 0 1]:
+                         * column 3 = dR t + dt */
+                        for (int r = 0; r < 3; ++r)
+                            for (int cc = 0; cc < 4; ++cc) {
+                                REAL acc = (cc == 3) ? T[r * 4 + 3] : (REAL)0;
+                                for (int k = 0; k < 3; ++k) acc += T[r * 4 + k] * A[k * 4 + cc];
+                                N[r * 4 + cc] = acc;
+                            }
+                    } else {
+                        FN(m34_mul)(T, A, N);
+                    }
+                    for (int e = 0; e < 12; ++e) T[e] = N[e];
+                    if (i < m) continue;
+                    for (int k = 0; k < fk->n_points; ++k) {
+                        if (fk->pt_chain[k] != c || fk->pt_frame[k] != i) continue;
+                        for (int r = 0; r < 3; ++r) {
+                            REAL dp = T[r * 4 + 3] + T[r * 4 + 0] * (REAL)fk->pt_off[k][0] +
+                                      T[r * 4 + 1] * (REAL)fk->pt_off[k][1] + T[r * 4 + 2] * (REAL)fk->pt_off[k][2];
+                            gq[fk->t_q[j0 + m]] += (REAL)fk->t_scale[j0 + m] * dp * gX[FN(tree_slot)(fk, k, r)];
+                        }
+                    }
+                }
+            }
+            j0 += n;
         }
     } break;
     case DCX_FK_SE2: {

@@ -59,7 +59,7 @@ def fkine(desc, q, dtype=np.float32):
     q = _arr(q, dtype).reshape(-1, desc.dof)
     X = np.empty((len(q), desc.n_points * desc.point_dim), dtype=dtype)
     getattr(lib(), "orc_fkine" + _sfx(dtype))(C.byref(desc), _p(q), C.c_int64(len(q)), _p(X))
-    return X.reshape(len(q), desc.n_points, desc.point_dim)
+    return X.reshape(len(q), *getattr(desc, "feature_shape", (desc.n_points, desc.point_dim)))
 
 
 def fkine_vjp(desc, q, gX, dtype=np.float32):

@@ -21,6 +21,41 @@ FK_NAMES = ["planar2", "planar3", "planar7", "se2", "se3", "baxter_left", "baxte
             "panda5", "dual_panda"]
 
 
+URDF_NAMES = ["urdf_panda", "urdf_panda_nogripper", "urdf_fetch_arm", "urdf_iiwa7", "urdf_allegro", "urdf_trifinger",
+              "urdf_jaco", "urdf_2link"]
+
+
+def urdf_model(name):
+    """the URDF-derived joint table stored with fk_<name>.npz (tools/make_golden_urdf.py)"""
+    import json
+    return json.loads(bytes(load("fk_" + name)["model"]).decode())
+
+
+def urdf_xml(model):
+    """URDF text of a stored joint table (kinematic content only) — exercises diffco_amd.urdf.parse_urdf"""
+    out = ['<?xml version="1.0"?>', '<robot name="golden">']
+    out += [f'  <link name="{ln}"/>' for ln in model["links"]]
+    fmt = lambda v: " ".join(repr(float(x)) for x in v)  # noqa: E731
+    for j in model["joints"]:
+        out.append(f'  <joint name="{j["name"]}" type="{j["type"]}">')
+        out.append(f'    <parent link="{j["parent"]}"/><child link="{j["child"]}"/>')
+        out.append(f'    <origin xyz="{fmt(j["xyz"])}" rpy="{fmt(j["rpy"])}"/>')
+        out.append(f'    <axis xyz="{fmt(j["axis"])}"/>')
+        if j["lower"] is not None:
+            out.append(f'    <limit lower="{j["lower"]!r}" upper="{j["upper"]!r}" effort="1" velocity="1"/>')
+        if j["mimic_joint"] is not None:
+            out.append(f'    <mimic joint="{j["mimic_joint"]}" multiplier="{j["mimic_multiplier"]!r}" '
+                       f'offset="{j["mimic_offset"]!r}"/>')
+        out.append("  </joint>")
+    out.append("</robot>")
+    return "\n".join(out)
+
+
+def urdf_robot(name, **kw):
+    from diffco_amd.urdf import URDFRobotFK
+    return URDFRobotFK(urdf_xml(urdf_model(name)), **kw)
+
+
 def load(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"))
 

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"libdcx.so does not export {n}"
     assert set(names) == set(_lib.SYMBOLS), "ctypes table and header disagree"
-    assert lib.dcx_version() == 100
+    assert lib.dcx_version() == 101
     assert isinstance(lib.dcx_device_count(), int)
 
 
@@ -36,13 +36,17 @@ def test_fk_desc_layout_matches_c(tmp_path):
     from diffco_amd._fkdesc import FkDesc
     prog = tmp_path / "sz.c"
     prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "dcx.h"\n'
-                    'int main(){printf("%zu %zu %zu %zu %zu", sizeof(dcx_fk_desc), offsetof(dcx_fk_desc, n_chains),'
-                    ' offsetof(dcx_fk_desc, base), offsetof(dcx_fk_desc, pt_off), offsetof(dcx_fk_desc, keypoints));}')
+                    'int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu", sizeof(dcx_fk_desc), offsetof(dcx_fk_desc, n_chains),'
+                    ' offsetof(dcx_fk_desc, base), offsetof(dcx_fk_desc, pt_off), offsetof(dcx_fk_desc, keypoints),'
+                    ' offsetof(dcx_fk_desc, t_n_chains), offsetof(dcx_fk_desc, t_base), offsetof(dcx_fk_desc, t_scale),'
+                    ' offsetof(dcx_fk_desc, t_fixed), offsetof(dcx_fk_desc, t_axis));}')
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
     assert [int(x) for x in out] == [ctypes.sizeof(FkDesc), FkDesc.n_chains.offset, FkDesc.base.offset,
-                                     FkDesc.pt_off.offset, FkDesc.keypoints.offset]
+                                     FkDesc.pt_off.offset, FkDesc.keypoints.offset, FkDesc.t_n_chains.offset,
+                                     FkDesc.t_base.offset, FkDesc.t_scale.offset, FkDesc.t_fixed.offset,
+                                     FkDesc.t_axis.offset]
 
 
 def test_traj_struct_layouts_match_c(tmp_path):
