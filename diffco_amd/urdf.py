@@ -122,7 +122,36 @@ def _flat34(T):
 
 # ----------------------------------------------------------------------------- compilation to DCX_FK_TREE
 def compile_tree(tree: Tree, base_transform=None, coord_major=True):
-    """-> (FkDesc, info) where info has dof, controlled joint names (dof order), limits and feature link names.
+    """-> (FkDesc, info) where info has dof, controlled joint names (dof order), limits and feature link names."""
+    chains, points, info = plan_tree(tree, base_transform)
+    return fd.tree_desc(info["dof"], chains, points, coord_major=coord_major), info
+
+
+def compile_trees(trees, base_transforms=None, coord_major=True):
+    """Several robots side by side (the reference's MultiURDFRobot, urdf_interface.py:700-741): the configuration is
+    the concatenation of the robots' configurations (split_configs :741-742) and the features are the robots'
+    feature links one robot after the other (tensorized_fkine_multi_robot, collision_checkers.py:374-384)."""
+    base_transforms = base_transforms if base_transforms is not None else [None] * len(trees)
+    chains, points, infos, q0 = [], [], [], 0
+    for tree, base in zip(trees, base_transforms):
+        ch, pt, info = plan_tree(tree, base)
+        for c in ch:
+            for jt in c["joints"]:
+                if jt["type"] != fd.DCX_J_FIXED:
+                    jt["q"] += q0
+        points += [(c + len(chains), f, off) for c, f, off in pt]
+        chains += ch
+        infos.append(info)
+        q0 += info["dof"]
+    info = dict(dof=q0, joint_names=[(i, n) for i, inf in enumerate(infos) for n in inf["joint_names"]],
+                joint_limits=np.concatenate([inf["joint_limits"] for inf in infos], axis=0),
+                feature_links=[(i, n) for i, inf in enumerate(infos) for n in inf["feature_links"]],
+                n_chains=len(chains), dofs=[inf["dof"] for inf in infos])
+    return fd.tree_desc(q0, chains, points, coord_major=coord_major), info
+
+
+def plan_tree(tree: Tree, base_transform=None):
+    """-> (chains, points, info): the arguments of `_fkdesc.tree_desc` for one robot.
 
     Every leaf of the tree becomes one serial chain; fixed joints are folded into the next movable joint's
     constant transform (float64 products, rounded once when stored), and a feature link behind a fixed joint
@@ -216,11 +245,10 @@ def compile_tree(tree: Tree, base_transform=None, coord_major=True):
         base = np.eye(4) if base_transform is None else np.asarray(base_transform, dtype=np.float64).reshape(4, 4)
         chains.append(dict(base=_flat34(base), joints=joints))
     assert all(p is not None for p in points)
-    desc = fd.tree_desc(len(controlled), chains, points, coord_major=coord_major)
     info = dict(dof=len(controlled), joint_names=[jt.name for jt in controlled],
                 controlled_links=[jt.child for jt in controlled], joint_limits=limits,
                 feature_links=feature_links, n_chains=len(chains))
-    return desc, info
+    return chains, points, info
 
 
 # ----------------------------------------------------------------------------- robot facade
@@ -236,8 +264,12 @@ class URDFRobotFK:
     def __init__(self, urdf, name="", base_transform=None, coord_major=True):
         self.name = name
         self.tree = parse_urdf(urdf)
-        bt = None if base_transform is None else torch.as_tensor(base_transform, dtype=torch.float64).cpu().numpy()
-        self._desc, info = compile_tree(self.tree, bt, coord_major=coord_major)
+        self.base_transform = None if base_transform is None else \
+            torch.as_tensor(base_transform, dtype=torch.float64).cpu().numpy().reshape(4, 4)
+        self._desc, info = compile_tree(self.tree, self.base_transform, coord_major=coord_major)
+        self._adopt(info)
+
+    def _adopt(self, info):
         self._n_dofs = self.dof = info["dof"]
         self.joint_names = info["joint_names"]
         self.joint_limits = torch.from_numpy(info["joint_limits"].copy())
@@ -272,3 +304,24 @@ class URDFRobotFK:
 
     def wrap(self, q):
         return q
+
+
+class MultiURDFRobotFK(URDFRobotFK):
+    """Several URDF robots as one transform — the kinematic half of the reference's `MultiURDFRobot`
+    (urdf_interface.py:700-862) with `ForwardKinematicsDiffCo.tensorized_fkine_multi_robot`
+    (collision_checkers.py:374-384): q = [q_robot0 | q_robot1 | ...], features = robot 0's links, then robot 1's.
+    `unique_position_link_names` holds (robot_index, link_name) pairs like the reference's."""
+
+    def __init__(self, urdf_robots, name=None, coord_major=True):
+        names = [r.name for r in urdf_robots]
+        if len(set(names)) != len(names):
+            raise ValueError("Robot names must be unique")  # urdf_interface.py:721
+        self.urdf_robots = list(urdf_robots)
+        self.name = "_".join(names) if name is None else name
+        self._desc, info = compile_trees([r.tree for r in urdf_robots], [r.base_transform for r in urdf_robots],
+                                         coord_major=coord_major)
+        self._adopt(info)
+        self._dofs = info["dofs"]
+
+    def split_configs(self, q):
+        return torch.split(q, self._dofs, dim=1)

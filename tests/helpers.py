@@ -56,6 +56,13 @@ def urdf_robot(name, **kw):
     return URDFRobotFK(urdf_xml(urdf_model(name)), **kw)
 
 
+def dual_panda_robot(**kw):
+    """the two-Panda MultiURDFRobotFK of fk_urdf_dual_panda.npz (bases from examples/tests/test_urdf_robot.py:59-74)"""
+    from diffco_amd.urdf import MultiURDFRobotFK, URDFRobotFK
+    xml, bases = urdf_xml(urdf_model("urdf_panda")), load("fk_urdf_dual_panda")["bases"]
+    return MultiURDFRobotFK([URDFRobotFK(xml, name=f"panda{i + 1}", base_transform=b) for i, b in enumerate(bases)], **kw)
+
+
 def load(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"))
 

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import URDF_NAMES, load, relerr, urdf_robot
+from helpers import URDF_NAMES, dual_panda_robot, load, relerr, urdf_robot
 
 pytestmark = pytest.mark.gpu
 
@@ -44,6 +44,29 @@ def test_tree_fkine_and_vjp(ops, name):
     lp = rob.link_positions(_t(d["q"]))
     k = len(rob.unique_position_link_names) - 1
     assert relerr(_n(lp[rob.unique_position_link_names[k]]), d["x64"][:, :, k]) < 2e-6
+
+
+def test_multi_robot_fkine_and_fused_score(ops):
+    from oracle import oracle
+    d, rob = load("fk_urdf_dual_panda"), dual_panda_robot()
+    q = _t(d["q"]).requires_grad_(True)
+    X = rob.fkine(q)
+    assert X.shape == d["x64"].shape == (48, 3, 18)
+    assert relerr(_n(X), d["x64"]) < 2e-6 and relerr(_n(X), d["x32"]) < 2e-6
+    (gq,) = torch.autograd.grad((X * _t(d["gx"])).sum(), q)
+    assert relerr(_n(gq), d["gq64"]) < 5e-6 and relerr(_n(gq), d["gq32"]) < 5e-6
+    # D = 54 features: the fused sweep runs on the next compiled width (64) with zero padding
+    # (supports from other configurations than the queries: at a coincidence the fp64 oracle sees the fp32 rounding
+    # of the support as a displacement, which is all that is left of a gradient whose other terms are tiny)
+    rng = np.random.default_rng(11)
+    lim = d["limits"]
+    sq = (rng.random((40, rob.dof)) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]).astype(np.float32)
+    sup = _n(rob.fkine(_t(sq))).reshape(40, -1)
+    W = rng.standard_normal((40, 1)).astype(np.float32)
+    m = ops.ScoreModel(rob.fk_desc(), 0, 10.0, 2.0, _t(sup), _t(W))
+    s, g = m.score_grad_raw(_t(d["q"]), None)
+    rs, rg, _ = oracle.score_grad(rob.fk_desc(), 0, 10.0, 2.0, sup, W, d["q"], dtype=np.float64)
+    assert relerr(_n(s), rs) < 1e-5 and relerr(_n(g), rg) < 1e-5
 
 
 def test_point_major_layout(ops):
@@ -140,3 +163,52 @@ def test_fused_adam_trajectory_on_a_urdf_robot(ops):
     assert sol.shape == (20, rob.dof)
     assert torch.allclose(sol[0], start, atol=1e-6) and torch.allclose(sol[-1], target, atol=1e-6)
     assert torch.isfinite(sol).all()
+
+
+def test_forward_kinematics_diffco_facade(ops):
+    """the reference's recommended facade (collision_checkers.py:318-509) on the HIP path: fit with a user ground
+    truth, verify, biased collision_score with leading batch dims, q_link_pos bypass, active-learning update"""
+    from diffco_amd.collision_checkers import ForwardKinematicsDiffCo, RBFDiffCo
+    rob = urdf_robot("urdf_panda")
+    k_tip = rob.unique_position_link_names.index("panda_virtual_ee_link")
+    centre = torch.tensor([0.35, 0.0, 0.55])
+
+    def ground_truth(q):  # 1 = in collision: the hand origin is inside a sphere
+        return ((rob.fkine(q.cuda()).cpu()[:, :, k_tip] - centre).norm(dim=1) < 0.35).float()
+
+    torch.manual_seed(0)
+    fkdc = ForwardKinematicsDiffCo(robot=rob, gamma=10, gt_check_func=ground_truth)
+    assert fkdc.unique_position_link_names == rob.unique_position_link_names
+    acc, tpr, tnr = fkdc.fit(num_samples=1500, verify_ratio=0.2, fix_joints=[7], fix_joint_values=[0.04])
+    assert acc > 0.85 and fkdc.perceptron_trained and float(fkdc.safety_bias) > 0
+    n_sup = len(fkdc.perceptron.gains)
+    assert 0 < n_sup < 1200
+    # collision_score: leading dims are kept, the bias is added, autograd reaches q
+    q = rob.rand_configs(12).reshape(3, 4, 8).requires_grad_(True)
+    s = fkdc.collision_score(q)
+    assert s.shape == (3, 4, 1)
+    raw = fkdc.perceptron.poly_score(q.detach().reshape(-1, 8)).reshape(3, 4, 1)
+    assert torch.allclose(s.detach(), raw + fkdc.safety_bias, atol=1e-6)
+    (g,) = torch.autograd.grad(s.sum(), q)
+    assert g.shape == q.shape and torch.isfinite(g).all() and g.abs().max() > 0
+    # link positions instead of configurations (transformed_point route)
+    X = rob.fkine(q.detach().reshape(-1, 8))
+    s2 = fkdc.collision_score(q_link_pos=X.reshape(3, 4, *X.shape[1:]))
+    assert torch.allclose(s2, s.detach(), atol=2e-5)
+    assert fkdc.collision(q.detach()).dtype == torch.bool
+    assert torch.allclose(fkdc.unnormalizer(fkdc.normalizer(q.detach())), q.detach(), atol=1e-5)
+    # active learning: supports survive as a jump start, the model stays accurate
+    acc2, _, _ = fkdc.update(num_samples=200, verify=0.2)
+    assert acc2 > 0.8
+    acc3, _, _ = fkdc.verify(num_samples=400)
+    assert acc3 > 0.85
+    # manifold-uniform sampling goes through the HIP vjp
+    qs, _, _ = fkdc._generate_dataset(None, None, None, 64, sample_transform='fkine')
+    assert qs.shape == (64, 8)
+    # configuration-space variant and the loud failure without a ground truth
+    rbf = RBFDiffCo(robot=rob, gamma=5, gt_check_func=ground_truth)
+    assert rbf.fit(num_samples=600, verify_ratio=0.2)[0] > 0.7
+    with pytest.raises(ValueError, match="no ground truth"):
+        ForwardKinematicsDiffCo(robot=rob).fit(num_samples=10)
+    with pytest.raises(NotImplementedError):
+        ForwardKinematicsDiffCo(robot=rob, environment={"box": {}})

@@ -5,7 +5,7 @@ on the reference's own URDF files."""
 import numpy as np
 import pytest
 
-from helpers import URDF_NAMES, load, relerr, urdf_model, urdf_robot, urdf_xml
+from helpers import URDF_NAMES, dual_panda_robot, load, relerr, urdf_model, urdf_robot, urdf_xml
 from oracle import oracle
 
 TOL64, TOL32 = 5e-8, 1e-6  # fp64: only the fp32 rounding of folded fixed joints separates the two; fp32: a few ulp
@@ -35,6 +35,22 @@ def test_urdf_bookkeeping_matches_reference(name):
     q = rob.rand_configs(50)
     assert q.shape == (50, rob.dof)
     assert bool(((q >= rob.joint_limits[:, 0]) & (q <= rob.joint_limits[:, 1])).all())
+
+
+def test_multi_robot_matches_reference():
+    """MultiURDFRobot + tensorized_fkine_multi_robot (urdf_interface.py:857-862, collision_checkers.py:374-384)"""
+    d, rob = load("fk_urdf_dual_panda"), dual_panda_robot()
+    assert rob.dof == 16 and [i for i, _ in rob.unique_position_link_names] == [0] * 9 + [1] * 9
+    assert np.array_equal(rob.joint_limits.numpy(), d["limits"])
+    assert [t.shape[1] for t in rob.split_configs(rob.rand_configs(3))] == [8, 8]
+    desc = rob.fk_desc()
+    assert relerr(oracle.fkine(desc, d["q"], np.float64), d["x64"]) < TOL64
+    assert relerr(oracle.fkine_vjp(desc, d["q"], d["gx"], np.float64), d["gq64"]) < TOL64
+    x32 = oracle.fkine(desc, d["q"], np.float32)
+    assert relerr(x32, d["x64"]) < TOL32 and relerr(x32, d["x32"]) < TOL32
+    from diffco_amd.urdf import MultiURDFRobotFK
+    with pytest.raises(ValueError, match="unique"):
+        MultiURDFRobotFK([urdf_robot("urdf_2link"), urdf_robot("urdf_2link")])
 
 
 def test_point_major_layout_is_a_transpose():

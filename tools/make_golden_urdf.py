@@ -109,11 +109,12 @@ R = import_reference()
 from diffco_amd import urdf as U  # noqa: E402  (host-side parser only; no GPU needed)
 
 
-def reference_robot(tree, dtype):
+def reference_robot(tree, dtype, base=None, name="golden"):
     """a reference URDFRobot whose _bodies were filled the way URDFRobot.__init__ (:378-418) fills them"""
     rob = object.__new__(R.ui.URDFRobot)
-    R.ui.RobotInterfaceBase.__init__(rob, name="golden", device="cpu")
-    rob.base_transform = R.sva.CoordinateTransform(torch.eye(3, dtype=dtype), torch.zeros(3, dtype=dtype), device="cpu")
+    R.ui.RobotInterfaceBase.__init__(rob, name=name, device="cpu")
+    base = torch.eye(4, dtype=dtype) if base is None else torch.as_tensor(base, dtype=torch.float32).to(dtype)
+    rob.base_transform = R.sva.CoordinateTransform(base[:3, :3], base[:3, 3], device="cpu")  # :365-366
     rob._n_dofs, rob._controlled_joints, rob._mimic_joints, rob._bodies = 0, [], defaultdict(list), []
     rob._body_name_to_idx_map = {}
     joint_by_name = {j.name: j for j in tree.joints}
@@ -164,6 +165,55 @@ def reference_checker(rob):
         if torch.any(link_body.joint_trans() != 0):
             chk.unique_position_link_names.append(link_body.name)
     return chk
+
+
+def gen_multi(out, gen):
+    """two Pandas facing each other with the base transforms of the reference's own URDF test
+    (examples/tests/test_urdf_robot.py:59-74), through MultiURDFRobot.compute_forward_kinematics_all_links
+    (urdf_interface.py:857-862) and ForwardKinematicsDiffCo.tensorized_fkine_multi_robot (collision_checkers.py:374-384)"""
+    import math
+    rel = ROBOTS["urdf_panda"]
+    tree = U.parse_urdf(open(os.path.join(REF, "diffco", "robot_data", rel)).read())
+
+    def base(x, pitch):  # tf.translation_matrix([x, 0, 0.8]) with tf.euler_matrix(0, pitch, 0) as rotation
+        c, s = math.cos(pitch), math.sin(pitch)
+        return np.array([[c, 0, s, x], [0, 1, 0, 0.0], [-s, 0, c, 0.8], [0, 0, 0, 1]], dtype=np.float64)
+
+    bases = [base(0.1, math.pi / 2), base(-0.1, -math.pi / 2)]
+    desc, info = U.compile_trees([tree, tree], bases)
+    res = {}
+    for dtype in (torch.float32, torch.float64):
+        torch.set_default_dtype(dtype)
+        multi = object.__new__(R.ui.MultiURDFRobot)
+        multi.urdf_robots = [reference_robot(tree, dtype, b, name=f"panda{i + 1}") for i, b in enumerate(bases)]
+        multi._bodies = [[body for body in robot._bodies] for robot in multi.urdf_robots]  # :739
+        chk = object.__new__(R.cc.ForwardKinematicsDiffCo)
+        chk.robot = multi
+        chk.unique_position_link_names = []
+        for robot_idx, link_body_list in enumerate(multi._bodies):  # collision_checkers.py:348-352
+            for link_body in link_body_list:
+                if torch.any(link_body.joint_trans() != 0):
+                    chk.unique_position_link_names.append((robot_idx, link_body.name))
+        assert chk.unique_position_link_names == info["feature_links"]
+        if dtype == torch.float32:
+            lim = torch.from_numpy(info["joint_limits"])
+            q = torch.rand(48, info["dof"], generator=gen) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]
+            q[0] = 0.0
+            gX = torch.randn(48, 3, len(info["feature_links"]), generator=gen)
+        qd = q.detach().clone().to(dtype).requires_grad_(True)
+        X = chk.tensorized_fkine_multi_robot(qd)
+        (gq,) = torch.autograd.grad((X * gX.to(dtype)).sum(), qd)
+        res[dtype] = (X.detach(), gq.detach())
+    torch.set_default_dtype(torch.float32)
+    np.savez_compressed(os.path.join(out, "fk_urdf_dual_panda.npz"), q=q.numpy(), x32=res[torch.float32][0].numpy(),
+                        gq32=res[torch.float32][1].numpy(), x64=res[torch.float64][0].numpy(),
+                        gq64=res[torch.float64][1].numpy(), gx=gX.numpy(), limits=info["joint_limits"],
+                        bases=np.stack(bases))
+    err = (res[torch.float32][0].double() - res[torch.float64][0]).abs().max().item()
+    print(f"  wrote fk_urdf_dual_panda.npz  dof={info['dof']} L={len(info['feature_links'])} chains={info['n_chains']} "
+          f"ref fp32-vs-fp64 {err:.2e}")
+    return dict(source=[rel, rel], dof=info["dof"], features=len(info["feature_links"]), chains=info["n_chains"],
+                ref_fp32_vs_fp64=err, stack="reference (multi-robot)")
 
 
 def main():
@@ -223,6 +273,7 @@ def main():
                               ref_fp32_vs_fp64=err, stack=stacked)
         print(f"  wrote fk_{name}.npz  dof={info['dof']} L={len(info['feature_links'])} chains={info['n_chains']} "
               f"ref fp32-vs-fp64 {err:.2e}")
+    manifest["urdf_dual_panda"] = gen_multi(out, gen)
     with open(os.path.join(out, "MANIFEST_urdf.json"), "w") as f:
         json.dump({"generator": "tools/make_golden_urdf.py", "torch": torch.__version__,
                    "reference": "ucsdarclab/diffco @ /root/reference (2025-03-21)", "robots": manifest}, f, indent=1)
