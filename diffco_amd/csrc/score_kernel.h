@@ -95,10 +95,14 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 //   bit 1: scalar loads of the next support row issued before the current row is consumed
 //   bit 2: explicit two-buffer software pipeline (overrides bit 1)
 //   bit 3: explicit four-buffer pipeline, two rows per stage (overrides bits 1, 2)
+//   bit 4: differences and gradient accumulators kept as packed pairs end to end (v_pk_fma_f32 for the gradient
+//          too; the compiler already finds this for even D, for odd D and C > 1 it does not)
 // Measured on MI355X (profiles/r01_sweep_variants.txt): packed d2 + the explicit four-buffer pipeline (9) is
 // fastest at every batch size (headline B=65536: 555 vs 485 (variant 3) vs ~470 (variant 0) M evals/s).
+// Bit 4 on top (profiles/r01_sweep_variants.txt, "variant 25"): headline unchanged, Panda D=21 +6 % (B=4096) /
+// +19 % (B=65536), C=5 +7 %.
 #ifndef DCX_SWEEP_VARIANT
-#define DCX_SWEEP_VARIANT 9
+#define DCX_SWEEP_VARIANT 25
 #endif
 
 // value K(d2) and g with dK/dx = g * (x - s)
@@ -234,6 +238,11 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
     for (int c = 0; c < CC; ++c) sc[c] = 0.0f;
 #pragma unroll
     for (int k = 0; k < D; ++k) gx[k] = 0.0f;
+#if DCX_SWEEP_VARIANT & 16
+    v2f gx2[D / 2 + 1];
+#pragma unroll
+    for (int k = 0; k < D / 2 + 1; ++k) gx2[k] = v2f{0.0f, 0.0f};
+#endif
 
     const int ybase = blockIdx.y * a.s_super;                               // this block's super-chunk
     const int yend = (ybase + a.s_super < a.S) ? (ybase + a.s_super) : a.S;
@@ -245,7 +254,24 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
     auto pair = [&](const float (&r)[L::RS]) __attribute__((always_inline)) {
         float dl[D];
         float d2;
-#if DCX_SWEEP_VARIANT & 1
+#if DCX_SWEEP_VARIANT & 16
+        v2f dp[D / 2 + 1];
+        {
+            v2f acc = {0.0f, 0.0f};
+#pragma unroll
+            for (int k = 0; k + 1 < D; k += 2) {
+                const v2f xv = {x[k], x[k + 1]};
+                const v2f rv = {r[k], r[k + 1]};
+                dp[k / 2] = xv - rv;
+                acc = __builtin_elementwise_fma(dp[k / 2], dp[k / 2], acc);
+            }
+            d2 = acc.x + acc.y;
+            if constexpr (D & 1) {
+                dl[D - 1] = x[D - 1] - r[D - 1];
+                d2 = fmaf(dl[D - 1], dl[D - 1], d2);
+            }
+        }
+#elif DCX_SWEEP_VARIANT & 1
         {   // squared distance on the packed-fp32 pipe: D/2 v_pk_add + D/2 v_pk_fma
             v2f acc = {0.0f, 0.0f};
 #pragma unroll
@@ -285,8 +311,15 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
                 for (int c = 0; c < CC; ++c) wb = fmaf(up[c], r[L::W_OFF + c], wb);
                 coef = g * wb;
             }
+#if DCX_SWEEP_VARIANT & 16
+            const v2f c2 = {coef, coef};
+#pragma unroll
+            for (int k = 0; k + 1 < D; k += 2) gx2[k / 2] = __builtin_elementwise_fma(c2, dp[k / 2], gx2[k / 2]);
+            if constexpr (D & 1) gx[D - 1] = fmaf(coef, dl[D - 1], gx[D - 1]);
+#else
 #pragma unroll
             for (int k = 0; k < D; ++k) gx[k] = fmaf(coef, dl[k], gx[k]);
+#endif
         }
     };
     // only the floats a row really carries are loaded (the tail of the padded stride is never touched)
@@ -356,6 +389,13 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
     }
 #endif
 
+#if DCX_SWEEP_VARIANT & 16
+#pragma unroll
+    for (int k = 0; k + 1 < D; k += 2) {
+        gx[k] = gx2[k / 2].x;
+        gx[k + 1] = gx2[k / 2].y;
+    }
+#endif
     DCX_TS(3);
     // ---- meet the NW partial sums in LDS; wave 0 finishes --------------------------------
     if (nw > 1) {
