@@ -159,12 +159,17 @@ struct LdsPlan {
 __host__ __device__ inline LdsPlan lds_plan(int dof, int d_fk, int frame_floats, int nw, int acc_floats) {
     LdsPlan p;
     p.q = 0;
-    p.x = p.q + ((64 * dof + 3) & ~3);
+    p.f = p.q + ((64 * dof + 3) & ~3);
+    p.x = p.f + 64 * frame_floats;
     p.g = p.x + 64 * d_fk;
-    p.f = p.g + 64 * d_fk;
-    p.red = p.f + 64 * frame_floats;
-    p.fk = p.red + (nw > 1 ? nw * acc_floats * 64 : 0);  // the FK program comes last: its size varies with the
-    p.total = p.fk;                                      // robot and only the host needs it (+ fk_prog_floats)
+    // The reduction scratch OVERLAYS X and G: X is dead once every wave has copied its features into registers
+    // (the kernel barriers after that copy), G is written only after wave 0 has read every partial.  Keeping
+    // the block under 40 KB is what lets four 8-wave blocks share a CU (32 waves) at the headline shape.
+    p.red = p.x;
+    const int end_xg = p.g + 64 * d_fk;
+    const int end_red = p.red + (nw > 1 ? nw * acc_floats * 64 : 0);
+    p.fk = end_xg > end_red ? end_xg : end_red;  // the FK program comes last: its size varies with the robot
+    p.total = p.fk;                              // and only the host needs it (+ fk_prog_floats)
     return p;
 }
 
@@ -223,6 +228,7 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
     float x[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) x[k] = (k < a.d_fk) ? sX[k * 64 + lane] : 0.0f;
+    if (nw > 1) __syncthreads();  // X is dead from here on: the partial sums reuse its LDS (lds_plan)
 
     float up[CC];
     if constexpr (MODE == MODE_GRAD_UP) {
