@@ -92,6 +92,16 @@ def kernel_matrix(kind, p0, p1, x: torch.Tensor, s: torch.Tensor) -> torch.Tenso
     return K.to(device=x.device, dtype=x.dtype)
 
 
+def solve(kmat: torch.Tensor, rhs: torch.Tensor) -> torch.Tensor:
+    """x with kmat @ x = rhs, solved on the GPU (LU through torch's hipSOLVER/rocSOLVER binding — a plain library
+    factorisation, the S x S system of fit_poly: reference kernel_perceptrons.py:283, deprecated/MultiDiffCo.py:149);
+    result on kmat's device and dtype.  Like every other op here it needs the GPU."""
+    _lib.require_gpu()
+    dev = _device(kmat.device)
+    x = torch.linalg.solve(kmat.detach().to(dev), rhs.detach().to(device=dev, dtype=kmat.dtype))
+    return x.to(device=kmat.device)
+
+
 # ----------------------------------------------------------------------------- perceptron trainer
 def train_perceptron_device(kind, p0, p1, beta, feats, y, gains, hypo, K, max_iteration):
     """The whole perceptron loop in one persistent launch (dcx_train_perceptron).  feats [N, D], y / gains / hypo

@@ -124,6 +124,14 @@ def run_trainer(kernel_func, feats, y, gains, hypo, K, beta, max_iteration, prog
     return g.to(device=out_dev, dtype=out_dtype), h.to(device=out_dev, dtype=out_dtype), Kd, it
 
 
+def solve_system(kernel_func, kmat, rhs):
+    """fit_poly's S x S solve: on the GPU for diffco_amd kernels (`_ops.solve`); a foreign kernel callable is user
+    code evaluated where its tensors live, like the host trainer above, and its system is solved there too."""
+    if isinstance(kernel_func, KernelFunc) and kernel_func.dcx_spec() is not None or isinstance(kernel_func, FKKernel):
+        return _ops.solve(kmat, rhs)
+    return torch.linalg.solve(kmat, rhs.to(kmat.dtype))
+
+
 def sub_block(K, idx, device, dtype):
     """K[idx][:, idx] gathered where K lives, then moved to (device, dtype)"""
     i = idx.to(K.device)

@@ -13,7 +13,7 @@ from time import time
 import torch
 
 from . import kernel
-from ._perceptron import FusedScorer, run_trainer, sub_block
+from ._perceptron import FusedScorer, run_trainer, solve_system, sub_block
 
 
 class CollisionChecker:
@@ -129,7 +129,7 @@ class DiffCo(CollisionChecker):
     def fit_poly(self, kernel_func=None, target='hypo', fkine=None):
         X, t = self._fit_inputs(kernel_func, target, fkine)
         kmat = self.rbf_kernel(X, X)
-        self.rbf_nodes = torch.linalg.solve(kmat, t.reshape(len(X), 1).to(kmat.dtype)).reshape(-1)
+        self.rbf_nodes = solve_system(self.rbf_kernel, kmat, t.reshape(len(X), 1).to(kmat.dtype)).reshape(-1)
         if self._cuda:
             self.cuda()
 
@@ -246,7 +246,7 @@ class MultiDiffCo(DiffCo):
             kmat[cross] = 0
             kmat[cross.T] = 0
         eye = torch.eye(len(kmat), dtype=kmat.dtype, device=kmat.device)
-        self.rbf_nodes = torch.linalg.solve(kmat + reg * eye, t.to(kmat.dtype))
+        self.rbf_nodes = solve_system(self.rbf_kernel, kmat + reg * eye, t.to(kmat.dtype))
         self.rbf_nodes[self.gains == 0] = 0
         assert self.rbf_nodes.shape == (len(self.support_points), self.num_class)
 
@@ -281,7 +281,7 @@ class DiffCoBeta(DiffCo):
             self.fkine, self.support_fkine = fkine, feats
         self.kernel_matrix = self.rbf_kernel(feats, feats)
         self.kernel_matrix = self.kernel_matrix + 0.1 * torch.eye(len(feats), dtype=self.kernel_matrix.dtype)
-        self.gains = torch.linalg.solve(self.kernel_matrix, da.reshape(-1, 1).to(self.kernel_matrix.dtype)).reshape(-1)
+        self.gains = solve_system(self.rbf_kernel, self.kernel_matrix, da.reshape(-1, 1).to(self.kernel_matrix.dtype)).reshape(-1)
         self.hypothesis = self.kernel_matrix @ self.gains
         self.rbf_nodes = self.gains
         self._score_feats = None

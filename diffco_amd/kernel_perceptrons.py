@@ -9,7 +9,7 @@ Drop-in for diffco/kernel_perceptrons.py:31-370 (class DiffCo): same constructor
   * `score` / `poly_score` (+ their gradient) are ONE fused HIP launch (FK -> kernel block ->
     weight contraction -> analytic gradient), never a materialised K[B,S] and never on the CPU.
   * `train` keeps the reference's sequential perceptron on the host; kernel rows come from the
-    HIP kernel-matrix kernel.  `fit_poly` solves the S x S system with torch.linalg.solve.
+    HIP kernel-matrix kernel.  `fit_poly` solves the S x S system on the GPU (`_ops.solve`: library LU).
 
 The old-API classes (`DiffCo(obstacles, ...)`, `MultiDiffCo`, `DiffCoBeta`) are in
 diffco_amd/deprecated.py, like the reference keeps them in diffco/deprecated/.
@@ -19,7 +19,7 @@ from time import time
 import torch as th
 
 from . import kernel
-from ._perceptron import FusedScorer, run_trainer, sub_block
+from ._perceptron import FusedScorer, run_trainer, solve_system, sub_block
 
 
 class Perceptron:
@@ -225,7 +225,7 @@ class DiffCo(Perceptron):
         Xs = self.support_transformed[:v]
         kmat = self.rbf_kernel(Xs, Xs)
         self.rbf_nodes.zero_()
-        self.rbf_nodes[:v] = th.linalg.solve(kmat, t[:v, None].to(kmat.dtype)).reshape(-1)
+        self.rbf_nodes[:v] = solve_system(self.rbf_kernel, kmat, t[:v, None].to(kmat.dtype)).reshape(-1)
         if self._cuda:
             self.cuda()
 
