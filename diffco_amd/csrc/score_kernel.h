@@ -413,15 +413,20 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
             for (int k = 0; k < D; ++k) mine[(CC + k) * 64] = gx[k];
         }
         __syncthreads();
+        // every wave folds a few of the ACC accumulators over the nw partial rows (wave 0's row first, then 1, 2, ...:
+        // the same order a single wave would use, so the sums do not depend on nw's parallelism) into row 0
+        for (int e = wave; e < ACC; e += nw) {
+            float v = sRed[e * 64 + lane];
+            for (int w = 1; w < nw; ++w) v += sRed[((size_t)w * ACC + e) * 64 + lane];
+            sRed[e * 64 + lane] = v;
+        }
+        __syncthreads();
         if (wave != 0) return;
-        for (int w = 1; w < nw; ++w) {
-            const float* o = sRed + (size_t)w * ACC * 64 + lane;
 #pragma unroll
-            for (int c = 0; c < CC; ++c) sc[c] += o[c * 64];
-            if constexpr (GRAD) {
+        for (int c = 0; c < CC; ++c) sc[c] = sRed[c * 64 + lane];
+        if constexpr (GRAD) {
 #pragma unroll
-                for (int k = 0; k < D; ++k) gx[k] += o[(CC + k) * 64];
-            }
+            for (int k = 0; k < D; ++k) gx[k] = sRed[(CC + k) * 64 + lane];
         }
     }
 
