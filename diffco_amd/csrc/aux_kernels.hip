@@ -103,7 +103,7 @@ __global__ __launch_bounds__(64) void score_finish_kernel(const FinishArgs a) {
     const int64_t b0 = (int64_t)blockIdx.x * 64;
     const int nb = (int)((a.B - b0) < 64 ? (a.B - b0) : 64);
     const int dof = a.dof;
-    const LdsPlan lp = lds_plan(dof, a.d_fk, a.frame_floats, 1, 0);
+    const LdsPlan lp = lds_plan(dof, a.d_fk, a.frame_floats, 0, 0);
     float* sQ = smem + lp.q;
     float* sX = smem + lp.x;
     float* sG = smem + lp.g;

@@ -64,8 +64,9 @@ int fail_hip(hipError_t e, const char* what) {
 launch_fn launch_for(int Dt) {
     switch (Dt) {
 #define DCX_CASE(D) case D: return launch_score_D##D;
-        DCX_CASE(2) DCX_CASE(4) DCX_CASE(6) DCX_CASE(8) DCX_CASE(12) DCX_CASE(16) DCX_CASE(21) DCX_CASE(24)
-        DCX_CASE(32) DCX_CASE(42) DCX_CASE(48) DCX_CASE(64) DCX_CASE(72)
+        DCX_CASE(2) DCX_CASE(4) DCX_CASE(6) DCX_CASE(8) DCX_CASE(12) DCX_CASE(16) DCX_CASE(18) DCX_CASE(21)
+        DCX_CASE(24) DCX_CASE(27) DCX_CASE(30) DCX_CASE(32) DCX_CASE(36) DCX_CASE(42) DCX_CASE(48) DCX_CASE(54)
+        DCX_CASE(60) DCX_CASE(64) DCX_CASE(72)
 #undef DCX_CASE
     default: return nullptr;
     }
@@ -200,6 +201,7 @@ int fk_device_copy(int device, const dcx_fk_desc& fk, FkProg** out) {
 //    supports are then also split across blocks (B=4096: 64 tiles on 256 CUs).
 struct Geometry {
     int nw, ys;
+    int red_slots;  // LDS rows of the cross-wave fold: nw (parallel fold) or 1 (waves take turns), see score_kernel.h
 };
 Geometry pick_geometry(const dcx_model* m, int64_t B, int acc_floats, bool allow_split) {
     const int cap = m->max_threads / 64;
@@ -226,7 +228,29 @@ Geometry pick_geometry(const dcx_model* m, int64_t B, int acc_floats, bool allow
     while (g.ys > 1 && m->S_active / (g.ys * g.nw) < 32) g.ys /= 2;
     while (g.nw > 1 && m->S_active / (g.ys * g.nw) < 32) g.nw /= 2;
     const int d_fk = m->fk.n_points * m->fk.point_dim;
-    while (g.nw > 1 && (lds_plan(m->fk.dof, d_fk, m->frame_floats, g.nw, acc_floats).total + m->prog_floats) * sizeof(float) > 64 * 1024) g.nw /= 2;
+    auto lds_bytes = [&](int nw, int slots) {
+        return (size_t)(lds_plan(m->fk.dof, d_fk, m->frame_floats, nw > 1 ? slots : 0, acc_floats, true).total + m->prog_floats) * sizeof(float);
+    };
+    g.red_slots = g.nw;
+    if (lds_bytes(g.nw, g.nw) > 64 * 1024) {
+        // Wide shapes (URDF hands, dual arms): nw partial rows of D + C floats per lane would leave one or two waves
+        // per CU.  Fold through ONE row instead (LDS no longer grows with nw) and take the block size that keeps the
+        // most waves resident: registers allow 4 * wps waves per CU, LDS 160 KB / block.
+        const int wps = sweep_min_waves(m->Dt, m->C, m->kf);
+        int best_nw = 1, best_waves = 0;
+        for (int nw = g.nw; nw >= 1; nw /= 2) {
+            const size_t lds = lds_bytes(nw, 1);
+            if (lds > 64 * 1024) continue;
+            const int by_lds = (int)((160 * 1024) / lds), by_regs = std::max(1, (4 * wps) / nw);
+            const int waves = std::min(by_lds, by_regs) * nw;
+            if (waves > best_waves) {
+                best_waves = waves;
+                best_nw = nw;
+            }
+        }
+        g.nw = best_nw;
+        g.red_slots = 1;
+    }
     return g;
 }
 
@@ -290,6 +314,7 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
     a.ys = g.ys;
     a.s_super = (m->S_active + g.ys - 1) / g.ys;
     a.s_chunk = (a.s_super + g.nw - 1) / g.nw;
+    a.red_slots = g.red_slots;
     a.dof = m->fk.dof;
     a.d_fk = d_fk;
     a.frame_floats = m->frame_floats;
@@ -307,7 +332,7 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
     a.ts = g_ts_dev;
     a.ts_block = std::getenv("DCX_TS_BLOCK") ? (unsigned)std::atoi(std::getenv("DCX_TS_BLOCK")) : 0u;
 #endif
-    const size_t lds = sizeof(float) * (lds_plan(a.dof, d_fk, m->frame_floats, g.nw, acc).total + m->prog_floats);
+    const size_t lds = sizeof(float) * (lds_plan(a.dof, d_fk, m->frame_floats, g.nw > 1 ? g.red_slots : 0, acc, true).total + m->prog_floats);
     if (g.ys == 1) {
         hipError_t e = m->launch(m->kf, m->C, mode, g.nw, lds, nblk, a, st);
         if (e != hipSuccess) return fail_hip(e, "score kernel launch");
@@ -336,7 +361,7 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
         f.hinge = hinge.on;
         f.hinge_margin = hinge.margin;
         f.hinge_weight = hinge.weight;
-        e = launch_score_finish(f, nblk, sizeof(float) * (lds_plan(a.dof, d_fk, m->frame_floats, 1, 0).total + m->prog_floats), st);
+        e = launch_score_finish(f, nblk, sizeof(float) * (lds_plan(a.dof, d_fk, m->frame_floats, 0, 0).total + m->prog_floats), st);
     }
     if (e != hipSuccess) return fail_hip(e, "split score launch");
     return DCX_OK;

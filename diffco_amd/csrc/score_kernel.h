@@ -59,6 +59,8 @@ struct ScoreArgs {
     float* partial;           // split launch: per (tile, y) partial sums [(tile*ys + y)][ACC][64]; null = finish in-kernel
     int32_t ys;               // support super-chunks (gridDim.y); block y sweeps [y*s_super, (y+1)*s_super)
     int32_t s_super;
+    int32_t red_slots;        // LDS rows for the cross-wave fold: nw (all waves write, fold in parallel) or 1 (waves
+                              // take turns through one row: wide shapes, where nw rows would cost occupancy)
 #ifdef DCX_TIMING
     unsigned long long* ts;   // developer builds: [16 slots][8 waves] cycle stamps of block (ts_block,0)
     unsigned int ts_block;
@@ -156,18 +158,20 @@ __device__ __forceinline__ void kernel_eval(float d2, const ScoreArgs& a, float&
 struct LdsPlan {
     int fk, q, x, g, f, red, total;
 };
-__host__ __device__ inline LdsPlan lds_plan(int dof, int d_fk, int frame_floats, int nw, int acc_floats) {
+__host__ __device__ inline LdsPlan lds_plan(int dof, int d_fk, int frame_floats, int red_slots, int acc_floats,
+                                            bool alias_xg = false) {
     LdsPlan p;
     p.q = 0;
     p.f = p.q + ((64 * dof + 3) & ~3);
     p.x = p.f + 64 * frame_floats;
-    p.g = p.x + 64 * d_fk;
+    // The fused kernel writes G only after the sweep, when X is dead (alias_xg); the split launch's finish kernel
+    // needs both at once.
+    p.g = alias_xg ? p.x : p.x + 64 * d_fk;
     // The reduction scratch OVERLAYS X and G: X is dead once every wave has copied its features into registers
-    // (the kernel barriers after that copy), G is written only after wave 0 has read every partial.  Keeping
-    // the block under 40 KB is what lets four 8-wave blocks share a CU (32 waves) at the headline shape.
+    // (the kernel barriers after that copy), G is written only after wave 0 has read every partial.
     p.red = p.x;
     const int end_xg = p.g + 64 * d_fk;
-    const int end_red = p.red + (nw > 1 ? nw * acc_floats * 64 : 0);
+    const int end_red = p.red + red_slots * acc_floats * 64;
     p.fk = end_xg > end_red ? end_xg : end_red;  // the FK program comes last: its size varies with the robot
     p.total = p.fk;                              // and only the host needs it (+ fk_prog_floats)
     return p;
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
     const int64_t b0 = (int64_t)blockIdx.x * 64;
     const int nb = (int)((a.B - b0) < 64 ? (a.B - b0) : 64);
     const int dof = a.dof;
-    const LdsPlan lp = lds_plan(dof, a.d_fk, a.frame_floats, nw, ACC);
+    const LdsPlan lp = lds_plan(dof, a.d_fk, a.frame_floats, nw > 1 ? a.red_slots : 0, ACC, true);
     float* sQ = smem + lp.q;
     float* sX = smem + lp.x;
     float* sG = smem + lp.g;
@@ -404,7 +408,30 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
 #endif
     DCX_TS(3);
     // ---- meet the NW partial sums in LDS; wave 0 finishes --------------------------------
-    if (nw > 1) {
+    if (nw > 1 && a.red_slots == 1) {
+        // one LDS row: waves 1 .. nw-1 hand their partial sums to wave 0 in turn (same summation order as below)
+        for (int w = 1; w < nw; ++w) {
+            if (wave == w) {
+#pragma unroll
+                for (int c = 0; c < CC; ++c) sRed[c * 64 + lane] = sc[c];
+                if constexpr (GRAD) {
+#pragma unroll
+                    for (int k = 0; k < D; ++k) sRed[(CC + k) * 64 + lane] = gx[k];
+                }
+            }
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int c = 0; c < CC; ++c) sc[c] += sRed[c * 64 + lane];
+                if constexpr (GRAD) {
+#pragma unroll
+                    for (int k = 0; k < D; ++k) gx[k] += sRed[(CC + k) * 64 + lane];
+                }
+            }
+            __syncthreads();
+        }
+        if (wave != 0) return;
+    } else if (nw > 1) {
         float* mine = sRed + (size_t)wave * ACC * 64 + lane;
 #pragma unroll
         for (int c = 0; c < CC; ++c) mine[c * 64] = sc[c];
