@@ -25,6 +25,7 @@
 // form is what makes the reference's own fp32 result ~1e-5 off.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include "fk_device.h"
 
@@ -106,6 +107,11 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #ifndef DCX_SWEEP_VARIANT
 #define DCX_SWEEP_VARIANT 25
 #endif
+// independent accumulator pairs for the squared distance (see pair())
+#ifndef DCX_D2_MULTI
+#define DCX_D2_MULTI 1
+#endif
+#define DCX_D2_ACCS(D) (!DCX_D2_MULTI ? 1 : (D) >= 32 ? 4 : (D) >= 16 ? 2 : 1)
 
 // value K(d2) and g with dK/dx = g * (x - s)
 template <int KF>
@@ -267,15 +273,22 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
 #if DCX_SWEEP_VARIANT & 16
         v2f dp[D / 2 + 1];
         {
-            v2f acc = {0.0f, 0.0f};
+            // NA independent accumulator pairs: a wide row's D/2 dependent v_pk_fma would otherwise be one serial
+            // chain, and wide shapes run at 2-4 waves per SIMD, too few to hide it
+            constexpr int NA = DCX_D2_ACCS(D);
+            v2f acc[NA];
+#pragma unroll
+            for (int i = 0; i < NA; ++i) acc[i] = v2f{0.0f, 0.0f};
 #pragma unroll
             for (int k = 0; k + 1 < D; k += 2) {
                 const v2f xv = {x[k], x[k + 1]};
                 const v2f rv = {r[k], r[k + 1]};
                 dp[k / 2] = xv - rv;
-                acc = __builtin_elementwise_fma(dp[k / 2], dp[k / 2], acc);
+                acc[(k / 2) % NA] = __builtin_elementwise_fma(dp[k / 2], dp[k / 2], acc[(k / 2) % NA]);
             }
-            d2 = acc.x + acc.y;
+#pragma unroll
+            for (int i = 1; i < NA; ++i) acc[0] += acc[i];
+            d2 = acc[0].x + acc[0].y;
             if constexpr (D & 1) {
                 dl[D - 1] = x[D - 1] - r[D - 1];
                 d2 = fmaf(dl[D - 1], dl[D - 1], d2);
@@ -341,6 +354,13 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
     };
 
 #if DCX_SWEEP_VARIANT & 8
+    // How many SGPRs a pipeline may keep in flight: ~100 exist, the kernel needs a dozen for itself.  Four whole rows
+    // (the deepest pipeline) fit up to 22 floats per row; wider rows run a two-buffer pipeline over whole rows
+    // (<= 38 floats) or over half rows.  Before this split the compiler kept the four-row pipeline
+    // alive for every width by parking SGPRs in VGPR lanes: D=24 +37 %, D=42 +75 %, D=60 +97 % VALU instructions
+    // (v_writelane / v_readlane) inside the sweep.
+    constexpr int PARTS = (4 * USED <= 88) ? 0 : (2 * USED <= 76) ? 1 : 2;
+    if constexpr (PARTS == 0) {
     // Explicit software pipeline, two rows per stage (4 row buffers): the wait before a stage covers loads
     // issued TWO row bodies earlier, which is what hides an L2-latency scalar miss when only a few waves
     // share a SIMD (small batches).  wait -> issue {C,D} -> body(A), body(B) -> wait -> issue {A,B} -> body(C), body(D)
@@ -374,6 +394,118 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
         if (j + 2 < j1) {
             load_row(rowC, j + 2);
             pair(rowC);
+        }
+    }
+    } else {
+        constexpr int PS = ((USED + PARTS - 1) / PARTS + 3) / 4 * 4;  // floats per part (pairs never straddle parts)
+        constexpr int NA = DCX_D2_ACCS(D);
+        float bufA[PS], bufB[PS];
+        // state of the row being consumed
+        v2f acc[NA];
+        v2f dp[D / 2 + 1];
+        float tail_d = 0.0f;   // odd D: the unpaired last feature's difference
+        float wv[CC];
+        float wsum = 0.0f;
+        auto load_part = [&](float (&dst)[PS], int j, auto pc) __attribute__((always_inline)) {
+            constexpr int P0 = decltype(pc)::value * PS;
+            constexpr int LEN = (USED - P0 < PS) ? (USED - P0) : PS;
+            cfloat_ptr r = rows + (size_t)j * L::RS + P0;
+#pragma unroll
+            for (int e = 0; e < LEN; ++e) dst[e] = r[e];
+        };
+        auto consume = [&](const float (&b)[PS], auto pc) __attribute__((always_inline)) {
+            constexpr int P0 = decltype(pc)::value * PS;
+            constexpr int LEN = (USED - P0 < PS) ? (USED - P0) : PS;
+            if constexpr (decltype(pc)::value == 0) {
+#pragma unroll
+                for (int i = 0; i < NA; ++i) acc[i] = v2f{0.0f, 0.0f};
+            }
+#pragma unroll
+            for (int e = 0; e < LEN; ++e) {
+                constexpr int unused = 0;
+                (void)unused;
+                const int g = P0 + e;  // compile-time after unrolling
+                if (g + 1 < D && (g & 1) == 0) {
+                    const v2f xv = {x[g], x[g + 1]};
+                    const v2f rv = {b[e], b[e + 1]};
+                    dp[g / 2] = xv - rv;
+                    acc[(g / 2) % NA] = __builtin_elementwise_fma(dp[g / 2], dp[g / 2], acc[(g / 2) % NA]);
+                } else if (g == D - 1 && (D & 1)) {
+                    tail_d = x[g] - b[e];
+                } else if (g >= D && g < D + CC) {
+                    wv[g - D] = b[e];
+                } else if (CC > 1 && g == D + CC) {
+                    wsum = b[e];
+                }
+            }
+            if constexpr (decltype(pc)::value == PARTS - 1) {  // the row is complete
+#pragma unroll
+                for (int i = 1; i < NA; ++i) acc[0] += acc[i];
+                float d2 = acc[0].x + acc[0].y;
+                if constexpr (D & 1) d2 = fmaf(tail_d, tail_d, d2);
+                float val, g;
+                kernel_eval<KF>(d2, a, val, g);
+#pragma unroll
+                for (int c = 0; c < CC; ++c) sc[c] = fmaf(wv[c], val, sc[c]);
+                if constexpr (GRAD) {
+                    float coef;
+                    if constexpr (MODE == MODE_GRAD_ROW) {
+                        coef = g * (CC > 1 ? wsum : wv[0]);
+                    } else {
+                        float wb = 0.0f;
+#pragma unroll
+                        for (int c = 0; c < CC; ++c) wb = fmaf(up[c], wv[c], wb);
+                        coef = g * wb;
+                    }
+                    const v2f c2 = {coef, coef};
+#pragma unroll
+                    for (int k = 0; k + 1 < D; k += 2) gx2[k / 2] = __builtin_elementwise_fma(c2, dp[k / 2], gx2[k / 2]);
+                    if constexpr (D & 1) gx[D - 1] = fmaf(coef, tail_d, gx[D - 1]);
+                }
+            }
+        };
+        using P0c = std::integral_constant<int, 0>;
+        using P1c = std::integral_constant<int, PARTS - 1>;
+        if (j0 < j1) {
+            const int jl = j1 - 1;
+            if constexpr (PARTS == 1) {
+                // two whole-row buffers: wait -> issue B -> consume A -> wait -> issue A -> consume B
+                load_part(bufA, j0, P0c{});
+                int j = j0;
+                for (; j + 1 < j1; j += 2) {
+                    __builtin_amdgcn_s_waitcnt(0xC07F);
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_part(bufB, j + 1, P0c{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    consume(bufA, P0c{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_waitcnt(0xC07F);
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_part(bufA, (j + 2 < j1) ? j + 2 : jl, P0c{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    consume(bufB, P0c{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (j < j1) consume(bufA, P0c{});  // bufA holds row j
+            } else {
+                // two half-row buffers: wait -> issue second half -> consume first half -> wait -> issue the next row's
+                // first half -> consume second half (row complete)
+                load_part(bufA, j0, P0c{});
+                for (int j = j0; j < j1; ++j) {
+                    __builtin_amdgcn_s_waitcnt(0xC07F);
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_part(bufB, j, P1c{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    consume(bufA, P0c{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_waitcnt(0xC07F);
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_part(bufA, (j + 1 < j1) ? j + 1 : jl, P0c{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    consume(bufB, P1c{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
     }
 #elif DCX_SWEEP_VARIANT & 4
