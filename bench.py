@@ -38,6 +38,9 @@ WORKLOADS = {
     "cfg2_panda": ("panda", (1, 1.0, 1.0), 1000, 1, 4096, "config #2 with PandaFK (D=21)"),
     "cfg3": ("baxter", (0, 10.0, 2.0), 2000, 5, 8192, "BASELINE config #3: MultiDiffCo C=5, RQ(10), S=2000, 8192 per GPU"),
     "cfg4": (None, (0, 10.0, 2.0), 10000, 1, 1 << 20, "BASELINE config #4: SE(3) no-FK (D=6), RQ(10), S=10k, 1M configs"),
+    # the reference's recommended facade (ForwardKinematicsDiffCo on panda.urdf, tutorial cell 13): URDF tree, 8 dof
+    "urdf_panda": ("urdf_panda", (1, 1.0, 1.0), 2000, 1, 65536,
+                   "URDF Panda with gripper (DCX_FK_TREE: 8 dof, 9 link origins, D=27), Polyharmonic(1,1), S=2000, C=1"),
     # config #5: a "step" is ONE fused Adam iteration over 256 restarts x 50 waypoints (= 12800 score+grad evals)
     "cfg5": ("baxter", (1, 1.0, 1.0), 2000, 1, 256 * 50,
              "BASELINE config #5: fused Adam trajopt, 7-DoF, 50 waypoints x 256 restarts per GPU, S=2000 "
@@ -65,7 +68,13 @@ def make_workload(name, batch, dev, seed=0):
         hi = -lo
         desc = _fkdesc.none_desc(6)
     else:
-        rob = {"baxter": model.BaxterLeftArmFK, "panda": model.PandaFK}[rob_name]()
+        if rob_name.startswith("urdf_"):
+            # joint table stored with the golden FK fixture (tests/golden/fk_urdf_*.npz; no URDF file needed)
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+            import helpers
+            rob = helpers.urdf_robot(rob_name)
+        else:
+            rob = {"baxter": model.BaxterLeftArmFK, "panda": model.PandaFK}[rob_name]()
         lo, hi = rob.limits[:, 0], rob.limits[:, 1]
         desc = rob.fk_desc()
     sup_q = torch.rand((S, len(lo)), generator=g) * (hi - lo) + lo

@@ -253,6 +253,157 @@ __device__ __forceinline__ void sincos_f32(float x, float* sn, float* cs) {
     *cs = ((q + 1) & 2) ? -c0 : c0;
 }
 
+// ---- DCX_FK_TREE chain composition and reverse sweep ---------------------------------------------------
+// Deliberately NOT inlined: inside the fused kernel their register demand would otherwise be planned into every
+// robot's prologue / epilogue (the DH headline kernel went from 12 to 108 bytes of scratch per lane, doubling its
+// HBM writes, when these bodies were inlined).
+__device__ __attribute__((noinline)) void fk_tree_chain(fk_cptr fk, float* sXcol, float* sFcol) {
+    // T <- T * F * Motion along every root-to-leaf chain (reference: RigidBody.forward_kinematics,
+    // collision_interfaces/rigid_body.py:82-140, unrolled); features = frame origins (+ constant offsets for
+    // links behind fixed joints), collision_checkers.py:386-393
+    const int nch = rfl(fk->n_chains), stride = rfl(fk->out_stride) * 64;
+    int n_slots2 = 0;
+    {
+        const int njt = rfl(fk->n_joints);
+        for (int j = 0; j < njt; ++j) n_slots2 += 2 * rfl(fk->tj[j].slot_owner);
+    }
+    for (int ch = 0; ch < nch; ++ch) {
+        float r00 = fk->base[ch][0], r01 = fk->base[ch][1], r02 = fk->base[ch][2], t0 = fk->base[ch][3];
+        float r10 = fk->base[ch][4], r11 = fk->base[ch][5], r12 = fk->base[ch][6], t1 = fk->base[ch][7];
+        float r20 = fk->base[ch][8], r21 = fk->base[ch][9], r22 = fk->base[ch][10], t2 = fk->base[ch][11];
+        const int jb = rfl(fk->chain_begin[ch]), je = rfl(fk->chain_end[ch]);
+        for (int j = jb; j < je; ++j) {
+            const auto* F = fk->tj[j].F;
+            // N = T * F
+            const float f00 = F[0], f01 = F[1], f02 = F[2], f03 = F[3], f10 = F[4], f11 = F[5], f12 = F[6], f13 = F[7];
+            const float f20 = F[8], f21 = F[9], f22 = F[10], f23 = F[11];
+            t0 = fmaf(r00, f03, fmaf(r01, f13, fmaf(r02, f23, t0)));
+            t1 = fmaf(r10, f03, fmaf(r11, f13, fmaf(r12, f23, t1)));
+            t2 = fmaf(r20, f03, fmaf(r21, f13, fmaf(r22, f23, t2)));
+            float n00 = fmaf(r00, f00, fmaf(r01, f10, r02 * f20)), n01 = fmaf(r00, f01, fmaf(r01, f11, r02 * f21)),
+                  n02 = fmaf(r00, f02, fmaf(r01, f12, r02 * f22));
+            float n10 = fmaf(r10, f00, fmaf(r11, f10, r12 * f20)), n11 = fmaf(r10, f01, fmaf(r11, f11, r12 * f21)),
+                  n12 = fmaf(r10, f02, fmaf(r11, f12, r12 * f22));
+            float n20 = fmaf(r20, f00, fmaf(r21, f10, r22 * f20)), n21 = fmaf(r20, f01, fmaf(r21, f11, r22 * f21)),
+                  n22 = fmaf(r20, f02, fmaf(r21, f12, r22 * f22));
+            const int type = rfl(fk->tj[j].type), slot = rfl(fk->tj[j].slot);
+            if (type == TJ_REV) {
+                // R <- N * Rz(v): columns 0, 1 rotate
+                const float s = sFcol[(2 * slot) * 64], c = sFcol[(2 * slot + 1) * 64];
+                r00 = fmaf(n00, c, n01 * s); r01 = fmaf(n01, c, -n00 * s); r02 = n02;
+                r10 = fmaf(n10, c, n11 * s); r11 = fmaf(n11, c, -n10 * s); r12 = n12;
+                r20 = fmaf(n20, c, n21 * s); r21 = fmaf(n21, c, -n20 * s); r22 = n22;
+            } else {
+                r00 = n00; r01 = n01; r02 = n02; r10 = n10; r11 = n11; r12 = n12; r20 = n20; r21 = n21; r22 = n22;
+                if (type == TJ_PRISM) {
+                    const float v = sFcol[(2 * slot) * 64];
+                    const float dx = fk->tj[j].ax * v, dy = fk->tj[j].ay * v, dz = fk->tj[j].az * v;
+                    t0 = fmaf(r00, dx, fmaf(r01, dy, fmaf(r02, dz, t0)));
+                    t1 = fmaf(r10, dx, fmaf(r11, dy, fmaf(r12, dz, t1)));
+                    t2 = fmaf(r20, dx, fmaf(r21, dy, fmaf(r22, dz, t2)));
+                }
+            }
+            const int pb = rfl(fk->tj[j].pt_begin), pe = rfl(fk->tj[j].pt_end);
+            for (int p = pb; p < pe; ++p) {
+                const float ox = fk->points[p].ox, oy = fk->points[p].oy, oz = fk->points[p].oz;
+                float* out = sXcol + rfl(fk->points[p].out_k) * 64;
+                out[0] = fmaf(r00, ox, fmaf(r01, oy, fmaf(r02, oz, t0)));
+                out[stride] = fmaf(r10, ox, fmaf(r11, oy, fmaf(r12, oz, t1)));
+                out[2 * stride] = fmaf(r20, ox, fmaf(r21, oy, fmaf(r22, oz, t2)));
+            }
+        }
+        float* fr = sFcol + (n_slots2 + 9 * ch) * 64;  // final rotation of this chain (for the reverse sweep)
+        fr[0] = r00; fr[64] = r01; fr[128] = r02; fr[192] = r10; fr[256] = r11; fr[320] = r12;
+        fr[384] = r20; fr[448] = r21; fr[512] = r22;
+    }
+}
+
+__device__ __attribute__((noinline)) void fk_tree_vjp(fk_cptr fk, const float* sFcol, const float* sGcol, float* gqRow) {
+    const int dof = rfl(fk->dof);
+    // Reverse-mode sweep through T_j = T_{j-1} F_j M_j(v_j), chain by chain; a joint repeated on several chains
+    // (shared prefix) or driven by the same q (mimic) simply accumulates.  With N = T_{j-1} F_j:
+    //   revolute : R_j = R_N Rz(v), t_j = t_N   ->  dL/dv = <R_N^T GR, dRz/dv>,  G_RN = GR Rz^T
+    //   prismatic: R_j = R_N, t_j = t_N + R_N a v -> dL/dv = Gt . (R_N a),        G_RN = GR + Gt (a v)^T
+    //   through F: G_R(j-1) = G_RN F_R^T + Gt F_t^T,  R_(j-1) = R_N F_R^T,  Gt unchanged
+    for (int i = 0; i < dof; ++i) gqRow[i] = 0.f;  // the sweep reads frames, not q
+    const int nch = rfl(fk->n_chains), stride = rfl(fk->out_stride) * 64;
+    int n_slots2 = 0;
+    {
+        const int njt = rfl(fk->n_joints);
+        for (int j = 0; j < njt; ++j) n_slots2 += 2 * rfl(fk->tj[j].slot_owner);
+    }
+    for (int ch = 0; ch < nch; ++ch) {
+        const float* fr = sFcol + (n_slots2 + 9 * ch) * 64;
+        float r00 = fr[0], r01 = fr[64], r02 = fr[128], r10 = fr[192], r11 = fr[256], r12 = fr[320];
+        float r20 = fr[384], r21 = fr[448], r22 = fr[512];
+        float G00 = 0.f, G01 = 0.f, G02 = 0.f, G10 = 0.f, G11 = 0.f, G12 = 0.f, G20 = 0.f, G21 = 0.f, G22 = 0.f;
+        float T0 = 0.f, T1 = 0.f, T2 = 0.f;
+        const int jb = rfl(fk->chain_begin[ch]), je = rfl(fk->chain_end[ch]);
+        for (int j = je - 1; j >= jb; --j) {
+            const int pb = rfl(fk->tj[j].pt_begin), pe = rfl(fk->tj[j].pt_end);
+            for (int p = pb; p < pe; ++p) {
+                const float* gin = sGcol + rfl(fk->points[p].out_k) * 64;
+                const float g0 = gin[0], g1 = gin[stride], g2 = gin[2 * stride];
+                const float ox = fk->points[p].ox, oy = fk->points[p].oy, oz = fk->points[p].oz;
+                T0 += g0; T1 += g1; T2 += g2;
+                G00 = fmaf(g0, ox, G00); G01 = fmaf(g0, oy, G01); G02 = fmaf(g0, oz, G02);
+                G10 = fmaf(g1, ox, G10); G11 = fmaf(g1, oy, G11); G12 = fmaf(g1, oz, G12);
+                G20 = fmaf(g2, ox, G20); G21 = fmaf(g2, oy, G21); G22 = fmaf(g2, oz, G22);
+            }
+            const int type = rfl(fk->tj[j].type), slot = rfl(fk->tj[j].slot);
+            if (type == TJ_REV) {
+                const float s = sFcol[(2 * slot) * 64], c = sFcol[(2 * slot + 1) * 64];
+                // R_N = R_j Rz^T: columns 0, 1 rotate back
+                const float p00 = fmaf(r00, c, -r01 * s), p01 = fmaf(r01, c, r00 * s);
+                const float p10 = fmaf(r10, c, -r11 * s), p11 = fmaf(r11, c, r10 * s);
+                const float p20 = fmaf(r20, c, -r21 * s), p21 = fmaf(r21, c, r20 * s);
+                // A = R_N^T GR, rows 0 and 1, columns 0 and 1 (dRz/dv = [[-s, -c, 0], [c, -s, 0], [0, 0, 0]])
+                const float A00 = fmaf(p00, G00, fmaf(p10, G10, p20 * G20)), A01 = fmaf(p00, G01, fmaf(p10, G11, p20 * G21));
+                const float A10 = fmaf(p01, G00, fmaf(p11, G10, p21 * G20)), A11 = fmaf(p01, G01, fmaf(p11, G11, p21 * G21));
+                const float dv = (c * A10 - s * A11) - (s * A00 + c * A01);
+                gqRow[rfl(fk->tj[j].q_index)] += fk->tj[j].scale * dv;
+                // G_RN = GR Rz^T
+                const float h00 = fmaf(G00, c, -G01 * s), h01 = fmaf(G01, c, G00 * s);
+                const float h10 = fmaf(G10, c, -G11 * s), h11 = fmaf(G11, c, G10 * s);
+                const float h20 = fmaf(G20, c, -G21 * s), h21 = fmaf(G21, c, G20 * s);
+                G00 = h00; G01 = h01; G10 = h10; G11 = h11; G20 = h20; G21 = h21;
+                r00 = p00; r01 = p01; r10 = p10; r11 = p11; r20 = p20; r21 = p21;
+            } else if (type == TJ_PRISM) {
+                const float v = sFcol[(2 * slot) * 64];
+                const float ax = fk->tj[j].ax, ay = fk->tj[j].ay, az = fk->tj[j].az;
+                const float w0 = fmaf(r00, ax, fmaf(r01, ay, r02 * az)), w1 = fmaf(r10, ax, fmaf(r11, ay, r12 * az)),
+                            w2 = fmaf(r20, ax, fmaf(r21, ay, r22 * az));
+                gqRow[rfl(fk->tj[j].q_index)] += fk->tj[j].scale * fmaf(T0, w0, fmaf(T1, w1, T2 * w2));
+                const float dx = ax * v, dy = ay * v, dz = az * v;
+                G00 = fmaf(T0, dx, G00); G01 = fmaf(T0, dy, G01); G02 = fmaf(T0, dz, G02);
+                G10 = fmaf(T1, dx, G10); G11 = fmaf(T1, dy, G11); G12 = fmaf(T1, dz, G12);
+                G20 = fmaf(T2, dx, G20); G21 = fmaf(T2, dy, G21); G22 = fmaf(T2, dz, G22);
+            }
+            // back through the constant transform F
+            const auto* F = fk->tj[j].F;
+            const float f00 = F[0], f01 = F[1], f02 = F[2], f03 = F[3], f10 = F[4], f11 = F[5], f12 = F[6], f13 = F[7];
+            const float f20 = F[8], f21 = F[9], f22 = F[10], f23 = F[11];
+            const float n00 = fmaf(G00, f00, fmaf(G01, f01, fmaf(G02, f02, T0 * f03)));
+            const float n01 = fmaf(G00, f10, fmaf(G01, f11, fmaf(G02, f12, T0 * f13)));
+            const float n02 = fmaf(G00, f20, fmaf(G01, f21, fmaf(G02, f22, T0 * f23)));
+            const float n10 = fmaf(G10, f00, fmaf(G11, f01, fmaf(G12, f02, T1 * f03)));
+            const float n11 = fmaf(G10, f10, fmaf(G11, f11, fmaf(G12, f12, T1 * f13)));
+            const float n12 = fmaf(G10, f20, fmaf(G11, f21, fmaf(G12, f22, T1 * f23)));
+            const float n20 = fmaf(G20, f00, fmaf(G21, f01, fmaf(G22, f02, T2 * f03)));
+            const float n21 = fmaf(G20, f10, fmaf(G21, f11, fmaf(G22, f12, T2 * f13)));
+            const float n22 = fmaf(G20, f20, fmaf(G21, f21, fmaf(G22, f22, T2 * f23)));
+            G00 = n00; G01 = n01; G02 = n02; G10 = n10; G11 = n11; G12 = n12; G20 = n20; G21 = n21; G22 = n22;
+            const float q00 = fmaf(r00, f00, fmaf(r01, f01, r02 * f02)), q01 = fmaf(r00, f10, fmaf(r01, f11, r02 * f12)),
+                        q02 = fmaf(r00, f20, fmaf(r01, f21, r02 * f22));
+            const float q10 = fmaf(r10, f00, fmaf(r11, f01, r12 * f02)), q11 = fmaf(r10, f10, fmaf(r11, f11, r12 * f12)),
+                        q12 = fmaf(r10, f20, fmaf(r11, f21, r12 * f22));
+            const float q20 = fmaf(r20, f00, fmaf(r21, f01, r22 * f02)), q21 = fmaf(r20, f10, fmaf(r21, f11, r22 * f12)),
+                        q22 = fmaf(r20, f20, fmaf(r21, f21, r22 * f22));
+            r00 = q00; r01 = q01; r02 = q02; r10 = q10; r11 = q11; r12 = q12; r20 = q20; r21 = q21; r22 = q22;
+        }
+    }
+}
+
 // ---- forward, phase A (every wave of the block): sin/cos of the joint angles -> frames ---------------
 // wave w of nw takes joints w, w+nw, ...   Caller synchronises the block afterwards.
 __device__ inline void fk_forward_trig(fk_cptr fk, const float* sQrow, float* sFcol, int wave, int nw) {
@@ -350,64 +501,7 @@ __device__ inline void fk_forward_chain(fk_cptr fk, const float* sQrow, float* s
             fr[384] = r20; fr[448] = r21; fr[512] = r22;
         }
     } else if (kind == DCX_FK_TREE) {
-        // T <- T * F * Motion along every root-to-leaf chain (reference: RigidBody.forward_kinematics,
-        // collision_interfaces/rigid_body.py:82-140, unrolled); features = frame origins (+ constant offsets for
-        // links behind fixed joints), collision_checkers.py:386-393
-        const int nch = rfl(fk->n_chains), stride = rfl(fk->out_stride) * 64;
-        int n_slots2 = 0;
-        {
-            const int njt = rfl(fk->n_joints);
-            for (int j = 0; j < njt; ++j) n_slots2 += 2 * rfl(fk->tj[j].slot_owner);
-        }
-        for (int ch = 0; ch < nch; ++ch) {
-            float r00 = fk->base[ch][0], r01 = fk->base[ch][1], r02 = fk->base[ch][2], t0 = fk->base[ch][3];
-            float r10 = fk->base[ch][4], r11 = fk->base[ch][5], r12 = fk->base[ch][6], t1 = fk->base[ch][7];
-            float r20 = fk->base[ch][8], r21 = fk->base[ch][9], r22 = fk->base[ch][10], t2 = fk->base[ch][11];
-            const int jb = rfl(fk->chain_begin[ch]), je = rfl(fk->chain_end[ch]);
-            for (int j = jb; j < je; ++j) {
-                const auto* F = fk->tj[j].F;
-                // N = T * F
-                const float f00 = F[0], f01 = F[1], f02 = F[2], f03 = F[3], f10 = F[4], f11 = F[5], f12 = F[6], f13 = F[7];
-                const float f20 = F[8], f21 = F[9], f22 = F[10], f23 = F[11];
-                t0 = fmaf(r00, f03, fmaf(r01, f13, fmaf(r02, f23, t0)));
-                t1 = fmaf(r10, f03, fmaf(r11, f13, fmaf(r12, f23, t1)));
-                t2 = fmaf(r20, f03, fmaf(r21, f13, fmaf(r22, f23, t2)));
-                float n00 = fmaf(r00, f00, fmaf(r01, f10, r02 * f20)), n01 = fmaf(r00, f01, fmaf(r01, f11, r02 * f21)),
-                      n02 = fmaf(r00, f02, fmaf(r01, f12, r02 * f22));
-                float n10 = fmaf(r10, f00, fmaf(r11, f10, r12 * f20)), n11 = fmaf(r10, f01, fmaf(r11, f11, r12 * f21)),
-                      n12 = fmaf(r10, f02, fmaf(r11, f12, r12 * f22));
-                float n20 = fmaf(r20, f00, fmaf(r21, f10, r22 * f20)), n21 = fmaf(r20, f01, fmaf(r21, f11, r22 * f21)),
-                      n22 = fmaf(r20, f02, fmaf(r21, f12, r22 * f22));
-                const int type = rfl(fk->tj[j].type), slot = rfl(fk->tj[j].slot);
-                if (type == TJ_REV) {
-                    // R <- N * Rz(v): columns 0, 1 rotate
-                    const float s = sFcol[(2 * slot) * 64], c = sFcol[(2 * slot + 1) * 64];
-                    r00 = fmaf(n00, c, n01 * s); r01 = fmaf(n01, c, -n00 * s); r02 = n02;
-                    r10 = fmaf(n10, c, n11 * s); r11 = fmaf(n11, c, -n10 * s); r12 = n12;
-                    r20 = fmaf(n20, c, n21 * s); r21 = fmaf(n21, c, -n20 * s); r22 = n22;
-                } else {
-                    r00 = n00; r01 = n01; r02 = n02; r10 = n10; r11 = n11; r12 = n12; r20 = n20; r21 = n21; r22 = n22;
-                    if (type == TJ_PRISM) {
-                        const float v = sFcol[(2 * slot) * 64];
-                        const float dx = fk->tj[j].ax * v, dy = fk->tj[j].ay * v, dz = fk->tj[j].az * v;
-                        t0 = fmaf(r00, dx, fmaf(r01, dy, fmaf(r02, dz, t0)));
-                        t1 = fmaf(r10, dx, fmaf(r11, dy, fmaf(r12, dz, t1)));
-                        t2 = fmaf(r20, dx, fmaf(r21, dy, fmaf(r22, dz, t2)));
-                    }
-                }
-                const int pb = rfl(fk->tj[j].pt_begin), pe = rfl(fk->tj[j].pt_end);
-                for (int p = pb; p < pe; ++p) {
-                    const float ox = fk->points[p].ox, oy = fk->points[p].oy, oz = fk->points[p].oz;
-                    float* out = sXcol + rfl(fk->points[p].out_k) * 64;
-                    out[0] = fmaf(r00, ox, fmaf(r01, oy, fmaf(r02, oz, t0)));
-                    out[stride] = fmaf(r10, ox, fmaf(r11, oy, fmaf(r12, oz, t1)));
-                    out[2 * stride] = fmaf(r20, ox, fmaf(r21, oy, fmaf(r22, oz, t2)));
-                }
-            }
-            float* fr = sFcol + (n_slots2 + 9 * ch) * 64;  // final rotation of this chain (for the reverse sweep)
-            fr[0] = r00; fr[64] = r01; fr[128] = r02; fr[192] = r10; fr[256] = r11; fr[320] = r12;
-            fr[384] = r20; fr[448] = r21; fr[512] = r22;
-        }
+        fk_tree_chain(fk, sXcol, sFcol);
     } else if (kind == DCX_FK_SE2) {
         const float x = sQrow[0], y = sQrow[1];
         float s, c;
@@ -527,88 +621,7 @@ __device__ inline void fk_vjp(fk_cptr fk, const float* sQrow, const float* sFcol
             }
         }
     } else if (kind == DCX_FK_TREE) {
-        // Reverse-mode sweep through T_j = T_{j-1} F_j M_j(v_j), chain by chain; a joint repeated on several chains
-        // (shared prefix) or driven by the same q (mimic) simply accumulates.  With N = T_{j-1} F_j:
-        //   revolute : R_j = R_N Rz(v), t_j = t_N   ->  dL/dv = <R_N^T GR, dRz/dv>,  G_RN = GR Rz^T
-        //   prismatic: R_j = R_N, t_j = t_N + R_N a v -> dL/dv = Gt . (R_N a),        G_RN = GR + Gt (a v)^T
-        //   through F: G_R(j-1) = G_RN F_R^T + Gt F_t^T,  R_(j-1) = R_N F_R^T,  Gt unchanged
-        for (int i = 0; i < dof; ++i) gqRow[i] = 0.f;  // the sweep reads frames, not q
-        const int nch = rfl(fk->n_chains), stride = rfl(fk->out_stride) * 64;
-        int n_slots2 = 0;
-        {
-            const int njt = rfl(fk->n_joints);
-            for (int j = 0; j < njt; ++j) n_slots2 += 2 * rfl(fk->tj[j].slot_owner);
-        }
-        for (int ch = 0; ch < nch; ++ch) {
-            const float* fr = sFcol + (n_slots2 + 9 * ch) * 64;
-            float r00 = fr[0], r01 = fr[64], r02 = fr[128], r10 = fr[192], r11 = fr[256], r12 = fr[320];
-            float r20 = fr[384], r21 = fr[448], r22 = fr[512];
-            float G00 = 0.f, G01 = 0.f, G02 = 0.f, G10 = 0.f, G11 = 0.f, G12 = 0.f, G20 = 0.f, G21 = 0.f, G22 = 0.f;
-            float T0 = 0.f, T1 = 0.f, T2 = 0.f;
-            const int jb = rfl(fk->chain_begin[ch]), je = rfl(fk->chain_end[ch]);
-            for (int j = je - 1; j >= jb; --j) {
-                const int pb = rfl(fk->tj[j].pt_begin), pe = rfl(fk->tj[j].pt_end);
-                for (int p = pb; p < pe; ++p) {
-                    const float* gin = sGcol + rfl(fk->points[p].out_k) * 64;
-                    const float g0 = gin[0], g1 = gin[stride], g2 = gin[2 * stride];
-                    const float ox = fk->points[p].ox, oy = fk->points[p].oy, oz = fk->points[p].oz;
-                    T0 += g0; T1 += g1; T2 += g2;
-                    G00 = fmaf(g0, ox, G00); G01 = fmaf(g0, oy, G01); G02 = fmaf(g0, oz, G02);
-                    G10 = fmaf(g1, ox, G10); G11 = fmaf(g1, oy, G11); G12 = fmaf(g1, oz, G12);
-                    G20 = fmaf(g2, ox, G20); G21 = fmaf(g2, oy, G21); G22 = fmaf(g2, oz, G22);
-                }
-                const int type = rfl(fk->tj[j].type), slot = rfl(fk->tj[j].slot);
-                if (type == TJ_REV) {
-                    const float s = sFcol[(2 * slot) * 64], c = sFcol[(2 * slot + 1) * 64];
-                    // R_N = R_j Rz^T: columns 0, 1 rotate back
-                    const float p00 = fmaf(r00, c, -r01 * s), p01 = fmaf(r01, c, r00 * s);
-                    const float p10 = fmaf(r10, c, -r11 * s), p11 = fmaf(r11, c, r10 * s);
-                    const float p20 = fmaf(r20, c, -r21 * s), p21 = fmaf(r21, c, r20 * s);
-                    // A = R_N^T GR, rows 0 and 1, columns 0 and 1 (dRz/dv = [[-s, -c, 0], [c, -s, 0], [0, 0, 0]])
-                    const float A00 = fmaf(p00, G00, fmaf(p10, G10, p20 * G20)), A01 = fmaf(p00, G01, fmaf(p10, G11, p20 * G21));
-                    const float A10 = fmaf(p01, G00, fmaf(p11, G10, p21 * G20)), A11 = fmaf(p01, G01, fmaf(p11, G11, p21 * G21));
-                    const float dv = (c * A10 - s * A11) - (s * A00 + c * A01);
-                    gqRow[rfl(fk->tj[j].q_index)] += fk->tj[j].scale * dv;
-                    // G_RN = GR Rz^T
-                    const float h00 = fmaf(G00, c, -G01 * s), h01 = fmaf(G01, c, G00 * s);
-                    const float h10 = fmaf(G10, c, -G11 * s), h11 = fmaf(G11, c, G10 * s);
-                    const float h20 = fmaf(G20, c, -G21 * s), h21 = fmaf(G21, c, G20 * s);
-                    G00 = h00; G01 = h01; G10 = h10; G11 = h11; G20 = h20; G21 = h21;
-                    r00 = p00; r01 = p01; r10 = p10; r11 = p11; r20 = p20; r21 = p21;
-                } else if (type == TJ_PRISM) {
-                    const float v = sFcol[(2 * slot) * 64];
-                    const float ax = fk->tj[j].ax, ay = fk->tj[j].ay, az = fk->tj[j].az;
-                    const float w0 = fmaf(r00, ax, fmaf(r01, ay, r02 * az)), w1 = fmaf(r10, ax, fmaf(r11, ay, r12 * az)),
-                                w2 = fmaf(r20, ax, fmaf(r21, ay, r22 * az));
-                    gqRow[rfl(fk->tj[j].q_index)] += fk->tj[j].scale * fmaf(T0, w0, fmaf(T1, w1, T2 * w2));
-                    const float dx = ax * v, dy = ay * v, dz = az * v;
-                    G00 = fmaf(T0, dx, G00); G01 = fmaf(T0, dy, G01); G02 = fmaf(T0, dz, G02);
-                    G10 = fmaf(T1, dx, G10); G11 = fmaf(T1, dy, G11); G12 = fmaf(T1, dz, G12);
-                    G20 = fmaf(T2, dx, G20); G21 = fmaf(T2, dy, G21); G22 = fmaf(T2, dz, G22);
-                }
-                // back through the constant transform F
-                const auto* F = fk->tj[j].F;
-                const float f00 = F[0], f01 = F[1], f02 = F[2], f03 = F[3], f10 = F[4], f11 = F[5], f12 = F[6], f13 = F[7];
-                const float f20 = F[8], f21 = F[9], f22 = F[10], f23 = F[11];
-                const float n00 = fmaf(G00, f00, fmaf(G01, f01, fmaf(G02, f02, T0 * f03)));
-                const float n01 = fmaf(G00, f10, fmaf(G01, f11, fmaf(G02, f12, T0 * f13)));
-                const float n02 = fmaf(G00, f20, fmaf(G01, f21, fmaf(G02, f22, T0 * f23)));
-                const float n10 = fmaf(G10, f00, fmaf(G11, f01, fmaf(G12, f02, T1 * f03)));
-                const float n11 = fmaf(G10, f10, fmaf(G11, f11, fmaf(G12, f12, T1 * f13)));
-                const float n12 = fmaf(G10, f20, fmaf(G11, f21, fmaf(G12, f22, T1 * f23)));
-                const float n20 = fmaf(G20, f00, fmaf(G21, f01, fmaf(G22, f02, T2 * f03)));
-                const float n21 = fmaf(G20, f10, fmaf(G21, f11, fmaf(G22, f12, T2 * f13)));
-                const float n22 = fmaf(G20, f20, fmaf(G21, f21, fmaf(G22, f22, T2 * f23)));
-                G00 = n00; G01 = n01; G02 = n02; G10 = n10; G11 = n11; G12 = n12; G20 = n20; G21 = n21; G22 = n22;
-                const float q00 = fmaf(r00, f00, fmaf(r01, f01, r02 * f02)), q01 = fmaf(r00, f10, fmaf(r01, f11, r02 * f12)),
-                            q02 = fmaf(r00, f20, fmaf(r01, f21, r02 * f22));
-                const float q10 = fmaf(r10, f00, fmaf(r11, f01, r12 * f02)), q11 = fmaf(r10, f10, fmaf(r11, f11, r12 * f12)),
-                            q12 = fmaf(r10, f20, fmaf(r11, f21, r12 * f22));
-                const float q20 = fmaf(r20, f00, fmaf(r21, f01, r22 * f02)), q21 = fmaf(r20, f10, fmaf(r21, f11, r22 * f12)),
-                            q22 = fmaf(r20, f20, fmaf(r21, f21, r22 * f22));
-                r00 = q00; r01 = q01; r02 = q02; r10 = q10; r11 = q11; r12 = q12; r20 = q20; r21 = q21; r22 = q22;
-            }
-        }
+        fk_tree_vjp(fk, sFcol, sGcol, gqRow);
     } else if (kind == DCX_FK_SE2) {
         float s, c;
         sincos_f32(sQrow[2], &s, &c);
