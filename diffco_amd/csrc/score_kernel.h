@@ -107,6 +107,15 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #ifndef DCX_SWEEP_VARIANT
 #define DCX_SWEEP_VARIANT 25
 #endif
+// four-row pipeline limits (SGPRs in flight; see PARTS below), measured: C > 1 holds more scalars of its own (C = 5,
+// D = 12: 72 row SGPRs park 96 lane moves per 4 rows, two rows in flight +22..45 %); C = 1: D = 21 (88) is 9..21 %
+// faster with two rows in flight, D = 18 (76) 4 % slower (profiles/r01_sweep_variants.txt)
+#ifndef DCX_P0_MAX_MULTI
+#define DCX_P0_MAX_MULTI 56
+#endif
+#ifndef DCX_P0_MAX_SINGLE
+#define DCX_P0_MAX_SINGLE 76
+#endif
 // independent accumulator pairs for the squared distance (see pair())
 #ifndef DCX_D2_MULTI
 #define DCX_D2_MULTI 1
@@ -359,7 +368,7 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
     // (<= 38 floats) or over half rows.  Before this split the compiler kept the four-row pipeline
     // alive for every width by parking SGPRs in VGPR lanes: D=24 +37 %, D=42 +75 %, D=60 +97 % VALU instructions
     // (v_writelane / v_readlane) inside the sweep.
-    constexpr int PARTS = (4 * USED <= 88) ? 0 : (2 * USED <= 76) ? 1 : 2;
+    constexpr int PARTS = (4 * USED <= (CC > 1 ? DCX_P0_MAX_MULTI : DCX_P0_MAX_SINGLE)) ? 0 : (2 * USED <= 76) ? 1 : 2;
     if constexpr (PARTS == 0) {
     // Explicit software pipeline, two rows per stage (4 row buffers): the wait before a stage covers loads
     // issued TWO row bodies earlier, which is what hides an L2-latency scalar miss when only a few waves
