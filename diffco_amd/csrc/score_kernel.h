@@ -93,20 +93,12 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define DCX_TS(slot) do { } while (0)
 #endif
 
-// Sweep code-generation variants, A/B-measured on MI355X (DESIGN.md "Measured choices"):
-//   bit 0: squared distance accumulated with packed fp32 (v_pk_fma_f32) instead of scalar v_fma_f32
-//   bit 1: scalar loads of the next support row issued before the current row is consumed
-//   bit 2: explicit two-buffer software pipeline (overrides bit 1)
-//   bit 3: explicit four-buffer pipeline, two rows per stage (overrides bits 1, 2)
-//   bit 4: differences and gradient accumulators kept as packed pairs end to end (v_pk_fma_f32 for the gradient
-//          too; the compiler already finds this for even D, for odd D and C > 1 it does not)
-// Measured on MI355X (profiles/r01_sweep_variants.txt): packed d2 + the explicit four-buffer pipeline (9) is
-// fastest at every batch size (headline B=65536: 555 vs 485 (variant 3) vs ~470 (variant 0) M evals/s).
-// Bit 4 on top (profiles/r01_sweep_variants.txt, "variant 25"): headline unchanged, Panda D=21 +6 % (B=4096) /
-// +19 % (B=65536), C=5 +7 %.
-#ifndef DCX_SWEEP_VARIANT
-#define DCX_SWEEP_VARIANT 25
-#endif
+// Code-generation choices of the sweep, each A/B-measured on MI355X against the alternatives (the variants lived
+// behind a build macro during the round; profiles/r01_sweep_variants.txt has the numbers, DESIGN.md the reasoning):
+//   * differences, squared distance and gradient accumulators as packed pairs end to end (v_pk_add / v_pk_fma);
+//   * an EXPLICIT software pipeline of the scalar row loads (wait -> issue next -> consume) instead of the
+//     compiler's schedule (15-20 % slower everywhere), four rows in flight for narrow rows (two were 11 % slower at
+//     small batches), fewer for wide rows (below).
 // four-row pipeline limits (SGPRs in flight; see PARTS below), measured: C > 1 holds more scalars of its own (C = 5,
 // D = 12: 72 row SGPRs park 96 lane moves per 4 rows, two rows in flight +22..45 %); C = 1: D = 21 (88) is 9..21 %
 // faster with two rows in flight, D = 18 (76) 4 % slower (profiles/r01_sweep_variants.txt)
@@ -263,11 +255,9 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
     for (int c = 0; c < CC; ++c) sc[c] = 0.0f;
 #pragma unroll
     for (int k = 0; k < D; ++k) gx[k] = 0.0f;
-#if DCX_SWEEP_VARIANT & 16
     v2f gx2[D / 2 + 1];
 #pragma unroll
     for (int k = 0; k < D / 2 + 1; ++k) gx2[k] = v2f{0.0f, 0.0f};
-#endif
 
     const int ybase = blockIdx.y * a.s_super;                               // this block's super-chunk
     const int yend = (ybase + a.s_super < a.S) ? (ybase + a.s_super) : a.S;
@@ -279,7 +269,6 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
     auto pair = [&](const float (&r)[L::RS]) __attribute__((always_inline)) {
         float dl[D];
         float d2;
-#if DCX_SWEEP_VARIANT & 16
         v2f dp[D / 2 + 1];
         {
             // NA independent accumulator pairs: a wide row's D/2 dependent v_pk_fma would otherwise be one serial
@@ -303,32 +292,6 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
                 d2 = fmaf(dl[D - 1], dl[D - 1], d2);
             }
         }
-#elif DCX_SWEEP_VARIANT & 1
-        {   // squared distance on the packed-fp32 pipe: D/2 v_pk_add + D/2 v_pk_fma
-            v2f acc = {0.0f, 0.0f};
-#pragma unroll
-            for (int k = 0; k + 1 < D; k += 2) {
-                const v2f xv = {x[k], x[k + 1]};
-                const v2f rv = {r[k], r[k + 1]};
-                const v2f d = xv - rv;
-                dl[k] = d.x;
-                dl[k + 1] = d.y;
-                acc = __builtin_elementwise_fma(d, d, acc);
-            }
-            d2 = acc.x + acc.y;
-            if constexpr (D & 1) {
-                dl[D - 1] = x[D - 1] - r[D - 1];
-                d2 = fmaf(dl[D - 1], dl[D - 1], d2);
-            }
-        }
-#else
-        d2 = 0.0f;
-#pragma unroll
-        for (int k = 0; k < D; ++k) {
-            dl[k] = x[k] - r[k];
-            d2 = fmaf(dl[k], dl[k], d2);
-        }
-#endif
         float val, g;
         kernel_eval<KF>(d2, a, val, g);
 #pragma unroll
@@ -343,15 +306,10 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
                 for (int c = 0; c < CC; ++c) wb = fmaf(up[c], r[L::W_OFF + c], wb);
                 coef = g * wb;
             }
-#if DCX_SWEEP_VARIANT & 16
             const v2f c2 = {coef, coef};
 #pragma unroll
             for (int k = 0; k + 1 < D; k += 2) gx2[k / 2] = __builtin_elementwise_fma(c2, dp[k / 2], gx2[k / 2]);
             if constexpr (D & 1) gx[D - 1] = fmaf(coef, dl[D - 1], gx[D - 1]);
-#else
-#pragma unroll
-            for (int k = 0; k < D; ++k) gx[k] = fmaf(coef, dl[k], gx[k]);
-#endif
         }
     };
     // only the floats a row really carries are loaded (the tail of the padded stride is never touched)
@@ -362,7 +320,6 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
         for (int e = 0; e < USED; ++e) dst[e] = r[e];
     };
 
-#if DCX_SWEEP_VARIANT & 8
     // How many SGPRs a pipeline may keep in flight: ~100 exist, the kernel needs a dozen for itself.  Four whole rows
     // (the deepest pipeline) fit up to 22 floats per row; wider rows run a two-buffer pipeline over whole rows
     // (<= 38 floats) or over half rows.  Before this split the compiler kept the four-row pipeline
@@ -517,36 +474,12 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
             }
         }
     }
-#elif DCX_SWEEP_VARIANT & 4
-    // Explicit two-buffer software pipeline.#elif DCX_SWEEP_VARIANT & 2
-    // software-pipelined: the scalar loads of row j+1 are in flight while row j is consumed
-    if (j0 < j1) {
-        float cur[L::RS], nxt[L::RS];
-        load_row(cur, j0);
-#pragma unroll 2
-        for (int j = j0; j < j1; ++j) {
-            load_row(nxt, (j + 1 < j1) ? j + 1 : j);
-            pair(cur);
-#pragma unroll
-            for (int e = 0; e < USED; ++e) cur[e] = nxt[e];
-        }
-    }
-#else
-#pragma unroll 2
-    for (int j = j0; j < j1; ++j) {
-        float cur[L::RS];
-        load_row(cur, j);
-        pair(cur);
-    }
-#endif
 
-#if DCX_SWEEP_VARIANT & 16
 #pragma unroll
     for (int k = 0; k + 1 < D; k += 2) {
         gx[k] = gx2[k / 2].x;
         gx[k + 1] = gx2[k / 2].y;
     }
-#endif
     DCX_TS(3);
     // ---- meet the NW partial sums in LDS; wave 0 finishes --------------------------------
     if (nw > 1 && a.red_slots == 1) {
