@@ -161,3 +161,88 @@ class TorchDHRobot:
             v = torch.tensor(off + [1.0], dtype=q.dtype)
             pts.append((cum[f] @ v)[:, :3])
         return torch.stack(pts, 1)
+
+
+# ---------------------------------------------------------------------------------------------
+# random URDF trees (tests of the DCX_FK_TREE path beyond the reference's robot files)
+def random_urdf_model(seed, n_links=9, max_children=2):
+    """joint table of a random kinematic tree: revolute / continuous / prismatic / fixed joints, axes +-x/y/z (and
+    off-axis vectors for prismatic joints), random origins, an occasional mimic joint"""
+    rng = np.random.default_rng(seed)
+    links = ["base"] + [f"l{i}" for i in range(1, n_links)]
+    joints, n_children, movable = [], {ln: 0 for ln in links}, []
+    for i in range(1, n_links):
+        cands = [ln for ln in links[:i] if n_children[ln] < max_children]
+        parent = cands[int(rng.integers(len(cands)))] if rng.random() < 0.4 else cands[-1]
+        n_children[parent] += 1
+        jtype = str(rng.choice(["revolute", "revolute", "continuous", "prismatic", "fixed"]))
+        axis = [0.0, 0.0, 0.0]
+        if jtype == "prismatic" and rng.random() < 0.5:
+            axis = rng.standard_normal(3).round(3).tolist()
+        else:
+            axis[int(rng.integers(3))] = float(rng.choice([-1.0, 1.0]))
+        xyz = (rng.standard_normal(3) * 0.3).round(4).tolist() if rng.random() < 0.85 else [0.0, 0.0, 0.0]
+        rpy = (rng.uniform(-np.pi, np.pi, 3)).round(4).tolist() if rng.random() < 0.7 else [0.0, 0.0, 0.0]
+        j = dict(name=f"j{i}", type=jtype, parent=parent, child=links[i], xyz=xyz, rpy=rpy, axis=axis, lower=None,
+                 upper=None, mimic_joint=None, mimic_multiplier=1.0, mimic_offset=0.0)
+        if jtype in ("revolute", "prismatic") and rng.random() < 0.8:
+            j["lower"], j["upper"] = -1.5, 2.0
+        if jtype != "fixed" and movable and rng.random() < 0.15:
+            j["mimic_joint"] = movable[int(rng.integers(len(movable)))]
+            j["mimic_multiplier"], j["mimic_offset"] = float(rng.choice([-1.0, 0.5, 2.0])), float(rng.uniform(-0.2, 0.2))
+        elif jtype != "fixed":
+            movable.append(j["name"])
+        joints.append(j)
+    return dict(links=links, joints=joints)
+
+
+def reference_tree_fk(model, q):
+    """independent float64 FK of a joint table, written from the URDF semantics the reference implements
+    (rigid_body.py:82-140): link frame = parent frame * origin * motion; returns {link: [B, 3] origin positions}"""
+    q = np.asarray(q, dtype=np.float64)
+    B = len(q)
+
+    def rot(axis_idx, ang):
+        c, s, R = np.cos(ang), np.sin(ang), np.zeros((B, 3, 3))
+        i, j, k = axis_idx, (axis_idx + 1) % 3, (axis_idx + 2) % 3
+        R[:, i, i] = 1
+        R[:, j, j], R[:, j, k], R[:, k, j], R[:, k, k] = c, -s, s, c
+        return R
+
+    f32 = lambda v: np.asarray(v, dtype=np.float32).astype(np.float64)  # noqa: E731  (the reference stores fp32)
+    child_joint = {j["child"]: j for j in model["joints"]}
+    dof, dof_of = 0, {}
+    for ln in model["links"]:  # dof order = link order
+        j = child_joint.get(ln)
+        if j is not None and j["type"] != "fixed" and j["mimic_joint"] is None:
+            dof_of[j["name"]] = dof
+            dof += 1
+    frames = {}
+
+    def frame(ln):
+        if ln in frames:
+            return frames[ln]
+        j = child_joint.get(ln)
+        if j is None:
+            R, t = np.tile(np.eye(3), (B, 1, 1)), np.zeros((B, 3))
+        else:
+            Rp, tp = frame(j["parent"])
+            r, p, y = f32(j["rpy"])
+            one = lambda a, idx: rot(idx, np.full(B, a))  # noqa: E731
+            Ro = one(y, 2) @ one(p, 1) @ one(r, 0)
+            R, t = Rp @ Ro, tp + np.einsum("bij,j->bi", Rp, f32(j["xyz"]))
+            if j["type"] != "fixed":
+                src = j["mimic_joint"] or j["name"]
+                v = q[:, dof_of[src]]
+                if j["mimic_joint"] is not None:
+                    v = v * j["mimic_multiplier"] + j["mimic_offset"]
+                ax = f32(j["axis"])
+                if j["type"] == "prismatic":
+                    t = t + np.einsum("bij,j->bi", R, ax)[:, :] * v[:, None]
+                else:
+                    idx = 0 if abs(ax[0]) == 1 else 1 if abs(ax[1]) == 1 else 2
+                    R = R @ rot(idx, np.sign(ax[idx]) * v)
+        frames[ln] = (R, t)
+        return frames[ln]
+
+    return {ln: frame(ln)[1] for ln in model["links"]}, dof

@@ -212,3 +212,32 @@ def test_forward_kinematics_diffco_facade(ops):
         ForwardKinematicsDiffCo(robot=rob).fit(num_samples=10)
     with pytest.raises(NotImplementedError):
         ForwardKinematicsDiffCo(robot=rob, environment={"box": {}})
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_trees_hip_vs_oracle(ops, seed):
+    """random kinematic trees (tests/helpers.random_urdf_model): HIP fkine / vjp / fused score+grad vs the fp64 oracle"""
+    from oracle import oracle
+    from helpers import random_urdf_model, urdf_xml
+    from diffco_amd.urdf import URDFRobotFK
+    rob = URDFRobotFK(urdf_xml(random_urdf_model(1000 + seed, n_links=5 + 2 * seed)))
+    if rob.dof == 0 or not rob.unique_position_link_names:
+        pytest.skip("degenerate tree")
+    desc = rob.fk_desc()
+    rng = np.random.default_rng(seed)
+    q = rng.uniform(-1.5, 1.5, (130, rob.dof)).astype(np.float32)
+    qt = _t(q).requires_grad_(True)
+    X = rob.fkine(qt)
+    ref = oracle.fkine(desc, q, np.float64)
+    assert relerr(_n(X), ref) < 2e-6
+    g = rng.standard_normal(ref.shape).astype(np.float32)
+    (gq,) = torch.autograd.grad((X * _t(g)).sum(), qt)
+    assert relerr(_n(gq), oracle.fkine_vjp(desc, q, g, np.float64)) < 5e-6
+    S = 150
+    sq = rng.uniform(-1.5, 1.5, (S, rob.dof)).astype(np.float32)
+    sup = _n(rob.fkine(_t(sq))).reshape(S, -1)
+    W = rng.standard_normal((S, 1)).astype(np.float32)
+    m = ops.ScoreModel(desc, 1, 1.0, 1.0, _t(sup), _t(W))
+    s, gr = m.score_grad_raw(_t(q), None)
+    rs, rg, _ = oracle.score_grad(desc, 1, 1.0, 1.0, sup, W, q, dtype=np.float64)
+    assert relerr(_n(s), rs) < 1e-5 and relerr(_n(gr), rg) < 1e-5

@@ -123,3 +123,35 @@ def test_limits_of_the_compiled_description():
               for i in range(30)]
     with pytest.raises(ValueError, match="compiled limits"):
         URDFRobotFK(urdf_xml(dict(links=links, joints=joints)))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_trees_against_an_independent_fk(seed):
+    """random kinematic trees (all joint types, signed axes, off-axis prismatic directions, mimic joints, branching):
+    the compiled DCX_FK_TREE description evaluated by the fp64 oracle equals an independent recursive FK, and the
+    oracle's J^T g equals a finite-difference derivative"""
+    from helpers import random_urdf_model, reference_tree_fk
+    from diffco_amd.urdf import URDFRobotFK
+    m = random_urdf_model(seed, n_links=6 + seed % 7)
+    try:
+        rob = URDFRobotFK(urdf_xml(m))
+    except ValueError as e:  # e.g. no movable joint at all: nothing to test
+        pytest.skip(str(e))
+    if rob.dof == 0 or not rob.unique_position_link_names:
+        pytest.skip("degenerate tree")
+    rng = np.random.default_rng(100 + seed)
+    q = rng.uniform(-1.2, 1.2, (16, rob.dof))
+    pos, dof = reference_tree_fk(m, q)
+    assert dof == rob.dof
+    want = np.stack([pos[ln] for ln in rob.unique_position_link_names], axis=-1)  # [B, 3, L]
+    desc = rob.fk_desc()
+    got = oracle.fkine(desc, q, np.float64)
+    assert np.abs(got - want).max() < 2e-7 * max(1.0, np.abs(want).max())  # only the fp32 storage of folded constants differs
+    g = rng.standard_normal(want.shape)
+    gq = oracle.fkine_vjp(desc, q, g, np.float64)
+    eps = 1e-6
+    for i in range(rob.dof):
+        dq = np.zeros_like(q)
+        dq[:, i] = eps
+        fd = ((oracle.fkine(desc, q + dq, np.float64) - oracle.fkine(desc, q - dq, np.float64)) * g).sum(axis=(1, 2)) / (2 * eps)
+        assert np.abs(fd - gq[:, i]).max() < 1e-6 * max(1.0, np.abs(gq).max())
