@@ -195,74 +195,17 @@ constexpr int sweep_min_waves(int D, int CC, int KF) {
     return need <= 64 ? 8 : need <= 72 ? 7 : need <= 80 ? 6 : need <= 96 ? 5 : need <= 128 ? 4 : need <= 168 ? 3 : need <= 256 ? 2 : 1;
 }
 
-template <int D, int KF, int CC, int MODE, int MAXT>
-__global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel(const ScoreArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+// ---- the sweep: supports [j0, j1) against this lane's configuration, rows broadcast through SGPRs ---------------
+// Accumulates into sc[] (scores) and gx[] (feature gradient; untouched for MODE_SCORE).  A function of its own so that
+// kernel variants can share it (e.g. the two-tile helper-wave experiment of DESIGN.md 3.1).
+template <int D, int KF, int CC, int MODE>
+__device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[D], const float (&up)[CC], int j0, int j1,
+                                           float (&sc)[CC], float (&gx)[D]) {
     using L = RowLayout<D, CC>;
     constexpr bool GRAD = (MODE != MODE_SCORE);
-    constexpr int ACC = (GRAD ? D : 0) + CC;
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nw = blockDim.x >> 6;
-    const int64_t b0 = (int64_t)blockIdx.x * 64;
-    const int nb = (int)((a.B - b0) < 64 ? (a.B - b0) : 64);
-    const int dof = a.dof;
-    const LdsPlan lp = lds_plan(dof, a.d_fk, a.frame_floats, nw > 1 ? a.red_slots : 0, ACC, true);
-    float* sQ = smem + lp.q;
-    float* sX = smem + lp.x;
-    float* sG = smem + lp.g;
-    float* sF = smem + lp.f;
-    float* sRed = smem + lp.red;
-
-    DCX_TS(0);
-    // ---- prologue: stage the FK description and the q rows (coalesced), FK per lane on wave 0 ----
-    const fk_cptr fk = stage_fk_prog(a.fk, smem + lp.fk, threadIdx.x, blockDim.x);
-    {
-        const float* qsrc = a.q + b0 * dof;
-        const int n = nb * dof;
-        for (int i = threadIdx.x; i < 64 * dof; i += blockDim.x) sQ[i] = qsrc[i < n ? i : (i % dof) + (nb - 1) * dof];
-    }
-    __syncthreads();
-    DCX_TS(1);
-#if defined(DCX_ABLATE) && (DCX_ABLATE & 2)  // timing ablation only (wrong results): no FK
-    if (wave == 0) for (int k = 0; k < a.d_fk; ++k) sX[k * 64 + lane] = sQ[lane * dof + (k % dof)];
-#else
-    fk_forward_trig(fk, sQ + lane * dof, sF + lane, wave, nw);   // all waves: sin/cos of the joint angles
-    __syncthreads();
-    DCX_TS(6);
-    if (wave == 0) fk_forward_chain(fk, sQ + lane * dof, sX + lane, sF + lane);
-#endif
-    __syncthreads();
-
-    DCX_TS(2);
-    float x[D];
-#pragma unroll
-    for (int k = 0; k < D; ++k) x[k] = (k < a.d_fk) ? sX[k * 64 + lane] : 0.0f;
-    if (nw > 1) __syncthreads();  // X is dead from here on: the partial sums reuse its LDS (lds_plan)
-
-    float up[CC];
-    if constexpr (MODE == MODE_GRAD_UP) {
-        const int64_t bl = b0 + (lane < nb ? lane : nb - 1);
-#pragma unroll
-        for (int c = 0; c < CC; ++c) up[c] = (a.one_hot >= 0) ? (c == a.one_hot ? 1.0f : 0.0f) : a.upstream[bl * CC + c];
-    }
-
-    // ---- the sweep: this wave's slice of the supports, rows broadcast through SGPRs ---------
-    float sc[CC];
-    float gx[D];
-#pragma unroll
-    for (int c = 0; c < CC; ++c) sc[c] = 0.0f;
-#pragma unroll
-    for (int k = 0; k < D; ++k) gx[k] = 0.0f;
     v2f gx2[D / 2 + 1];
 #pragma unroll
     for (int k = 0; k < D / 2 + 1; ++k) gx2[k] = v2f{0.0f, 0.0f};
-
-    const int ybase = blockIdx.y * a.s_super;                               // this block's super-chunk
-    const int yend = (ybase + a.s_super < a.S) ? (ybase + a.s_super) : a.S;
-    const int j0 = (ybase + wave * a.s_chunk < yend) ? (ybase + wave * a.s_chunk) : yend;
-    const int j1 = (j0 + a.s_chunk < yend) ? (j0 + a.s_chunk) : yend;
     cfloat_ptr rows = (cfloat_ptr)(uintptr_t)a.rows;
 
     // one support row against this lane's configuration; `r` is wave-uniform (SGPRs)
@@ -477,9 +420,77 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
 
 #pragma unroll
     for (int k = 0; k + 1 < D; k += 2) {
-        gx[k] = gx2[k / 2].x;
-        gx[k + 1] = gx2[k / 2].y;
+        gx[k] += gx2[k / 2].x;
+        gx[k + 1] += gx2[k / 2].y;
     }
+}
+
+template <int D, int KF, int CC, int MODE, int MAXT>
+__global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel(const ScoreArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using L = RowLayout<D, CC>;
+    constexpr bool GRAD = (MODE != MODE_SCORE);
+    constexpr int ACC = (GRAD ? D : 0) + CC;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = blockDim.x >> 6;
+    const int64_t b0 = (int64_t)blockIdx.x * 64;
+    const int nb = (int)((a.B - b0) < 64 ? (a.B - b0) : 64);
+    const int dof = a.dof;
+    const LdsPlan lp = lds_plan(dof, a.d_fk, a.frame_floats, nw > 1 ? a.red_slots : 0, ACC, true);
+    float* sQ = smem + lp.q;
+    float* sX = smem + lp.x;
+    float* sG = smem + lp.g;
+    float* sF = smem + lp.f;
+    float* sRed = smem + lp.red;
+
+    DCX_TS(0);
+    // ---- prologue: stage the FK description and the q rows (coalesced), FK per lane on wave 0 ----
+    const fk_cptr fk = stage_fk_prog(a.fk, smem + lp.fk, threadIdx.x, blockDim.x);
+    {
+        const float* qsrc = a.q + b0 * dof;
+        const int n = nb * dof;
+        for (int i = threadIdx.x; i < 64 * dof; i += blockDim.x) sQ[i] = qsrc[i < n ? i : (i % dof) + (nb - 1) * dof];
+    }
+    __syncthreads();
+    DCX_TS(1);
+#if defined(DCX_ABLATE) && (DCX_ABLATE & 2)  // timing ablation only (wrong results): no FK
+    if (wave == 0) for (int k = 0; k < a.d_fk; ++k) sX[k * 64 + lane] = sQ[lane * dof + (k % dof)];
+#else
+    fk_forward_trig(fk, sQ + lane * dof, sF + lane, wave, nw);   // all waves: sin/cos of the joint angles
+    __syncthreads();
+    DCX_TS(6);
+    if (wave == 0) fk_forward_chain(fk, sQ + lane * dof, sX + lane, sF + lane);
+#endif
+    __syncthreads();
+
+    DCX_TS(2);
+    float x[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) x[k] = (k < a.d_fk) ? sX[k * 64 + lane] : 0.0f;
+    if (nw > 1) __syncthreads();  // X is dead from here on: the partial sums reuse its LDS (lds_plan)
+
+    float up[CC];
+    if constexpr (MODE == MODE_GRAD_UP) {
+        const int64_t bl = b0 + (lane < nb ? lane : nb - 1);
+#pragma unroll
+        for (int c = 0; c < CC; ++c) up[c] = (a.one_hot >= 0) ? (c == a.one_hot ? 1.0f : 0.0f) : a.upstream[bl * CC + c];
+    }
+
+    // ---- the sweep: this wave's slice of the supports ----------------------------------------
+    float sc[CC];
+    float gx[D];
+#pragma unroll
+    for (int c = 0; c < CC; ++c) sc[c] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < D; ++k) gx[k] = 0.0f;
+    const int ybase = blockIdx.y * a.s_super;                               // this block's super-chunk
+    const int yend = (ybase + a.s_super < a.S) ? (ybase + a.s_super) : a.S;
+    const int j0 = (ybase + wave * a.s_chunk < yend) ? (ybase + wave * a.s_chunk) : yend;
+    const int j1 = (j0 + a.s_chunk < yend) ? (j0 + a.s_chunk) : yend;
+
+    sweep_rows<D, KF, CC, MODE>(a, x, up, j0, j1, sc, gx);
     DCX_TS(3);
     // ---- meet the NW partial sums in LDS; wave 0 finishes --------------------------------
     if (nw > 1 && a.red_slots == 1) {
