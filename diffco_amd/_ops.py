@@ -227,4 +227,6 @@ class _ScoreFn(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, gs, _gjac):
         (jac,) = ctx.saved_tensors  # [B, C, dof]
+        if jac.shape[-2] == 1:  # single output: one elementwise kernel instead of multiply + reduce
+            return (gs * jac[:, 0, :]).reshape(ctx.in_shape), None
         return (gs.unsqueeze(-1) * jac).sum(dim=-2).reshape(ctx.in_shape), None

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""tools/api_latency.py — developer tool (GPU box): wall-clock latency of the Python API around the fused kernel for
+trajectory-sized batches (the reference's optimisers call poly_score with 20-50 waypoints): poly_score forward,
+forward + backward, and the raw C-ABI call, per call."""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from diffco_amd import kernel, model  # noqa: E402
+from diffco_amd.kernel_perceptrons import DiffCo  # noqa: E402
+
+rob = model.BaxterLeftArmFK()
+lim = rob.limits
+S = 2000
+torch.manual_seed(0)
+dev = torch.device("cuda")
+dc = DiffCo(kernel_func=kernel.RQKernel(10.0), transform=rob.fkine)
+sq = torch.rand(S, 7) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]
+dc.support_points = sq.to(dev)
+dc.support_transformed = rob.fkine(sq.to(dev))
+dc.gains = torch.randn(S, device=dev)
+dc.rbf_kernel = kernel.Polyharmonic(1, 1.0)
+dc.rbf_nodes = torch.randn(S, device=dev)
+
+
+def timeit(fn, n=300):
+    for _ in range(20):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e6
+
+
+for where in ("cuda", "cpu"):
+    for B in (20, 256, 4096):
+        q = (torch.rand(B, 7) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]).to(where)
+        qg = q.clone().requires_grad_(True)
+        m = dc._poly_fused.model(dc.transform, dc.rbf_kernel, dc.support_transformed, dc.rbf_nodes, dev)
+        q32 = q.to(dev).float().contiguous()
+
+        def fwd():
+            with torch.no_grad():
+                return dc.poly_score(q)
+
+        def fwd_bwd():
+            s = dc.poly_score(qg)
+            (g,) = torch.autograd.grad(s.sum(), qg)
+            return g
+
+        def raw():
+            return m.score_grad_raw(q32)
+
+        print(f"q on {where:<4} B={B:<5} poly_score {timeit(fwd):7.1f} us   + backward {timeit(fwd_bwd):7.1f} us   "
+              f"raw dcx_score_grad {timeit(raw):7.1f} us")
