@@ -59,3 +59,23 @@ for where in ("cuda", "cpu"):
 
         print(f"q on {where:<4} B={B:<5} poly_score {timeit(fwd):7.1f} us   + backward {timeit(fwd_bwd):7.1f} us   "
               f"raw dcx_score_grad {timeit(raw):7.1f} us")
+
+# PCIe-inclusive rate at the headline shape: host q in, host score + grad out (pageable and pinned buffers)
+B = 65536
+m = dc._poly_fused.model(dc.transform, dc.rbf_kernel, dc.support_transformed, dc.rbf_nodes, dev)
+for pinned in (False, True):
+    q = torch.rand(B, 7) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]
+    s_h, g_h = torch.empty(B, 1), torch.empty(B, 7)
+    if pinned:
+        q, s_h, g_h = q.pin_memory(), s_h.pin_memory(), g_h.pin_memory()
+
+    def roundtrip():
+        qd = q.to(dev, non_blocking=True)
+        s, g = m.score_grad_raw(qd)
+        s_h.copy_(s, non_blocking=True)
+        g_h.copy_(g, non_blocking=True)
+        torch.cuda.synchronize()
+
+    us = timeit(roundtrip, 100)
+    print(f"headline B={B} host->device->host ({'pinned' if pinned else 'pageable'}): {us:8.1f} us  = {B / us:7.1f} M evals/s "
+          f"(4.06 MB over PCIe per call)")
