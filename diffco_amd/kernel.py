@@ -7,7 +7,6 @@ kernel-matrix kernel (libdcx.so `dcx_kernel_matrix`); inside DiffCo.score / poly
 rbf_score the kernel is never materialised — those fuse it with the FK and the weight
 contraction (`dcx_score*`).  No CPU arithmetic lives here.
 """
-import torch
 
 from . import _ops
 from ._fkdesc import DCX_K_MQ, DCX_K_POLY, DCX_K_RQ

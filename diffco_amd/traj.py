@@ -15,7 +15,6 @@ reference optimises in fp64 on the host).
 import ctypes as C
 import time
 
-import numpy as np
 import torch
 
 from . import _lib, _ops

@@ -4,7 +4,6 @@ caller's device; none of this is on the score/grad hot path).  Reference: utils.
 87-101 (dense_path).  DH2mat / euler2mat live on the device (csrc/fk_device.h)."""
 import math
 
-import numpy as np
 import torch
 
 

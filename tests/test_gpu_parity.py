@@ -6,7 +6,6 @@ max|a - ref| / max|ref|.  HIP vs the fp64 referee must be <= 1e-5; HIP vs the re
 output must be <= 1e-5 plus the reference's own distance from the referee (its torch.cdist GEMM
 form is up to ~1e-4 off for large coordinates); HIP vs the fp32 oracle <= 1e-5.
 """
-import os
 
 import numpy as np
 import pytest

@@ -5,7 +5,6 @@ golden fixtures (tests/golden/fk_urdf_*.npz); supports and weights are synthetic
 import os
 import sys
 
-import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
