@@ -257,7 +257,10 @@ Geometry pick_geometry(const dcx_model* m, int64_t B, int acc_floats, bool allow
 // This stream's scratch buffer for the partial rows of a split launch, grown on demand.  Returns nullptr when
 // it cannot be provided right now (the stream is being captured into a graph and the buffer does not exist
 // yet, or the allocation failed): the caller then uses the unsplit geometry, which is always valid.
+constexpr size_t kTileCounters = 64;                         // arrival counters at the head of a scratch buffer
+constexpr size_t kScratchHead = kTileCounters * sizeof(unsigned int);
 float* split_scratch(const dcx_model* m, hipStream_t st, size_t bytes) {
+    bytes += kScratchHead;
     std::lock_guard<std::mutex> lock(m->mu);
     dcx_model::Scratch* slot = nullptr;
     for (auto& sc : m->scratch)
@@ -277,6 +280,12 @@ float* split_scratch(const dcx_model* m, hipStream_t st, size_t bytes) {
     }
     if (hipMalloc((void**)&slot->ptr, bytes) != hipSuccess) {
         (void)hipGetLastError();
+        slot->ptr = nullptr;
+        return nullptr;
+    }
+    if (hipMemset(slot->ptr, 0, kScratchHead) != hipSuccess) {  // the kernels leave the counters at zero themselves
+        (void)hipGetLastError();
+        (void)hipFree(slot->ptr);
         slot->ptr = nullptr;
         return nullptr;
     }
@@ -300,6 +309,15 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
     if (g.ys > 1) {
         part = split_scratch(m, st, (size_t)nblk * g.ys * acc * 64 * sizeof(float));
         if (!part) g = pick_geometry(m, B, acc, false);
+    }
+    unsigned int* counters = nullptr;
+    if (part) {
+        const bool second_launch = std::getenv("DCX_SPLIT_FINISH_KERNEL") != nullptr;  // A/B and tests
+        // graph-replay timings (profiles/r01_sweep_small_batch_graph.txt): finishing inside the launch saves the second
+        // launch and its FK (B=1024: 27.1 -> 23.3 us headline, 24.4 -> 20.0 us config #2) but every block's release fence
+        // is an L2 write-back, which loses once there are hundreds of blocks (B=8192: 35.9 -> 43.2 us)
+        if (nblk <= 32 && !second_launch) counters = reinterpret_cast<unsigned int*>(part);
+        part = reinterpret_cast<float*>(reinterpret_cast<char*>(part) + kScratchHead);
     }
     if (nblk > 0x7fffffffLL) return fail(DCX_ERR_UNSUPPORTED, "batch too large for one launch");
     ScoreArgs a{};
@@ -339,8 +357,9 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
         return DCX_OK;
     }
     a.partial = part;
+    a.tile_done = counters;
     hipError_t e = m->launch(m->kf, m->C, mode, g.nw, lds, nblk, a, st);
-    if (e == hipSuccess) {
+    if (e == hipSuccess && counters == nullptr) {
         FinishArgs f{};
         f.partial = part;
         f.fk = m->fk_dev;

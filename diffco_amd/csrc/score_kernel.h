@@ -58,6 +58,9 @@ struct ScoreArgs {
     int32_t one_hot;          // MODE_GRAD_UP: >= 0 selects upstream = e_{one_hot} (Jacobian rows); -1 = use upstream[]
     int64_t grad_stride;      // floats between consecutive configurations' gradient rows (dof, or C*dof for jac)
     float* partial;           // split launch: per (tile, y) partial sums [(tile*ys + y)][ACC][64]; null = finish in-kernel
+    unsigned int* tile_done;  // split launch: per-tile arrival counters (zero between launches).  Non-null: the LAST of a
+                              // tile's ys blocks to arrive adds the partial rows and finishes in this launch; null: a
+                              // second launch (score_finish_kernel) does
     int32_t ys;               // support super-chunks (gridDim.y); block y sweeps [y*s_super, (y+1)*s_super)
     int32_t s_super;
     int32_t red_slots;        // LDS rows for the cross-wave fold: nw (all waves write, fold in parallel) or 1 (waves
@@ -428,7 +431,6 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
 template <int D, int KF, int CC, int MODE, int MAXT>
 __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel(const ScoreArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    using L = RowLayout<D, CC>;
     constexpr bool GRAD = (MODE != MODE_SCORE);
     constexpr int ACC = (GRAD ? D : 0) + CC;
 
@@ -553,7 +555,33 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
 #pragma unroll
             for (int k = 0; k < D; ++k) out[(CC + k) * 64] = gx[k];
         }
-        return;
+        if (a.tile_done == nullptr) return;
+        // "last block done": publish this block's row, count arrivals; whoever sees ys-1 earlier arrivals owns the
+        // tile, re-reads ALL ys rows in the fixed order y = 0, 1, ... (so the result does not depend on which block
+        // came last) and carries on into the ordinary epilogue with its own q rows and FK frames (every block of a
+        // tile computed the same ones).  No block ever waits for another.
+        __threadfence();
+        unsigned int arrived = 0;
+        if (lane == 0) arrived = atomicAdd(a.tile_done + blockIdx.x, 1u);
+        arrived = __builtin_amdgcn_readfirstlane(arrived);
+        if (arrived != (unsigned int)a.ys - 1u) return;
+        if (lane == 0) a.tile_done[blockIdx.x] = 0u;  // ready for the next launch on this stream
+        __threadfence();
+        const float* part = a.partial + (size_t)blockIdx.x * a.ys * ACC * 64 + lane;
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+            float v = __builtin_nontemporal_load(part + c * 64);
+            for (int y = 1; y < a.ys; ++y) v += __builtin_nontemporal_load(part + ((size_t)y * ACC + c) * 64);
+            sc[c] = v;
+        }
+        if constexpr (GRAD) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                float v = __builtin_nontemporal_load(part + (CC + k) * 64);
+                for (int y = 1; y < a.ys; ++y) v += __builtin_nontemporal_load(part + ((size_t)y * ACC + CC + k) * 64);
+                gx[k] = v;
+            }
+        }
     }
 
     if (a.score != nullptr && lane < nb) {

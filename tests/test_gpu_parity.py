@@ -152,6 +152,28 @@ def test_support_slicing_is_invariant(ops, name, monkeypatch):
             assert relerr(a, b) < 3e-6
 
 
+@pytest.mark.parametrize("name", ["cfg2_baxter_poly1", "cfg3_baxter_rq_c5"])
+def test_split_launch_finish_modes_agree_bitwise(ops, name, monkeypatch):
+    """small batches split the supports across blocks; the rows are added either by the last block to arrive
+    (in-launch, arrival counters) or by a second launch — same fixed order, so the results are bit-identical, and the
+    counters are back at zero after every launch (three launches in a row)"""
+    d = load(name)
+    kind, p0, p1 = case_kernel(d)
+    m = ops.ScoreModel(desc_for(CASE_ROBOT[name]), kind, p0, p1, _t(d["sup_x32"].reshape(len(d["sup_x32"]), -1)), _t(d["weights"]))
+    q = _t(d["q"][:150])
+    up = _t(d["upstream"][:150]) if m.C > 1 and "upstream" in d.files else None
+    monkeypatch.delenv("DCX_SPLIT_FINISH_KERNEL", raising=False)
+    runs = [m.score_grad_raw(q, up) for _ in range(3)]
+    monkeypatch.setenv("DCX_SPLIT_FINISH_KERNEL", "1")
+    s2, g2 = m.score_grad_raw(q, up)
+    for s1, g1 in runs:
+        assert torch.equal(s1, s2) and torch.equal(g1, g2)
+    monkeypatch.delenv("DCX_SPLIT_FINISH_KERNEL")
+    monkeypatch.setenv("DCX_YS", "1")  # and the unsplit launch agrees to rounding
+    s3, g3 = m.score_grad_raw(q, up)
+    assert relerr(_n(s3), _n(s2)) < 3e-6 and relerr(_n(g3), _n(g2)) < 3e-6
+
+
 def test_ragged_empty_and_padding(ops, monkeypatch):
     monkeypatch.setenv("DCX_NW", "4")  # fixed slicing: results are then bit-identical across batch sizes
     d = load("cfg2_baxter_poly1")
