@@ -315,8 +315,8 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
         const bool second_launch = std::getenv("DCX_SPLIT_FINISH_KERNEL") != nullptr;  // A/B and tests
         // graph-replay timings (profiles/r01_sweep_small_batch_graph.txt): finishing inside the launch saves the second
         // launch and its FK (B=1024: 27.1 -> 23.3 us headline, 24.4 -> 20.0 us config #2) but every block's release fence
-        // is an L2 write-back, which loses once there are hundreds of blocks (B=8192: 35.9 -> 43.2 us)
-        if (nblk <= 32 && !second_launch) counters = reinterpret_cast<unsigned int*>(part);
+        // is an L2 write-back, which loses once there are hundreds of blocks (B=8192: 35.9 -> 43.2 us); at 64 tiles config #2 still gains 6-7 %
+        if (nblk <= 64 && !second_launch) counters = reinterpret_cast<unsigned int*>(part);
         part = reinterpret_cast<float*>(reinterpret_cast<char*>(part) + kScratchHead);
     }
     if (nblk > 0x7fffffffLL) return fail(DCX_ERR_UNSUPPORTED, "batch too large for one launch");
