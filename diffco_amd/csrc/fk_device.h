@@ -40,15 +40,23 @@ struct FkProgJoint {  // DCX_FK_DH, 8 dwords
     float theta0, a, d, sin_alpha, cos_alpha;
     int32_t pt_begin, pt_end;  // control points attached to this joint's frame: points[pt_begin .. pt_end)
 };
-// DCX_FK_TREE joint, 24 dwords:  T <- T * [F] * Motion.  The host has already conjugated x/y revolute axes onto z
-// (a signed permutation, exact in fp32), so the device knows one rotation: Rz(v).
+// DCX_FK_TREE node, 28 dwords:  T <- T_parent * [F] * Motion.  The root-to-leaf chains of the public description
+// are merged back into a tree on the host (a joint repeated on several chains becomes ONE node), nodes are stored in
+// depth-first order, and the host has conjugated x/y revolute axes onto z (a signed permutation, exact in fp32), so
+// the device knows one rotation: Rz(v).
 enum { TJ_FIXED = 0, TJ_REV = 1, TJ_PRISM = 2 };
 struct FkProgTreeJoint {
+    // integers first (one run of LDS reads feeds every wave-uniform decision of a node)
     int32_t type, q_index;
-    float scale, offset;       // joint variable v = scale * q[q_index] + offset
-    int32_t slot, slot_owner;  // frames slot of (sin v, cos v) or (v, -); owner = first joint that uses the slot
+    int32_t slot, slot_owner;  // frames slot of (sin v, cos v) or (v, -); owner = first node that uses the slot
     int32_t pt_begin, pt_end;
-    float ax, ay, az, pad;     // prismatic direction
+    int32_t start;             // where this node's parent frame comes from: -1 = the previous node (registers),
+                               // -2 - b = base[b] (a root), s >= 0 = the frame parked in branch slot s
+    int32_t park;              // >= 0: this node's frame is parked in that branch slot (it has further children)
+    int32_t leaf;              // >= 0: no node continues from this one in registers; its rotation goes to leaf slot
+    int32_t pad0;
+    float scale, offset;       // joint variable v = scale * q[q_index] + offset
+    float ax, ay, az, pad1;    // prismatic direction
     float F[12];               // row-major 3x4 constant transform applied before the motion
 };
 struct FkProgPoint {  // 4 dwords
@@ -58,6 +66,7 @@ struct FkProgPoint {  // 4 dwords
 struct FkProg {
     int32_t kind, dof, n_points, point_dim;
     int32_t n_chains, n_joints, out_stride, n_dwords;  // n_dwords: how much of this struct the kind uses
+    int32_t f_leaf, f_park, f_adj, n_branch;           // DCX_FK_TREE: frames offsets (floats per lane), see TreePlan
     int32_t chain_begin[kMaxProgChains], chain_end[kMaxProgChains];  // joint ranges
     float base[kMaxProgChains][12];
     FkProgPoint points[DCX_MAX_POINTS];
@@ -85,77 +94,140 @@ __host__ __device__ inline int fk_prog_floats(const dcx_fk_desc& fk) {
     return (kFkProgHeadDwords + per * fk_joint_count(fk) + 3) & ~3;
 }
 
-// DCX_FK_TREE: joints that read the same joint variable (a shared prefix repeated in several chains, or mimic
-// joints with equal multiplier/offset) share one frames slot.  Returns the number of slots.
-inline int tree_slots(const dcx_fk_desc& fk, int* slot_of, int* owner) {
-    const int n = fk_joint_count(fk);
-    int n_slots = 0;
-    for (int j = 0; j < n; ++j) {
-        slot_of[j] = -1;
-        owner[j] = 0;
-        if (fk.t_type[j] == DCX_J_FIXED) continue;
-        const bool prism = fk.t_type[j] == DCX_J_PRISMATIC;
-        for (int i = 0; i < j && slot_of[j] < 0; ++i)
-            if (fk.t_type[i] != DCX_J_FIXED && (fk.t_type[i] == DCX_J_PRISMATIC) == prism && fk.t_q[i] == fk.t_q[j] &&
-                fk.t_scale[i] == fk.t_scale[j] && fk.t_offset[i] == fk.t_offset[j])
-                slot_of[j] = slot_of[i];
-        if (slot_of[j] < 0) {
-            slot_of[j] = n_slots++;
-            owner[j] = 1;
+// DCX_FK_TREE host planner: merge the chains into a tree, assign frames slots.
+//   trig slots  : nodes that read the same joint variable (mimic joints with equal multiplier/offset) share (sin, cos)
+//   leaf slots  : 9 floats, the rotation of a node nothing continues from (start of a reverse sweep segment)
+//   branch slots: 12 floats, the frame of a node with further children (forward: parked [R|t]; reverse: the adjoint
+//                 the later children add up, in a second bank of 12)
+// frames layout per lane: [2 * n_slots trig][9 * n_leaves][12 * n_branch parked frames][12 * n_branch adjoint sums]
+struct TreePlan {
+    int n_nodes, n_slots, n_leaves, n_branch;
+    int parent[DCX_MAX_TREE_JOINTS];                // node index, or -1 - b for a root on base b
+    int src[DCX_MAX_TREE_JOINTS];                   // index into the description's t_* arrays
+    int node_of[DCX_MAX_TREE_JOINTS];               // description joint (flat index) -> node
+    int slot[DCX_MAX_TREE_JOINTS], owner[DCX_MAX_TREE_JOINTS];
+    int park[DCX_MAX_TREE_JOINTS], leaf[DCX_MAX_TREE_JOINTS], start[DCX_MAX_TREE_JOINTS];
+};
+inline bool tree_same_joint(const dcx_fk_desc& fk, int a, int b) {
+    return fk.t_type[a] == fk.t_type[b] && fk.t_q[a] == fk.t_q[b] && fk.t_scale[a] == fk.t_scale[b] &&
+           fk.t_offset[a] == fk.t_offset[b] && memcmp(fk.t_fixed[a], fk.t_fixed[b], sizeof(fk.t_fixed[a])) == 0 &&
+           memcmp(fk.t_axis[a], fk.t_axis[b], sizeof(fk.t_axis[a])) == 0;
+}
+inline void plan_tree(const dcx_fk_desc& fk, TreePlan& tp) {
+    tp.n_nodes = tp.n_slots = tp.n_leaves = tp.n_branch = 0;
+    int flat = 0;
+    for (int c = 0; c < fk.t_n_chains; ++c) {
+        int cur = -1 - c;  // root on this chain's base
+        for (int i = 0; i < fk.t_chain_len[c]; ++i, ++flat) {
+            int found = -1;
+            for (int n = 0; n < tp.n_nodes && found < 0; ++n) {
+                bool same_parent = tp.parent[n] == cur;
+                if (!same_parent && cur < 0 && tp.parent[n] < 0)  // roots on different but equal bases
+                    same_parent = memcmp(fk.t_base[-1 - cur], fk.t_base[-1 - tp.parent[n]], sizeof(fk.t_base[0])) == 0;
+                if (same_parent && tree_same_joint(fk, tp.src[n], flat)) found = n;
+            }
+            if (found < 0) {
+                found = tp.n_nodes++;
+                tp.parent[found] = cur;
+                tp.src[found] = flat;
+            }
+            tp.node_of[flat] = found;
+            cur = found;
         }
     }
-    return n_slots;
+    for (int n = 0; n < tp.n_nodes; ++n) {
+        tp.park[n] = tp.leaf[n] = -1;
+        // trig slot
+        const int a = tp.src[n];
+        tp.slot[n] = -1;
+        tp.owner[n] = 0;
+        if (fk.t_type[a] != DCX_J_FIXED) {
+            const bool prism = fk.t_type[a] == DCX_J_PRISMATIC;
+            for (int m = 0; m < n && tp.slot[n] < 0; ++m) {
+                const int b = tp.src[m];
+                if (fk.t_type[b] != DCX_J_FIXED && (fk.t_type[b] == DCX_J_PRISMATIC) == prism && fk.t_q[b] == fk.t_q[a] &&
+                    fk.t_scale[b] == fk.t_scale[a] && fk.t_offset[b] == fk.t_offset[a])
+                    tp.slot[n] = tp.slot[m];
+            }
+            if (tp.slot[n] < 0) {
+                tp.slot[n] = tp.n_slots++;
+                tp.owner[n] = 1;
+            }
+        }
+    }
+    for (int n = 0; n < tp.n_nodes; ++n) {
+        if (tp.parent[n] < 0) {
+            tp.start[n] = -2 - (-1 - tp.parent[n]);  // root: base index b encoded as -2 - b
+        } else if (tp.parent[n] == n - 1) {
+            tp.start[n] = -1;
+        } else {
+            const int par = tp.parent[n];
+            if (tp.park[par] < 0) tp.park[par] = tp.n_branch++;
+            tp.start[n] = tp.park[par];
+        }
+        if (n + 1 == tp.n_nodes || tp.parent[n + 1] != n) tp.leaf[n] = tp.n_leaves++;
+    }
 }
 
 // host: DCX_FK_TREE -> program.  Revolute joints about x / y are rewritten as rotations about z:
 //   Rx(v) = P Rz(v) P^T,  P = [e_y e_z e_x];   Ry(v) = P' Rz(v) P'^T,  P' = P P = [e_z e_x e_y]
-// with the permutation folded into the neighbouring constants (F_j <- P_{j-1}^T F_j P_j, control-point offsets
-// o <- P_j^T o).  Permuting entries does not round, so the chain computes exactly the values the x/y forms would.
+// with the permutation folded into the neighbouring constants (F_j <- P_parent^T F_j P_j, control-point offsets
+// o <- P_j^T o).  Permuting entries does not round, so the tree computes exactly the values the x/y forms would.
 inline void build_tree_prog(const dcx_fk_desc& fk, FkProg& p) {
-    int slot_of[DCX_MAX_TREE_JOINTS], owner[DCX_MAX_TREE_JOINTS];
-    tree_slots(fk, slot_of, owner);
+    TreePlan tp;
+    plan_tree(fk, tp);
     p.n_chains = fk.t_n_chains;
     p.out_stride = fk.t_coord_major ? fk.n_points : 1;
-    static const int perm_of[3][3] = {{1, 2, 0}, {2, 0, 1}, {0, 1, 2}};  // column c of P is e_{perm[c]}: REV_X, REV_Y, identity
-    int nj = 0, np = 0;
-    for (int c = 0; c < fk.t_n_chains; ++c) {
-        p.chain_begin[c] = nj;
+    p.n_joints = tp.n_nodes;
+    p.f_leaf = 2 * tp.n_slots;
+    p.f_park = p.f_leaf + 9 * tp.n_leaves;
+    p.f_adj = p.f_park + 12 * tp.n_branch;
+    p.n_branch = tp.n_branch;
+    for (int c = 0; c < fk.t_n_chains; ++c)
         for (int e = 0; e < 12; ++e) p.base[c][e] = fk.t_base[c][e];
-        const int* prev = perm_of[2];
-        for (int i = 0; i < fk.t_chain_len[c]; ++i, ++nj) {
-            FkProgTreeJoint& J = p.tj[nj];
-            const int t = fk.t_type[nj];
-            const int* cur = t == DCX_J_REV_X ? perm_of[0] : t == DCX_J_REV_Y ? perm_of[1] : perm_of[2];
-            J.type = (t == DCX_J_FIXED) ? TJ_FIXED : (t == DCX_J_PRISMATIC) ? TJ_PRISM : TJ_REV;
-            J.q_index = fk.t_q[nj];
-            J.scale = fk.t_scale[nj];
-            J.offset = fk.t_offset[nj];
-            J.slot = slot_of[nj] < 0 ? 0 : slot_of[nj];
-            J.slot_owner = owner[nj];
-            J.ax = fk.t_axis[nj][0];
-            J.ay = fk.t_axis[nj][1];
-            J.az = fk.t_axis[nj][2];
-            // (P_prev^T F P_cur): row r of the result is row prev[r] of F; column k of its rotation is column cur[k]
-            for (int r = 0; r < 3; ++r) {
-                for (int k = 0; k < 3; ++k) J.F[r * 4 + k] = fk.t_fixed[nj][prev[r] * 4 + cur[k]];
-                J.F[r * 4 + 3] = fk.t_fixed[nj][prev[r] * 4 + 3];
-            }
-            J.pt_begin = np;
-            for (int k = 0; k < fk.n_points; ++k) {
-                if (fk.pt_chain[k] != c || fk.pt_frame[k] != i) continue;
-                const float* o = fk.pt_off[k];
-                p.points[np].ox = o[cur[0]];  // P_cur^T o
-                p.points[np].oy = o[cur[1]];
-                p.points[np].oz = o[cur[2]];
-                p.points[np].out_k = fk.t_coord_major ? k : 3 * k;
-                ++np;
-            }
-            J.pt_end = np;
-            prev = cur;
+    static const int perm_of[3][3] = {{1, 2, 0}, {2, 0, 1}, {0, 1, 2}};  // column c of P is e_{perm[c]}: REV_X, REV_Y, identity
+    auto perm = [&](int node) -> const int* {
+        if (node < 0) return perm_of[2];
+        const int t = fk.t_type[tp.src[node]];
+        return t == DCX_J_REV_X ? perm_of[0] : t == DCX_J_REV_Y ? perm_of[1] : perm_of[2];
+    };
+    int np = 0, flat_of_chain[DCX_MAX_TREE_CHAINS + 1];
+    flat_of_chain[0] = 0;
+    for (int c = 0; c < fk.t_n_chains; ++c) flat_of_chain[c + 1] = flat_of_chain[c] + fk.t_chain_len[c];
+    for (int n = 0; n < tp.n_nodes; ++n) {
+        FkProgTreeJoint& J = p.tj[n];
+        const int a = tp.src[n], t = fk.t_type[a];
+        const int *prev = perm(tp.parent[n]), *cur = perm(n);
+        J.type = (t == DCX_J_FIXED) ? TJ_FIXED : (t == DCX_J_PRISMATIC) ? TJ_PRISM : TJ_REV;
+        J.q_index = fk.t_q[a];
+        J.scale = fk.t_scale[a];
+        J.offset = fk.t_offset[a];
+        J.slot = tp.slot[n] < 0 ? 0 : tp.slot[n];
+        J.slot_owner = tp.owner[n];
+        J.ax = fk.t_axis[a][0];
+        J.ay = fk.t_axis[a][1];
+        J.az = fk.t_axis[a][2];
+        J.start = tp.start[n];
+        J.park = tp.park[n];
+        J.leaf = tp.leaf[n];
+        // (P_prev^T F P_cur): row r of the result is row prev[r] of F; column k of its rotation is column cur[k]
+        for (int r = 0; r < 3; ++r) {
+            for (int k = 0; k < 3; ++k) J.F[r * 4 + k] = fk.t_fixed[a][prev[r] * 4 + cur[k]];
+            J.F[r * 4 + 3] = fk.t_fixed[a][prev[r] * 4 + 3];
         }
-        p.chain_end[c] = nj;
+        J.pt_begin = np;
+        for (int k = 0; k < fk.n_points; ++k) {
+            const int f = flat_of_chain[fk.pt_chain[k]] + fk.pt_frame[k];
+            if (tp.node_of[f] != n) continue;
+            const float* o = fk.pt_off[k];
+            p.points[np].ox = o[cur[0]];  // P_cur^T o
+            p.points[np].oy = o[cur[1]];
+            p.points[np].oz = o[cur[2]];
+            p.points[np].out_k = fk.t_coord_major ? k : 3 * k;
+            ++np;
+        }
+        J.pt_end = np;
     }
-    p.n_joints = nj;
 }
 
 // host: compile the public description into the device program
@@ -213,8 +285,9 @@ inline int fk_frame_floats(const dcx_fk_desc& fk) {
     }
     if (fk.kind == DCX_FK_PLANAR) return 2 * fk.dof;
     if (fk.kind == DCX_FK_TREE) {
-        int slot_of[DCX_MAX_TREE_JOINTS], owner[DCX_MAX_TREE_JOINTS];
-        return 2 * tree_slots(fk, slot_of, owner) + 9 * fk.t_n_chains;
+        TreePlan tp;
+        plan_tree(fk, tp);
+        return 2 * tp.n_slots + 9 * tp.n_leaves + 24 * tp.n_branch;
     }
     return 0;
 }
@@ -258,148 +331,178 @@ __device__ __forceinline__ void sincos_f32(float x, float* sn, float* cs) {
 // robot's prologue / epilogue (the DH headline kernel went from 12 to 108 bytes of scratch per lane, doubling its
 // HBM writes, when these bodies were inlined).
 __device__ __attribute__((noinline)) void fk_tree_chain(fk_cptr fk, float* sXcol, float* sFcol) {
-    // T <- T * F * Motion along every root-to-leaf chain (reference: RigidBody.forward_kinematics,
-    // collision_interfaces/rigid_body.py:82-140, unrolled); features = frame origins (+ constant offsets for
-    // links behind fixed joints), collision_checkers.py:386-393
-    const int nch = rfl(fk->n_chains), stride = rfl(fk->out_stride) * 64;
-    int n_slots2 = 0;
-    {
-        const int njt = rfl(fk->n_joints);
-        for (int j = 0; j < njt; ++j) n_slots2 += 2 * rfl(fk->tj[j].slot_owner);
-    }
-    for (int ch = 0; ch < nch; ++ch) {
-        float r00 = fk->base[ch][0], r01 = fk->base[ch][1], r02 = fk->base[ch][2], t0 = fk->base[ch][3];
-        float r10 = fk->base[ch][4], r11 = fk->base[ch][5], r12 = fk->base[ch][6], t1 = fk->base[ch][7];
-        float r20 = fk->base[ch][8], r21 = fk->base[ch][9], r22 = fk->base[ch][10], t2 = fk->base[ch][11];
-        const int jb = rfl(fk->chain_begin[ch]), je = rfl(fk->chain_end[ch]);
-        for (int j = jb; j < je; ++j) {
-            const auto* F = fk->tj[j].F;
-            // N = T * F
-            const float f00 = F[0], f01 = F[1], f02 = F[2], f03 = F[3], f10 = F[4], f11 = F[5], f12 = F[6], f13 = F[7];
-            const float f20 = F[8], f21 = F[9], f22 = F[10], f23 = F[11];
-            t0 = fmaf(r00, f03, fmaf(r01, f13, fmaf(r02, f23, t0)));
-            t1 = fmaf(r10, f03, fmaf(r11, f13, fmaf(r12, f23, t1)));
-            t2 = fmaf(r20, f03, fmaf(r21, f13, fmaf(r22, f23, t2)));
-            float n00 = fmaf(r00, f00, fmaf(r01, f10, r02 * f20)), n01 = fmaf(r00, f01, fmaf(r01, f11, r02 * f21)),
-                  n02 = fmaf(r00, f02, fmaf(r01, f12, r02 * f22));
-            float n10 = fmaf(r10, f00, fmaf(r11, f10, r12 * f20)), n11 = fmaf(r10, f01, fmaf(r11, f11, r12 * f21)),
-                  n12 = fmaf(r10, f02, fmaf(r11, f12, r12 * f22));
-            float n20 = fmaf(r20, f00, fmaf(r21, f10, r22 * f20)), n21 = fmaf(r20, f01, fmaf(r21, f11, r22 * f21)),
-                  n22 = fmaf(r20, f02, fmaf(r21, f12, r22 * f22));
-            const int type = rfl(fk->tj[j].type), slot = rfl(fk->tj[j].slot);
-            if (type == TJ_REV) {
-                // R <- N * Rz(v): columns 0, 1 rotate
-                const float s = sFcol[(2 * slot) * 64], c = sFcol[(2 * slot + 1) * 64];
-                r00 = fmaf(n00, c, n01 * s); r01 = fmaf(n01, c, -n00 * s); r02 = n02;
-                r10 = fmaf(n10, c, n11 * s); r11 = fmaf(n11, c, -n10 * s); r12 = n12;
-                r20 = fmaf(n20, c, n21 * s); r21 = fmaf(n21, c, -n20 * s); r22 = n22;
-            } else {
-                r00 = n00; r01 = n01; r02 = n02; r10 = n10; r11 = n11; r12 = n12; r20 = n20; r21 = n21; r22 = n22;
-                if (type == TJ_PRISM) {
-                    const float v = sFcol[(2 * slot) * 64];
-                    const float dx = fk->tj[j].ax * v, dy = fk->tj[j].ay * v, dz = fk->tj[j].az * v;
-                    t0 = fmaf(r00, dx, fmaf(r01, dy, fmaf(r02, dz, t0)));
-                    t1 = fmaf(r10, dx, fmaf(r11, dy, fmaf(r12, dz, t1)));
-                    t2 = fmaf(r20, dx, fmaf(r21, dy, fmaf(r22, dz, t2)));
-                }
-            }
-            const int pb = rfl(fk->tj[j].pt_begin), pe = rfl(fk->tj[j].pt_end);
-            for (int p = pb; p < pe; ++p) {
-                const float ox = fk->points[p].ox, oy = fk->points[p].oy, oz = fk->points[p].oz;
-                float* out = sXcol + rfl(fk->points[p].out_k) * 64;
-                out[0] = fmaf(r00, ox, fmaf(r01, oy, fmaf(r02, oz, t0)));
-                out[stride] = fmaf(r10, ox, fmaf(r11, oy, fmaf(r12, oz, t1)));
-                out[2 * stride] = fmaf(r20, ox, fmaf(r21, oy, fmaf(r22, oz, t2)));
+    // T_j = T_parent(j) * F_j * Motion_j over the tree in depth-first order (reference: RigidBody.forward_kinematics,
+    // collision_interfaces/rigid_body.py:82-140); features = frame origins (+ constant offsets for links behind fixed
+    // joints), collision_checkers.py:386-393
+    const int stride = rfl(fk->out_stride) * 64, njt = rfl(fk->n_joints);
+    const int f_leaf = rfl(fk->f_leaf), f_park = rfl(fk->f_park);
+    float r00 = 1.f, r01 = 0.f, r02 = 0.f, r10 = 0.f, r11 = 1.f, r12 = 0.f, r20 = 0.f, r21 = 0.f, r22 = 1.f;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+    for (int j = 0; j < njt; ++j) {
+        const int start = rfl(fk->tj[j].start);
+        if (start <= -2) {  // a root: the frame is base[b]
+            const auto* Bm = fk->base[-2 - start];
+            r00 = Bm[0]; r01 = Bm[1]; r02 = Bm[2]; t0 = Bm[3];
+            r10 = Bm[4]; r11 = Bm[5]; r12 = Bm[6]; t1 = Bm[7];
+            r20 = Bm[8]; r21 = Bm[9]; r22 = Bm[10]; t2 = Bm[11];
+        } else if (start >= 0) {  // a later child of a branch node: its parent's frame was parked
+            const float* pk = sFcol + (f_park + 12 * start) * 64;
+            r00 = pk[0]; r01 = pk[64]; r02 = pk[128]; t0 = pk[192];
+            r10 = pk[256]; r11 = pk[320]; r12 = pk[384]; t1 = pk[448];
+            r20 = pk[512]; r21 = pk[576]; r22 = pk[640]; t2 = pk[704];
+        }
+        const auto* F = fk->tj[j].F;
+        // N = T * F
+        const float f00 = F[0], f01 = F[1], f02 = F[2], f03 = F[3], f10 = F[4], f11 = F[5], f12 = F[6], f13 = F[7];
+        const float f20 = F[8], f21 = F[9], f22 = F[10], f23 = F[11];
+        t0 = fmaf(r00, f03, fmaf(r01, f13, fmaf(r02, f23, t0)));
+        t1 = fmaf(r10, f03, fmaf(r11, f13, fmaf(r12, f23, t1)));
+        t2 = fmaf(r20, f03, fmaf(r21, f13, fmaf(r22, f23, t2)));
+        float n00 = fmaf(r00, f00, fmaf(r01, f10, r02 * f20)), n01 = fmaf(r00, f01, fmaf(r01, f11, r02 * f21)),
+              n02 = fmaf(r00, f02, fmaf(r01, f12, r02 * f22));
+        float n10 = fmaf(r10, f00, fmaf(r11, f10, r12 * f20)), n11 = fmaf(r10, f01, fmaf(r11, f11, r12 * f21)),
+              n12 = fmaf(r10, f02, fmaf(r11, f12, r12 * f22));
+        float n20 = fmaf(r20, f00, fmaf(r21, f10, r22 * f20)), n21 = fmaf(r20, f01, fmaf(r21, f11, r22 * f21)),
+              n22 = fmaf(r20, f02, fmaf(r21, f12, r22 * f22));
+        const int type = rfl(fk->tj[j].type), slot = rfl(fk->tj[j].slot);
+        if (type == TJ_REV) {
+            // R <- N * Rz(v): columns 0, 1 rotate
+            const float s = sFcol[(2 * slot) * 64], c = sFcol[(2 * slot + 1) * 64];
+            r00 = fmaf(n00, c, n01 * s); r01 = fmaf(n01, c, -n00 * s); r02 = n02;
+            r10 = fmaf(n10, c, n11 * s); r11 = fmaf(n11, c, -n10 * s); r12 = n12;
+            r20 = fmaf(n20, c, n21 * s); r21 = fmaf(n21, c, -n20 * s); r22 = n22;
+        } else {
+            r00 = n00; r01 = n01; r02 = n02; r10 = n10; r11 = n11; r12 = n12; r20 = n20; r21 = n21; r22 = n22;
+            if (type == TJ_PRISM) {
+                const float v = sFcol[(2 * slot) * 64];
+                const float dx = fk->tj[j].ax * v, dy = fk->tj[j].ay * v, dz = fk->tj[j].az * v;
+                t0 = fmaf(r00, dx, fmaf(r01, dy, fmaf(r02, dz, t0)));
+                t1 = fmaf(r10, dx, fmaf(r11, dy, fmaf(r12, dz, t1)));
+                t2 = fmaf(r20, dx, fmaf(r21, dy, fmaf(r22, dz, t2)));
             }
         }
-        float* fr = sFcol + (n_slots2 + 9 * ch) * 64;  // final rotation of this chain (for the reverse sweep)
-        fr[0] = r00; fr[64] = r01; fr[128] = r02; fr[192] = r10; fr[256] = r11; fr[320] = r12;
-        fr[384] = r20; fr[448] = r21; fr[512] = r22;
+        const int pb = rfl(fk->tj[j].pt_begin), pe = rfl(fk->tj[j].pt_end);
+        for (int p = pb; p < pe; ++p) {
+            const float ox = fk->points[p].ox, oy = fk->points[p].oy, oz = fk->points[p].oz;
+            float* out = sXcol + rfl(fk->points[p].out_k) * 64;
+            out[0] = fmaf(r00, ox, fmaf(r01, oy, fmaf(r02, oz, t0)));
+            out[stride] = fmaf(r10, ox, fmaf(r11, oy, fmaf(r12, oz, t1)));
+            out[2 * stride] = fmaf(r20, ox, fmaf(r21, oy, fmaf(r22, oz, t2)));
+        }
+        const int park = rfl(fk->tj[j].park), leaf = rfl(fk->tj[j].leaf);
+        if (park >= 0) {  // further children start from this frame
+            float* pk = sFcol + (f_park + 12 * park) * 64;
+            pk[0] = r00; pk[64] = r01; pk[128] = r02; pk[192] = t0;
+            pk[256] = r10; pk[320] = r11; pk[384] = r12; pk[448] = t1;
+            pk[512] = r20; pk[576] = r21; pk[640] = r22; pk[704] = t2;
+        }
+        if (leaf >= 0) {  // nothing continues from here in registers: the reverse sweep restarts from this rotation
+            float* fr = sFcol + (f_leaf + 9 * leaf) * 64;
+            fr[0] = r00; fr[64] = r01; fr[128] = r02; fr[192] = r10; fr[256] = r11; fr[320] = r12;
+            fr[384] = r20; fr[448] = r21; fr[512] = r22;
+        }
     }
 }
 
 __device__ __attribute__((noinline)) void fk_tree_vjp(fk_cptr fk, const float* sFcol, const float* sGcol, float* gqRow) {
     const int dof = rfl(fk->dof);
-    // Reverse-mode sweep through T_j = T_{j-1} F_j M_j(v_j), chain by chain; a joint repeated on several chains
-    // (shared prefix) or driven by the same q (mimic) simply accumulates.  With N = T_{j-1} F_j:
+    // Reverse-mode sweep through T_j = T_parent(j) F_j M_j(v_j) over the tree; joints driven by the same q (mimic)
+    // simply accumulate.  With N = T_parent F_j:
     //   revolute : R_j = R_N Rz(v), t_j = t_N   ->  dL/dv = <R_N^T GR, dRz/dv>,  G_RN = GR Rz^T
     //   prismatic: R_j = R_N, t_j = t_N + R_N a v -> dL/dv = Gt . (R_N a),        G_RN = GR + Gt (a v)^T
     //   through F: G_R(j-1) = G_RN F_R^T + Gt F_t^T,  R_(j-1) = R_N F_R^T,  Gt unchanged
     for (int i = 0; i < dof; ++i) gqRow[i] = 0.f;  // the sweep reads frames, not q
-    const int nch = rfl(fk->n_chains), stride = rfl(fk->out_stride) * 64;
-    int n_slots2 = 0;
-    {
-        const int njt = rfl(fk->n_joints);
-        for (int j = 0; j < njt; ++j) n_slots2 += 2 * rfl(fk->tj[j].slot_owner);
-    }
-    for (int ch = 0; ch < nch; ++ch) {
-        const float* fr = sFcol + (n_slots2 + 9 * ch) * 64;
-        float r00 = fr[0], r01 = fr[64], r02 = fr[128], r10 = fr[192], r11 = fr[256], r12 = fr[320];
-        float r20 = fr[384], r21 = fr[448], r22 = fr[512];
-        float G00 = 0.f, G01 = 0.f, G02 = 0.f, G10 = 0.f, G11 = 0.f, G12 = 0.f, G20 = 0.f, G21 = 0.f, G22 = 0.f;
-        float T0 = 0.f, T1 = 0.f, T2 = 0.f;
-        const int jb = rfl(fk->chain_begin[ch]), je = rfl(fk->chain_end[ch]);
-        for (int j = je - 1; j >= jb; --j) {
-            const int pb = rfl(fk->tj[j].pt_begin), pe = rfl(fk->tj[j].pt_end);
-            for (int p = pb; p < pe; ++p) {
-                const float* gin = sGcol + rfl(fk->points[p].out_k) * 64;
-                const float g0 = gin[0], g1 = gin[stride], g2 = gin[2 * stride];
-                const float ox = fk->points[p].ox, oy = fk->points[p].oy, oz = fk->points[p].oz;
-                T0 += g0; T1 += g1; T2 += g2;
-                G00 = fmaf(g0, ox, G00); G01 = fmaf(g0, oy, G01); G02 = fmaf(g0, oz, G02);
-                G10 = fmaf(g1, ox, G10); G11 = fmaf(g1, oy, G11); G12 = fmaf(g1, oz, G12);
-                G20 = fmaf(g2, ox, G20); G21 = fmaf(g2, oy, G21); G22 = fmaf(g2, oz, G22);
-            }
-            const int type = rfl(fk->tj[j].type), slot = rfl(fk->tj[j].slot);
-            if (type == TJ_REV) {
-                const float s = sFcol[(2 * slot) * 64], c = sFcol[(2 * slot + 1) * 64];
-                // R_N = R_j Rz^T: columns 0, 1 rotate back
-                const float p00 = fmaf(r00, c, -r01 * s), p01 = fmaf(r01, c, r00 * s);
-                const float p10 = fmaf(r10, c, -r11 * s), p11 = fmaf(r11, c, r10 * s);
-                const float p20 = fmaf(r20, c, -r21 * s), p21 = fmaf(r21, c, r20 * s);
-                // A = R_N^T GR, rows 0 and 1, columns 0 and 1 (dRz/dv = [[-s, -c, 0], [c, -s, 0], [0, 0, 0]])
-                const float A00 = fmaf(p00, G00, fmaf(p10, G10, p20 * G20)), A01 = fmaf(p00, G01, fmaf(p10, G11, p20 * G21));
-                const float A10 = fmaf(p01, G00, fmaf(p11, G10, p21 * G20)), A11 = fmaf(p01, G01, fmaf(p11, G11, p21 * G21));
-                const float dv = (c * A10 - s * A11) - (s * A00 + c * A01);
-                gqRow[rfl(fk->tj[j].q_index)] += fk->tj[j].scale * dv;
-                // G_RN = GR Rz^T
-                const float h00 = fmaf(G00, c, -G01 * s), h01 = fmaf(G01, c, G00 * s);
-                const float h10 = fmaf(G10, c, -G11 * s), h11 = fmaf(G11, c, G10 * s);
-                const float h20 = fmaf(G20, c, -G21 * s), h21 = fmaf(G21, c, G20 * s);
-                G00 = h00; G01 = h01; G10 = h10; G11 = h11; G20 = h20; G21 = h21;
-                r00 = p00; r01 = p01; r10 = p10; r11 = p11; r20 = p20; r21 = p21;
-            } else if (type == TJ_PRISM) {
-                const float v = sFcol[(2 * slot) * 64];
-                const float ax = fk->tj[j].ax, ay = fk->tj[j].ay, az = fk->tj[j].az;
-                const float w0 = fmaf(r00, ax, fmaf(r01, ay, r02 * az)), w1 = fmaf(r10, ax, fmaf(r11, ay, r12 * az)),
-                            w2 = fmaf(r20, ax, fmaf(r21, ay, r22 * az));
-                gqRow[rfl(fk->tj[j].q_index)] += fk->tj[j].scale * fmaf(T0, w0, fmaf(T1, w1, T2 * w2));
-                const float dx = ax * v, dy = ay * v, dz = az * v;
-                G00 = fmaf(T0, dx, G00); G01 = fmaf(T0, dy, G01); G02 = fmaf(T0, dz, G02);
-                G10 = fmaf(T1, dx, G10); G11 = fmaf(T1, dy, G11); G12 = fmaf(T1, dz, G12);
-                G20 = fmaf(T2, dx, G20); G21 = fmaf(T2, dy, G21); G22 = fmaf(T2, dz, G22);
-            }
-            // back through the constant transform F
-            const auto* F = fk->tj[j].F;
-            const float f00 = F[0], f01 = F[1], f02 = F[2], f03 = F[3], f10 = F[4], f11 = F[5], f12 = F[6], f13 = F[7];
-            const float f20 = F[8], f21 = F[9], f22 = F[10], f23 = F[11];
-            const float n00 = fmaf(G00, f00, fmaf(G01, f01, fmaf(G02, f02, T0 * f03)));
-            const float n01 = fmaf(G00, f10, fmaf(G01, f11, fmaf(G02, f12, T0 * f13)));
-            const float n02 = fmaf(G00, f20, fmaf(G01, f21, fmaf(G02, f22, T0 * f23)));
-            const float n10 = fmaf(G10, f00, fmaf(G11, f01, fmaf(G12, f02, T1 * f03)));
-            const float n11 = fmaf(G10, f10, fmaf(G11, f11, fmaf(G12, f12, T1 * f13)));
-            const float n12 = fmaf(G10, f20, fmaf(G11, f21, fmaf(G12, f22, T1 * f23)));
-            const float n20 = fmaf(G20, f00, fmaf(G21, f01, fmaf(G22, f02, T2 * f03)));
-            const float n21 = fmaf(G20, f10, fmaf(G21, f11, fmaf(G22, f12, T2 * f13)));
-            const float n22 = fmaf(G20, f20, fmaf(G21, f21, fmaf(G22, f22, T2 * f23)));
-            G00 = n00; G01 = n01; G02 = n02; G10 = n10; G11 = n11; G12 = n12; G20 = n20; G21 = n21; G22 = n22;
-            const float q00 = fmaf(r00, f00, fmaf(r01, f01, r02 * f02)), q01 = fmaf(r00, f10, fmaf(r01, f11, r02 * f12)),
-                        q02 = fmaf(r00, f20, fmaf(r01, f21, r02 * f22));
-            const float q10 = fmaf(r10, f00, fmaf(r11, f01, r12 * f02)), q11 = fmaf(r10, f10, fmaf(r11, f11, r12 * f12)),
-                        q12 = fmaf(r10, f20, fmaf(r11, f21, r12 * f22));
-            const float q20 = fmaf(r20, f00, fmaf(r21, f01, r22 * f02)), q21 = fmaf(r20, f10, fmaf(r21, f11, r22 * f12)),
-                        q22 = fmaf(r20, f20, fmaf(r21, f21, r22 * f22));
-            r00 = q00; r01 = q01; r02 = q02; r10 = q10; r11 = q11; r12 = q12; r20 = q20; r21 = q21; r22 = q22;
+    const int stride = rfl(fk->out_stride) * 64, njt = rfl(fk->n_joints);
+    const int f_leaf = rfl(fk->f_leaf), f_adj = rfl(fk->f_adj), n_branch = rfl(fk->n_branch);
+    float* sFw = const_cast<float*>(sFcol);  // the adjoint sums of branch nodes live in the frames area
+    for (int e = 0; e < 12 * n_branch; ++e) sFw[(f_adj + e) * 64] = 0.f;
+    float r00 = 1.f, r01 = 0.f, r02 = 0.f, r10 = 0.f, r11 = 1.f, r12 = 0.f, r20 = 0.f, r21 = 0.f, r22 = 1.f;
+    float G00 = 0.f, G01 = 0.f, G02 = 0.f, G10 = 0.f, G11 = 0.f, G12 = 0.f, G20 = 0.f, G21 = 0.f, G22 = 0.f;
+    float T0 = 0.f, T1 = 0.f, T2 = 0.f;
+    // nodes in reverse depth-first order: every child has been processed before its parent
+    for (int j = njt - 1; j >= 0; --j) {
+        const int leaf = rfl(fk->tj[j].leaf), park = rfl(fk->tj[j].park);
+        if (leaf >= 0) {  // no child handed its state over in registers: restart from this node's own rotation
+            const float* fr = sFcol + (f_leaf + 9 * leaf) * 64;
+            r00 = fr[0]; r01 = fr[64]; r02 = fr[128]; r10 = fr[192]; r11 = fr[256]; r12 = fr[320];
+            r20 = fr[384]; r21 = fr[448]; r22 = fr[512];
+            G00 = G01 = G02 = G10 = G11 = G12 = G20 = G21 = G22 = 0.f;
+            T0 = T1 = T2 = 0.f;
+        }
+        if (park >= 0) {  // plus what the children that started from the parked frame sent back
+            const float* ad = sFcol + (f_adj + 12 * park) * 64;
+            G00 += ad[0]; G01 += ad[64]; G02 += ad[128]; T0 += ad[192];
+            G10 += ad[256]; G11 += ad[320]; G12 += ad[384]; T1 += ad[448];
+            G20 += ad[512]; G21 += ad[576]; G22 += ad[640]; T2 += ad[704];
+        }
+        const int pb = rfl(fk->tj[j].pt_begin), pe = rfl(fk->tj[j].pt_end);
+        for (int p = pb; p < pe; ++p) {
+            const float* gin = sGcol + rfl(fk->points[p].out_k) * 64;
+            const float g0 = gin[0], g1 = gin[stride], g2 = gin[2 * stride];
+            const float ox = fk->points[p].ox, oy = fk->points[p].oy, oz = fk->points[p].oz;
+            T0 += g0; T1 += g1; T2 += g2;
+            G00 = fmaf(g0, ox, G00); G01 = fmaf(g0, oy, G01); G02 = fmaf(g0, oz, G02);
+            G10 = fmaf(g1, ox, G10); G11 = fmaf(g1, oy, G11); G12 = fmaf(g1, oz, G12);
+            G20 = fmaf(g2, ox, G20); G21 = fmaf(g2, oy, G21); G22 = fmaf(g2, oz, G22);
+        }
+        const int type = rfl(fk->tj[j].type), slot = rfl(fk->tj[j].slot);
+        if (type == TJ_REV) {
+            const float s = sFcol[(2 * slot) * 64], c = sFcol[(2 * slot + 1) * 64];
+            // R_N = R_j Rz^T: columns 0, 1 rotate back
+            const float p00 = fmaf(r00, c, -r01 * s), p01 = fmaf(r01, c, r00 * s);
+            const float p10 = fmaf(r10, c, -r11 * s), p11 = fmaf(r11, c, r10 * s);
+            const float p20 = fmaf(r20, c, -r21 * s), p21 = fmaf(r21, c, r20 * s);
+            // A = R_N^T GR, rows 0 and 1, columns 0 and 1 (dRz/dv = [[-s, -c, 0], [c, -s, 0], [0, 0, 0]])
+            const float A00 = fmaf(p00, G00, fmaf(p10, G10, p20 * G20)), A01 = fmaf(p00, G01, fmaf(p10, G11, p20 * G21));
+            const float A10 = fmaf(p01, G00, fmaf(p11, G10, p21 * G20)), A11 = fmaf(p01, G01, fmaf(p11, G11, p21 * G21));
+            const float dv = (c * A10 - s * A11) - (s * A00 + c * A01);
+            gqRow[rfl(fk->tj[j].q_index)] += fk->tj[j].scale * dv;
+            // G_RN = GR Rz^T
+            const float h00 = fmaf(G00, c, -G01 * s), h01 = fmaf(G01, c, G00 * s);
+            const float h10 = fmaf(G10, c, -G11 * s), h11 = fmaf(G11, c, G10 * s);
+            const float h20 = fmaf(G20, c, -G21 * s), h21 = fmaf(G21, c, G20 * s);
+            G00 = h00; G01 = h01; G10 = h10; G11 = h11; G20 = h20; G21 = h21;
+            r00 = p00; r01 = p01; r10 = p10; r11 = p11; r20 = p20; r21 = p21;
+        } else if (type == TJ_PRISM) {
+            const float v = sFcol[(2 * slot) * 64];
+            const float ax = fk->tj[j].ax, ay = fk->tj[j].ay, az = fk->tj[j].az;
+            const float w0 = fmaf(r00, ax, fmaf(r01, ay, r02 * az)), w1 = fmaf(r10, ax, fmaf(r11, ay, r12 * az)),
+                        w2 = fmaf(r20, ax, fmaf(r21, ay, r22 * az));
+            gqRow[rfl(fk->tj[j].q_index)] += fk->tj[j].scale * fmaf(T0, w0, fmaf(T1, w1, T2 * w2));
+            const float dx = ax * v, dy = ay * v, dz = az * v;
+            G00 = fmaf(T0, dx, G00); G01 = fmaf(T0, dy, G01); G02 = fmaf(T0, dz, G02);
+            G10 = fmaf(T1, dx, G10); G11 = fmaf(T1, dy, G11); G12 = fmaf(T1, dz, G12);
+            G20 = fmaf(T2, dx, G20); G21 = fmaf(T2, dy, G21); G22 = fmaf(T2, dz, G22);
+        }
+        // back through the constant transform F
+        const auto* F = fk->tj[j].F;
+        const float f00 = F[0], f01 = F[1], f02 = F[2], f03 = F[3], f10 = F[4], f11 = F[5], f12 = F[6], f13 = F[7];
+        const float f20 = F[8], f21 = F[9], f22 = F[10], f23 = F[11];
+        const float n00 = fmaf(G00, f00, fmaf(G01, f01, fmaf(G02, f02, T0 * f03)));
+        const float n01 = fmaf(G00, f10, fmaf(G01, f11, fmaf(G02, f12, T0 * f13)));
+        const float n02 = fmaf(G00, f20, fmaf(G01, f21, fmaf(G02, f22, T0 * f23)));
+        const float n10 = fmaf(G10, f00, fmaf(G11, f01, fmaf(G12, f02, T1 * f03)));
+        const float n11 = fmaf(G10, f10, fmaf(G11, f11, fmaf(G12, f12, T1 * f13)));
+        const float n12 = fmaf(G10, f20, fmaf(G11, f21, fmaf(G12, f22, T1 * f23)));
+        const float n20 = fmaf(G20, f00, fmaf(G21, f01, fmaf(G22, f02, T2 * f03)));
+        const float n21 = fmaf(G20, f10, fmaf(G21, f11, fmaf(G22, f12, T2 * f13)));
+        const float n22 = fmaf(G20, f20, fmaf(G21, f21, fmaf(G22, f22, T2 * f23)));
+        G00 = n00; G01 = n01; G02 = n02; G10 = n10; G11 = n11; G12 = n12; G20 = n20; G21 = n21; G22 = n22;
+        const float q00 = fmaf(r00, f00, fmaf(r01, f01, r02 * f02)), q01 = fmaf(r00, f10, fmaf(r01, f11, r02 * f12)),
+                    q02 = fmaf(r00, f20, fmaf(r01, f21, r02 * f22));
+        const float q10 = fmaf(r10, f00, fmaf(r11, f01, r12 * f02)), q11 = fmaf(r10, f10, fmaf(r11, f11, r12 * f12)),
+                    q12 = fmaf(r10, f20, fmaf(r11, f21, r12 * f22));
+        const float q20 = fmaf(r20, f00, fmaf(r21, f01, r22 * f02)), q21 = fmaf(r20, f10, fmaf(r21, f11, r22 * f12)),
+                    q22 = fmaf(r20, f20, fmaf(r21, f21, r22 * f22));
+        r00 = q00; r01 = q01; r02 = q02; r10 = q10; r11 = q11; r12 = q12; r20 = q20; r21 = q21; r22 = q22;
+        // (R, GR, Gt) now refer to the parent frame.  A child that started from a parked frame adds its adjoint to the
+        // parent's sum; a child that continued in registers just carries on; a root's parent adjoint is dropped.
+        const int start = rfl(fk->tj[j].start);
+        if (start >= 0) {
+            float* ad = sFw + (f_adj + 12 * start) * 64;
+            ad[0] += G00; ad[64] += G01; ad[128] += G02; ad[192] += T0;
+            ad[256] += G10; ad[320] += G11; ad[384] += G12; ad[448] += T1;
+            ad[512] += G20; ad[576] += G21; ad[640] += G22; ad[704] += T2;
         }
     }
 }

@@ -104,12 +104,14 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 //     small batches), fewer for wide rows (below).
 // four-row pipeline limits (SGPRs in flight; see PARTS below), measured: C > 1 holds more scalars of its own (C = 5,
 // D = 12: 72 row SGPRs park 96 lane moves per 4 rows, two rows in flight +22..45 %); C = 1: D = 21 (88) is 9..21 %
-// faster with two rows in flight, D = 18 (76) 4 % slower (profiles/r01_sweep_variants.txt)
+// faster with two rows in flight; D = 16 / 18 (68 / 76) sit on the edge — whether the compiler parks there changes
+// with unrelated code (a 13 % swing at D = 18) — so they take the two-row pipeline as well
+// (profiles/r01_sweep_variants.txt, tools/check_sgpr_parking.py)
 #ifndef DCX_P0_MAX_MULTI
 #define DCX_P0_MAX_MULTI 56
 #endif
 #ifndef DCX_P0_MAX_SINGLE
-#define DCX_P0_MAX_SINGLE 76
+#define DCX_P0_MAX_SINGLE 56
 #endif
 // independent accumulator pairs for the squared distance (see pair())
 #ifndef DCX_D2_MULTI
