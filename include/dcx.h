@@ -112,8 +112,8 @@ typedef struct dcx_fk_desc {
      * next t_chain_len[c] entries).  A chain starts from t_base[c] (row-major 3x4) and every joint applies
      *     T <- T * [t_fixed | as 3x4] * Motion(t_type, t_scale * q[t_q] + t_offset)
      * i.e. the joint's <origin> followed by its motion, as rigid_body.py:100-126 composes them.  A URDF
-     * tree becomes one chain per leaf; joints on a shared prefix are simply repeated (their gradient
-     * contributions add up).  Mimic joints use the driver's t_q with the mimic multiplier/offset
+     * tree becomes one chain per leaf; joints on a shared prefix are simply repeated (the library merges
+     * identical prefixes back into one node when it compiles the description, so they are computed once).  Mimic joints use the driver's t_q with the mimic multiplier/offset
      * (rigid_body.py:93-94); an axis of -1 is a negative t_scale (rigid_body.py:103-108).
      * Control point k is pt_off[k] in the frame after joint pt_frame[k] (index within its chain) of chain
      * pt_chain[k].  t_coord_major != 0 lays the features out as [3][n_points] (feature j*n_points + k), the
