@@ -179,6 +179,7 @@ inline void build_tree_prog(const dcx_fk_desc& fk, FkProg& p) {
     p.n_chains = fk.t_n_chains;
     p.out_stride = fk.t_coord_major ? fk.n_points : 1;
     p.n_joints = tp.n_nodes;
+    p.n_dwords = (kFkProgHeadDwords + (int)(sizeof(FkProgTreeJoint) / 4) * tp.n_nodes + 3) & ~3;  // stage the merged nodes only
     p.f_leaf = 2 * tp.n_slots;
     p.f_park = p.f_leaf + 9 * tp.n_leaves;
     p.f_adj = p.f_park + 12 * tp.n_branch;
