@@ -111,3 +111,44 @@ def test_oracle_is_not_imported_by_the_product():
                 assert "oracle" not in txt.lower().replace("no oracle", ""), f"{f} mentions the oracle"
     code = "import sys; import diffco_amd; assert not any(m.startswith('oracle') for m in sys.modules), 'oracle imported'"
     subprocess.run([sys.executable, "-c", code], check=True, cwd=ROOT)
+
+
+def test_tree_description_is_validated_before_any_device_work():
+    """argument checking of DCX_FK_TREE descriptions happens on the host, ahead of the device: a malformed tree is
+    DCX_ERR_INVALID / DCX_ERR_UNSUPPORTED with a message even on a box without a GPU"""
+    from diffco_amd import _fkdesc as fd
+    from diffco_amd import _lib
+    lib = _lib.load()
+    ident = fd.IDENTITY_BASE
+
+    def good():
+        return fd.tree_desc(2, [dict(joints=[dict(type=fd.DCX_J_REV_Z, q=0, fixed=ident),
+                                             dict(type=fd.DCX_J_PRISMATIC, q=1, fixed=ident, axis=(0, 0, 1))])],
+                            [(0, 0, (0, 0, 0)), (0, 1, (0.1, 0, 0))])
+
+    def rc_of(desc):
+        buf = (ctypes.c_float * 64)()
+        p = ctypes.cast(buf, ctypes.c_void_p)
+        return lib.dcx_fkine(0, ctypes.byref(desc), p, 1, p, None), lib.dcx_last_error().decode()
+
+    rc, msg = rc_of(good())
+    assert rc in (0, 4), msg  # fine, or "no device" on a CPU box — never an argument error
+    d = good()
+    d.t_type[1] = 9
+    assert rc_of(d)[0] == 1 and "joint type" in rc_of(d)[1]
+    d = good()
+    d.t_q[0] = 5
+    assert rc_of(d)[0] == 1 and "t_q" in rc_of(d)[1]
+    d = good()
+    d.pt_frame[1] = 7
+    assert rc_of(d)[0] == 1 and "missing frame" in rc_of(d)[1]
+    d = good()
+    d.t_n_chains = 9
+    assert rc_of(d)[0] == 2  # DCX_ERR_UNSUPPORTED: more chains than DCX_MAX_TREE_CHAINS
+    d = good()
+    d.t_chain_len[0] = 0
+    assert rc_of(d)[0] == 1
+    with pytest.raises(ValueError, match="outside"):
+        fd.tree_desc(1, [dict(joints=[dict(type=fd.DCX_J_REV_X, q=3, fixed=ident)])], [(0, 0, (0, 0, 0))])
+    with pytest.raises(ValueError, match="does not exist"):
+        fd.tree_desc(1, [dict(joints=[dict(type=fd.DCX_J_REV_X, q=0, fixed=ident)])], [(0, 2, (0, 0, 0))])
