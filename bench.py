@@ -65,7 +65,8 @@ def make_workload(name, batch, dev, seed=0):
     from diffco_amd import _fkdesc, _ops, model
     rob_name, kspec, S, C, B, desc_txt = WORKLOADS[name]
     B = batch or B
-    g = torch.Generator().manual_seed(seed)
+    g = torch.Generator().manual_seed(0)               # the model (supports, weights) is the same on every rank
+    gq = torch.Generator().manual_seed(1000 + seed)    # the batch shard is the rank's own
     if rob_name is None:
         lo = torch.tensor([-10.0] * 3 + [-np.pi] * 3)
         hi = -lo
@@ -84,7 +85,7 @@ def make_workload(name, batch, dev, seed=0):
     W = torch.randn((S, C), generator=g)
     if name == "cfg3":  # 40 % of the entries zeroed per class (mimics deprecated/MultiDiffCo.py:152-153)
         W = W * (torch.rand((S, C), generator=g) >= 0.4)
-    q = torch.rand((B, len(lo)), generator=g) * (hi - lo) + lo
+    q = torch.rand((B, len(lo)), generator=gq) * (hi - lo) + lo
     sup = _ops.fkine(desc, sup_q.to(dev)).reshape(S, -1)
     m = _ops.ScoreModel(desc, *kspec, sup, W.to(dev), device=dev)
     return dict(name=name, text=desc_txt, model=m, desc=desc, kspec=kspec, S=S, C=C, B=B, D=desc.feature_dim,
