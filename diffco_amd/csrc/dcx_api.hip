@@ -257,7 +257,7 @@ Geometry pick_geometry(const dcx_model* m, int64_t B, int acc_floats, bool allow
 // This stream's scratch buffer for the partial rows of a split launch, grown on demand.  Returns nullptr when
 // it cannot be provided right now (the stream is being captured into a graph and the buffer does not exist
 // yet, or the allocation failed): the caller then uses the unsplit geometry, which is always valid.
-constexpr size_t kTileCounters = 64;                         // arrival counters at the head of a scratch buffer
+constexpr size_t kTileCounters = 1024;                       // arrival counters at the head of a scratch buffer
 constexpr size_t kScratchHead = kTileCounters * sizeof(unsigned int);
 float* split_scratch(const dcx_model* m, hipStream_t st, size_t bytes) {
     bytes += kScratchHead;
@@ -316,7 +316,9 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
         // graph-replay timings (profiles/r01_sweep_small_batch_graph.txt): finishing inside the launch saves the second
         // launch and its FK (B=1024: 27.1 -> 23.3 us headline, 24.4 -> 20.0 us config #2) but every block's release fence
         // is an L2 write-back, which loses once there are hundreds of blocks (B=8192: 35.9 -> 43.2 us); at 64 tiles config #2 still gains 6-7 %
-        if (nblk <= 64 && !second_launch) counters = reinterpret_cast<unsigned int*>(part);
+        int64_t inlaunch_max = 64;
+        if (const char* e = std::getenv("DCX_INLAUNCH_TILES")) inlaunch_max = std::min<int64_t>(std::atoll(e), (int64_t)kTileCounters);
+        if (nblk <= inlaunch_max && !second_launch) counters = reinterpret_cast<unsigned int*>(part);
         part = reinterpret_cast<float*>(reinterpret_cast<char*>(part) + kScratchHead);
     }
     if (nblk > 0x7fffffffLL) return fail(DCX_ERR_UNSUPPORTED, "batch too large for one launch");
