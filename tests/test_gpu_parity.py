@@ -283,3 +283,35 @@ def test_config4_se3_streaming(ops):
     rest = ops.ScoreModel(desc, 0, 10.0, 2.0, sup[5000:], W[5000:]).score_grad_raw(q)
     assert float((half[0] + rest[0] - s).abs().max()) < 3e-6 * float(s.abs().max())
     assert float((half[1] + rest[1] - gr).abs().max()) < 3e-6 * float(gr.abs().max())
+
+
+@pytest.mark.parametrize("B", [200, 5000])
+def test_hip_graph_capture_and_replay(ops, B):
+    """the launches carry no allocation and no synchronisation, so a caller can capture them into a HIP graph: small
+    batch (split launch, finished inside the launch with per-tile arrival counters that must be back at zero after
+    every replay) and a larger one (plain launch); replays reproduce the eager result bit for bit"""
+    d = load("cfg2_baxter_poly1")
+    kind, p0, p1 = case_kernel(d)
+    m = ops.ScoreModel(desc_for("baxter_left"), kind, p0, p1, _t(d["sup_x32"].reshape(len(d["sup_x32"]), -1)), _t(d["weights"]))
+    rng = np.random.default_rng(3)
+    q = _t(np.tile(d["q"], (B // len(d["q"]) + 1, 1))[:B] + rng.normal(0, 0.05, (B, d["q"].shape[1])).astype(np.float32))
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        s0, g0 = m.score_grad_raw(q)          # warm-up on the capture stream: its scratch buffer now exists
+        torch.cuda.current_stream().synchronize()
+        s = torch.empty_like(s0)
+        g = torch.empty_like(g0)
+        import ctypes as C
+        from diffco_amd import _lib
+        lib = _lib.load()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=side):
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            _lib.check(lib.dcx_score_grad(m._h, C.c_void_p(q.data_ptr()), B, None, C.c_void_p(s.data_ptr()),
+                                          C.c_void_p(g.data_ptr()), st))
+    for _ in range(3):
+        s.zero_()
+        g.zero_()
+        gr.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(s, s0) and torch.equal(g, g0)
