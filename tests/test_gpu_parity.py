@@ -315,3 +315,25 @@ def test_hip_graph_capture_and_replay(ops, B):
         gr.replay()
         torch.cuda.synchronize()
         assert torch.equal(s, s0) and torch.equal(g, g0)
+
+
+def test_concurrent_streams_share_a_model(ops):
+    """a model handle is immutable: launches on different streams may overlap (each stream gets its own scratch for
+    split launches); interleaved small and large batches on three streams reproduce the serial results"""
+    d = load("cfg2_baxter_poly1")
+    kind, p0, p1 = case_kernel(d)
+    m = ops.ScoreModel(desc_for("baxter_left"), kind, p0, p1, _t(d["sup_x32"].reshape(len(d["sup_x32"]), -1)), _t(d["weights"]))
+    rng = np.random.default_rng(5)
+    qs = [_t(rng.uniform(-1.5, 1.5, (n, 7)).astype(np.float32)) for n in (130, 700, 9000)]
+    want = [m.score_grad_raw(q) for q in qs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in qs]
+    got = [[] for _ in qs]
+    for rep in range(6):
+        for i, (st, q) in enumerate(zip(streams, qs)):
+            with torch.cuda.stream(st):
+                got[i].append(m.score_grad_raw(q))
+    torch.cuda.synchronize()
+    for i, (s0, g0) in enumerate(want):
+        for s, g in got[i]:
+            assert torch.equal(s, s0) and torch.equal(g, g0)
