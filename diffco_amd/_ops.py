@@ -194,7 +194,7 @@ class ScoreModel:
     # autograd-aware ------------------------------------------------------------------------
     def score(self, q: torch.Tensor) -> torch.Tensor:
         """[B, C] scores for q [B, dof]; differentiable w.r.t. q (gradient from the fused HIP pass)."""
-        return _ScoreFn.apply(q, self)[0]
+        return _ScoreFn.apply(q, self)
 
     def score_and_grad(self, q: torch.Tensor, upstream: torch.Tensor = None):
         """(score [B, C], d(sum_c upstream*score)/dq [B, dof]) in ONE launch, no autograd graph."""
@@ -204,29 +204,48 @@ class ScoreModel:
         return s.to(device=q.device, dtype=q.dtype), g.to(device=q.device, dtype=q.dtype)
 
 
+def _is_batched(t):
+    """True inside torch.vmap (e.g. torch.autograd.functional.jacobian(vectorize=True) batching the backward)"""
+    ft = getattr(torch._C, "_functorch", None)
+    for name in ("is_batchedtensor", "is_legacy_batchedtensor"):  # torch.vmap / the legacy vmap autograd still uses
+        f = getattr(ft, name, None)
+        if f is not None and f(t):
+            return True
+    return False
+
+
 class _ScoreFn(torch.autograd.Function):
-    """score = model(q).  When q needs a gradient the forward launch also produces the Jacobian
-    (C == 1: the fused score+grad pass; C > 1: one sweep per class), so backward is a tiny torch
-    contraction — which keeps `torch.autograd.functional.jacobian(vectorize=True)` (vmap over the
-    backward, optim.py:211-216 in the reference) working on this op."""
+    """score = model(q), differentiable w.r.t. q.
+
+    C == 1: when q needs a gradient the forward launch is the fused score+gradient pass and backward is one
+    elementwise multiply.  C > 1: forward is the score-only sweep; backward runs ONE sweep with the actual upstream
+    (`dcx_score_grad`) — unless it is being vmapped (`torch.autograd.functional.jacobian(vectorize=True)`, the
+    reference's optim.py:211-216, batches the backward over one-hot upstreams): then the full Jacobian is formed once
+    (`dcx_score_jac`, one sweep per class) and contracted with torch ops, which vmap can batch."""
 
     @staticmethod
     def forward(ctx, q, model):
         q32 = _f32(q.reshape(-1, model.dof), model.dev)
-        if ctx.needs_input_grad[0]:
+        ctx.model, ctx.in_shape, ctx.in_dtype, ctx.in_device = model, q.shape, q.dtype, q.device
+        if ctx.needs_input_grad[0] and model.C == 1:
             s, jac = model.score_jac_raw(q32)
-            jac = jac.to(device=q.device, dtype=q.dtype)
+            ctx.save_for_backward(jac.to(device=q.device, dtype=q.dtype))
         else:
-            s, jac = model.score_raw(q32), q.new_zeros(())
-        ctx.save_for_backward(jac)
-        ctx.in_shape = q.shape
-        ctx.mark_non_differentiable(jac)
-        return s.to(device=q.device, dtype=q.dtype), jac
+            s = model.score_raw(q32)
+            ctx.save_for_backward(q32)
+        return s.to(device=q.device, dtype=q.dtype)
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, gs, _gjac):
-        (jac,) = ctx.saved_tensors  # [B, C, dof]
-        if jac.shape[-2] == 1:  # single output: one elementwise kernel instead of multiply + reduce
-            return (gs * jac[:, 0, :]).reshape(ctx.in_shape), None
-        return (gs.unsqueeze(-1) * jac).sum(dim=-2).reshape(ctx.in_shape), None
+    def backward(ctx, gs):
+        (saved,) = ctx.saved_tensors
+        model = ctx.model
+        if model.C == 1:  # saved = d score / d q  [B, 1, dof]
+            return (gs * saved[:, 0, :]).reshape(ctx.in_shape), None
+        q32 = saved
+        if _is_batched(gs):
+            _, jac = model.score_jac_raw(q32)  # [B, C, dof]
+            jac = jac.to(device=ctx.in_device, dtype=ctx.in_dtype)
+            return (gs.unsqueeze(-1) * jac).sum(dim=-2).reshape(ctx.in_shape), None
+        _, g = model.score_grad_raw(q32, _f32(gs.reshape(-1, model.C), model.dev), want_score=False)
+        return g.to(device=ctx.in_device, dtype=ctx.in_dtype).reshape(ctx.in_shape), None
