@@ -241,3 +241,29 @@ def test_random_trees_hip_vs_oracle(ops, seed):
     s, gr = m.score_grad_raw(_t(q), None)
     rs, rg, _ = oracle.score_grad(desc, 1, 1.0, 1.0, sup, W, q, dtype=np.float64)
     assert relerr(_n(s), rs) < 1e-5 and relerr(_n(gr), rg) < 1e-5
+
+
+def test_host_optimisers_accept_a_urdf_robot(ops):
+    """adam / SLSQP (givengrad) / trust-constr drive a URDF robot through the same entry points as a DH arm: the path
+    terms use per-link norms of the [W, 3, L] features, the collision constraint its analytic fused Jacobian"""
+    from diffco_amd import DiffCo, kernel, optim
+    rob = urdf_robot("urdf_iiwa7")
+    torch.manual_seed(7)
+    q = rob.rand_configs(300)
+    X = rob.fkine(q.cuda()).cpu()
+    dist = (X[:, :, -1] - torch.tensor([0.45, 0.0, 0.55])).norm(dim=1) - 0.25
+    labels = torch.where(dist < 0, 1.0, -1.0)
+    dc = DiffCo(kernel_func=kernel.RQKernel(gamma=10), transform=rob.fkine)
+    dc.train(q, labels, max_iteration=len(q), distance=dist)
+    dc.fit_poly(kernel_func=kernel.Polyharmonic(k=1, epsilon=1), target="label")
+    free = q[labels < 0]
+    start, target = free[0], free[1]
+    init = torch.from_numpy(np.linspace(start.numpy(), target.numpy(), 10)).double()
+    base = dict(N_WAYPOINTS=10, NUM_RE_TRIALS=1, safety_margin=-0.2, max_speed=0.4, seed=3, history=False,
+                init_solution=init, extra_optimizer_options={"disp": False})
+    for fn, iters in ((optim.adam_traj_optimize, 25), (optim.givengrad_traj_optimize, 8), (optim.trustconstr_traj_optimize, 6)):
+        rec = fn(rob, dc.poly_score, start, target, dict(base, MAXITER=iters))
+        sol = torch.as_tensor(rec["solution"])
+        assert sol.shape == (10, rob.dof) and torch.isfinite(sol).all()
+        assert torch.allclose(sol[0].float(), start, atol=1e-5) and torch.allclose(sol[-1].float(), target, atol=1e-5)
+        assert np.isfinite(rec["cost"])
