@@ -20,6 +20,7 @@ documented behaviour for the attributes used above is restated: missing <origin>
 """
 import math
 import os
+import re
 import xml.etree.ElementTree as ET
 from dataclasses import dataclass, field
 from typing import List, Optional
@@ -68,9 +69,19 @@ def parse_urdf(source) -> Tree:
     if isinstance(source, (bytes, str)) and not str(source).lstrip().startswith("<"):
         if not os.path.exists(source):
             raise FileNotFoundError(source)
-        root = ET.parse(source).getroot()
-    else:
-        root = ET.fromstring(source)
+        with open(source, "rb") as f:
+            source = f.read()
+    text = source.decode() if isinstance(source, bytes) else source
+    try:
+        root = ET.fromstring(text)
+    except ET.ParseError as e:
+        if "unbound prefix" not in str(e):
+            raise
+        # simulator blocks with undeclared namespace prefixes (<sensor:camera> inside <gazebo>, as in the reference's
+        # fetch.urdf): the prefixes carry no kinematic content, so they are flattened instead of rejected
+        text = re.sub(r"<(/?)([A-Za-z_][\w.-]*):", r"<\1\2_", text)
+        text = re.sub(r"(\s)([A-Za-z_][\w.-]*):([A-Za-z_][\w.-]*)=", r"\1\2_\3=", text)
+        root = ET.fromstring(text)
     if root.tag != "robot":
         raise ValueError("URDF: the root element must be <robot>")
     links = [ln.get("name") for ln in root.findall("link")]

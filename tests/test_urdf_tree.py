@@ -155,3 +155,16 @@ def test_random_trees_against_an_independent_fk(seed):
         dq[:, i] = eps
         fd = ((oracle.fkine(desc, q + dq, np.float64) - oracle.fkine(desc, q - dq, np.float64)) * g).sum(axis=(1, 2)) / (2 * eps)
         assert np.abs(fd - gq[:, i]).max() < 1e-6 * max(1.0, np.abs(gq).max())
+
+
+def test_undeclared_namespace_prefixes_are_tolerated():
+    """simulator blocks such as <gazebo><sensor:camera>…</sensor:camera></gazebo> (the reference's fetch.urdf) use
+    prefixes no xmlns declares; they carry no kinematics and must not stop the robot from loading"""
+    from diffco_amd.urdf import URDFRobotFK
+    m = urdf_model("urdf_2link")
+    xml = urdf_xml(m).replace("</robot>", '<gazebo reference="x"><sensor:camera name="rgb" a:b="1"><hfov>50</hfov>'
+                                          "</sensor:camera></gazebo></robot>")
+    a, b = URDFRobotFK(xml), URDFRobotFK(urdf_xml(m))
+    assert a.fk_desc().key() == b.fk_desc().key()
+    with pytest.raises(Exception):
+        URDFRobotFK("<robot><link name='a'></robot>")  # genuinely malformed XML still fails
