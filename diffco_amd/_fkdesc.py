@@ -16,7 +16,7 @@ DCX_FK_NONE, DCX_FK_PLANAR, DCX_FK_DH, DCX_FK_SE2, DCX_FK_SE3, DCX_FK_TREE = ran
 DCX_J_FIXED, DCX_J_REV_X, DCX_J_REV_Y, DCX_J_REV_Z, DCX_J_PRISMATIC = range(5)
 DCX_K_RQ, DCX_K_POLY, DCX_K_MQ = range(3)
 MAX_JOINTS, MAX_CHAINS, MAX_POINTS, MAX_DOF, MAX_D, MAX_C = 16, 2, 24, 32, 72, 8
-MAX_TREE_CHAINS, MAX_TREE_JOINTS = 8, 64
+MAX_TREE_CHAINS, MAX_TREE_JOINTS, MAX_TREE_BASES = 16, 64, 4
 
 
 class FkDesc(C.Structure):
@@ -137,6 +137,9 @@ def tree_desc(dof, chains, points, coord_major=True):
             fixed=[12 floats, row-major 3x4], axis=(x, y, z))]) — one entry per root-to-leaf path;
     points: list of (chain, frame, (ox, oy, oz)) in feature order."""
     n_j = sum(len(ch["joints"]) for ch in chains)
+    n_bases = len({tuple(float(v) for v in ch.get("base", IDENTITY_BASE)) for ch in chains})
+    if n_bases > MAX_TREE_BASES:
+        raise ValueError(f"kinematic tree: {n_bases} distinct base transforms (max {MAX_TREE_BASES})")
     if (len(chains) > MAX_TREE_CHAINS or n_j > MAX_TREE_JOINTS or len(points) > MAX_POINTS or dof > MAX_DOF
             or 3 * len(points) > MAX_D):
         raise ValueError(

@@ -106,6 +106,15 @@ int check_fk(const dcx_fk_desc& fk) {
             total += fk.t_chain_len[c];
             if (total > DCX_MAX_TREE_JOINTS) return fail(DCX_ERR_UNSUPPORTED, "DCX_FK_TREE more than DCX_MAX_TREE_JOINTS joints over all chains");
         }
+        {
+            int n_bases = 0, rep[DCX_MAX_TREE_CHAINS];
+            for (int c = 0; c < fk.t_n_chains; ++c) {
+                bool seen = false;
+                for (int k = 0; k < n_bases && !seen; ++k) seen = std::memcmp(fk.t_base[c], fk.t_base[rep[k]], sizeof(fk.t_base[0])) == 0;
+                if (!seen) rep[n_bases++] = c;
+            }
+            if (n_bases > DCX_MAX_TREE_BASES) return fail(DCX_ERR_UNSUPPORTED, "DCX_FK_TREE more than DCX_MAX_TREE_BASES distinct base transforms");
+        }
         for (int j = 0; j < total; ++j) {
             if (fk.t_type[j] < DCX_J_FIXED || fk.t_type[j] > DCX_J_PRISMATIC) return fail(DCX_ERR_INVALID, "DCX_FK_TREE unknown joint type");
             if (fk.t_type[j] != DCX_J_FIXED && (fk.t_q[j] < 0 || fk.t_q[j] >= fk.dof)) return fail(DCX_ERR_INVALID, "DCX_FK_TREE t_q out of range");

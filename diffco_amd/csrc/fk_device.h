@@ -33,7 +33,8 @@
 namespace dcx {
 
 constexpr int kMaxProgJoints = DCX_MAX_CHAINS * DCX_MAX_JOINTS;
-constexpr int kMaxProgChains = DCX_MAX_TREE_CHAINS > DCX_MAX_CHAINS ? DCX_MAX_TREE_CHAINS : DCX_MAX_CHAINS;
+// base transforms the program carries: one per DH chain, one per DISTINCT base of a tree's chains
+constexpr int kMaxProgChains = DCX_MAX_TREE_BASES > DCX_MAX_CHAINS ? DCX_MAX_TREE_BASES : DCX_MAX_CHAINS;
 
 struct FkProgJoint {  // DCX_FK_DH, 8 dwords
     int32_t q_index;
@@ -101,7 +102,9 @@ __host__ __device__ inline int fk_prog_floats(const dcx_fk_desc& fk) {
 //                 the later children add up, in a second bank of 12)
 // frames layout per lane: [2 * n_slots trig][9 * n_leaves][12 * n_branch parked frames][12 * n_branch adjoint sums]
 struct TreePlan {
-    int n_nodes, n_slots, n_leaves, n_branch;
+    int n_nodes, n_slots, n_leaves, n_branch, n_bases;
+    int base_chain[DCX_MAX_TREE_BASES];             // a chain that carries distinct base b
+    int base_of_chain[DCX_MAX_TREE_CHAINS];
     int parent[DCX_MAX_TREE_JOINTS];                // node index, or -1 - b for a root on base b
     int src[DCX_MAX_TREE_JOINTS];                   // index into the description's t_* arrays
     int node_of[DCX_MAX_TREE_JOINTS];               // description joint (flat index) -> node
@@ -114,17 +117,24 @@ inline bool tree_same_joint(const dcx_fk_desc& fk, int a, int b) {
            memcmp(fk.t_axis[a], fk.t_axis[b], sizeof(fk.t_axis[a])) == 0;
 }
 inline void plan_tree(const dcx_fk_desc& fk, TreePlan& tp) {
-    tp.n_nodes = tp.n_slots = tp.n_leaves = tp.n_branch = 0;
+    tp.n_nodes = tp.n_slots = tp.n_leaves = tp.n_branch = tp.n_bases = 0;
+    for (int c = 0; c < fk.t_n_chains; ++c) {
+        int b = -1;
+        for (int k = 0; k < tp.n_bases && b < 0; ++k)
+            if (memcmp(fk.t_base[c], fk.t_base[tp.base_chain[k]], sizeof(fk.t_base[0])) == 0) b = k;
+        if (b < 0 && tp.n_bases < DCX_MAX_TREE_BASES) {
+            b = tp.n_bases++;
+            tp.base_chain[b] = c;
+        }
+        tp.base_of_chain[c] = b < 0 ? 0 : b;  // more distinct bases than DCX_MAX_TREE_BASES is rejected by check_fk
+    }
     int flat = 0;
     for (int c = 0; c < fk.t_n_chains; ++c) {
-        int cur = -1 - c;  // root on this chain's base
+        int cur = -1 - tp.base_of_chain[c];  // root on this chain's base
         for (int i = 0; i < fk.t_chain_len[c]; ++i, ++flat) {
             int found = -1;
             for (int n = 0; n < tp.n_nodes && found < 0; ++n) {
-                bool same_parent = tp.parent[n] == cur;
-                if (!same_parent && cur < 0 && tp.parent[n] < 0)  // roots on different but equal bases
-                    same_parent = memcmp(fk.t_base[-1 - cur], fk.t_base[-1 - tp.parent[n]], sizeof(fk.t_base[0])) == 0;
-                if (same_parent && tree_same_joint(fk, tp.src[n], flat)) found = n;
+                if (tp.parent[n] == cur && tree_same_joint(fk, tp.src[n], flat)) found = n;
             }
             if (found < 0) {
                 found = tp.n_nodes++;
@@ -184,8 +194,8 @@ inline void build_tree_prog(const dcx_fk_desc& fk, FkProg& p) {
     p.f_park = p.f_leaf + 9 * tp.n_leaves;
     p.f_adj = p.f_park + 12 * tp.n_branch;
     p.n_branch = tp.n_branch;
-    for (int c = 0; c < fk.t_n_chains; ++c)
-        for (int e = 0; e < 12; ++e) p.base[c][e] = fk.t_base[c][e];
+    for (int b = 0; b < tp.n_bases; ++b)
+        for (int e = 0; e < 12; ++e) p.base[b][e] = fk.t_base[tp.base_chain[b]][e];
     static const int perm_of[3][3] = {{1, 2, 0}, {2, 0, 1}, {0, 1, 2}};  // column c of P is e_{perm[c]}: REV_X, REV_Y, identity
     auto perm = [&](int node) -> const int* {
         if (node < 0) return perm_of[2];

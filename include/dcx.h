@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DCX_VERSION 101 /* 0.1.1: dcx_fk_desc grew the DCX_FK_TREE section (appended; older offsets unchanged) */
+#define DCX_VERSION 102 /* 0.1.2: DCX_FK_TREE section appended to dcx_fk_desc (older offsets unchanged); 16 chains */
 
 /* ---- status codes ---------------------------------------------------------------- */
 #define DCX_OK 0
@@ -69,7 +69,8 @@ extern "C" {
 #define DCX_MAX_DOF 32
 #define DCX_MAX_D 72  /* feature width n_points * point_dim the fused kernels are compiled for */
 #define DCX_MAX_C 8   /* weight columns (classes) the fused kernels are compiled for           */
-#define DCX_MAX_TREE_CHAINS 8  /* root-to-leaf paths of a DCX_FK_TREE                           */
+#define DCX_MAX_TREE_CHAINS 16 /* root-to-leaf paths of a DCX_FK_TREE                           */
+#define DCX_MAX_TREE_BASES 4   /* distinct base transforms among them (robots side by side)     */
 #define DCX_MAX_TREE_JOINTS 64 /* joints summed over all paths (shared prefixes count per path) */
 
 /*

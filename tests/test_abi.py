@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"libdcx.so does not export {n}"
     assert set(names) == set(_lib.SYMBOLS), "ctypes table and header disagree"
-    assert lib.dcx_version() == 101
+    assert lib.dcx_version() == 102
     assert isinstance(lib.dcx_device_count(), int)
 
 
@@ -143,7 +143,7 @@ def test_tree_description_is_validated_before_any_device_work():
     d.pt_frame[1] = 7
     assert rc_of(d)[0] == 1 and "missing frame" in rc_of(d)[1]
     d = good()
-    d.t_n_chains = 9
+    d.t_n_chains = 17
     assert rc_of(d)[0] == 2  # DCX_ERR_UNSUPPORTED: more chains than DCX_MAX_TREE_CHAINS
     d = good()
     d.t_chain_len[0] = 0

@@ -47,6 +47,9 @@ ROBOTS = {
 }
 
 
+LATER = {"urdf_fetch": "fetch_description/urdf/fetch.urdf"}  # whole robot: 14 dof, 21 links, 9 leaves, gazebo blocks
+LATER_SEEDS = {"urdf_fetch": 5151}
+
 ABSENT = ("fcl", "trimesh", "yourdfpy", "rospy", "curobo")
 
 
@@ -223,7 +226,13 @@ def main():
     out = os.path.abspath(args.out)
     gen = torch.Generator().manual_seed(4242)
     manifest = {}
-    for name, rel in ROBOTS.items():
+    gen_main_after_robots = None
+    # (robots added later draw from their own generator so that the fixtures above keep their bytes)
+    for name, rel in list(ROBOTS.items()) + list(LATER.items()):
+        if name in LATER:
+            if gen_main_after_robots is None:
+                gen_main_after_robots = gen  # the state gen_multi continues from (keeps fk_urdf_dual_panda.npz unchanged)
+            gen = torch.Generator().manual_seed(LATER_SEEDS[name])
         text = open(os.path.join(REF, "diffco", "robot_data", rel)).read()
         tree = U.parse_urdf(text)
         desc, info = U.compile_tree(tree)
@@ -273,7 +282,7 @@ def main():
                               ref_fp32_vs_fp64=err, stack=stacked)
         print(f"  wrote fk_{name}.npz  dof={info['dof']} L={len(info['feature_links'])} chains={info['n_chains']} "
               f"ref fp32-vs-fp64 {err:.2e}")
-    manifest["urdf_dual_panda"] = gen_multi(out, gen)
+    manifest["urdf_dual_panda"] = gen_multi(out, gen_main_after_robots)
     with open(os.path.join(out, "MANIFEST_urdf.json"), "w") as f:
         json.dump({"generator": "tools/make_golden_urdf.py", "torch": torch.__version__,
                    "reference": "ucsdarclab/diffco @ /root/reference (2025-03-21)", "robots": manifest}, f, indent=1)
