@@ -15,7 +15,7 @@ import torch
 DCX_FK_NONE, DCX_FK_PLANAR, DCX_FK_DH, DCX_FK_SE2, DCX_FK_SE3, DCX_FK_TREE = range(6)
 DCX_J_FIXED, DCX_J_REV_X, DCX_J_REV_Y, DCX_J_REV_Z, DCX_J_PRISMATIC = range(5)
 DCX_K_RQ, DCX_K_POLY, DCX_K_MQ = range(3)
-MAX_JOINTS, MAX_CHAINS, MAX_POINTS, MAX_DOF, MAX_D, MAX_C = 16, 2, 24, 32, 72, 8
+MAX_JOINTS, MAX_CHAINS, MAX_POINTS, MAX_DOF, MAX_D, MAX_C = 16, 2, 32, 32, 96, 8
 MAX_TREE_CHAINS, MAX_TREE_JOINTS, MAX_TREE_BASES = 16, 64, 4
 
 

@@ -66,7 +66,7 @@ launch_fn launch_for(int Dt) {
 #define DCX_CASE(D) case D: return launch_score_D##D;
         DCX_CASE(2) DCX_CASE(4) DCX_CASE(6) DCX_CASE(8) DCX_CASE(12) DCX_CASE(16) DCX_CASE(18) DCX_CASE(21)
         DCX_CASE(24) DCX_CASE(27) DCX_CASE(30) DCX_CASE(32) DCX_CASE(36) DCX_CASE(42) DCX_CASE(48) DCX_CASE(54)
-        DCX_CASE(60) DCX_CASE(64) DCX_CASE(72)
+        DCX_CASE(60) DCX_CASE(64) DCX_CASE(72) DCX_CASE(84) DCX_CASE(96)
 #undef DCX_CASE
     default: return nullptr;
     }

@@ -8,7 +8,7 @@
 namespace dcx {
 
 // feature widths the sweep is compiled for; any D <= DCX_MAX_D is zero-padded up to the next one
-static constexpr int kTemplateD[] = {2, 4, 6, 8, 12, 16, 18, 21, 24, 27, 30, 32, 36, 42, 48, 54, 60, 64, 72};
+static constexpr int kTemplateD[] = {2, 4, 6, 8, 12, 16, 18, 21, 24, 27, 30, 32, 36, 42, 48, 54, 60, 64, 72, 84, 96};
 static constexpr int kNumTemplateD = sizeof(kTemplateD) / sizeof(int);
 
 inline int template_d_for(int D) {
@@ -31,7 +31,8 @@ DCX_DECLARE_LAUNCH(2)  DCX_DECLARE_LAUNCH(4)  DCX_DECLARE_LAUNCH(6)  DCX_DECLARE
 DCX_DECLARE_LAUNCH(12) DCX_DECLARE_LAUNCH(16) DCX_DECLARE_LAUNCH(18) DCX_DECLARE_LAUNCH(21)
 DCX_DECLARE_LAUNCH(24) DCX_DECLARE_LAUNCH(27) DCX_DECLARE_LAUNCH(30) DCX_DECLARE_LAUNCH(32)
 DCX_DECLARE_LAUNCH(36) DCX_DECLARE_LAUNCH(42) DCX_DECLARE_LAUNCH(48) DCX_DECLARE_LAUNCH(54)
-DCX_DECLARE_LAUNCH(60) DCX_DECLARE_LAUNCH(64) DCX_DECLARE_LAUNCH(72)
+DCX_DECLARE_LAUNCH(60) DCX_DECLARE_LAUNCH(64) DCX_DECLARE_LAUNCH(72) DCX_DECLARE_LAUNCH(84)
+DCX_DECLARE_LAUNCH(96)
 #undef DCX_DECLARE_LAUNCH
 
 // aux_kernels.hip

@@ -270,10 +270,10 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
 
     // How many SGPRs a pipeline may keep in flight: ~100 exist, the kernel needs a dozen for itself.  Four whole rows
     // (the deepest pipeline) fit up to 22 floats per row; wider rows run a two-buffer pipeline over whole rows
-    // (<= 38 floats) or over half rows.  Before this split the compiler kept the four-row pipeline
+    // (<= 38 floats), over half rows, or over thirds of a row (D > 75).  Before this split the compiler kept the four-row pipeline
     // alive for every width by parking SGPRs in VGPR lanes: D=24 +37 %, D=42 +75 %, D=60 +97 % VALU instructions
     // (v_writelane / v_readlane) inside the sweep.
-    constexpr int PARTS = (4 * USED <= (CC > 1 ? DCX_P0_MAX_MULTI : DCX_P0_MAX_SINGLE)) ? 0 : (2 * USED <= 76) ? 1 : 2;
+    constexpr int PARTS = (4 * USED <= (CC > 1 ? DCX_P0_MAX_MULTI : DCX_P0_MAX_SINGLE)) ? 0 : (USED + 37) / 38;  // parts of <= 38 floats
     if constexpr (PARTS == 0) {
     // Explicit software pipeline, two rows per stage (4 row buffers): the wait before a stage covers loads
     // issued TWO row bodies earlier, which is what hides an L2-latency scalar miss when only a few waves
@@ -401,7 +401,7 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (j < j1) consume(bufA, P0c{});  // bufA holds row j
-            } else {
+            } else if constexpr (PARTS == 2) {
                 // two half-row buffers: wait -> issue second half -> consume first half -> wait -> issue the next row's
                 // first half -> consume second half (row complete)
                 load_part(bufA, j0, P0c{});
@@ -418,6 +418,46 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
                     __builtin_amdgcn_sched_barrier(0);
                     consume(bufB, P1c{});
                     __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                // three or more parts per row (D > 75): the same two buffers, alternating over the part stream; with an
+                // odd part count a row boundary flips the buffer parity, so the loop body covers two rows
+                auto step = [&](auto self, auto uc, int j) __attribute__((always_inline)) -> void {
+                    constexpr int U = decltype(uc)::value;          // position in the two-row part stream
+                    constexpr int NU = U + 1;                        // the part requested now
+                    __builtin_amdgcn_s_waitcnt(0xC07F);
+                    __builtin_amdgcn_sched_barrier(0);
+                    {
+                        const int jr = j + NU / PARTS;
+                        const int row = jr < j1 ? jr : jl;
+                        if constexpr (NU % 2 == 0) load_part(bufA, row, std::integral_constant<int, NU % PARTS>{});
+                        else load_part(bufB, row, std::integral_constant<int, NU % PARTS>{});
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (U % 2 == 0) consume(bufA, std::integral_constant<int, U % PARTS>{});
+                    else consume(bufB, std::integral_constant<int, U % PARTS>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (U + 1 < 2 * PARTS) self(self, std::integral_constant<int, U + 1>{}, j);
+                };
+                load_part(bufA, j0, P0c{});
+                int j = j0;
+                for (; j + 1 < j1; j += 2) step(step, P0c{}, j);
+                if (j < j1) {  // one row left; bufA holds its first part (2 * PARTS steps keep the parity)
+                    auto tail = [&](auto self, auto pc) __attribute__((always_inline)) -> void {
+                        constexpr int P = decltype(pc)::value;
+                        __builtin_amdgcn_s_waitcnt(0xC07F);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (P + 1 < PARTS) {
+                            if constexpr ((P + 1) % 2 == 0) load_part(bufA, j, std::integral_constant<int, P + 1>{});
+                            else load_part(bufB, j, std::integral_constant<int, P + 1>{});
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (P % 2 == 0) consume(bufA, pc);
+                        else consume(bufB, pc);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (P + 1 < PARTS) self(self, std::integral_constant<int, P + 1>{});
+                    };
+                    tail(tail, P0c{});
                 }
             }
         }

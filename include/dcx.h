@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DCX_VERSION 102 /* 0.1.2: DCX_FK_TREE section appended to dcx_fk_desc (older offsets unchanged); 16 chains */
+#define DCX_VERSION 103 /* 0.1.3: dcx_fk_desc carries the DCX_FK_TREE section; 32 control points, D <= 96 */
 
 /* ---- status codes ---------------------------------------------------------------- */
 #define DCX_OK 0
@@ -65,9 +65,9 @@ extern "C" {
 
 #define DCX_MAX_JOINTS 16 /* per chain */
 #define DCX_MAX_CHAINS 2
-#define DCX_MAX_POINTS 24
+#define DCX_MAX_POINTS 32
 #define DCX_MAX_DOF 32
-#define DCX_MAX_D 72  /* feature width n_points * point_dim the fused kernels are compiled for */
+#define DCX_MAX_D 96  /* feature width n_points * point_dim the fused kernels are compiled for */
 #define DCX_MAX_C 8   /* weight columns (classes) the fused kernels are compiled for           */
 #define DCX_MAX_TREE_CHAINS 16 /* root-to-leaf paths of a DCX_FK_TREE                           */
 #define DCX_MAX_TREE_BASES 4   /* distinct base transforms among them (robots side by side)     */

@@ -22,7 +22,7 @@ FK_NAMES = ["planar2", "planar3", "planar7", "se2", "se3", "baxter_left", "baxte
 
 
 URDF_NAMES = ["urdf_panda", "urdf_panda_nogripper", "urdf_fetch_arm", "urdf_iiwa7", "urdf_allegro", "urdf_trifinger",
-              "urdf_jaco", "urdf_2link", "urdf_fetch"]
+              "urdf_jaco", "urdf_2link", "urdf_fetch", "urdf_iiwa7_allegro"]
 
 
 def urdf_model(name):

@@ -39,7 +39,7 @@ for D in (2, 3, 5, 7, 9, 12, 13, 14, 16, 17, 18, 19, 21, 23, 24, 25, 27, 30, 31,
     CASES.append(("none", D, int(_rng.integers(1, 9)), int(_rng.integers(len(KERNELS)))))
 for D in (4, 8, 18, 22, 26, 36, 38, 42, 44, 48, 54, 60, 62, 64):
     CASES.append(("planar", D, int(_rng.integers(1, 9)), int(_rng.integers(len(KERNELS)))))
-for D in (27, 33, 39, 45, 51, 57, 63, 66, 69, 72):
+for D in (27, 33, 39, 45, 51, 57, 63, 66, 69, 72, 75, 78, 84, 87, 90, 96):
     CASES.append(("se3", D, int(_rng.integers(1, 9)), int(_rng.integers(len(KERNELS)))))
 for C in range(1, 9):  # every class count at a half-row width and at a two-row width
     CASES.append(("planar", 40, C, C % len(KERNELS)))

@@ -92,7 +92,8 @@ def test_structural_zeros_survive_the_reverse_sweep(ops):
 
 @pytest.mark.parametrize("name,kspec,C", [("urdf_panda", (1, 1.0, 1.0), 1), ("urdf_fetch_arm", (0, 10.0, 2.0), 1),
                                           ("urdf_allegro", (1, 1.0, 1.0), 3), ("urdf_trifinger", (0, 3.0, 3.0), 2),
-                                          ("urdf_jaco", (2, 0.7, 0.0), 1)])
+                                          ("urdf_jaco", (2, 0.7, 0.0), 1), ("urdf_fetch", (1, 1.0, 1.0), 1),
+                                          ("urdf_iiwa7_allegro", (1, 1.0, 1.0), 1), ("urdf_iiwa7_allegro", (0, 10.0, 2.0), 2)])
 def test_fused_score_grad_on_urdf_trees(ops, name, kspec, C):
     """K(T(q), supports) @ W and its gradient with the tree fused into the sweep kernel, vs the fp64 oracle"""
     from oracle import oracle

@@ -115,12 +115,12 @@ def test_parser_rejects_what_the_reference_cannot_move():
 
 
 def test_limits_of_the_compiled_description():
-    """28 feature links (iiwa7 + allegro) exceed DCX_MAX_POINTS: a clear error, never a silent truncation"""
+    """more feature links than DCX_MAX_POINTS (32): a clear error, never a silent truncation"""
     from diffco_amd.urdf import URDFRobotFK
-    links = ["base"] + [f"l{i}" for i in range(30)]
+    links = ["base"] + [f"l{i}" for i in range(40)]
     joints = [dict(name=f"j{i}", type="revolute", parent=links[i], child=links[i + 1], xyz=[0, 0, 0.1], rpy=[0, 0, 0],
                    axis=[0, 0, 1], lower=-1.0, upper=1.0, mimic_joint=None, mimic_multiplier=1.0, mimic_offset=0.0)
-              for i in range(30)]
+              for i in range(40)]
     with pytest.raises(ValueError, match="compiled limits"):
         URDFRobotFK(urdf_xml(dict(links=links, joints=joints)))
 

@@ -43,6 +43,7 @@ if __name__ == "__main__":
     S = 2000
     for B in (4096, 65536):
         run("panda DH (7 pts)", model.PandaFK(), S, B)
-        for n in ("urdf_panda_nogripper", "urdf_panda", "urdf_fetch_arm", "urdf_jaco", "urdf_allegro"):
+        for n in ("urdf_panda_nogripper", "urdf_panda", "urdf_fetch_arm", "urdf_jaco", "urdf_allegro", "urdf_fetch",
+                  "urdf_iiwa7_allegro"):
             run(n, H.urdf_robot(n), S, B)
         run("urdf_dual_panda", H.dual_panda_robot(), S, B)

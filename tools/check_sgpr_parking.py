@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "diffco_amd", "csrc")
-WIDTHS = [2, 4, 6, 8, 12, 16, 18, 21, 24, 27, 30, 32, 36, 42, 48, 54, 60, 64, 72]
+WIDTHS = [2, 4, 6, 8, 12, 16, 18, 21, 24, 27, 30, 32, 36, 42, 48, 54, 60, 64, 72, 84, 96]
 
 
 def compile_width(d):

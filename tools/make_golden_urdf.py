@@ -47,8 +47,9 @@ ROBOTS = {
 }
 
 
-LATER = {"urdf_fetch": "fetch_description/urdf/fetch.urdf"}  # whole robot: 14 dof, 21 links, 9 leaves, gazebo blocks
-LATER_SEEDS = {"urdf_fetch": 5151}
+LATER = {"urdf_fetch": "fetch_description/urdf/fetch.urdf",        # whole robot: 14 dof, 21 links, 9 leaves, gazebo blocks
+         "urdf_iiwa7_allegro": "kuka_iiwa/urdf/iiwa7_allegro.urdf"}  # arm + hand: 23 dof, 28 links (D = 84)
+LATER_SEEDS = {"urdf_fetch": 5151, "urdf_iiwa7_allegro": 6161}
 
 ABSENT = ("fcl", "trimesh", "yourdfpy", "rospy", "curobo")
 
