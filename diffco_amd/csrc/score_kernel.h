@@ -336,8 +336,6 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
             }
 #pragma unroll
             for (int e = 0; e < LEN; ++e) {
-                constexpr int unused = 0;
-                (void)unused;
                 const int g = P0 + e;  // compile-time after unrolling
                 if (g + 1 < D && (g & 1) == 0) {
                     const v2f xv = {x[g], x[g + 1]};
