@@ -10,8 +10,9 @@ kernels of libdcx.  `fused_adam_traj_optimize` (diffco_amd/traj.py) is the batch
 Differences worth knowing:
   * the straight-line initial path is built with numpy from array views of the endpoints (the reference's
     `torch.from_numpy(np.linspace(tensor, tensor))` breaks under numpy 2 / torch 2.10 — SURVEY.md §8c);
-  * trust-constr gets a quasi-Newton (BFGS) constraint Hessian: the exact one needs second derivatives
-    of the score, which the HIP path does not provide (ask with options['exact_hessian'] -> NotImplementedError).
+  * trust-constr's collision-constraint Hessian (the reference double-backwards through dist_est) is built from
+    central differences of the fused analytic gradient, chained exactly through the dense-path geometry
+    (`_ScipyTerms.hess_collision`); a BFGS model when dist_est is not a fusable diffco_amd score.
 """
 import time
 from typing import Dict
@@ -248,6 +249,59 @@ class _ScipyTerms:
             J.index_put_((row, seg + 1), a, accumulate=True)
         return J[:, 1:-1].numpy().reshape(n_seg, -1)
 
+    HESS_FD_STEP = 4e-3  # rad (or m): fp32 gradient noise ~1e-6 / step against step^2 truncation
+
+    def hess_collision(self, x, v):
+        """[(W-2)*dof, (W-2)*dof] Hessian of v . collision(x), the `hess` of the reference's trust-constr constraint
+        (optim.py:380-391, a double backward through dist_est).  With a fusable dist_est the per-point score
+        Hessians are central differences of the ANALYTIC fused gradient — all 2*dof probes of every dense point in
+        one `dcx_score_grad` launch — and the dense-path geometry is chained exactly: the second-order Taylor
+        model of hinge(score) around each dense point, composed with dense_n(p), has the same Hessian in p as the
+        constraint itself, and autograd differentiates that small fp64 surrogate twice on the host.
+        Otherwise: the reference's route (needs a twice-differentiable dist_est)."""
+        v = torch.as_tensor(np.asarray(v), dtype=torch.float64)
+        m = self._fused_model()
+        if m is not None and self.dense_cap is None:
+            return self._hess_collision_fused(x, v, m)
+        p = self.prob.full(x)
+        count = self.prob.cnt_check
+        H = torch.autograd.functional.hessian(
+            lambda z: torch.dot(self.prob.segment_collision(z, self.dist_est, self.dense_cap), v), p,
+            create_graph=False, strict=False, vectorize=True, outer_jacobian_strategy='reverse-mode')
+        self.prob.cnt_check = count
+        W, dof = p.shape
+        return H[1:-1, :, 1:-1, :].numpy().reshape((W - 2) * dof, -1)
+
+    def _hess_collision_fused(self, x, v, model):
+        prob = self.prob
+        p = prob.full(x).detach()
+        W, dof = p.shape
+        ms = prob.max_speed
+        dense, seg, step = utils.dense_path_indexed(p, ms)
+        pts, seg, step = dense[1:-1], seg[1:-1], step[1:-1]
+        n_seg, n_pt = W - 1, len(pts)
+        if n_pt == 0:
+            return np.zeros(((W - 2) * dof, (W - 2) * dof))
+        per = -(-n_pt // n_seg)
+        eps = self.HESS_FD_STEP
+        probes = pts[:, None, None, :] + eps * torch.stack([torch.eye(dof), -torch.eye(dof)]).to(pts.dtype)[None]
+        q32 = torch.cat([pts, probes.reshape(-1, dof)]).to(device=model.dev, dtype=torch.float32).contiguous()
+        s, g = model.score_grad_raw(q32)
+        s, g = s.double().cpu()[:n_pt, 0], g.double().cpu()
+        active = -((s - prob.safety_margin) > 0).double() * v[torch.arange(n_pt) // per]  # d(v.c)/d score_n
+        gp = g[n_pt:].reshape(n_pt, 2, dof, dof)
+        S = (gp[:, 0] - gp[:, 1]) / (2 * eps)
+        S = 0.5 * (S + S.transpose(1, 2)) * active[:, None, None]
+        h = g[:n_pt] * active[:, None]
+
+        def taylor(z):
+            delta = z[1:] - z[:-1]
+            unit = delta / delta.norm(dim=1, keepdim=True)
+            d = z[seg] + (step * ms)[:, None] * unit[seg] - pts
+            return (h * d).sum() + 0.5 * torch.einsum('ni,nij,nj->', d, S, d)
+        H = torch.autograd.functional.hessian(taylor, p, vectorize=True)
+        return H[1:-1, :, 1:-1, :].numpy().reshape((W - 2) * dof, -1)
+
     def joint_limit(self, x):
         return -self.prob.joint_limit_violation(self.prob.full(x).detach()).item()
 
@@ -296,14 +350,24 @@ def givengrad_traj_optimize(robot, dist_est, start_cfg, target_cfg, options):
 
 
 def trustconstr_traj_optimize(robot, dist_est, start_cfg, target_cfg, options):
-    """trust-constr with analytic first derivatives and a BFGS model of the constraint Hessian"""
-    if options.get('exact_hessian'):
-        raise NotImplementedError("exact constraint Hessians need second derivatives of the score kernel")
+    """trust-constr with analytic first derivatives and a Hessian of the collision constraint (reference
+    optim.py:486-492).  options['constraint_hessian']: 'auto' (default) = the fused finite-difference-of-analytic-
+    gradient Hessian when dist_est is a fusable diffco_amd score, else a BFGS model; 'fused' / 'autograd' (the
+    reference's double backward through dist_est) / 'bfgs' force one."""
     max_iter = options['MAXITER']
+    mode = options.get('constraint_hessian', 'auto')
+    if mode not in ('auto', 'fused', 'autograd', 'bfgs'):
+        raise ValueError(f"constraint_hessian: {mode!r}")
 
     def run(terms, x0):
+        fused = terms._fused_model() is not None and terms.dense_cap is None
+        if mode == 'fused' and not fused:
+            raise ValueError("constraint_hessian='fused' needs dist_est to be a single-output diffco_amd score of this robot")
+        if mode == 'autograd':
+            terms._model = None
+        hess = BFGS() if mode == 'bfgs' or (mode == 'auto' and not fused) else terms.hess_collision
         return minimize(terms.cost, x0, jac=terms.grad_cost, method='trust-constr',
-                        constraints=[NonlinearConstraint(terms.collision, 0, np.inf, jac=terms.jac_collision, hess=BFGS()),
+                        constraints=[NonlinearConstraint(terms.collision, 0, np.inf, jac=terms.jac_collision, hess=hess),
                                      NonlinearConstraint(terms.joint_limit, 0, np.inf, jac=terms.grad_joint_limit,
                                                          hess=BFGS())],
                         options={'maxiter': max_iter, **options.get('extra_optimizer_options', {})})

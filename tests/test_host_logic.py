@@ -246,3 +246,32 @@ def test_analytic_constraint_jacobian_matches_autograd():
     Jb = terms.jac_collision(x)
     assert Ja.shape == Jb.shape == (5, 12) and np.abs(Jb).max() > 1.0
     assert np.abs(Ja - Jb).max() < 1e-6 * np.abs(Jb).max()  # the fused route evaluates the points in fp32
+
+
+def test_constraint_hessian_from_gradient_differences_matches_double_backward():
+    """trust-constr's `hess`: central differences of the (stand-in) analytic gradient at the dense points, chained
+    through the dense-path geometry by autograd on the Taylor surrogate, equal the reference's double backward
+    through dist_est (optim.py:380-391)"""
+    from diffco_amd import optim
+    g = torch.Generator().manual_seed(1)
+    p = torch.randn((6, 3), generator=g, dtype=torch.float64)
+
+    class FakeModel:
+        C, dev = 1, torch.device("cpu")
+
+        def score_grad_raw(self, q, upstream=None, want_score=True):
+            return torch.sin(q.double()).sum(1, keepdim=True), torch.cos(q.double())
+
+    class Rob:
+        dof, limits = 3, torch.tensor([[-3.0, 3.0]] * 3)
+    prob = optim._PathProblem(Rob(), p[0], p[-1], {"N_WAYPOINTS": 6, "max_speed": 0.3, "safety_margin": 0.1})
+    prob.init_path = p.clone()
+    terms = optim._ScipyTerms(prob, lambda q: torch.sin(q).sum(1, keepdim=True))
+    x = p[1:-1].reshape(-1).numpy()
+    v = np.random.default_rng(0).standard_normal(5)
+    Ha = terms._hess_collision_fused(x, torch.from_numpy(v), FakeModel())
+    terms._model = None  # the reference's route
+    Hb = terms.hess_collision(x, v)
+    assert Ha.shape == Hb.shape == (12, 12) and np.abs(Hb).max() > 0.5
+    assert np.abs(Ha - Ha.T).max() < 1e-12
+    assert np.abs(Ha - Hb).max() < 1e-5 * np.abs(Hb).max()  # step^2 / 6 truncation of the central difference
