@@ -109,12 +109,38 @@ __global__ __launch_bounds__(64) void score_finish_kernel(const FinishArgs a) {
     float* sG = smem + lp.g;
     float* sF = smem + lp.f;
     const float* part = a.partial + (size_t)blockIdx.x * a.ys * a.acc * 64 + lane;
+    // v[u] = rows y = 0, 1, ... of accumulators e0 .. e0+n-1 added in that order; 8 accumulators x 2 rows of loads in
+    // flight at a time (one load per round trip made this kernel latency-bound: ys * acc dependent L2 reads)
+    constexpr int EC = 8;
+    auto fold = [&](int e0, int n, float* v) {
+#pragma unroll
+        for (int u = 0; u < EC; ++u) v[u] = 0.0f;
+        int y = 0;
+        for (; y + 1 < a.ys; y += 2) {
+            float r0[EC], r1[EC];
+#pragma unroll
+            for (int u = 0; u < EC; ++u) {
+                const int e = e0 + (u < n ? u : 0);
+                r0[u] = part[((size_t)y * a.acc + e) * 64];
+                r1[u] = part[((size_t)(y + 1) * a.acc + e) * 64];
+            }
+#pragma unroll
+            for (int u = 0; u < EC; ++u) v[u] = (v[u] + r0[u]) + r1[u];
+        }
+        if (y < a.ys) {
+#pragma unroll
+            for (int u = 0; u < EC; ++u) v[u] += part[((size_t)y * a.acc + e0 + (u < n ? u : 0)) * 64];
+        }
+    };
     float score0 = 0.0f;
-    for (int c = 0; c < a.C; ++c) {
-        float v = 0.0f;
-        for (int y = 0; y < a.ys; ++y) v += part[((size_t)y * a.acc + c) * 64];
-        if (c == 0) score0 = v;
-        if (a.score != nullptr && lane < nb) a.score[(b0 + lane) * a.C + c] = v;
+    for (int c0 = 0; c0 < a.C; c0 += EC) {
+        float v[EC];
+        const int n = (a.C - c0) < EC ? (a.C - c0) : EC;
+        fold(c0, n, v);
+        if (c0 == 0) score0 = v[0];
+#pragma unroll
+        for (int u = 0; u < EC; ++u)
+            if (u < n && a.score != nullptr && lane < nb) a.score[(b0 + lane) * a.C + c0 + u] = v[u];
     }
     if (!a.want_grad) return;
     const fk_cptr fk = stage_fk_prog(a.fk, smem + lp.fk, lane, 64);
@@ -126,10 +152,13 @@ __global__ __launch_bounds__(64) void score_finish_kernel(const FinishArgs a) {
     float scale = 1.0f;
     if (a.C == 1 && a.upstream != nullptr) scale = a.upstream[b0 + (lane < nb ? lane : nb - 1)];
     if (a.C == 1 && a.hinge) scale = (score0 - a.hinge_margin > 0.0f) ? a.hinge_weight : 0.0f;
-    for (int k = 0; k < a.d_fk; ++k) {
-        float v = 0.0f;
-        for (int y = 0; y < a.ys; ++y) v += part[((size_t)y * a.acc + a.C + k) * 64];
-        sG[k * 64 + lane] = v * scale;
+    for (int k0 = 0; k0 < a.d_fk; k0 += EC) {
+        float v[EC];
+        const int n = (a.d_fk - k0) < EC ? (a.d_fk - k0) : EC;
+        fold(a.C + k0, n, v);
+#pragma unroll
+        for (int u = 0; u < EC; ++u)
+            if (u < n) sG[(k0 + u) * 64 + lane] = v[u] * scale;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();

@@ -305,6 +305,17 @@ inline int fk_frame_floats(const dcx_fk_desc& fk) {
 
 typedef const __attribute__((address_space(3))) FkProg* fk_cptr;
 
+// Developer-only per-joint stamps inside the FK phases (build with -DDCX_TIMING; see score_kernel.h DCX_TS)
+#ifdef DCX_TIMING
+static __shared__ unsigned long long* dcx_fk_ts;
+#define DCX_FK_TS(slot, col)                                                                     \
+    do {                                                                                         \
+        if (dcx_fk_ts && (threadIdx.x & 63) == 0) dcx_fk_ts[(slot) * 8 + (col)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define DCX_FK_TS(slot, col) do { } while (0)
+#endif
+
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // all threads of the block copy the program global -> LDS (coalesced); caller synchronises
@@ -313,6 +324,9 @@ __device__ __forceinline__ fk_cptr stage_fk_prog(const FkProg* g, float* lds, in
     uint32_t* dst = reinterpret_cast<uint32_t*>(lds);
     const int n = rfl(g->n_dwords);
     for (int i = tid; i < n; i += nthreads) dst[i] = src[i];
+#ifdef DCX_TIMING
+    if (tid == 0) dcx_fk_ts = nullptr;  // the fused kernel points it at its stamp buffer afterwards
+#endif
     return (fk_cptr)(uintptr_t)(uint32_t)(uintptr_t)lds;  // generic -> LDS: the low 32 bits are the LDS offset
 }
 
@@ -609,6 +623,7 @@ __device__ inline void fk_forward_chain(fk_cptr fk, const float* sQrow, float* s
                     out[64] = fmaf(r10, ox, fmaf(r11, oy, fmaf(r12, oz, t1)));
                     out[128] = fmaf(r20, ox, fmaf(r21, oy, fmaf(r22, oz, t2)));
                 }
+                DCX_FK_TS(7 + (j < 8 ? j : 8), 0);
             }
             float* fr = sFcol + (2 * njt + 9 * ch) * 64;  // final rotation of this chain (for the reverse sweep)
             fr[0] = r00; fr[64] = r01; fr[128] = r02; fr[192] = r10; fr[256] = r11; fr[320] = r12;
@@ -732,6 +747,7 @@ __device__ inline void fk_vjp(fk_cptr fk, const float* sQrow, const float* sFcol
                 const float n22 = fmaf(G21, sa, fmaf(G22, ca, T2 * d));
                 G00 = n00; G01 = n01; G02 = n02; G10 = n10; G11 = n11; G12 = n12; G20 = n20; G21 = n21; G22 = n22;
                 r00 = p00; r01 = p01; r02 = p02; r10 = p10; r11 = p11; r12 = p12; r20 = p20; r21 = p21; r22 = p22;
+                DCX_FK_TS(7 + (j < 8 ? j : 8), 1);
             }
         }
     } else if (kind == DCX_FK_TREE) {

@@ -490,6 +490,9 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
     DCX_TS(0);
     // ---- prologue: stage the FK description and the q rows (coalesced), FK per lane on wave 0 ----
     const fk_cptr fk = stage_fk_prog(a.fk, smem + lp.fk, threadIdx.x, blockDim.x);
+#ifdef DCX_TIMING
+    if (threadIdx.x == 0) dcx_fk_ts = (a.ts && blockIdx.x == a.ts_block && blockIdx.y == 0) ? a.ts : nullptr;
+#endif
     {
         const float* qsrc = a.q + b0 * dof;
         const int n = nb * dof;
@@ -589,39 +592,77 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
         // split launch (small batches): this block saw only its super-chunk; score_finish_kernel adds the
         // ys partial rows in a fixed order (deterministic) and applies J^T
         float* out = a.partial + ((size_t)blockIdx.x * a.ys + blockIdx.y) * ACC * 64 + lane;
+        if (a.tile_done == nullptr) {
 #pragma unroll
-        for (int c = 0; c < CC; ++c) out[c * 64] = sc[c];
-        if constexpr (GRAD) {
+            for (int c = 0; c < CC; ++c) out[c * 64] = sc[c];
+            if constexpr (GRAD) {
 #pragma unroll
-            for (int k = 0; k < D; ++k) out[(CC + k) * 64] = gx[k];
+                for (int k = 0; k < D; ++k) out[(CC + k) * 64] = gx[k];
+            }
+            return;
         }
-        if (a.tile_done == nullptr) return;
         // "last block done": publish this block's row, count arrivals; whoever sees ys-1 earlier arrivals owns the
         // tile, re-reads ALL ys rows in the fixed order y = 0, 1, ... (so the result does not depend on which block
         // came last) and carries on into the ordinary epilogue with its own q rows and FK frames (every block of a
         // tile computed the same ones).  No block ever waits for another.
-        __threadfence();
-        unsigned int arrived = 0;
-        if (lane == 0) arrived = atomicAdd(a.tile_done + blockIdx.x, 1u);
-        arrived = __builtin_amdgcn_readfirstlane(arrived);
-        if (arrived != (unsigned int)a.ys - 1u) return;
-        if (lane == 0) a.tile_done[blockIdx.x] = 0u;  // ready for the next launch on this stream
-        __threadfence();
-        const float* part = a.partial + (size_t)blockIdx.x * a.ys * ACC * 64 + lane;
+        // The row goes out as agent-scope (write-through) stores, so the release fence in front of the counter has
+        // no dirty L2 lines of this block to write back; the owner's acquire fence then makes every row visible.
 #pragma unroll
-        for (int c = 0; c < CC; ++c) {
-            float v = __builtin_nontemporal_load(part + c * 64);
-            for (int y = 1; y < a.ys; ++y) v += __builtin_nontemporal_load(part + ((size_t)y * ACC + c) * 64);
-            sc[c] = v;
-        }
+        for (int c = 0; c < CC; ++c) __hip_atomic_store(out + c * 64, sc[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if constexpr (GRAD) {
 #pragma unroll
-            for (int k = 0; k < D; ++k) {
-                float v = __builtin_nontemporal_load(part + (CC + k) * 64);
-                for (int y = 1; y < a.ys; ++y) v += __builtin_nontemporal_load(part + ((size_t)y * ACC + CC + k) * 64);
-                gx[k] = v;
+            for (int k = 0; k < D; ++k)
+                __hip_atomic_store(out + (CC + k) * 64, gx[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        DCX_FK_TS(7, 2);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        DCX_FK_TS(8, 2);
+        unsigned int arrived = 0;
+        if (lane == 0) arrived = __hip_atomic_fetch_add(a.tile_done + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        arrived = __builtin_amdgcn_readfirstlane(arrived);
+        DCX_FK_TS(9, 2);
+        if (arrived != (unsigned int)a.ys - 1u) return;
+        if (lane == 0) a.tile_done[blockIdx.x] = 0u;  // ready for the next launch on this stream
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        DCX_FK_TS(10, 2);
+        // rows y = 0, 1, ... added in that order (0 + r0 + r1 + ..., as score_finish_kernel does); the loads of up to
+        // 16 accumulators x YU rows are in flight together — one load per round trip cost 4-9 k cycles here
+        const float* part = a.partial + (size_t)blockIdx.x * a.ys * ACC * 64 + lane;
+        constexpr int EC = ACC < 16 ? ACC : 16;
+        constexpr int YU = 2;
+#pragma unroll
+        for (int e0 = 0; e0 < ACC; e0 += EC) {
+            float tot[EC];
+#pragma unroll
+            for (int u = 0; u < EC; ++u) tot[u] = 0.0f;
+            for (int y = 0; y < a.ys; y += YU) {
+                float r[YU][EC];
+#pragma unroll
+                for (int v = 0; v < YU; ++v) {
+                    const int yy = (y + v < a.ys) ? y + v : y;  // past the end: re-read row y, not added
+#pragma unroll
+                    for (int u = 0; u < EC; ++u)
+                        if (e0 + u < ACC) r[v][u] = __builtin_nontemporal_load(part + ((size_t)yy * ACC + e0 + u) * 64);
+                }
+#pragma unroll
+                for (int v = 0; v < YU; ++v) {
+                    if (y + v < a.ys) {
+#pragma unroll
+                        for (int u = 0; u < EC; ++u)
+                            if (e0 + u < ACC) tot[u] += r[v][u];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < EC; ++u) {
+                const int e = e0 + u;
+                if (e < ACC) {
+                    if (e < CC) sc[e < CC ? e : 0] = tot[u];
+                    else if constexpr (GRAD) gx[(e - CC) < D && e >= CC ? e - CC : 0] = tot[u];
+                }
             }
         }
+        DCX_FK_TS(11, 2);
     }
 
     if (a.score != nullptr && lane < nb) {
@@ -638,6 +679,7 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
 #pragma unroll
         for (int k = 0; k < D; ++k)
             if (k < a.d_fk) sG[k * 64 + lane] = gx[k] * scale;
+        DCX_FK_TS(12, 2);
         // J^T gX per lane.  The gradient row is built in place of the lane's own q row: every
         // fk_vjp branch reads what it needs from the q row before its first write to gq.
         float* gq = smem + lp.q;

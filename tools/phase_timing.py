@@ -33,4 +33,10 @@ print(f"workload {args.workload} B={args.batch} env NW={os.environ.get('DCX_NW')
 for slot, name in enumerate(names):
     row = [buf[slot * 8 + wv] for wv in range(8)]
     print(f"{name:<18}" + " ".join(f"{(v - t0) if v else -1:>9d}" for v in row))
+for j in range(9):
+    print(f"joint {j}: chain done {buf[(7 + j) * 8] - t0 if buf[(7 + j) * 8] else -1:>9d}   J^T done "
+          f"{buf[(7 + j) * 8 + 1] - t0 if buf[(7 + j) * 8 + 1] else -1:>9d}")
+for j, nm in enumerate(["partial row stored", "release fence", "arrival counted", "second fence", "rows re-read", "G staged"]):
+    v = buf[(7 + j) * 8 + 2]
+    print(f"finish: {nm:<20} {v - t0 if v else -1:>9d}")
 print("(cycles of the constant 100 MHz s_memtime/readcyclecounter clock unless the part reports shader clocks)")
