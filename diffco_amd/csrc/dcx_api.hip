@@ -218,10 +218,13 @@ Geometry pick_geometry(const dcx_model* m, int64_t B, int acc_floats, bool allow
     Geometry g;
     g.ys = 1;
     if (allow_split && 2 * tiles <= m->n_cu) {
-        // graph-replay timings, headline: B=1024 36 -> 27.5 us, B=4096 36 -> 28.5 us with ys=4..8;
-        // at 200 tiles (B=12800) the split already loses (39 vs 45 us)
-        g.ys = (int)std::min<int64_t>(8, (2 * (int64_t)m->n_cu) / tiles);
-        g.nw = std::min(8, cap);
+        // Small batches: split the supports over ys blocks per tile until there is one block per CU, but keep ~250
+        // supports per block, 16 waves each.  Graph-replay grid over ys x nw (profiles/r01_split_grid.txt): headline
+        // (S=2000) B=1024 18.0 us at ys=8, B=4096 20.9 us at ys=4, B=8192 27.0 us at ys=2; config #2 (S=1000) B=4096
+        // 17.7 us at ys=4 (19.2 at ys=2, 23.5 at ys=8)
+        const int64_t want = std::min<int64_t>((int64_t)m->n_cu / tiles, m->S_active / 250);
+        while (2 * g.ys <= want && g.ys < 32) g.ys *= 2;
+        g.nw = std::min(16, cap);
     } else {
         g.nw = std::min((tiles <= 4 * (int64_t)m->n_cu) ? 16 : 8, cap);
     }
@@ -233,9 +236,11 @@ Geometry pick_geometry(const dcx_model* m, int64_t B, int acc_floats, bool allow
         const int v = std::atoi(e);
         if (v >= 1) g.nw = std::min(v, cap);
     }
-    // keep >= 32 supports per wave slice
-    while (g.ys > 1 && m->S_active / (g.ys * g.nw) < 32) g.ys /= 2;
-    while (g.nw > 1 && m->S_active / (g.ys * g.nw) < 32) g.nw /= 2;
+    // keep >= 15 supports per wave slice
+    int min_rows = 15;
+    if (const char* e = std::getenv("DCX_MIN_ROWS")) min_rows = std::max(1, std::atoi(e));
+    while (g.ys > 1 && m->S_active / (g.ys * g.nw) < min_rows) g.ys /= 2;
+    while (g.nw > 1 && m->S_active / (g.ys * g.nw) < min_rows) g.nw /= 2;
     const int d_fk = m->fk.n_points * m->fk.point_dim;
     auto lds_bytes = [&](int nw, int slots) {
         return (size_t)(lds_plan(m->fk.dof, d_fk, m->frame_floats, nw > 1 ? slots : 0, acc_floats, true).total + m->prog_floats) * sizeof(float);
@@ -323,9 +328,10 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
     if (part) {
         const bool second_launch = std::getenv("DCX_SPLIT_FINISH_KERNEL") != nullptr;  // A/B and tests
         // graph-replay timings (profiles/r01_sweep_small_batch_graph.txt): finishing inside the launch saves the second
-        // launch and its FK (B=1024: 27.1 -> 23.3 us headline, 24.4 -> 20.0 us config #2) but every block's release fence
-        // is an L2 write-back, which loses once there are hundreds of blocks (B=8192: 35.9 -> 43.2 us); at 64 tiles config #2 still gains 6-7 %
-        int64_t inlaunch_max = 64;
+        // launch and its FK.  With the rows written through L2 and re-read two at a time it wins at every batch the
+        // split is used for (<= n_cu / 2 tiles): B=1024 23.3 -> 19.1 us, B=4096 29.9 -> 21.8 us, B=8192 32.5 -> 30.0 us
+        // headline; 19.9 -> 18.2, 23.6 -> 19.4, 24.2 -> 21.2 us config #2
+        int64_t inlaunch_max = 128;
         if (const char* e = std::getenv("DCX_INLAUNCH_TILES")) inlaunch_max = std::min<int64_t>(std::atoll(e), (int64_t)kTileCounters);
         if (nblk <= inlaunch_max && !second_launch) counters = reinterpret_cast<unsigned int*>(part);
         part = reinterpret_cast<float*>(reinterpret_cast<char*>(part) + kScratchHead);

@@ -588,7 +588,7 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
     }
 
     DCX_TS(4);
-    if (a.partial != nullptr) {
+    if (__builtin_expect(a.partial != nullptr, 0)) {
         // split launch (small batches): this block saw only its super-chunk; score_finish_kernel adds the
         // ys partial rows in a fixed order (deterministic) and applies J^T
         float* out = a.partial + ((size_t)blockIdx.x * a.ys + blockIdx.y) * ACC * 64 + lane;
