@@ -225,6 +225,13 @@ Geometry pick_geometry(const dcx_model* m, int64_t B, int acc_floats, bool allow
         const int64_t want = std::min<int64_t>((int64_t)m->n_cu / tiles, m->S_active / 250);
         while (2 * g.ys <= want && g.ys < 32) g.ys *= 2;
         g.nw = std::min(16, cap);
+    } else if (allow_split && 3 * tiles <= 2 * (int64_t)m->n_cu && (int64_t)m->S_active * m->Dt >= 18000) {
+        // between n_cu / 2 and 2 n_cu / 3 tiles: thirds of the supports put at most two blocks (2/3 of a tile's sweep)
+        // on a CU instead of one whole tile: headline B=9216 36.5 -> 32.1 us, B=10240 36.8 -> 32.6 us; beyond that
+        // (B=12800, ys = 3, 4, 5, 8) the replicated FK and the finish cost more than the better balance gives, and so
+        // they do for a light sweep (config #2, S * D = 12 000: 24.0 -> 25.0 us)
+        g.ys = 3;
+        g.nw = std::min(16, cap);
     } else {
         g.nw = std::min((tiles <= 4 * (int64_t)m->n_cu) ? 16 : 8, cap);
     }
@@ -331,7 +338,7 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
         // launch and its FK.  With the rows written through L2 and re-read two at a time it wins at every batch the
         // split is used for (<= n_cu / 2 tiles): B=1024 23.3 -> 19.1 us, B=4096 29.9 -> 21.8 us, B=8192 32.5 -> 30.0 us
         // headline; 19.9 -> 18.2, 23.6 -> 19.4, 24.2 -> 21.2 us config #2
-        int64_t inlaunch_max = 128;
+        int64_t inlaunch_max = 256;
         if (const char* e = std::getenv("DCX_INLAUNCH_TILES")) inlaunch_max = std::min<int64_t>(std::atoll(e), (int64_t)kTileCounters);
         if (nblk <= inlaunch_max && !second_launch) counters = reinterpret_cast<unsigned int*>(part);
         part = reinterpret_cast<float*>(reinterpret_cast<char*>(part) + kScratchHead);
