@@ -174,6 +174,34 @@ def test_split_launch_finish_modes_agree_bitwise(ops, name, monkeypatch):
     assert relerr(_n(s3), _n(s2)) < 3e-6 and relerr(_n(g3), _n(g2)) < 3e-6
 
 
+def test_split_launch_protocol_stress(ops, monkeypatch):
+    """the cross-block hand-over of a split launch (write-through partial rows, release fence, arrival counter, acquire
+    fence, re-read) under load: 300 back-to-back launches at batch sizes that exercise every split geometry (ys = 8, 4,
+    2 and the thirds split), alternating between two streams on one model, each result bit-identical to the
+    second-launch finish of the same inputs — a stale or torn row would show up as a mismatch"""
+    g = torch.Generator().manual_seed(11)
+    desc = desc_for("baxter_left")
+    S = 2000
+    sup = torch.randn((S, 12), generator=g).cuda()
+    w = torch.randn((S, 1), generator=g).cuda()
+    m = ops.ScoreModel(desc, 1, 1.0, 1.0, sup, w)  # Polyharmonic(1, 1)
+    sizes = [64, 1000, 2048, 4096, 8192, 9216, 10240]
+    qs = {n: ((torch.rand((n, 7), generator=g) - 0.5) * 4).cuda() for n in sizes}
+    monkeypatch.setenv("DCX_SPLIT_FINISH_KERNEL", "1")
+    want = {n: m.score_grad_raw(qs[n]) for n in sizes}
+    torch.cuda.synchronize()
+    monkeypatch.delenv("DCX_SPLIT_FINISH_KERNEL")
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    got = []
+    for it in range(300):
+        n = sizes[it % len(sizes)]
+        with torch.cuda.stream(streams[it % 2]):
+            got.append((n, m.score_grad_raw(qs[n])))
+    torch.cuda.synchronize()
+    for n, (s1, g1) in got:
+        assert torch.equal(s1, want[n][0]) and torch.equal(g1, want[n][1]), n
+
+
 def test_ragged_empty_and_padding(ops, monkeypatch):
     monkeypatch.setenv("DCX_NW", "4")  # fixed slicing: results are then bit-identical across batch sizes
     d = load("cfg2_baxter_poly1")
