@@ -203,11 +203,12 @@ int fk_device_copy(int device, const dcx_fk_desc& fk, FkProg** out) {
 }
 
 // Launch geometry.  nw = waves per block (support slices inside a block), ys = support super-chunks across
-// blocks (split launch, finished by score_finish_kernel).  Measured on MI355X (profiles/r01_sweep_variants.txt):
+// blocks (split launch, finished inside the launch by the last block of a tile to arrive, or by score_finish_kernel).
+// Measured on MI355X (profiles/r01_sweep_variants.txt, r01_split_grid.txt):
 //  * occupancy is what hides the scalar-load latency of the sweep, so even a huge batch wants 8 waves per block
 //    (B=1M: nw=1 436, nw=8 687 M evals/s) and a mid-size one 16 (B=65536: 548 vs 555);
 //  * a batch with fewer 64-configuration tiles than CUs cannot fill the chip with one block per tile: the
-//    supports are then also split across blocks (B=4096: 64 tiles on 256 CUs).
+//    supports are then also split across blocks (B=4096: 64 tiles on 256 CUs -> 4 blocks per tile).
 struct Geometry {
     int nw, ys;
     int red_slots;  // LDS rows of the cross-wave fold: nw (parallel fold) or 1 (waves take turns), see score_kernel.h
