@@ -320,17 +320,20 @@ struct Hinge {
     float margin = 0.f, weight = 0.f;
 };
 
+// nz > 1 (MODE_GRAD_UP): the nz classes' one-hot sweeps in ONE launch (gridDim.z), rows to grad + z * dof.  Returns
+// DCX_ERR_UNSUPPORTED without launching when that form is not available (split launch without arrival counters).
 int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstream, float* score, float* grad,
-              int mode, int one_hot, int64_t grad_stride, hipStream_t st, Hinge hinge = Hinge()) {
+              int mode, int one_hot, int64_t grad_stride, hipStream_t st, Hinge hinge = Hinge(), int nz = 1) {
     if (B == 0) return DCX_OK;
     const int d_fk = m->fk.n_points * m->fk.point_dim;
     const int acc = (mode == MODE_SCORE ? 0 : m->Dt) + m->C;
-    Geometry g = pick_geometry(m, B, acc, true);
     const int64_t nblk = (B + 63) / 64;
+    // the split rule sees nz launches' worth of tiles: the classes fill the chip too
+    Geometry g = pick_geometry(m, B * nz, acc, true);
     float* part = nullptr;
     if (g.ys > 1) {
-        part = split_scratch(m, st, (size_t)nblk * g.ys * acc * 64 * sizeof(float));
-        if (!part) g = pick_geometry(m, B, acc, false);
+        part = split_scratch(m, st, (size_t)nblk * nz * g.ys * acc * 64 * sizeof(float));
+        if (!part) g = pick_geometry(m, B * nz, acc, false);
     }
     unsigned int* counters = nullptr;
     if (part) {
@@ -341,7 +344,7 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
         // headline; 19.9 -> 18.2, 23.6 -> 19.4, 24.2 -> 21.2 us config #2
         int64_t inlaunch_max = 256;
         if (const char* e = std::getenv("DCX_INLAUNCH_TILES")) inlaunch_max = std::min<int64_t>(std::atoll(e), (int64_t)kTileCounters);
-        if (nblk <= inlaunch_max && !second_launch) counters = reinterpret_cast<unsigned int*>(part);
+        if (nblk * nz <= inlaunch_max && !second_launch) counters = reinterpret_cast<unsigned int*>(part);
         part = reinterpret_cast<float*>(reinterpret_cast<char*>(part) + kScratchHead);
     }
     if (nblk > 0x7fffffffLL) return fail(DCX_ERR_UNSUPPORTED, "batch too large for one launch");
@@ -363,6 +366,7 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
     a.frame_floats = m->frame_floats;
     a.kind = m->kind;
     a.one_hot = one_hot;
+    a.nz = nz;
     a.grad_stride = grad_stride;
     a.kp0 = m->kp0;
     a.kp1 = m->kp1;
@@ -381,6 +385,7 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
         if (e != hipSuccess) return fail_hip(e, "score kernel launch");
         return DCX_OK;
     }
+    if (nz > 1 && counters == nullptr) return DCX_ERR_UNSUPPORTED;  // score_finish_kernel has no class dimension
     a.partial = part;
     a.tile_done = counters;
     hipError_t e = m->launch(m->kf, m->C, mode, g.nw, lds, nblk, a, st);
@@ -586,7 +591,14 @@ int dcx_score_jac(const dcx_model* m, const float* q, int64_t B, float* score, f
     if (B < 0 || (B > 0 && (!q || !jac))) return fail(DCX_ERR_INVALID, "q / jac is NULL or B < 0");
     if (int rc = set_device(m->device)) return rc;
     if (m->C == 1) return run_score(m, q, B, nullptr, score, jac, MODE_GRAD_ROW, -1, m->fk.dof, (hipStream_t)stream);
-    // one sweep per class with a one-hot upstream; rows land interleaved in jac[b, c, :]
+    // one sweep per class with a one-hot upstream; rows land interleaved in jac[b, c, :].  Up to ~2 waves of blocks the
+    // C sweeps go out as ONE launch (grid z = class) and run side by side; a batch that fills the chip by itself gains
+    // nothing from that and keeps one launch per class.
+    if ((B + 63) / 64 * m->C <= 2 * (int64_t)m->n_cu && !std::getenv("DCX_JAC_PER_CLASS")) {
+        int rc = run_score(m, q, B, nullptr, score, jac, MODE_GRAD_UP, -1, (int64_t)m->C * m->fk.dof, (hipStream_t)stream,
+                           Hinge(), m->C);
+        if (rc != DCX_ERR_UNSUPPORTED) return rc;
+    }
     for (int c = 0; c < m->C; ++c) {
         int rc = run_score(m, q, B, nullptr, c == 0 ? score : nullptr, jac + (int64_t)c * m->fk.dof, MODE_GRAD_UP, c,
                            (int64_t)m->C * m->fk.dof, (hipStream_t)stream);

@@ -15,7 +15,7 @@ constexpr int kMaxT = kD <= 16 ? 1024 : (kD <= 48 ? 512 : 256);
 
 template <int KF, int CC, int MODE>
 hipError_t go(int nw, size_t lds, int64_t nblk, const ScoreArgs& a, hipStream_t st) {
-    score_kernel<kD, KF, CC, MODE, kMaxT><<<dim3((unsigned)nblk, (unsigned)(a.ys > 1 ? a.ys : 1)), dim3(64 * nw), lds, st>>>(a);
+    score_kernel<kD, KF, CC, MODE, kMaxT><<<dim3((unsigned)nblk, (unsigned)(a.ys > 1 ? a.ys : 1), (unsigned)(a.nz > 1 ? a.nz : 1)), dim3(64 * nw), lds, st>>>(a);
     return hipGetLastError();
 }
 

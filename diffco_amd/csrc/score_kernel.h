@@ -56,6 +56,8 @@ struct ScoreArgs {
     int32_t frame_floats;     // per-lane LDS floats for FK frames
     int32_t kind;             // DCX_K_* (used by KF_GEN)
     int32_t one_hot;          // MODE_GRAD_UP: >= 0 selects upstream = e_{one_hot} (Jacobian rows); -1 = use upstream[]
+    int32_t nz;               // MODE_GRAD_UP, > 1: gridDim.z = nz classes in ONE launch, block z takes upstream = e_z and writes
+                              // grad + z * dof (all Jacobian rows at once: the per-class sweeps of a small batch run side by side)
     int64_t grad_stride;      // floats between consecutive configurations' gradient rows (dof, or C*dof for jac)
     float* partial;           // split launch: per (tile, y) partial sums [(tile*ys + y)][ACC][64]; null = finish in-kernel
     unsigned int* tile_done;  // split launch: per-tile arrival counters (zero between launches).  Non-null: the LAST of a
@@ -478,6 +480,7 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nw = blockDim.x >> 6;
     const int64_t b0 = (int64_t)blockIdx.x * 64;
+    const size_t tile = (size_t)blockIdx.x * gridDim.z + blockIdx.z;  // scratch rows / arrival counter of this (tile, class)
     const int nb = (int)((a.B - b0) < 64 ? (a.B - b0) : 64);
     const int dof = a.dof;
     const LdsPlan lp = lds_plan(dof, a.d_fk, a.frame_floats, nw > 1 ? a.red_slots : 0, ACC, true);
@@ -519,8 +522,9 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
     float up[CC];
     if constexpr (MODE == MODE_GRAD_UP) {
         const int64_t bl = b0 + (lane < nb ? lane : nb - 1);
+        const int hot = (a.nz > 1) ? (int)blockIdx.z : a.one_hot;
 #pragma unroll
-        for (int c = 0; c < CC; ++c) up[c] = (a.one_hot >= 0) ? (c == a.one_hot ? 1.0f : 0.0f) : a.upstream[bl * CC + c];
+        for (int c = 0; c < CC; ++c) up[c] = (hot >= 0) ? (c == hot ? 1.0f : 0.0f) : a.upstream[bl * CC + c];
     }
 
     // ---- the sweep: this wave's slice of the supports ----------------------------------------
@@ -591,7 +595,7 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
     if (__builtin_expect(a.partial != nullptr, 0)) {
         // split launch (small batches): this block saw only its super-chunk; score_finish_kernel adds the
         // ys partial rows in a fixed order (deterministic) and applies J^T
-        float* out = a.partial + ((size_t)blockIdx.x * a.ys + blockIdx.y) * ACC * 64 + lane;
+        float* out = a.partial + (tile * a.ys + blockIdx.y) * ACC * 64 + lane;
         if (a.tile_done == nullptr) {
 #pragma unroll
             for (int c = 0; c < CC; ++c) out[c * 64] = sc[c];
@@ -618,16 +622,16 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         DCX_FK_TS(8, 2);
         unsigned int arrived = 0;
-        if (lane == 0) arrived = __hip_atomic_fetch_add(a.tile_done + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) arrived = __hip_atomic_fetch_add(a.tile_done + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         arrived = __builtin_amdgcn_readfirstlane(arrived);
         DCX_FK_TS(9, 2);
         if (arrived != (unsigned int)a.ys - 1u) return;
-        if (lane == 0) a.tile_done[blockIdx.x] = 0u;  // ready for the next launch on this stream
+        if (lane == 0) a.tile_done[tile] = 0u;  // ready for the next launch on this stream
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         DCX_FK_TS(10, 2);
         // rows y = 0, 1, ... added in that order (0 + r0 + r1 + ..., as score_finish_kernel does); the loads of up to
         // 16 accumulators x YU rows are in flight together — one load per round trip cost 4-9 k cycles here
-        const float* part = a.partial + (size_t)blockIdx.x * a.ys * ACC * 64 + lane;
+        const float* part = a.partial + tile * a.ys * ACC * 64 + lane;
         constexpr int EC = ACC < 16 ? ACC : 16;
         constexpr int YU = 2;
 #pragma unroll
@@ -665,7 +669,7 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
         DCX_FK_TS(11, 2);
     }
 
-    if (a.score != nullptr && lane < nb) {
+    if (a.score != nullptr && lane < nb && blockIdx.z == 0) {
 #pragma unroll
         for (int c = 0; c < CC; ++c) a.score[(b0 + lane) * CC + c] = sc[c];
     }
@@ -692,7 +696,7 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
         // rows -> HBM, coalesced (LDS ops of one wave complete in order; no other wave is alive)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
-        float* gdst = a.grad + b0 * a.grad_stride;
+        float* gdst = a.grad + b0 * a.grad_stride + (a.nz > 1 ? (size_t)blockIdx.z * dof : 0);
         const int n = nb * dof;
         if (a.grad_stride == dof) {
             for (int i = lane; i < n; i += 64) gdst[i] = gq[i];

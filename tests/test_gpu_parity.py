@@ -174,6 +174,29 @@ def test_split_launch_finish_modes_agree_bitwise(ops, name, monkeypatch):
     assert relerr(_n(s3), _n(s2)) < 3e-6 and relerr(_n(g3), _n(g2)) < 3e-6
 
 
+@pytest.mark.parametrize("ys", [1, 4])
+def test_jacobian_rows_in_one_launch_equal_one_launch_per_class(ops, ys, monkeypatch):
+    """C > 1: `dcx_score_jac` sends the C one-hot sweeps of a small batch out as ONE launch (grid z = class); with the
+    geometry pinned it is bit-identical to one launch per class, also when the split launch has no arrival counters
+    (then the per-class route is taken) and three times in a row (counters of every (tile, class) back at zero)"""
+    d = load("cfg3_baxter_rq_c5")
+    m, _, _ = _model(ops, "cfg3_baxter_rq_c5", d)
+    q = _t(d["q"][:333])
+    monkeypatch.setenv("DCX_NW", "8")
+    monkeypatch.setenv("DCX_YS", str(ys))
+    monkeypatch.setenv("DCX_MIN_ROWS", "1")
+    runs = [m.score_jac_raw(q) for _ in range(3)]
+    monkeypatch.setenv("DCX_JAC_PER_CLASS", "1")
+    s2, j2 = m.score_jac_raw(q)
+    monkeypatch.delenv("DCX_JAC_PER_CLASS")
+    monkeypatch.setenv("DCX_SPLIT_FINISH_KERNEL", "1")
+    s3, j3 = m.score_jac_raw(q)
+    for s1, j1 in runs:
+        assert torch.equal(s1, s2) and torch.equal(j1, j2)
+    assert torch.equal(s3, s2) and torch.equal(j3, j2)
+    assert float(j2.abs().max()) > 0
+
+
 def test_split_launch_protocol_stress(ops, monkeypatch):
     """the cross-block hand-over of a split launch (write-through partial rows, release fence, arrival counter, acquire
     fence, re-read) under load: 300 back-to-back launches at batch sizes that exercise every split geometry (ys = 8, 4,
