@@ -197,6 +197,16 @@ def test_scipy_optimizers_run_on_a_toy_problem():
         assert sol.shape == (8, 2) and torch.allclose(sol[0], start.double()) and torch.allclose(sol[-1], target.double())
         assert float(bump(sol).max()) < 0.0 + 1e-3, fn.__name__  # the path leaves the bump
         assert rec["cnt_check"] > 0 and np.isfinite(rec["cost"])
+    # trust-constr's constraint Hessian: a foreign dist_est gets a BFGS model by default ('auto'); 'autograd' is the
+    # reference's double backward (optim.py:380-391); 'fused' needs a diffco_amd score
+    for mode in ("bfgs", "autograd"):
+        rec = optim.trustconstr_traj_optimize(Point2D(), bump, start, target, dict(opts, constraint_hessian=mode))
+        sol = torch.tensor(rec["solution"], dtype=torch.float64)
+        assert float(bump(sol).max()) < 1e-3, mode
+    with pytest.raises(ValueError):
+        optim.trustconstr_traj_optimize(Point2D(), bump, start, target, dict(opts, constraint_hessian="fused"))
+    with pytest.raises(ValueError):
+        optim.trustconstr_traj_optimize(Point2D(), bump, start, target, dict(opts, constraint_hessian="exact"))
     rec = optim.gradient_free_traj_optimize(Point2D(), bump, start, target, dict(opts, MAXITER=15))
     assert len(rec["solution"]) == 8 and np.isfinite(rec["cost"])
     two = dict(opts, init_solution=torch.stack([start, target]).double())
