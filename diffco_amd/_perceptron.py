@@ -159,23 +159,23 @@ def kernel_spec(kernel_func):
 
 
 class FusedScorer:
-    """Caches the ScoreModel built from (transform, kernel, supports, weights) and rebuilds it when
-    any of them changes (identity or in-place version)."""
+    """Caches the ScoreModel built from (transform, kernel, supports, weights) and rebuilds it when any of them
+    changes.  The cache holds strong references to the two tensors it was built from and compares by identity plus
+    in-place version, so a freed-and-reallocated tensor at the same address can never alias the cached model; edits
+    that bypass the version counter (`t.data[...] = ...`, `set_`) must be followed by `invalidate()` — the checkers
+    call it from train / fit_poly / to / filter_support_points_."""
 
     def __init__(self):
-        self._key, self._model = None, None
-
-    @staticmethod
-    def _tkey(t):
-        return (t.data_ptr(), t._version, tuple(t.shape), t.dtype, str(t.device))
+        self._key, self._model, self._sup, self._w = None, None, None, None
 
     def model(self, transform, kernel_func, support_feat, weights, device=None):
         spec = kernel_spec(kernel_func)
         desc = transform_desc(transform)
-        key = (None if desc is None else desc.key(), spec, self._tkey(support_feat), self._tkey(weights), str(device))
-        if key != self._key:
+        key = (None if desc is None else desc.key(), spec, support_feat._version, weights._version,
+               tuple(support_feat.shape), tuple(weights.shape), str(device))
+        if self._model is None or self._sup is not support_feat or self._w is not weights or key != self._key:
             self._model = _ops.ScoreModel(desc, spec[0], spec[1], spec[2], support_feat, weights, device=device)
-            self._key = key
+            self._key, self._sup, self._w = key, support_feat, weights
         return self._model
 
     def score(self, transform, kernel_func, support_feat, weights, point):
@@ -190,4 +190,4 @@ class FusedScorer:
         return m.score(point.reshape(-1, m.dof))
 
     def invalidate(self):
-        self._key, self._model = None, None
+        self._key, self._model, self._sup, self._w = None, None, None, None

@@ -1,6 +1,7 @@
 // dcx_api.hip — the C ABI declared in include/dcx.h: model lifetime, argument checking,
 // launch geometry.  No torch types cross this boundary.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -29,8 +30,8 @@ struct dcx_model {
     launch_fn launch = nullptr;
     int32_t max_threads = 0;
     int32_t n_cu = 256;
-    // scratch for split launches (small batches): one buffer per stream that has used this model, so that
-    // launches on different streams never share partial rows.  Guarded by `mu`; never shrinks.
+    // scratch for split launches (small batches): one fixed-size buffer per stream that has used this model, so that
+    // launches on different streams never share partial rows.  Guarded by `mu`; freed only by dcx_model_destroy.
     struct Scratch {
         hipStream_t stream;
         float* ptr;
@@ -202,6 +203,30 @@ int fk_device_copy(int device, const dcx_fk_desc& fk, FkProg** out) {
     return DCX_OK;
 }
 
+// Developer knobs: overrides of the geometry rules below for tests and A/B tools.  The DCX_* environment variables are
+// read ONCE, when the library first needs them; afterwards only dcx_debug_set() changes a knob.  Nothing on the launch
+// path calls getenv.  -1 = "use the rule".
+struct Knobs {
+    std::atomic<int64_t> ys{-1}, nw{-1}, min_rows{-1}, split_finish_kernel{-1}, inlaunch_tiles{-1}, jac_per_class{-1},
+        mfma{-1};
+    Knobs() {
+        auto rd = [](const char* name, std::atomic<int64_t>& dst, bool flag) {
+            if (const char* e = std::getenv(name)) dst = flag ? 1 : std::atoll(e);
+        };
+        rd("DCX_YS", ys, false);
+        rd("DCX_NW", nw, false);
+        rd("DCX_MIN_ROWS", min_rows, false);
+        rd("DCX_SPLIT_FINISH_KERNEL", split_finish_kernel, true);
+        rd("DCX_INLAUNCH_TILES", inlaunch_tiles, false);
+        rd("DCX_JAC_PER_CLASS", jac_per_class, true);
+        rd("DCX_MFMA", mfma, false);
+    }
+};
+Knobs& knobs() {
+    static Knobs k;
+    return k;
+}
+
 // Launch geometry.  nw = waves per block (support slices inside a block), ys = support super-chunks across
 // blocks (split launch, finished inside the launch by the last block of a tile to arrive, or by score_finish_kernel).
 // Measured on MI355X (profiles/r01_sweep_variants.txt, r01_split_grid.txt):
@@ -236,17 +261,12 @@ Geometry pick_geometry(const dcx_model* m, int64_t B, int acc_floats, bool allow
     } else {
         g.nw = std::min((tiles <= 4 * (int64_t)m->n_cu) ? 16 : 8, cap);
     }
-    if (const char* e = std::getenv("DCX_YS")) {
-        const int v = std::atoi(e);
-        if (v >= 1 && allow_split) g.ys = std::min(v, 64);
-    }
-    if (const char* e = std::getenv("DCX_NW")) {
-        const int v = std::atoi(e);
-        if (v >= 1) g.nw = std::min(v, cap);
-    }
+    const Knobs& kn = knobs();
+    if (const int64_t v = kn.ys; v >= 1 && allow_split) g.ys = (int)std::min<int64_t>(v, 64);
+    if (const int64_t v = kn.nw; v >= 1) g.nw = (int)std::min<int64_t>(v, cap);
     // keep >= 15 supports per wave slice
     int min_rows = 15;
-    if (const char* e = std::getenv("DCX_MIN_ROWS")) min_rows = std::max(1, std::atoi(e));
+    if (const int64_t v = kn.min_rows; v >= 1) min_rows = (int)v;
     while (g.ys > 1 && m->S_active / (g.ys * g.nw) < min_rows) g.ys /= 2;
     while (g.nw > 1 && m->S_active / (g.ys * g.nw) < min_rows) g.nw /= 2;
     const int d_fk = m->fk.n_points * m->fk.point_dim;
@@ -276,43 +296,37 @@ Geometry pick_geometry(const dcx_model* m, int64_t B, int acc_floats, bool allow
     return g;
 }
 
-// This stream's scratch buffer for the partial rows of a split launch, grown on demand.  Returns nullptr when
-// it cannot be provided right now (the stream is being captured into a graph and the buffer does not exist
-// yet, or the allocation failed): the caller then uses the unsplit geometry, which is always valid.
+// This stream's scratch buffer for the partial rows of a split launch.  It is allocated ONCE per (model, stream), at
+// the size of the largest split geometry the rules above can produce for this model (at most 2 * n_cu blocks, each
+// with one row of Dt + C accumulators x 64 lanes), and lives until dcx_model_destroy: a HIP graph captured on the
+// stream keeps a valid pointer for the model's lifetime, and nothing on this path synchronises, frees or reallocates.
+// Returns nullptr when the buffer cannot be provided right now (first use of this stream happens during a graph
+// capture, the allocation failed, or a developer knob asks for more rows than the rules ever would): the caller then
+// uses the unsplit geometry, which is always valid.
 constexpr size_t kTileCounters = 1024;                       // arrival counters at the head of a scratch buffer
 constexpr size_t kScratchHead = kTileCounters * sizeof(unsigned int);
 float* split_scratch(const dcx_model* m, hipStream_t st, size_t bytes) {
     bytes += kScratchHead;
     std::lock_guard<std::mutex> lock(m->mu);
-    dcx_model::Scratch* slot = nullptr;
     for (auto& sc : m->scratch)
-        if (sc.stream == st) slot = &sc;
-    if (slot && slot->bytes >= bytes) return slot->ptr;
+        if (sc.stream == st) return sc.bytes >= bytes ? sc.ptr : nullptr;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
-    if (!slot) {
-        m->scratch.push_back({st, nullptr, 0});
-        slot = &m->scratch.back();
-    }
-    if (slot->ptr) {  // growing: enqueued work may still read the old buffer
-        (void)hipStreamSynchronize(st);
-        (void)hipFree(slot->ptr);
-        slot->ptr = nullptr;
-        slot->bytes = 0;
-    }
-    if (hipMalloc((void**)&slot->ptr, bytes) != hipSuccess) {
+    const size_t fixed = kScratchHead + (size_t)2 * m->n_cu * (m->Dt + m->C) * 64 * sizeof(float);
+    if (bytes > fixed) return nullptr;
+    float* p = nullptr;
+    if (hipMalloc((void**)&p, fixed) != hipSuccess) {
         (void)hipGetLastError();
-        slot->ptr = nullptr;
         return nullptr;
     }
-    if (hipMemset(slot->ptr, 0, kScratchHead) != hipSuccess) {  // the kernels leave the counters at zero themselves
+    // zero the arrival counters on the SAME stream (the kernels leave them at zero themselves afterwards)
+    if (hipMemsetAsync(p, 0, kScratchHead, st) != hipSuccess) {
         (void)hipGetLastError();
-        (void)hipFree(slot->ptr);
-        slot->ptr = nullptr;
+        (void)hipFree(p);
         return nullptr;
     }
-    slot->bytes = bytes;
-    return slot->ptr;
+    m->scratch.push_back({st, p, fixed});
+    return p;
 }
 
 struct Hinge {
@@ -337,13 +351,13 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
     }
     unsigned int* counters = nullptr;
     if (part) {
-        const bool second_launch = std::getenv("DCX_SPLIT_FINISH_KERNEL") != nullptr;  // A/B and tests
+        const bool second_launch = knobs().split_finish_kernel > 0;  // A/B and tests
         // graph-replay timings (profiles/r01_sweep_small_batch_graph.txt): finishing inside the launch saves the second
         // launch and its FK.  With the rows written through L2 and re-read two at a time it wins at every batch the
         // split is used for (<= n_cu / 2 tiles): B=1024 23.3 -> 19.1 us, B=4096 29.9 -> 21.8 us, B=8192 32.5 -> 30.0 us
         // headline; 19.9 -> 18.2, 23.6 -> 19.4, 24.2 -> 21.2 us config #2
         int64_t inlaunch_max = 256;
-        if (const char* e = std::getenv("DCX_INLAUNCH_TILES")) inlaunch_max = std::min<int64_t>(std::atoll(e), (int64_t)kTileCounters);
+        if (const int64_t v = knobs().inlaunch_tiles; v >= 0) inlaunch_max = std::min<int64_t>(v, (int64_t)kTileCounters);
         if (nblk * nz <= inlaunch_max && !second_launch) counters = reinterpret_cast<unsigned int*>(part);
         part = reinterpret_cast<float*>(reinterpret_cast<char*>(part) + kScratchHead);
     }
@@ -429,6 +443,18 @@ int dcx_debug_read_ts(unsigned long long* out) {  // developer builds only
 #endif
 
 int dcx_version(void) { return DCX_VERSION; }
+
+int dcx_debug_set(const char* name, int64_t value) {
+    if (!name) return fail(DCX_ERR_INVALID, "knob name is NULL");
+    Knobs& k = knobs();
+    const std::string n(name);
+    std::atomic<int64_t>* dst = n == "ys" ? &k.ys : n == "nw" ? &k.nw : n == "min_rows" ? &k.min_rows
+        : n == "split_finish_kernel" ? &k.split_finish_kernel : n == "inlaunch_tiles" ? &k.inlaunch_tiles
+        : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : nullptr;
+    if (!dst) return fail(DCX_ERR_INVALID, "unknown knob: " + n);
+    *dst = value;
+    return DCX_OK;
+}
 
 const char* dcx_last_error(void) { return g_err.c_str(); }
 
@@ -594,7 +620,7 @@ int dcx_score_jac(const dcx_model* m, const float* q, int64_t B, float* score, f
     // one sweep per class with a one-hot upstream; rows land interleaved in jac[b, c, :].  Up to ~2 waves of blocks the
     // C sweeps go out as ONE launch (grid z = class) and run side by side; a batch that fills the chip by itself gains
     // nothing from that and keeps one launch per class.
-    if ((B + 63) / 64 * m->C <= 2 * (int64_t)m->n_cu && !std::getenv("DCX_JAC_PER_CLASS")) {
+    if ((B + 63) / 64 * m->C <= 2 * (int64_t)m->n_cu && !(knobs().jac_per_class > 0)) {
         int rc = run_score(m, q, B, nullptr, score, jac, MODE_GRAD_UP, -1, (int64_t)m->C * m->fk.dof, (hipStream_t)stream,
                            Hinge(), m->C);
         if (rc != DCX_ERR_UNSUPPORTED) return rc;

@@ -91,7 +91,9 @@ __device__ bool class_step(const TrainArgs& a, int c, float* sX, Best* sB, int* 
                 const float dl = sX[k] - xj[k];
                 d2 = fmaf(dl, dl, d2);
             }
-            Ki[j] = kernel_value(a, d2);
+            const float kv = kernel_value(a, d2);
+            Ki[j] = kv;
+            a.K[(size_t)j * N + i] = kv;  // and column i, like the reference's K[:, i] = K[i] (kernel_perceptrons.py:117-119)
         }
         __syncthreads();
     }
@@ -99,7 +101,8 @@ __device__ bool class_step(const TrainArgs& a, int c, float* sX, Best* sB, int* 
     if (worst.v <= 0.0f) {
         // 3. margin violated: move sample i onto its target (beta scales the positive target)
         const float yi = a.y[(size_t)i * C + c], hi = a.hypo[(size_t)i * C + c];
-        const float target = (yi > 0.f ? a.beta : 1.0f) * yi;  // beta^((1+y)/2) * y
+        // beta^((1+y)/2) * y (kernel_perceptrons.py:121); exact shortcuts for the usual +-1 labels
+        const float target = (yi == 1.0f ? a.beta : yi == -1.0f ? 1.0f : powf(a.beta, 0.5f * (1.0f + yi))) * yi;
         const float step = __fdiv_rn(__fsub_rn(target, hi), kii);
         __syncthreads();  // everyone has read hypo[i] before it changes
         for (int j = tid; j < N; j += NT) {
@@ -185,6 +188,20 @@ __global__ __launch_bounds__(NT) void perceptron_reg_kernel(const TrainArgs a) {
     int* sCnt = reinterpret_cast<int*>(sB + 16);              // [16]
     float* sS = reinterpret_cast<float*>(sCnt + 16);          // [4] broadcast slots
     const int tid = threadIdx.x, N = a.N;
+    {
+        // The margin form below needs y in {-1, +1}.  Any other label (0/1 labels, y = 0) takes the generic loop,
+        // which computes y*h and beta^((1+y)/2)*y with the actual y like the reference does.
+        int bad = 0;
+        for (int j = tid; j < N; j += NT) bad |= (a.y[j] != 1.0f && a.y[j] != -1.0f);
+        if (__syncthreads_or(bad)) {
+            int it = 0;
+            bool converged = false;
+            for (; it < a.max_iter; ++it)
+                if (class_step(a, 0, sX, sB, sCnt)) { converged = true; break; }
+            if (tid == 0) { a.info[0] = it; a.info[1] = converged ? 1 : 0; }
+            return;
+        }
+    }
     // Per-sample state in "margin form": m = y*h and yg = y*g.  With y in {-1,+1} every update below is the
     // reference's update multiplied by an exact sign, so the roundings (and the argmin sequence) are identical,
     // and the label itself shrinks to one bit.
@@ -237,6 +254,7 @@ __global__ __launch_bounds__(NT) void perceptron_reg_kernel(const TrainArgs a) {
                 }
                 const float kv = kernel_value(a, d2);
                 Ki[j] = kv;
+                a.K[(size_t)j * N + i] = kv;  // column i as well (the reference fills K[i, :] and K[:, i] together)
                 if (j == i) sS[3] = kv;
             }
             __syncthreads();

@@ -59,8 +59,15 @@ class DiffCo(CollisionChecker):
         self.__dict__.update(st)
         self._score_fused, self._rbf_fused = FusedScorer(), FusedScorer()
 
+    def _reset_caches(self):
+        """the supports / weights are about to change: drop the cached FK features and device models"""
+        self._score_feats = None
+        self._score_fused.invalidate()
+        self._rbf_fused.invalidate()
+
     # ------------------------------------------------------------------------------ training
     def initialize(self, X, y):
+        self._reset_caches()
         self.support_points = X.clone()
         self.y = y.reshape(-1).clone()
         assert len(self.y) == len(X)
@@ -106,10 +113,11 @@ class DiffCo(CollisionChecker):
         self.distance = self.distance[mask] if self.distance is not None else None
         self.gains = self.gains[mask]
         self.kernel_matrix = sub_block(self.kernel_matrix, idx, self.gains.device, self.gains.dtype)
-        self._score_feats = None
+        self._reset_caches()
 
     # ------------------------------------------------------------------------------ spline fit
     def _fit_inputs(self, kernel_func, target, fkine):
+        self._reset_caches()
         X = self.support_points
         if fkine is not None:
             X = fkine(X).reshape([len(X), -1]).detach()
@@ -142,7 +150,7 @@ class DiffCo(CollisionChecker):
             t = getattr(self, name, None)
             if t is not None:
                 setattr(self, name, t.to(device))
-        self._score_feats = None
+        self._reset_caches()
         self._cuda = device.type == 'cuda'
 
     @property
@@ -200,6 +208,7 @@ class MultiDiffCo(DiffCo):
         self.num_class = None
 
     def initialize(self, X, y, gains=None, hypothesis=None, kernel_matrix=None):
+        self._reset_caches()
         self.support_points = X.clone()
         self.y = y.clone()
         n = len(X)
@@ -284,5 +293,5 @@ class DiffCoBeta(DiffCo):
         self.gains = solve_system(self.rbf_kernel, self.kernel_matrix, da.reshape(-1, 1).to(self.kernel_matrix.dtype)).reshape(-1)
         self.hypothesis = self.kernel_matrix @ self.gains
         self.rbf_nodes = self.gains
-        self._score_feats = None
+        self._reset_caches()
         print('DiffCo training done. {:.4f} secs cost'.format(time() - t0))

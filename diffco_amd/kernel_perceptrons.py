@@ -70,6 +70,11 @@ class DiffCo(Perceptron):
         self.__dict__.update(st)
         self._score_fused, self._poly_fused, self._polyx_fused = FusedScorer(), FusedScorer(), FusedScorer()
 
+    def _invalidate_fused(self):
+        """drop the cached device models: the state they were built from is about to change"""
+        for f in (self._score_fused, self._poly_fused, self._polyx_fused):
+            f.invalidate()
+
     @property
     def valid_supports(self):
         return self._valid_supports
@@ -148,6 +153,7 @@ class DiffCo(Perceptron):
         # persistent device trainer for diffco_amd kernels (one launch for the whole loop), host loop otherwise
         gains, hypo, K, it = run_trainer(self.kernel_func, Xt, y, gains, hypo, K, self.beta, max_iteration, progress,
                                          cold=not update)
+        self._invalidate_fused()
         if verbose:
             progress.close()
             print(f'Ended at iteration {it}, cost {time() - t0:.4f} secs')
@@ -201,6 +207,7 @@ class DiffCo(Perceptron):
         assert resid <= 1e-4 + 1e-8, f"diff: {resid}"
 
     def filter_support_points_(self, mask):
+        self._invalidate_fused()
         idx = th.where(mask)[0]
         self.support_points = self.support_points[mask]
         self.support_transformed = self.support_points if self.transform is None else self.support_transformed[mask]
@@ -221,6 +228,7 @@ class DiffCo(Perceptron):
         else:
             raise ValueError(f"unknown fit target {target!r}")
         self.rbf_kernel = kernel_func
+        self._invalidate_fused()
         v = self.valid_supports
         Xs = self.support_transformed[:v]
         kmat = self.rbf_kernel(Xs, Xs)
@@ -235,6 +243,7 @@ class DiffCo(Perceptron):
 
     def to(self, device):
         device = th.device(device)
+        self._invalidate_fused()
         for name in ('support_points', 'support_transformed', 'rbf_nodes', 'gains'):
             t = getattr(self, name, None)
             if t is not None:

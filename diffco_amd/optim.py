@@ -217,11 +217,11 @@ class _ScipyTerms:
         if m is not None and self.dense_cap is None:
             return self._jac_collision_fused(x, m)
         p = self.prob.full(x)
-        count = self.prob.cnt_check
+        # the forward pass inside counts len(dense) checks, like the reference's jac_con_collision_free, which calls
+        # con_collision_free once (optim.py:209-218 -> :190-197)
         jac = torch.autograd.functional.jacobian(
             lambda z: self.prob.segment_collision(z, self.dist_est, self.dense_cap), p, create_graph=False,
             strict=False, vectorize=True, strategy='reverse-mode')
-        self.prob.cnt_check = count  # derivative evaluations are not counted as checks by the reference
         return jac[:, 1:-1].numpy().reshape(jac.shape[0], -1)
 
     def _jac_collision_fused(self, x, model):
@@ -230,6 +230,7 @@ class _ScipyTerms:
         W, dof = p.shape
         ms = prob.max_speed
         dense, seg, step = utils.dense_path_indexed(p, ms)
+        prob.cnt_check += len(dense)  # one evaluation of the constraint, as the reference counts it (optim.py:197)
         pts, seg, step = dense[1:-1], seg[1:-1], step[1:-1]
         n_seg, n_pt = W - 1, len(pts)
         per = -(-n_pt // n_seg) if n_pt else 0
@@ -264,11 +265,9 @@ class _ScipyTerms:
         if m is not None and self.dense_cap is None:
             return self._hess_collision_fused(x, v, m)
         p = self.prob.full(x)
-        count = self.prob.cnt_check
-        H = torch.autograd.functional.hessian(
+        H = torch.autograd.functional.hessian(  # counts len(dense) checks, like hess_con_collision_free (optim.py:380-391)
             lambda z: torch.dot(self.prob.segment_collision(z, self.dist_est, self.dense_cap), v), p,
             create_graph=False, strict=False, vectorize=True, outer_jacobian_strategy='reverse-mode')
-        self.prob.cnt_check = count
         W, dof = p.shape
         return H[1:-1, :, 1:-1, :].numpy().reshape((W - 2) * dof, -1)
 
@@ -278,6 +277,7 @@ class _ScipyTerms:
         W, dof = p.shape
         ms = prob.max_speed
         dense, seg, step = utils.dense_path_indexed(p, ms)
+        prob.cnt_check += len(dense)  # the reference's Hessian evaluates the constraint once (optim.py:384)
         pts, seg, step = dense[1:-1], seg[1:-1], step[1:-1]
         n_seg, n_pt = W - 1, len(pts)
         if n_pt == 0:

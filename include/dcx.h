@@ -17,7 +17,11 @@
  *   - Return value: 0 = DCX_OK, otherwise an error code; text via dcx_last_error()
  *     (thread-local).  Nothing throws or exits across the ABI.
  *   - A model handle's numerical state is immutable after creation: concurrent calls on distinct
- *     streams are legal (small-batch launches keep one internal scratch buffer per stream).
+ *     streams are legal (small-batch launches keep one internal scratch buffer per stream, allocated on
+ *     the stream's first small-batch call and freed only by dcx_model_destroy).  A HIP graph captured
+ *     from these calls holds that buffer: keep the model alive while the graph exists, and replay the
+ *     graph on the stream it was captured on (or at least never concurrently with other small-batch
+ *     calls of the same model on the capture stream — they share the buffer's arrival counters).
  */
 #ifndef DCX_H
 #define DCX_H
@@ -138,6 +142,14 @@ int dcx_version(void);
 const char* dcx_last_error(void);
 int dcx_device_count(void);
 
+/* Developer knobs for tests and A/B tools: override one of the launch-geometry rules (they change how the work
+ * is split over blocks, never what is computed).  name: "ys" (support super-chunks per tile), "nw" (waves per
+ * block), "min_rows" (supports per wave slice), "split_finish_kernel" (1 = finish split launches with a second
+ * launch), "inlaunch_tiles", "jac_per_class" (1 = one launch per class in dcx_score_jac), "mfma" (0 = never use the
+ * MFMA contraction, 1 = use it wherever it is compiled).  value < 0 restores the rule.  The initial values come
+ * from the DCX_YS / DCX_NW / ... environment variables, read once at library load; no launch calls getenv.   */
+int dcx_debug_set(const char* name, int64_t value);
+
 /* ---- model = inference state of a kernel perceptron ------------------------------- */
 /* Replaces the state DiffCo.score/poly_score read: support_transformed[S,m,d] + gains[S]
  * or rbf_nodes[S] (kernel_perceptrons.py:41-53, 143-196, 282-283); old API support_fkine[S,D]
@@ -229,10 +241,12 @@ int dcx_traj_adam_run(const dcx_model* model, const dcx_traj_state* st, const dc
 /* DiffCo.train_perceptron kernel_perceptrons.py:98-137 and MultiDiffCo.train_perceptron
  * deprecated/MultiDiffCo.py:50-83 as one persistent launch: worst-margin search, lazily filled kernel rows,
  * margin fix / support retirement, until convergence or max_iteration.
- *   feats [N, D] dev   transformed samples          y [N, C] dev   labels in {-1, +1}
+ *   feats [N, D] dev   transformed samples          y [N, C] dev   labels (normally -1 / +1; any other value
+ *                 is used as given: margin y*h, target beta^((1+y)/2)*y, like the reference's expressions)
  *   gains, hypothesis [N, C] dev in/out (zeros for a cold start, previous state for a jump start)
- *   kernel_matrix [N, N] dev in/out: zeros = "row not computed yet"; rows are filled on first use
- *                 (only rows, not columns: K is symmetric and the trainer reads rows and the diagonal)
+ *   kernel_matrix [N, N] dev in/out: zeros = "row not computed yet"; row i AND column i are filled when sample i
+ *                 is first selected (K[i, :] = K[:, i] = k(x_i, X), kernel_perceptrons.py:117-119), so the sub-block
+ *                 over the kept supports is complete even for a sample that was never selected itself
  *   info [2] dev out: iterations used, 1 if converged                                                    */
 int dcx_train_perceptron(int device, int kernel_kind, const float* kparams, float beta, const float* feats, int64_t N,
                          int32_t D, const float* y, int32_t C, float* gains, float* hypothesis, float* kernel_matrix,

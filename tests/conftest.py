@@ -16,3 +16,20 @@ def pytest_configure(config):
 def _built_oracle():
     from oracle import oracle
     oracle.build()
+
+
+_KNOBS = ("ys", "nw", "min_rows", "split_finish_kernel", "inlaunch_tiles", "jac_per_class", "mfma")
+
+
+@pytest.fixture
+def knob():
+    """knob(name, value): override one launch-geometry rule of libdcx through dcx_debug_set (value < 0 restores the
+    rule); every knob goes back to its rule when the test ends"""
+    from diffco_amd import _lib
+    lib = _lib.load()
+
+    def set_knob(name, value):
+        _lib.check(lib.dcx_debug_set(name.encode(), int(value)))
+    yield set_knob
+    for k in _KNOBS:
+        lib.dcx_debug_set(k.encode(), -1)

@@ -330,3 +330,58 @@ def test_device_trainer_equals_host_trainer_and_reference(monkeypatch):
     assert torch.all((big.hypothesis > 0) == (big.y > 0)) and 10 < big.valid_supports < 20000
     s = big.score(Xb[:4096])
     assert float(((s > 0) == (yb[:4096] > 0)).float().mean()) > 0.99
+
+
+@pytest.mark.parametrize("mns", [None, 16])
+@pytest.mark.parametrize("n", [60, 5000])
+def test_device_trainer_all_equal_labels_then_update(mns, n):
+    """an all-free sample set leaves ONE support; the force-kept second one was never selected, so its
+    kernel-matrix entries exist only because the trainer mirrors row i into column i like the reference
+    (kernel_perceptrons.py:117-119).  Both asserts the reference passes must pass here: `hypothesis == K @ gains`
+    inside train() with max_num_supports, and inside jump_start_initialize on the next train(update=True).
+    n = 60 runs the register-resident kernel, n = 5000 its 20-per-thread form."""
+    from diffco_amd import kernel
+    from diffco_amd.kernel_perceptrons import DiffCo
+    rob = make_robot("baxter_left")
+    g = torch.Generator().manual_seed(5)
+    lim = rob.limits
+    X = torch.rand((n, 7), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]
+    dc = DiffCo(kernel_func=kernel.RQKernel(10.0), beta=1.0, transform=rob.fkine, max_num_supports=mns)
+    dc.train(X, -torch.ones(n), max_iteration=500)
+    v = dc.valid_supports
+    assert v == 2 and int((dc.gains != 0).sum()) == 1
+    K = dc.kernel_matrix[:v, :v]
+    assert float(K[0, 1]) == float(K[1, 0]) != 0.0
+    assert torch.allclose(dc.kernel_matrix @ dc.gains, dc.hypothesis, atol=1e-5)
+    # active-learning round: new samples with both labels, the two supports as the warm start
+    Xn = torch.rand((200, 7), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]
+    yn = torch.where(rob.fkine(Xn)[:, -1, 2] > 0.3, 1.0, -1.0)
+    Xa = torch.cat([Xn, dc.support_points[:v]])
+    ya = torch.cat([yn, dc.y[:v]])
+    mask = torch.cat([torch.zeros(200, dtype=torch.bool), torch.ones(v, dtype=torch.bool)])
+    if mns is not None:
+        dc.max_num_supports = 202
+    dc.train(Xa, ya, update=True, exist_mask=mask, max_iteration=2000)
+    v = dc.valid_supports
+    assert torch.all((dc.hypothesis[:v] > 0) == (dc.y[:v] > 0))
+    assert torch.allclose(dc.kernel_matrix @ dc.gains, dc.hypothesis, atol=1e-4)
+
+
+def test_device_trainer_labels_outside_plus_minus_one():
+    """0/1 labels (and y = 0, which the reference pulls towards 0): the register-resident kernel's margin form needs
+    +-1 labels, so such a label set takes the generic loop — same result as the host loop with the actual y"""
+    from diffco_amd import _ops
+    from diffco_amd import _perceptron as P
+    from diffco_amd import kernel
+    g = torch.Generator().manual_seed(9)
+    feats = torch.rand((300, 6), generator=g)
+    y = (feats[:, 0] > 0.5).float()                    # labels in {0, 1}
+    y[:7] = 0.5
+    kf = kernel.RQKernel(10.0)
+    z = torch.zeros(300)
+    gd, hd, Kd, it_d, _ = _ops.train_perceptron_device(0, 10.0, 2.0, 2.0, feats, y, z, z, None, 400)
+    gh, hh, Kh = z.clone(), z.clone(), torch.zeros(300, 300)
+    it_h = P.train_perceptron(y.clone(), hh, gh, Kh, P.RowFiller(kf, feats, torch.device("cpu")), 2.0, 400)
+    assert it_d in (it_h, it_h + 1)
+    np.testing.assert_array_equal(_np(gd) != 0, gh.numpy() != 0)
+    assert relerr(_np(gd), gh.numpy()) < 1e-4 and relerr(_np(hd), hh.numpy()) < 1e-4

@@ -129,7 +129,7 @@ def test_score_grad_vs_oracle_and_reference(ops, name):
 
 
 @pytest.mark.parametrize("name", ["cfg2_baxter_poly1", "cfg3_baxter_rq_c5", "misc_dualpanda_rq"])
-def test_support_slicing_is_invariant(ops, name, monkeypatch):
+def test_support_slicing_is_invariant(ops, name, knob):
     """every launch geometry — waves per block (support slices meeting in LDS) x support super-chunks across
     blocks (split launch + finish kernel) — gives the same answer"""
     d = load(name)
@@ -139,21 +139,21 @@ def test_support_slicing_is_invariant(ops, name, monkeypatch):
     outs = []
     for ys in (1, 2, 4, 8):
         for nw in (1, 2, 4, 8, 16):
-            monkeypatch.setenv("DCX_NW", str(nw))
-            monkeypatch.setenv("DCX_YS", str(ys))
+            knob("nw", nw)
+            knob("ys", ys)
             s, g = m.score_grad_raw(q, up)
             s0 = m.score_raw(q)
             _, jac = m.score_jac_raw(q)
             outs.append((_n(s), _n(g), _n(s0), _n(jac)))
-    monkeypatch.delenv("DCX_NW")
-    monkeypatch.delenv("DCX_YS")
+    knob("nw", -1)
+    knob("ys", -1)
     for o in outs[1:]:
         for a, b in zip(o, outs[0]):
             assert relerr(a, b) < 3e-6
 
 
 @pytest.mark.parametrize("name", ["cfg2_baxter_poly1", "cfg3_baxter_rq_c5"])
-def test_split_launch_finish_modes_agree_bitwise(ops, name, monkeypatch):
+def test_split_launch_finish_modes_agree_bitwise(ops, name, knob):
     """small batches split the supports across blocks; the rows are added either by the last block to arrive
     (in-launch, arrival counters) or by a second launch — same fixed order, so the results are bit-identical, and the
     counters are back at zero after every launch (three launches in a row)"""
@@ -162,34 +162,34 @@ def test_split_launch_finish_modes_agree_bitwise(ops, name, monkeypatch):
     m = ops.ScoreModel(desc_for(CASE_ROBOT[name]), kind, p0, p1, _t(d["sup_x32"].reshape(len(d["sup_x32"]), -1)), _t(d["weights"]))
     q = _t(d["q"][:150])
     up = _t(d["upstream"][:150]) if m.C > 1 and "upstream" in d.files else None
-    monkeypatch.delenv("DCX_SPLIT_FINISH_KERNEL", raising=False)
+    knob("split_finish_kernel", -1)
     runs = [m.score_grad_raw(q, up) for _ in range(3)]
-    monkeypatch.setenv("DCX_SPLIT_FINISH_KERNEL", "1")
+    knob("split_finish_kernel", 1)
     s2, g2 = m.score_grad_raw(q, up)
     for s1, g1 in runs:
         assert torch.equal(s1, s2) and torch.equal(g1, g2)
-    monkeypatch.delenv("DCX_SPLIT_FINISH_KERNEL")
-    monkeypatch.setenv("DCX_YS", "1")  # and the unsplit launch agrees to rounding
+    knob("split_finish_kernel", -1)
+    knob("ys", 1)  # and the unsplit launch agrees to rounding
     s3, g3 = m.score_grad_raw(q, up)
     assert relerr(_n(s3), _n(s2)) < 3e-6 and relerr(_n(g3), _n(g2)) < 3e-6
 
 
 @pytest.mark.parametrize("ys", [1, 4])
-def test_jacobian_rows_in_one_launch_equal_one_launch_per_class(ops, ys, monkeypatch):
+def test_jacobian_rows_in_one_launch_equal_one_launch_per_class(ops, ys, knob):
     """C > 1: `dcx_score_jac` sends the C one-hot sweeps of a small batch out as ONE launch (grid z = class); with the
     geometry pinned it is bit-identical to one launch per class, also when the split launch has no arrival counters
     (then the per-class route is taken) and three times in a row (counters of every (tile, class) back at zero)"""
     d = load("cfg3_baxter_rq_c5")
     m, _, _ = _model(ops, "cfg3_baxter_rq_c5", d)
     q = _t(d["q"][:333])
-    monkeypatch.setenv("DCX_NW", "8")
-    monkeypatch.setenv("DCX_YS", str(ys))
-    monkeypatch.setenv("DCX_MIN_ROWS", "1")
+    knob("nw", 8)
+    knob("ys", ys)
+    knob("min_rows", 1)
     runs = [m.score_jac_raw(q) for _ in range(3)]
-    monkeypatch.setenv("DCX_JAC_PER_CLASS", "1")
+    knob("jac_per_class", 1)
     s2, j2 = m.score_jac_raw(q)
-    monkeypatch.delenv("DCX_JAC_PER_CLASS")
-    monkeypatch.setenv("DCX_SPLIT_FINISH_KERNEL", "1")
+    knob("jac_per_class", -1)
+    knob("split_finish_kernel", 1)
     s3, j3 = m.score_jac_raw(q)
     for s1, j1 in runs:
         assert torch.equal(s1, s2) and torch.equal(j1, j2)
@@ -197,7 +197,7 @@ def test_jacobian_rows_in_one_launch_equal_one_launch_per_class(ops, ys, monkeyp
     assert float(j2.abs().max()) > 0
 
 
-def test_split_launch_protocol_stress(ops, monkeypatch):
+def test_split_launch_protocol_stress(ops, knob):
     """the cross-block hand-over of a split launch (write-through partial rows, release fence, arrival counter, acquire
     fence, re-read) under load: 300 back-to-back launches at batch sizes that exercise every split geometry (ys = 8, 4,
     2 and the thirds split), alternating between two streams on one model, each result bit-identical to the
@@ -210,10 +210,10 @@ def test_split_launch_protocol_stress(ops, monkeypatch):
     m = ops.ScoreModel(desc, 1, 1.0, 1.0, sup, w)  # Polyharmonic(1, 1)
     sizes = [64, 1000, 2048, 4096, 8192, 9216, 10240]
     qs = {n: ((torch.rand((n, 7), generator=g) - 0.5) * 4).cuda() for n in sizes}
-    monkeypatch.setenv("DCX_SPLIT_FINISH_KERNEL", "1")
+    knob("split_finish_kernel", 1)
     want = {n: m.score_grad_raw(qs[n]) for n in sizes}
     torch.cuda.synchronize()
-    monkeypatch.delenv("DCX_SPLIT_FINISH_KERNEL")
+    knob("split_finish_kernel", -1)
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     got = []
     for it in range(300):
@@ -225,8 +225,8 @@ def test_split_launch_protocol_stress(ops, monkeypatch):
         assert torch.equal(s1, want[n][0]) and torch.equal(g1, want[n][1]), n
 
 
-def test_ragged_empty_and_padding(ops, monkeypatch):
-    monkeypatch.setenv("DCX_NW", "4")  # fixed slicing: results are then bit-identical across batch sizes
+def test_ragged_empty_and_padding(ops, knob):
+    knob("nw", 4)  # fixed slicing: results are then bit-identical across batch sizes
     d = load("cfg2_baxter_poly1")
     m, desc, (kind, p0, p1) = _model(ops, "cfg2_baxter_poly1", d)
     q = _t(d["q"])
@@ -283,11 +283,11 @@ def _rand_q(rob, B, g):
 
 @pytest.mark.parametrize("B,S,C,kspec", [(65536, 2000, 1, (1, 1.0, 1.0)), (65536, 2000, 5, (0, 10.0, 2.0)),
                                           (4096, 1000, 1, (0, 10.0, 2.0))])
-def test_full_size_properties(ops, B, S, C, kspec, monkeypatch):
+def test_full_size_properties(ops, B, S, C, kspec, knob):
     """headline / config #2 / config #3 sizes: linearity in the weights, additivity over a support
     split, invariance to batch order, and an fp64 spot check of 64 random rows."""
     from oracle import oracle
-    monkeypatch.setenv("DCX_NW", "4")
+    knob("nw", 4)
     rob, desc, sup, W, g = _rand_setup(ops, "baxter_left", S, C, kspec)
     q = _rand_q(rob, B, g)
     m = ops.ScoreModel(desc, *kspec, sup, W)

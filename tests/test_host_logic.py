@@ -63,6 +63,25 @@ def test_max_num_supports_padding():
     assert float(dm.rbf_nodes[v:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("mns", [None, 8])
+def test_all_equal_labels_keep_a_second_support(mns):
+    """an all-free sample set trains to ONE support; the 'keep at least two' rule (kernel_perceptrons.py:139-141)
+    then keeps a sample that was never selected, whose kernel-matrix entries against the real support must be there
+    (the reference fills row AND column on selection) for `hypothesis == K @ gains` — asserted inside train() with
+    max_num_supports and inside jump_start_initialize on the next train(update=True) (tests/test_gpu_api.py)"""
+    from diffco_amd.kernel_perceptrons import DiffCo
+    g = torch.Generator().manual_seed(3)
+    X = torch.rand((40, 3), generator=g)
+    y = -torch.ones(40)
+    dc = DiffCo(kernel_func=TorchKernel("rq", 10.0, 2.0), beta=1.0, transform=None, max_num_supports=mns)
+    dc.train(X, y, max_iteration=200)
+    v = dc.valid_supports
+    assert v == 2 and int((dc.gains != 0).sum()) == 1
+    assert torch.allclose(dc.kernel_matrix @ dc.gains, dc.hypothesis, atol=1e-5)
+    assert float(dc.kernel_matrix[:v, :v].abs().min()) > 0 or float(dc.kernel_matrix[1, 1]) == 0.0
+    assert float(dc.kernel_matrix[0, 1]) == float(dc.kernel_matrix[1, 0]) != 0.0
+
+
 def test_old_api_multiclass_trainer_matches_reference():
     from diffco_amd import deprecated, kernel
     d = load("trained_multi_planar2")

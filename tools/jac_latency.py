@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/jac_latency.py — developer tool (GPU box): time of `dcx_score_jac` (all C Jacobian rows) for small batches of
 BASELINE config #3's model (C = 5), as ONE launch with the classes in grid z vs one launch per class
-(DCX_JAC_PER_CLASS=1).  HIP-event time over back-to-back calls."""
+(dcx_debug_set("jac_per_class", 1)).  HIP-event time over back-to-back calls."""
 import os
 import sys
 
@@ -17,10 +17,7 @@ for B in (64, 256, 1024, 4096, 8192):
     m, q = w["model"], w["q"]
     row = []
     for per_class in (False, True):
-        if per_class:
-            os.environ["DCX_JAC_PER_CLASS"] = "1"
-        else:
-            os.environ.pop("DCX_JAC_PER_CLASS", None)
+        m._lib.dcx_debug_set(b"jac_per_class", 1 if per_class else -1)
         for _ in range(5):
             s, j = m.score_jac_raw(q)
         torch.cuda.synchronize()

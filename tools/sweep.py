@@ -46,10 +46,7 @@ def child(args):
                 # free of the Python/ctypes launch overhead that dominates below ~50 us per call
                 side = torch.cuda.Stream(dev)
                 for nw in args.nw:
-                    if nw:
-                        os.environ["DCX_NW"] = str(nw)
-                    else:
-                        os.environ.pop("DCX_NW", None)
+                    lib.dcx_debug_set(b"nw", nw if nw else -1)
                     with torch.cuda.stream(side):   # warm up ON the capture stream (per-stream scratch, lazy init)
                         launch()
                     torch.cuda.synchronize()
@@ -62,10 +59,7 @@ def child(args):
                 st = Ct.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             for rnd in range(args.rounds + 1):
                 for nw in args.nw:
-                    if nw:
-                        os.environ["DCX_NW"] = str(nw)
-                    else:
-                        os.environ.pop("DCX_NW", None)
+                    lib.dcx_debug_set(b"nw", nw if nw else -1)
                     if not args.graph:
                         launch()
                     torch.cuda.synchronize()
