@@ -387,6 +387,10 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
     a.hinge = hinge.on;
     a.hinge_margin = hinge.margin;
     a.hinge_weight = hinge.weight;
+    // MFMA form of the gradient fold: compiled for even D <= 16 with the two specialised kernel functions; needs every
+    // wave to own a slice of the LDS reduction scratch (nw > 1, parallel fold)
+    a.mfma = (mode != MODE_SCORE && m->Dt <= 16 && (m->Dt % 2) == 0 && m->kf != KF_GEN && g.nw > 1 && g.red_slots == g.nw &&
+              knobs().mfma != 0 && knobs().mfma > 0) ? 1 : 0;
 #ifdef DCX_TIMING
     if (!g_ts_dev && hipMalloc((void**)&g_ts_dev, sizeof(unsigned long long) * 16 * 8) == hipSuccess)
         (void)hipMemset(g_ts_dev, 0, sizeof(unsigned long long) * 16 * 8);
@@ -552,6 +556,7 @@ int dcx_model_create(dcx_model** out, int device, const dcx_fk_desc* fk, int ker
     }
     hipError_t e = hipSuccess;
     if (kept > 0) {
+        rows.resize(rows.size() + 8 * (size_t)m->RS + 16, 0.0f);  // the MFMA B-operand loads run up to 7 rows + 15 floats ahead
         e = hipMalloc((void**)&m->rows_dev, rows.size() * sizeof(float));
         if (e == hipSuccess) e = hipMemcpy(m->rows_dev, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice);
     }

@@ -13,8 +13,18 @@ namespace {
 constexpr int kD = DCX_INST_D;
 constexpr int kMaxT = kD <= 16 ? 1024 : (kD <= 48 ? 512 : 256);
 
+// widths / modes that carry the MFMA form of the gradient fold (sweep_rows_mfma)
+template <int KF, int MODE>
+constexpr bool kHasMfma = (kD <= 16) && (kD % 2 == 0) && (MODE != MODE_SCORE) && (KF != KF_GEN);
+
 template <int KF, int CC, int MODE>
 hipError_t go(int nw, size_t lds, int64_t nblk, const ScoreArgs& a, hipStream_t st) {
+    if constexpr (kHasMfma<KF, MODE>) {
+        if (a.mfma) {
+            score_kernel<kD, KF, CC, MODE, kMaxT, true><<<dim3((unsigned)nblk, (unsigned)(a.ys > 1 ? a.ys : 1), (unsigned)(a.nz > 1 ? a.nz : 1)), dim3(64 * nw), lds, st>>>(a);
+            return hipGetLastError();
+        }
+    }
     score_kernel<kD, KF, CC, MODE, kMaxT><<<dim3((unsigned)nblk, (unsigned)(a.ys > 1 ? a.ys : 1), (unsigned)(a.nz > 1 ? a.nz : 1)), dim3(64 * nw), lds, st>>>(a);
     return hipGetLastError();
 }

@@ -72,6 +72,7 @@ struct ScoreArgs {
     unsigned int ts_block;
 #endif
     float kp0, kp1;           // kernel parameters
+    int32_t mfma;             // 1: the launch uses the MFMA form of the gradient fold (score_kernel<..., MF = true>)
     int32_t hinge;            // C == 1: gradient of weight * clamp(score - margin, 0) instead of the score's
     float hinge_margin, hinge_weight;
 };
@@ -470,7 +471,172 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
     }
 }
 
-template <int D, int KF, int CC, int MODE, int MAXT>
+// ---- the sweep with the (configurations x supports) . (supports x features) contraction on the matrix cores ------
+// The gradient fold  gX[b, :] = sum_j coef_bj (x_b - s_j)  is  x_b * (sum_j coef_bj) - (coef[B, S] . s[S, D])[b, :].
+// The second term is a dense GEMM; here it runs on v_mfma_f32_16x16x4_f32 (exact fp32, an fmaf chain in k order — the
+// same arithmetic as the VALU form) while the VALU keeps the per-pair work that is not GEMM-shaped (differences,
+// squared distance, kernel function).  The VALU and matrix pipes issue side by side, so the D fma per pair of the
+// gradient accumulation leave the critical pipe altogether.
+//   * A operand (16 configurations x 4 supports): the four coefficients a lane computed for supports j .. j+3 sit in
+//     four VGPRs; a 4x4 transpose of the 16-lane groups (2 v_permlane32_swap + 2 v_permlane16_swap) turns them into
+//     the A fragments of the wave's four 16-configuration tiles.
+//   * B operand (4 supports x 16 columns): one dword per lane straight from the support rows (lane l reads column
+//     l % 16 of row j + l / 16), prefetched one step ahead.  Columns >= D are never read back.
+//   * the expanded form cancels (x * sum(coef) against coef . s), so it is only ever applied to SHORT runs of
+//     supports: every MF_FLUSH steps the four accumulators go through this wave's LDS scratch back to the
+//     lane-per-configuration layout, are combined with x * sum(coef) of the same run, and restart from zero.  A run's
+//     partial sums stay within 4 * MF_FLUSH supports' worth of magnitude, so the rounding of the subtraction is
+//     ~1e-6 of the result even when every weight has the same sign (distance-regression models).
+#ifndef DCX_MF_FLUSH
+#define DCX_MF_FLUSH 16
+#endif
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <int D, int KF, int CC, int MODE>
+__device__ __forceinline__ void sweep_rows_mfma(const ScoreArgs& a, const float (&x)[D], const float (&up)[CC], int j0, int j1,
+                                                float (&sc)[CC], float (&gx)[D], float* wscr, int lane) {
+    using L = RowLayout<D, CC>;
+    static_assert(D <= 16 && (D % 2) == 0 && MODE != MODE_SCORE, "MFMA sweep: even D <= 16, gradient modes");
+    constexpr int PITCH = D + 1;  // odd pitch: conflict-free ds_read across configurations
+    cfloat_ptr rows = (cfloat_ptr)(uintptr_t)a.rows;
+    const float* rows_g = a.rows;
+    const int grp = lane >> 4, col = lane & 15;
+    v4f acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
+    float asum = 0.0f;
+    float near2 = 1e-30f;  // pairs closer than 1e-3 |x| take the direct form (see pair)
+#pragma unroll
+    for (int k = 0; k < D; ++k) near2 = fmaf(1e-6f * x[k], x[k], near2);
+
+    // one support row: score accumulation on the VALU, returns the gradient coefficient
+    auto pair = [&](const float (&r)[L::RS]) __attribute__((always_inline)) -> float {
+        v2f d2a = {0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k + 1 < D; k += 2) {
+            const v2f xv = {x[k], x[k + 1]};
+            const v2f rv = {r[k], r[k + 1]};
+            const v2f dv = xv - rv;
+            d2a = __builtin_elementwise_fma(dv, dv, d2a);
+        }
+        const float d2 = d2a.x + d2a.y;
+        float val, g;
+        kernel_eval<KF>(d2, a, val, g);
+#pragma unroll
+        for (int c = 0; c < CC; ++c) sc[c] = fmaf(r[L::W_OFF + c], val, sc[c]);
+        float coef;
+        if constexpr (MODE == MODE_GRAD_ROW) {
+            coef = g * r[CC > 1 ? L::WSUM_OFF : L::W_OFF];
+        } else {
+            float wb = 0.0f;
+#pragma unroll
+            for (int c = 0; c < CC; ++c) wb = fmaf(up[c], r[L::W_OFF + c], wb);
+            coef = g * wb;
+        }
+        // A query (almost) on top of a support: coef ~ 1/r is huge and the expanded form would subtract two huge
+        // numbers.  Such a pair takes the direct form  gx += coef * (x - s)  here and leaves the GEMM with a zero
+        // coefficient (r == 0 contributes exactly zero, like the VALU sweep).  Rare: one wave-uniform branch per row.
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(d2 < near2) != 0, 0)) {
+            if (d2 < near2) {
+#pragma unroll
+                for (int k = 0; k < D; ++k) gx[k] = fmaf(coef, x[k] - r[k], gx[k]);
+                coef = 0.0f;
+            }
+        }
+        asum += coef;
+        return coef;
+    };
+    constexpr int USED = D + CC + (CC > 1 ? 1 : 0);
+    auto load_row = [&](float (&dst)[L::RS], int j) __attribute__((always_inline)) {
+        cfloat_ptr r = rows + (size_t)j * L::RS;
+#pragma unroll
+        for (int e = 0; e < USED; ++e) dst[e] = r[e];
+    };
+    // accumulators -> lane-per-configuration layout through this wave's LDS scratch; gx += x * asum - (coef . s)
+    auto flush = [&]() __attribute__((always_inline)) {
+        if (col < D) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wscr[(16 * t + 4 * grp + i) * PITCH + col] = acc[t][i];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < D; ++k) gx[k] = fmaf(x[k], asum, gx[k] - wscr[lane * PITCH + k]);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
+        asum = 0.0f;
+    };
+    // the four coefficients of a step -> A fragments of the four 16-configuration tiles, then the MFMAs
+    auto contract = [&](float c0, float c1, float c2, float c3, float bv) __attribute__((always_inline)) {
+        auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(c0), __float_as_uint(c2), false, false);
+        auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(c1), __float_as_uint(c3), false, false);
+        auto t01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
+        auto t23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(t01[0]), bv, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(t01[1]), bv, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(t23[0]), bv, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(t23[1]), bv, acc[3], 0, 0, 0);
+    };
+
+    if (j0 < j1) {
+        float rowA[L::RS], rowB[L::RS], rowC[L::RS], rowD[L::RS];
+        const int jl = j1 - 1;  // clamp target for the look-ahead loads (harmless re-reads at the end)
+        // B operand: lane l reads column l % 16 of row j + l / 16.  A uniform base that advances by four rows per step
+        // plus a constant per-lane offset (saddr + voffset addressing, no per-step vector address arithmetic).  Rows
+        // past this wave's slice are real rows of the next slice or the zeroed tail padding of the row array
+        // (dcx_model_create pads it): they only ever meet a zero coefficient.
+        const float* bp = rows_g + (size_t)j0 * L::RS;
+        const int boff = grp * L::RS + col;
+        load_row(rowA, j0);
+        load_row(rowB, (j0 + 1 < j1) ? j0 + 1 : jl);
+        float bcur = bp[boff];
+        int j = j0, since = 0;
+        for (; j + 3 < j1; j += 4) {
+            bp += 4 * L::RS;
+            const float bnext = bp[boff];
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_sched_barrier(0);
+            load_row(rowC, j + 2);
+            load_row(rowD, j + 3);
+            __builtin_amdgcn_sched_barrier(0);
+            const float c0 = pair(rowA);
+            const float c1 = pair(rowB);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_sched_barrier(0);
+            load_row(rowA, (j + 4 < j1) ? j + 4 : jl);
+            load_row(rowB, (j + 5 < j1) ? j + 5 : jl);
+            __builtin_amdgcn_sched_barrier(0);
+            const float c2 = pair(rowC);
+            const float c3 = pair(rowD);
+            contract(c0, c1, c2, c3, bcur);
+            __builtin_amdgcn_sched_barrier(0);
+            bcur = bnext;
+            if (++since == DCX_MF_FLUSH) {
+                flush();
+                since = 0;
+            }
+        }
+        // up to three rows left (rowA / rowB hold rows j and j+1): absent rows contribute a zero coefficient
+        if (j < j1) {
+            float c0 = pair(rowA), c1 = 0.0f, c2 = 0.0f;
+            if (j + 1 < j1) c1 = pair(rowB);
+            if (j + 2 < j1) {
+                load_row(rowC, j + 2);
+                c2 = pair(rowC);
+            }
+            contract(c0, c1, c2, 0.0f, bcur);
+        }
+        flush();
+    }
+}
+
+template <int D, int KF, int CC, int MODE, int MAXT, bool MF = false>
 __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel(const ScoreArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr bool GRAD = (MODE != MODE_SCORE);
@@ -539,7 +705,12 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
     const int j0 = (ybase + wave * a.s_chunk < yend) ? (ybase + wave * a.s_chunk) : yend;
     const int j1 = (j0 + a.s_chunk < yend) ? (j0 + a.s_chunk) : yend;
 
-    sweep_rows<D, KF, CC, MODE>(a, x, up, j0, j1, sc, gx);
+    if constexpr (MF) {
+        // this wave's slice of the reduction scratch doubles as its transpose buffer (X is dead, the fold comes later)
+        sweep_rows_mfma<D, KF, CC, MODE>(a, x, up, j0, j1, sc, gx, sRed + (size_t)wave * ACC * 64, lane);
+    } else {
+        sweep_rows<D, KF, CC, MODE>(a, x, up, j0, j1, sc, gx);
+    }
     DCX_TS(3);
     // ---- meet the NW partial sums in LDS; wave 0 finishes --------------------------------
     if (nw > 1 && a.red_slots == 1) {

@@ -27,6 +27,14 @@ def _n(t):
     return t.detach().cpu().numpy()
 
 
+@pytest.fixture(autouse=True, params=["valu", "mfma"])
+def fold_pipe(request, knob):
+    """every test of this file runs twice: gradient fold on the VALU (knob mfma = 0) and on the matrix cores
+    (v_mfma_f32_16x16x4_f32, knob mfma = 1; shapes without an MFMA instantiation take the VALU form either way)"""
+    knob("mfma", 1 if request.param == "mfma" else 0)
+    yield request.param
+
+
 @pytest.fixture(scope="module")
 def ops():
     from diffco_amd import _lib, _ops
