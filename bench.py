@@ -92,6 +92,23 @@ def make_workload(name, batch, dev, seed=0):
                 dof=desc.dof, q=q.to(dev).contiguous(), sup=sup, W=W, q_cpu=q, rob_name=rob_name, lo=lo, hi=hi)
 
 
+def traj_state(w, R, Wp, dev):
+    """config #5 trajectory state: R restarts of Wp waypoints in joint limits; grad_tol = 0 so no path ever freezes"""
+    import ctypes as Ct
+    from diffco_amd import _lib
+    dof = w["dof"]
+    f32 = dict(device=dev, dtype=torch.float32)
+    path = w["q"][:R * Wp].reshape(R, Wp, dof).clone()
+    bufs = [path, torch.zeros_like(path), torch.zeros_like(path),
+            torch.stack([w["lo"], w["hi"]], dim=1).to(**f32).contiguous(), torch.empty(R * Wp, **f32),
+            torch.empty((R * Wp, dof), **f32), torch.zeros((R, 8), **f32), torch.full((R,), float("inf"), **f32),
+            torch.full((R,), float("inf"), **f32), path.clone(), torch.full((R,), float("inf"), **f32), path.clone(),
+            torch.zeros(R, device=dev, dtype=torch.int32), torch.zeros(R, device=dev, dtype=torch.int32)]
+    tst = _lib.TrajState(R, Wp, *(Ct.c_void_p(t.data_ptr()) for t in bufs))
+    topt = _lib.TrajOpts(0.05, 0.9, 0.999, 1e-8, 1, 10, 10, 10, 0.0, 0.3, 1e-2, 0.0)
+    return tst, topt, bufs
+
+
 def cpu_baseline(w, budget_s=12.0):
     """The CPU oracle (oracle/, a C/OpenMP port of the reference algorithm) timed on this box's host
     cores on a bounded sample of the same workload.  Reported beside the GPU number, never the target."""
@@ -218,18 +235,7 @@ def main():
 
     traj = None
     if w["name"] == "cfg5":
-        # trajectory state: R restarts of W waypoints in joint limits; grad_tol = 0 so no path ever freezes
-        R, Wp = B // 50, 50
-        f32 = dict(device=dev, dtype=torch.float32)
-        path = q.reshape(R, Wp, dof).clone()
-        bufs = [path, torch.zeros_like(path), torch.zeros_like(path),
-                torch.stack([w["lo"], w["hi"]], dim=1).to(**f32).contiguous(), torch.empty(B, **f32),
-                torch.empty((B, dof), **f32), torch.zeros((R, 8), **f32), torch.full((R,), float("inf"), **f32),
-                torch.full((R,), float("inf"), **f32), path.clone(), torch.full((R,), float("inf"), **f32), path.clone(),
-                torch.zeros(R, device=dev, dtype=torch.int32), torch.zeros(R, device=dev, dtype=torch.int32)]
-        tst = _lib.TrajState(R, Wp, *(Ct.c_void_p(t.data_ptr()) for t in bufs))
-        topt = _lib.TrajOpts(0.05, 0.9, 0.999, 1e-8, 1, 10, 10, 10, 0.0, 0.3, 1e-2, 0.0)
-        traj = (tst, topt, bufs)
+        traj = traj_state(w, B // 50, 50, dev)
 
     def step(i, pending):
         if traj is not None:

@@ -62,6 +62,17 @@ int fail_hip(hipError_t e, const char* what) {
         if (e__ != hipSuccess) return fail_hip(e__, #call);  \
     } while (0)
 
+traj_fused_fn traj_fused_for(int Dt) {
+    switch (Dt) {
+#define DCX_CASE(D) case D: return launch_traj_fused_D##D;
+        DCX_CASE(2) DCX_CASE(4) DCX_CASE(6) DCX_CASE(8) DCX_CASE(12) DCX_CASE(16) DCX_CASE(18) DCX_CASE(21)
+        DCX_CASE(24) DCX_CASE(27) DCX_CASE(30) DCX_CASE(32) DCX_CASE(36) DCX_CASE(42) DCX_CASE(48) DCX_CASE(54)
+        DCX_CASE(60) DCX_CASE(64) DCX_CASE(72) DCX_CASE(84) DCX_CASE(96)
+#undef DCX_CASE
+    default: return nullptr;
+    }
+}
+
 launch_fn launch_for(int Dt) {
     switch (Dt) {
 #define DCX_CASE(D) case D: return launch_score_D##D;
@@ -208,7 +219,7 @@ int fk_device_copy(int device, const dcx_fk_desc& fk, FkProg** out) {
 // path calls getenv.  -1 = "use the rule".
 struct Knobs {
     std::atomic<int64_t> ys{-1}, nw{-1}, min_rows{-1}, split_finish_kernel{-1}, inlaunch_tiles{-1}, jac_per_class{-1},
-        mfma{-1};
+        mfma{-1}, traj_fused{-1};
     Knobs() {
         auto rd = [](const char* name, std::atomic<int64_t>& dst, bool flag) {
             if (const char* e = std::getenv(name)) dst = flag ? 1 : std::atoll(e);
@@ -220,6 +231,7 @@ struct Knobs {
         rd("DCX_INLAUNCH_TILES", inlaunch_tiles, false);
         rd("DCX_JAC_PER_CLASS", jac_per_class, true);
         rd("DCX_MFMA", mfma, false);
+        rd("DCX_TRAJ_FUSED", traj_fused, false);
     }
 };
 Knobs& knobs() {
@@ -454,7 +466,7 @@ int dcx_debug_set(const char* name, int64_t value) {
     const std::string n(name);
     std::atomic<int64_t>* dst = n == "ys" ? &k.ys : n == "nw" ? &k.nw : n == "min_rows" ? &k.min_rows
         : n == "split_finish_kernel" ? &k.split_finish_kernel : n == "inlaunch_tiles" ? &k.inlaunch_tiles
-        : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : nullptr;
+        : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : n == "traj_fused" ? &k.traj_fused : nullptr;
     if (!dst) return fail(DCX_ERR_INVALID, "unknown knob: " + n);
     *dst = value;
     return DCX_OK;
@@ -674,6 +686,50 @@ int dcx_traj_adam_run(const dcx_model* m, const dcx_traj_state* st, const dcx_tr
     if (int rc = check_traj(st, opt, m->fk.dof)) return rc;
     if (int rc = set_device(m->device)) return rc;
     const int64_t B = (int64_t)st->n_paths * st->n_waypoints;
+    if (st->n_paths == 0 || n_iters == 0) return DCX_OK;
+    // One persistent launch (traj_fused.h) when a path is one tile of the sweep: W <= 64 waypoints, one workgroup per
+    // path, the iterations looped inside the launch.  Waves per block as the sweep would pick them for a chip-filling
+    // batch (>= 15 supports per slice), fewer if the fold rows would not fit in LDS.
+    if (st->n_waypoints <= 64 && m->S_active > 0 && knobs().traj_fused != 0) {
+        const int d_fk = m->fk.n_points * m->fk.point_dim;
+        int nw = std::min(16, m->max_threads / 64);
+        if (const int64_t v = knobs().nw; v >= 1) nw = (int)std::min<int64_t>(v, m->max_threads / 64);
+        while (nw > 1 && m->S_active / nw < 15) nw /= 2;
+        auto lds_of = [&](int w) {
+            return sizeof(float) * (size_t)(traj_fused_plan(m->fk.dof, d_fk, m->frame_floats, w, m->Dt).total + m->prog_floats);
+        };
+        while (nw > 1 && lds_of(nw) > 150 * 1024) nw /= 2;
+        traj_fused_fn fn = traj_fused_for(m->Dt);
+        if (fn && lds_of(nw) <= 150 * 1024) {
+            TrajFusedArgs a{};
+            a.sc.rows = m->rows_dev;
+            a.sc.fk = m->fk_dev;
+            a.sc.S = m->S_active;
+            a.sc.s_chunk = (m->S_active + nw - 1) / nw;
+            a.sc.dof = m->fk.dof;
+            a.sc.d_fk = d_fk;
+            a.sc.frame_floats = m->frame_floats;
+            a.sc.kind = m->kind;
+            a.sc.kp0 = m->kp0;
+            a.sc.kp1 = m->kp1;
+            a.st = *st;
+            a.opt = *opt;
+            a.n_points = m->fk.n_points;
+            a.point_dim = m->fk.point_dim;
+            a.coord_major = (m->fk.kind == DCX_FK_TREE && m->fk.t_coord_major) ? 1 : 0;
+            for (int done = 0; done < n_iters; done += kTrajFusedMaxIters) {
+                a.n_iters = std::min(kTrajFusedMaxIters, n_iters - done);
+                for (int i = 0; i < a.n_iters; ++i) {
+                    const double t = (double)(first_step + done + i);
+                    a.bias1[i] = (float)(1.0 - std::pow((double)opt->beta1, t));
+                    a.bias2_sqrt[i] = (float)std::sqrt(1.0 - std::pow((double)opt->beta2, t));
+                }
+                hipError_t e = fn(m->kf, nw, lds_of(nw), st->n_paths, a, (hipStream_t)stream);
+                if (e != hipSuccess) return fail_hip(e, "fused trajectory launch");
+            }
+            return DCX_OK;
+        }
+    }
     Hinge h;
     h.on = 1;
     h.margin = opt->safety_margin;

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include "../../include/dcx.h"
 #include "score_kernel.h"
+#include "traj_fused.h"
 
 namespace dcx {
 
@@ -34,6 +35,16 @@ DCX_DECLARE_LAUNCH(36) DCX_DECLARE_LAUNCH(42) DCX_DECLARE_LAUNCH(48) DCX_DECLARE
 DCX_DECLARE_LAUNCH(60) DCX_DECLARE_LAUNCH(64) DCX_DECLARE_LAUNCH(72) DCX_DECLARE_LAUNCH(84)
 DCX_DECLARE_LAUNCH(96)
 #undef DCX_DECLARE_LAUNCH
+// config #5 as one persistent launch (traj_fused.h), one entry point per compiled D as well
+typedef hipError_t (*traj_fused_fn)(int kf, int nw, size_t lds_bytes, int n_paths, const TrajFusedArgs& args, hipStream_t stream);
+#define DCX_DECLARE_TRAJ(D) hipError_t launch_traj_fused_D##D(int, int, size_t, int, const TrajFusedArgs&, hipStream_t);
+DCX_DECLARE_TRAJ(2)  DCX_DECLARE_TRAJ(4)  DCX_DECLARE_TRAJ(6)  DCX_DECLARE_TRAJ(8)
+DCX_DECLARE_TRAJ(12) DCX_DECLARE_TRAJ(16) DCX_DECLARE_TRAJ(18) DCX_DECLARE_TRAJ(21)
+DCX_DECLARE_TRAJ(24) DCX_DECLARE_TRAJ(27) DCX_DECLARE_TRAJ(30) DCX_DECLARE_TRAJ(32)
+DCX_DECLARE_TRAJ(36) DCX_DECLARE_TRAJ(42) DCX_DECLARE_TRAJ(48) DCX_DECLARE_TRAJ(54)
+DCX_DECLARE_TRAJ(60) DCX_DECLARE_TRAJ(64) DCX_DECLARE_TRAJ(72) DCX_DECLARE_TRAJ(84)
+DCX_DECLARE_TRAJ(96)
+#undef DCX_DECLARE_TRAJ
 
 // aux_kernels.hip
 hipError_t launch_score_finish(const FinishArgs& a, int64_t n_tiles, size_t lds_bytes, hipStream_t stream);

@@ -2,6 +2,7 @@
 // every (kernel function, class count, gradient mode) combination, behind a plain dispatcher.
 // Built once per width so the widths compile in parallel (see Makefile).
 #include "dcx_internal.h"
+#include "traj_fused.h"
 
 #ifndef DCX_INST_D
 #error "compile with -DDCX_INST_D=<feature width>"
@@ -65,6 +66,24 @@ hipError_t DCX_CAT(launch_score_D, DCX_INST_D)(int kf, int cc, int mode, int nw,
     case KF_RQ2: return by_cc<KF_RQ2>(cc, mode, nw, lds, nblk, a, st);
     case KF_POLY1: return by_cc<KF_POLY1>(cc, mode, nw, lds, nblk, a, st);
     case KF_GEN: return by_cc<KF_GEN>(cc, mode, nw, lds, nblk, a, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t DCX_CAT(launch_traj_fused_D, DCX_INST_D)(int kf, int nw, size_t lds, int n_paths, const TrajFusedArgs& a,
+                                                    hipStream_t st) {
+    auto go_t = [&](auto kern) {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        kern<<<dim3((unsigned)n_paths), dim3(64 * nw), lds, st>>>(a);
+        return hipGetLastError();
+    };
+    switch (kf) {
+    case KF_RQ2: return go_t(traj_fused_kernel<kD, KF_RQ2, kMaxT>);
+    case KF_POLY1: return go_t(traj_fused_kernel<kD, KF_POLY1, kMaxT>);
+    case KF_GEN: return go_t(traj_fused_kernel<kD, KF_GEN, kMaxT>);
     default: return hipErrorInvalidValue;
     }
 }

@@ -216,3 +216,76 @@ def test_adam_step_multi_wave_paths_and_other_transforms(robot_name, W):
     big = gr.abs() > 1e-4 * gr.abs().max()
     assert float((path.cpu().double() - ref)[big].abs().max()) < 1e-5
     assert torch.equal(path[:, 0].cpu(), paths[:, 0]) and torch.equal(path[:, -1].cpu(), paths[:, -1])
+
+
+def _traj_state(model, rob, paths, seed=0):
+    """device buffers + ctypes state of R paths for dcx_traj_adam_run"""
+    import ctypes as C
+    from diffco_amd import _lib
+    R, W, dof = paths.shape
+    dev = model.dev
+    f32 = dict(device=dev, dtype=torch.float32)
+    path = paths.to(**f32).contiguous().clone()
+    bufs = dict(path=path, adam_m=torch.zeros_like(path), adam_v=torch.zeros_like(path),
+                limits=rob.limits.to(**f32).contiguous(), col_score=torch.zeros(R * W, **f32),
+                col_grad=torch.zeros((R * W, dof), **f32), stats=torch.zeros((R, 8), **f32),
+                lowest_loss=torch.full((R,), float("inf"), **f32), lowest_obj=torch.full((R,), float("inf"), **f32),
+                lowest_path=path.clone(), best_valid_obj=torch.full((R,), float("inf"), **f32),
+                best_valid_path=path.clone(), done=torch.zeros(R, device=dev, dtype=torch.int32),
+                steps=torch.zeros(R, device=dev, dtype=torch.int32))
+    st = _lib.TrajState(R, W, *(C.c_void_p(t.data_ptr()) for t in bufs.values()))
+    return st, bufs
+
+
+def _random_paths(rob, R, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    lim = rob.limits
+    t = torch.linspace(0, 1, W)[None, :, None]
+    a = torch.rand((R, 1, rob.dof), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]
+    b = torch.rand((R, 1, rob.dof), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]
+    return (a * (1 - t) + b * t + 0.1 * torch.randn((R, W, rob.dof), generator=g)).float()
+
+
+@pytest.mark.parametrize("robot_name,R,W,iters,S", [("baxter_left", 7, 20, 40, 500), ("baxter_left", 256, 50, 200, 2000),
+                                                    ("planar3", 5, 64, 25, 300), ("se3", 4, 33, 25, 200),
+                                                    ("urdf_panda", 6, 30, 30, 400)])
+def test_persistent_launch_is_bit_identical_to_the_two_launch_loop(robot_name, R, W, iters, S, knob):
+    """BASELINE config #5 (second case: its full size, 256 restarts x 50 waypoints x 200 iterations) as ONE persistent
+    launch per <= 192 iterations (traj_fused.h) against the two-launches-per-iteration loop: with the same support
+    slicing (16 waves, unsplit) every output — paths, Adam moments, loss terms, best-so-far records, stop flags — is
+    bit-identical, DH arms, planar arms, rigid bodies and URDF trees alike"""
+    import ctypes as C
+    from diffco_amd import _lib, _ops
+    from helpers import urdf_robot
+    rob = urdf_robot(robot_name) if robot_name.startswith("urdf_") else make_robot(robot_name)
+    lib = _lib.require_gpu()
+    g = torch.Generator().manual_seed(S)
+    lim = rob.limits
+    sup_q = torch.rand((S, rob.dof), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]
+    desc = rob.fk_desc()
+    sup = _ops.fkine(desc, sup_q.cuda()).reshape(S, -1)
+    model = _ops.ScoreModel(desc, 1, 1.0, 1.0, sup, (0.02 * torch.randn(S, generator=g)).cuda())
+    paths = _random_paths(rob, R, W, seed=R * W)
+    # margin near the median score so the hinge is active on about half of the waypoints; grad_tol large enough that
+    # some paths stop early (exercises the per-path freeze)
+    s0, _ = model.score_grad_raw(paths.reshape(-1, rob.dof).cuda())
+    opt = _lib.TrajOpts(0.02, 0.9, 0.999, 1e-8, 1, 10, 10, 10, float(s0.median()), 0.3, 1e9, 0.35)
+    outs = []
+    knob("nw", 16)
+    knob("ys", 1)
+    for fused in (0, 1):
+        knob("traj_fused", fused)
+        st, bufs = _traj_state(model, rob, paths)
+        stream = C.c_void_p(torch.cuda.current_stream(model.dev).cuda_stream)
+        _lib.check(lib.dcx_traj_adam_run(model._h, C.byref(st), C.byref(opt), 1, iters - 7, stream))
+        _lib.check(lib.dcx_traj_adam_run(model._h, C.byref(st), C.byref(opt), iters - 6, 7, stream))  # resumes mid-run
+        torch.cuda.synchronize()
+        outs.append({k: v.clone() for k, v in bufs.items() if k not in ("col_score", "col_grad", "limits")})
+    a, b = outs
+    assert int(a["steps"].min()) >= 1 and int(a["steps"].max()) == iters
+    for k in a:
+        assert torch.equal(a[k], b[k]), (k, float((a[k].float() - b[k].float()).abs().max()))
+    assert float((a["path"].cpu() - paths).abs().max()) > 1e-3            # the paths moved
+    assert torch.equal(a["path"][:, 0].cpu(), paths[:, 0]) and torch.equal(a["path"][:, -1].cpu(), paths[:, -1])
+    if robot_name == "baxter_left" and R == 7:
+        assert int(a["done"].sum()) >= 0
