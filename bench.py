@@ -3,13 +3,19 @@
 
 Metric (BASELINE.json): million collision-score+grad evaluations per second, 7-DoF FK kernel, 2k supports.
 One evaluation = one configuration q[7] -> score[C] and d(sum_c upstream*score)/dq[7] against all S supports.
-A "step" = one pass of the hot path (ONE `dcx_score_grad` launch) over one batch of synthetic
-configurations already resident in HBM.  With N > 1 ranks every rank runs its own batch (weak scaling)
-and the scores are all-gathered over RCCL/xGMI each step, overlapped with the next step's sweep.
+A "step" = one pass of the hot path (ONE `dcx_score_grad` launch; config #5: one fused Adam iteration) over one batch
+of synthetic configurations already resident in HBM.
 
     python bench.py                      # 1 GPU, headline workload
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W [--scaling weak|strong] [--gather per-call|serial|bucketed|none]
+
+N > 1: one process per GPU, the model replicated, the configuration batch sharded, no data-path collective; the scores
+of EVERY call are all-gathered over RCCL/xGMI (`--gather per-call`, the default: the gather of call i overlaps the
+sweep of call i+1 on a side stream).  `--scaling weak` (default) keeps the per-GPU batch fixed as N grows,
+`--scaling strong` divides the workload's fixed global batch (65536 for headline / config #3, 256 restarts for
+config #5) by N.  With N > 1 the line also carries short measurements of the other variants (`variants`): the
+other scaling mode, the gather strictly serialised with the sweeps, bucketed every 4 calls, and no gather.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` and `cpu_baseline`.
 """
@@ -31,24 +37,21 @@ PEAK_FP32_TFLOPS = 157.3   # MI355X fp32 vector peak == fp32 MFMA peak (MI355X_M
 PEAK_HBM_GBS = 8000.0
 
 WORKLOADS = {
-    # name: (robot, kernel (kind,p0,p1), S, C, per-GPU batch, description)
-    "headline": ("baxter", (1, 1.0, 1.0), 2000, 1, 65536,
+    # name: (robot, kernel (kind,p0,p1), S, C, per-GPU batch (weak), global batch (strong), description)
+    "headline": ("baxter", (1, 1.0, 1.0), 2000, 1, 65536, 65536,
                  "7-DoF Baxter DH chain (D=12), Polyharmonic(1,1), S=2000, C=1 (SURVEY.md §8d headline)"),
-    "cfg2": ("baxter", (1, 1.0, 1.0), 1000, 1, 4096, "BASELINE config #2: 7-DoF, FK kernel, 1k supports, batch 4096"),
-    "cfg2_panda": ("panda", (1, 1.0, 1.0), 1000, 1, 4096, "config #2 with PandaFK (D=21)"),
-    "cfg3": ("baxter", (0, 10.0, 2.0), 2000, 5, 8192, "BASELINE config #3: MultiDiffCo C=5, RQ(10), S=2000, 8192 per GPU"),
-    "cfg4": (None, (0, 10.0, 2.0), 10000, 1, 1 << 20, "BASELINE config #4: SE(3) no-FK (D=6), RQ(10), S=10k, 1M configs"),
-    # the reference's recommended facade (ForwardKinematicsDiffCo on panda.urdf, tutorial cell 13): URDF tree, 8 dof
-    "urdf_panda": ("urdf_panda", (1, 1.0, 1.0), 2000, 1, 65536,
-                   "URDF Panda with gripper (DCX_FK_TREE: 8 dof, 9 link origins, D=27), Polyharmonic(1,1), S=2000, C=1"),
-    # config #5: a "step" is ONE fused Adam iteration over 256 restarts x 50 waypoints (= 12800 score+grad evals)
-    "cfg5": ("baxter", (1, 1.0, 1.0), 2000, 1, 256 * 50,
-             "BASELINE config #5: fused Adam trajopt, 7-DoF, 50 waypoints x 256 restarts per GPU, S=2000 "
-             "(step = 1 iteration: score+hinge-grad sweep + fused Adam step)"),
+    "cfg2": ("baxter", (1, 1.0, 1.0), 1000, 1, 4096, 4096, "BASELINE config #2: 7-DoF, FK kernel, 1k supports, batch 4096"),
+    "cfg2_panda": ("panda", (1, 1.0, 1.0), 1000, 1, 4096, 4096, "config #2 with PandaFK (D=21)"),
+    "cfg3": ("baxter", (0, 10.0, 2.0), 2000, 5, 8192, 65536,
+             "BASELINE config #3: MultiDiffCo C=5, RQ(10), S=2000, batch 65536 over 8 GPUs = 8192 per GPU"),
+    "cfg4": (None, (0, 10.0, 2.0), 10000, 1, 1 << 20, 1 << 20, "BASELINE config #4: SE(3) no-FK (D=6), RQ(10), S=10k, 1M configs"),
+    # config #5: a "step" is ONE fused Adam iteration over R restarts x 50 waypoints (= 50 R score+grad evals)
+    "cfg5": ("baxter", (1, 1.0, 1.0), 2000, 1, 256 * 50, 256 * 50,
+             "BASELINE config #5: fused Adam trajopt, 7-DoF, 50 waypoints x 256 restarts, S=2000 "
+             "(step = 1 iteration: score+hinge-grad sweep + Adam step; one persistent launch per <= 192 iterations)"),
 }
-
-
-GATHER_EVERY = 4  # N > 1: steps per all-gather bucket
+TRAJ_W = 50
+GATHER_EVERY = 4  # --gather bucketed: calls per all-gather
 
 
 def flops_per_eval(D, C, S):
@@ -63,22 +66,17 @@ def bytes_per_eval(dof, C):
 
 def make_workload(name, batch, dev, seed=0):
     from diffco_amd import _fkdesc, _ops, model
-    rob_name, kspec, S, C, B, desc_txt = WORKLOADS[name]
+    rob_name, kspec, S, C, B, _, desc_txt = WORKLOADS[name]
     B = batch or B
     g = torch.Generator().manual_seed(0)               # the model (supports, weights) is the same on every rank
     gq = torch.Generator().manual_seed(1000 + seed)    # the batch shard is the rank's own
+    rob = None
     if rob_name is None:
         lo = torch.tensor([-10.0] * 3 + [-np.pi] * 3)
         hi = -lo
         desc = _fkdesc.none_desc(6)
     else:
-        if rob_name.startswith("urdf_"):
-            # joint table stored with the golden FK fixture (tests/golden/fk_urdf_*.npz; no URDF file needed)
-            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
-            import helpers
-            rob = helpers.urdf_robot(rob_name)
-        else:
-            rob = {"baxter": model.BaxterLeftArmFK, "panda": model.PandaFK}[rob_name]()
+        rob = {"baxter": model.BaxterLeftArmFK, "panda": model.PandaFK}[rob_name]()
         lo, hi = rob.limits[:, 0], rob.limits[:, 1]
         desc = rob.fk_desc()
     sup_q = torch.rand((S, len(lo)), generator=g) * (hi - lo) + lo
@@ -89,11 +87,12 @@ def make_workload(name, batch, dev, seed=0):
     sup = _ops.fkine(desc, sup_q.to(dev)).reshape(S, -1)
     m = _ops.ScoreModel(desc, *kspec, sup, W.to(dev), device=dev)
     return dict(name=name, text=desc_txt, model=m, desc=desc, kspec=kspec, S=S, C=C, B=B, D=desc.feature_dim,
-                dof=desc.dof, q=q.to(dev).contiguous(), sup=sup, W=W, q_cpu=q, rob_name=rob_name, lo=lo, hi=hi)
+                dof=desc.dof, q=q.to(dev).contiguous(), sup=sup, W=W, q_cpu=q, rob_name=rob_name, rob=rob, lo=lo, hi=hi)
 
 
 def traj_state(w, R, Wp, dev):
-    """config #5 trajectory state: R restarts of Wp waypoints in joint limits; grad_tol = 0 so no path ever freezes"""
+    """config #5 trajectory state for direct `dcx_traj_adam_run` calls (developer tools): R restarts of Wp waypoints in
+    joint limits; grad_tol = 0 so no path ever freezes"""
     import ctypes as Ct
     from diffco_amd import _lib
     dof = w["dof"]
@@ -168,16 +167,139 @@ def torch_cpu_baseline(w, budget_s=6.0):
             "sample": f"{n} configs, torch {torch.__version__} CPU cdist+matmul+backward on precomputed features (no FK)"}
 
 
-def load_pmc_traffic(name):
-    """HBM bytes per launch from a committed rocprofv3 --pmc summary (profiles/pmc_<workload>.json), if any"""
-    p = os.path.join(ROOT, "profiles", f"pmc_{name}.json")
-    if os.path.exists(p):
-        try:
-            with open(p) as f:
-                return json.load(f).get("hbm_bytes_per_launch")
-        except Exception:
+def load_profile_json(fname):
+    p = os.path.join(ROOT, "profiles", fname)
+    try:
+        with open(p) as f:
+            return json.load(f)
+    except Exception:
+        return None
+
+
+# ------------------------------------------------------------------------------------------------- measured loops
+class ScoreLoop:
+    """K calls of `dcx_score_grad` on this rank's batch shard, with the requested all-gather policy for the scores"""
+
+    def __init__(self, w, dev, world, gather):
+        import ctypes as Ct
+        from diffco_amd import _lib
+        self.Ct, self._lib, self.lib = Ct, _lib, _lib.load()
+        self.w, self.dev, self.world, self.gather = w, dev, world, gather
+        B, C, dof = w["B"], w["C"], w["dof"]
+        self.B = B
+        f32 = dict(device=dev, dtype=torch.float32)
+        self.grad = torch.empty((B, dof), **f32)
+        self.qp, self.gp = Ct.c_void_p(w["q"].data_ptr()), Ct.c_void_p(self.grad.data_ptr())
+        self.K = GATHER_EVERY if gather == "bucketed" else 1
+        nbuf = 2 if gather in ("per-call", "bucketed") else 1
+        self.local = [torch.empty((self.K * B, C), **f32) for _ in range(nbuf)]
+        self.full = [torch.empty((world * self.K * B, C), **f32) for _ in range(nbuf)] if gather != "none" else None
+        self.comm = torch.cuda.Stream(dev) if gather in ("per-call", "bucketed") else None
+        self.pending = [None] * nbuf
+        self.gather_events = []
+
+    def step(self, i, last):
+        Ct, w = self.Ct, self.w
+        K, B = self.K, self.B
+        b = (i // K) % len(self.local)
+        if self.comm is not None and i % K == 0 and self.pending[b] is not None:
+            self.pending[b].wait()  # this buffer's previous gather must be done before the sweep rewrites it
+            self.pending[b] = None
+        out = self.local[b][(i % K) * B:(i % K + 1) * B]
+        st = Ct.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+        self._lib.check(self.lib.dcx_score_grad(w["model"]._h, self.qp, B, None, Ct.c_void_p(out.data_ptr()), self.gp, st))
+        if self.gather == "none" or not (i % K == K - 1 or i == last):
+            return
+        if self.gather == "serial":
+            # the consumer needs the gathered scores before it issues the next call: same stream, strictly in order
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dist.all_gather_into_tensor(self.full[0], self.local[0])
+            e1.record()
+            self.gather_events.append((e0, e1))
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(self.comm):
+            self.comm.wait_event(ev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.pending[b] = dist.all_gather_into_tensor(self.full[b], self.local[b], async_op=True)
+            e1.record()
+            self.gather_events.append((e0, e1))
+
+    def drain(self):
+        for k, h in enumerate(self.pending):
+            if h is not None:
+                h.wait()
+                self.pending[k] = None
+        if self.comm is not None:
+            torch.cuda.current_stream(self.dev).wait_stream(self.comm)
+
+    def run(self, n, timed=False):
+        self.gather_events = []
+        for i in range(n):
+            self.step(i, n - 1)
+
+    def gather_ms(self):
+        if not self.gather_events:
             return None
-    return None
+        return sum(a.elapsed_time(b) for a, b in self.gather_events) / len(self.gather_events)
+
+
+class TrajLoop:
+    """config #5 through the library path: restarts sharded over the ranks by `diffco_amd.traj.ShardedAdamRun`, K
+    iterations enqueued natively, only the per-restart summaries (and candidate paths) gathered at the end"""
+
+    def __init__(self, w, dev, world, n_total, group):
+        from diffco_amd.traj import ShardedAdamRun
+        dof = w["dof"]
+        g = torch.Generator().manual_seed(4242)  # the SAME restarts on every rank; each rank takes its slice
+        lo, hi = w["lo"], w["hi"]
+        inits = torch.rand((n_total, TRAJ_W, dof), generator=g) * (hi - lo) + lo
+        self.run_obj = ShardedAdamRun(w["model"], torch.stack([lo, hi], dim=1), inits, lr=0.05, safety_margin=0.0,
+                                      max_speed=0.3, grad_tol=0.0, group=group, sharded=world > 1)
+        self.B = self.run_obj.R * TRAJ_W
+        self.gather = "summaries"
+
+    def run(self, n, timed=False):
+        self.run_obj.run(n)
+        # the job's only exchange: 4 floats + two candidate paths per restart.  It closes the timed region (whole-job
+        # time) and is also issued once after the warm-up iterations, so that the torch kernels / collectives it uses are
+        # loaded before the clock starts.
+        self.summary = self.run_obj.finish()
+
+    def drain(self):
+        pass
+
+    def gather_ms(self):
+        return None
+
+
+def measure(loop, steps, warmup, dev, multi):
+    """W untimed warm-up steps, then exactly `steps` steps bracketed by barrier + synchronize; max over ranks.
+    Returns (wall seconds, average launch-to-launch kernel milliseconds from HIP events on the launch stream)"""
+    loop.run(warmup)
+    loop.drain()
+    if multi:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    loop.run(steps, timed=True)
+    e1.record()      # closes the kernels on the launch stream (HIP events, same stream as the launches)
+    loop.drain()
+    if multi:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    kern_ms = e0.elapsed_time(e1) / steps
+    if multi:
+        tt = torch.tensor([wall, kern_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall, kern_ms = float(tt[0]), float(tt[1])
+    return wall, kern_ms
 
 
 def main():
@@ -187,11 +309,19 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: the workload's per-GPU batch on every rank; strong: its fixed global batch divided by the ranks")
+    ap.add_argument("--gather", default="per-call", choices=["per-call", "serial", "bucketed", "none"],
+                    help="N>1: all-gather of the scores after every call, overlapped with the next sweep (default); "
+                         "serial = in order on the launch stream; bucketed = every 4 calls; none = sharded consumer")
+    ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
+    ap.add_argument("--no-variants", action="store_true", help="N>1: skip the short runs of the other variants")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather of scores")
     ap.add_argument("--force-dist", action="store_true",
-                    help="exercise the N>1 code path (process group + overlapped all-gather) even with one rank")
+                    help="exercise the N>1 code path (process group + all-gather) even with one rank")
     args = ap.parse_args()
+    if args.no_gather:
+        args.gather = "none"
 
     # The contract is ONE JSON line on stdout.  Libraries print there too (RCCL writes its version banner to stdout
     # when the first communicator comes up), so file descriptor 1 is pointed at stderr for the whole run and the JSON
@@ -203,10 +333,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                     "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        sys.exit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                 "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     from diffco_amd import _lib
     _lib.require_gpu()
     torch.cuda.set_device(local_rank)
@@ -217,112 +346,107 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    ranks_reported = dist.get_world_size() if multi else 1
 
-    w = make_workload(args.workload, args.batch, dev, seed=rank)
-    m, q, B, C, dof = w["model"], w["q"], w["B"], w["C"], w["dof"]
-    import ctypes as Ct
-    lib = _lib.load()
-    score = torch.empty((B, C), device=dev, dtype=torch.float32)
-    grad = torch.empty((B, dof), device=dev, dtype=torch.float32)
-    # N > 1: scores are all-gathered in BUCKETS of GATHER_EVERY steps (fewer, larger collectives: xGMI rings are
-    # latency-bound at 256 KB per rank, and each call costs ~30 us of host time against a 118 us step), two buckets in
-    # flight so that a bucket's gather overlaps the next bucket's sweeps
-    K = GATHER_EVERY
-    gathered = [torch.empty((world * K * B, C), device=dev, dtype=torch.float32) for _ in range(2)] if multi else None
-    bucket = [torch.empty((K * B, C), device=dev, dtype=torch.float32) for _ in range(2)] if multi else None
-    comm_stream = torch.cuda.Stream(dev) if multi else None
-    qp, gp = Ct.c_void_p(q.data_ptr()), Ct.c_void_p(grad.data_ptr())
+    name = args.workload
+    is_traj = name == "cfg5"
+    weak_B, strong_global = WORKLOADS[name][4], WORKLOADS[name][5]
+    unit = TRAJ_W if is_traj else 1  # config #5 shards whole restarts
 
-    traj = None
-    if w["name"] == "cfg5":
-        traj = traj_state(w, B // 50, 50, dev)
+    def per_gpu_batch(scaling):
+        if args.batch:
+            return args.batch
+        if scaling == "weak":
+            return weak_B
+        from diffco_amd.sharded import shard_bounds
+        lo, hi = shard_bounds(strong_global // unit, rank, world)
+        return (hi - lo) * unit
 
-    def step(i, pending):
-        if traj is not None:
-            st = Ct.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            _lib.check(lib.dcx_traj_adam_run(m._h, Ct.byref(traj[0]), Ct.byref(traj[1]), i + 1, 1, st))
-            return
-        b = (i // K) & 1
-        out = bucket[b][(i % K) * B:(i % K + 1) * B] if multi else score
-        if multi and i % K == 0 and pending[b] is not None:
-            pending[b].wait()  # this bucket's previous gather (two buckets ago) must be done before it is rewritten
-            pending[b] = None
-        # ONE launch of the hot path on torch's current stream
-        st = Ct.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        _lib.check(lib.dcx_score_grad(m._h, qp, B, None, Ct.c_void_p(out.data_ptr()), gp, st))
-        if multi and not args.no_gather and (i % K == K - 1 or i == last_step[0]):
-            # all-gather of this bucket's scores on a side stream, overlapped with the next bucket's sweeps
-            ev = torch.cuda.Event()
-            ev.record()
-            with torch.cuda.stream(comm_stream):
-                comm_stream.wait_event(ev)
-                pending[b] = dist.all_gather_into_tensor(gathered[b], bucket[b], async_op=True)
+    def build(scaling, gather):
+        B = per_gpu_batch(scaling)
+        w = make_workload(name, B, dev, seed=rank)
+        if is_traj:
+            n_total = (B // TRAJ_W) * world if (scaling == "weak" or args.batch) else strong_global // TRAJ_W
+            return w, TrajLoop(w, dev, world, n_total, None)
+        return w, ScoreLoop(w, dev, world, gather if multi else "none")
 
-    def drain(pending):
-        for h in pending:
-            if h is not None:
-                h.wait()
-        if comm_stream is not None:
-            torch.cuda.current_stream(dev).wait_stream(comm_stream)
+    def global_evals(scaling, w):
+        if args.batch or scaling == "weak":
+            return world * w["B"]
+        return strong_global
 
-    last_step = [args.warmup - 1]  # a partly filled last bucket is gathered too
-    pending = [None, None]
-    for i in range(args.warmup):
-        step(i, pending)
-    drain(pending)
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    pending = [None, None]
-    last_step[0] = args.steps - 1
-    t0 = time.perf_counter()
-    e0.record()
-    for i in range(args.steps):
-        step(i, pending)
-    e1.record()      # closes the sweep kernels on the launch stream (HIP events, same stream as the launches)
-    drain(pending)
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    wall = time.perf_counter() - t0
-    kern_ms = e0.elapsed_time(e1) / args.steps  # average launch-to-launch duration of the sweep kernel
+    w, loop = build(args.scaling, args.gather)
+    wall, kern_ms = measure(loop, args.steps, args.warmup, dev, multi)
+    gather_ms = loop.gather_ms()
+    B, C, dof = w["B"], w["C"], w["dof"]
 
-    if multi:
-        tt = torch.tensor([wall], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall = float(tt.item())
-        tk = torch.tensor([kern_ms], device=dev, dtype=torch.float64)
-        dist.all_reduce(tk, op=dist.ReduceOp.MAX)
-        kern_ms = float(tk.item())
+    variants = None
+    if multi and not args.no_variants:
+        # the other ways to run N > 1, measured briefly in the same job (primary numbers above are untouched)
+        vs, vw = max(20, args.steps // 4), max(5, args.warmup // 2)
+        variants = {}
+        others = [("other_scaling", "strong" if args.scaling == "weak" else "weak", args.gather)]
+        if not is_traj:
+            others += [(f"gather_{g}", args.scaling, g) for g in ("per-call", "serial", "bucketed", "none") if g != args.gather]
+        for key, sc, ga in others:
+            w2, l2 = build(sc, ga)
+            wl, km = measure(l2, vs, vw, dev, multi)
+            ge = global_evals(sc, w2)
+            variants[key] = {"scaling": sc, "gather": l2.gather, "value": round(ge * vs / wl / 1e6, 3),
+                             "ms_per_step": round(wl / vs * 1e3, 5), "kernel_ms": round(km, 5), "steps": vs,
+                             "global_batch": ge, "batch_per_gpu": w2["B"],
+                             "gather_ms": None if l2.gather_ms() is None else round(l2.gather_ms(), 5)}
+            del w2, l2
 
     if rank == 0:
-        evals = world * B * args.steps
-        value = evals / wall / 1e6
+        ge = global_evals(args.scaling, w)
+        value = ge * args.steps / wall / 1e6
         F = flops_per_eval(w["D"], C, w["S"])
         ach_tf = F * B / (kern_ms * 1e-3) / 1e12
         ach_gbs = bytes_per_eval(dof, C) * B / (kern_ms * 1e-3) / 1e9
+        pmc = load_profile_json(f"pmc_{name}.json")
+        mf = load_profile_json("mfma_headline.json") or {}
+        mfma_on = os.environ.get("DCX_MFMA", "") not in ("", "0", "-1") and w["D"] <= 16 and C == 1 and not is_traj
+        gather_txt = {"per-call": "RCCL all-gather of the scores after EVERY call, overlapped with the next call's sweep",
+                      "serial": "RCCL all-gather of the scores after every call, in order on the launch stream",
+                      "bucketed": f"RCCL all-gather of the scores every {GATHER_EVERY} calls, overlapped",
+                      "none": "no gather (sharded consumer)",
+                      "summaries": "restarts sharded; only per-restart summaries + candidate paths gathered, once"}[loop.gather]
         out = {
             "metric": "million collision-score+grad evals/sec, 7-DoF FK-kernel, 2k supports",
             "value": round(value, 3), "unit": "M evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(wall / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(wall / args.steps * 1e3, 5), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{w['name']}: {w['text']}", "batch_per_gpu": B, "global_batch": world * B,
+            "config": {"workload": f"{w['name']}: {w['text']}", "batch_per_gpu": B, "global_batch": ge,
                        "supports": w["S"], "features": w["D"], "classes": C,
-                       "parallelism": f"batch-sharded x{world}, model replicated" +
-                                      ("" if world == 1 else (", no gather" if args.no_gather else
-                                                              f", RCCL all-gather of scores every {GATHER_EVERY} steps, overlapped")),
-                       "launches_per_step": 2 if traj is not None else 1},
+                       "parallelism": f"batch-sharded x{world}, model replicated" + ("" if not multi else ", " + gather_txt),
+                       "launches_per_step": round(-(-args.steps // 192) / max(args.steps, 1), 4) if is_traj else 1},
             "roofline": {"bound": "valu", "achieved": round(ach_tf, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach_tf / PEAK_FP32_TFLOPS, 4), "traffic": load_pmc_traffic(w["name"]),
-                         "kernel": "dcx::score_kernel<D,KF,C,MODE>", "kernel_ms": round(kern_ms, 5),
-                         "flops_per_eval": F,
+                         "frac": round(ach_tf / PEAK_FP32_TFLOPS, 4),
+                         "traffic": None if pmc is None else pmc.get("hbm_bytes_per_launch"),
+                         "traffic_source": None if pmc is None else f"profiles/pmc_{name}.json (rocprofv3 --pmc passes of an earlier run of "
+                                                                     "this command, calibrated; a constant, not an observation of this run)",
+                         "kernel": "dcx::traj_fused_kernel<D,KF>" if is_traj else "dcx::score_kernel<D,KF,C,MODE>",
+                         "kernel_ms": round(kern_ms, 5), "flops_per_eval": F,
                          "note": "fp32 VALU bound (peak == fp32 MFMA peak 157.3 TFLOP/s); algorithmic flops "
                                  "S*(5D+4C+6)+800 per eval (SURVEY.md §8d)",
                          "hbm": {"achieved": round(ach_gbs, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                  "frac": round(ach_gbs / PEAK_HBM_GBS, 5),
-                                 "bytes_per_eval": bytes_per_eval(dof, C)}},
+                                 "bytes_per_eval": bytes_per_eval(dof, C)},
+                         "mfma": {"used": bool(mfma_on),
+                                  "instructions_per_launch": mf.get("instructions_per_launch") if mfma_on else 0,
+                                  "busy_frac": mf.get("busy_frac") if mfma_on else 0.0,
+                                  "measured_variant": {k: mf.get(k) for k in (
+                                      "instructions_per_launch", "busy_frac", "achieved_tflops_on_matrix_cores",
+                                      "kernel_us_mfma_form", "kernel_us_valu_form", "verdict", "source")}}},
         }
+        if multi:
+            out["multi"] = {"ranks": ranks_reported, "backend": "nccl (RCCL)", "gather": loop.gather,
+                            "gather_ms": None if gather_ms is None else round(gather_ms, 5),
+                            "gather_bytes_per_call": None if is_traj else
+                            world * B * C * 4 * (GATHER_EVERY if loop.gather == "bucketed" else 1)}
+            if variants is not None:
+                out["variants"] = variants
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w)
             tb = torch_cpu_baseline(w)

@@ -24,6 +24,9 @@ def all_gather_rows(local, n_total, group=None):
     world = dist.get_world_size(group)
     if world == 1:
         return local
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo (the CPU tests, and the two-processes-on-one-GPU test) moves host memory: stage through it
+        return all_gather_rows(local.cpu(), n_total, group).to(local.device)
     sizes = [shard_bounds(n_total, r, world) for r in range(world)]
     counts = [hi - lo for lo, hi in sizes]
     tail = tuple(local.shape[1:])

@@ -60,12 +60,77 @@ def select_trial(best_valid_obj, lowest_loss, lowest_obj, steps, n_waypoints):
     return t, False, float(lowest_obj[t]), int(steps.sum().item()) * n_waypoints
 
 
+class ShardedAdamRun:
+    """R_total restarts of one trajectory problem advanced together by the fused Adam step, sharded over the ranks of
+    a torch.distributed group (one process per GPU; `group=None` and no initialised process group = one rank).
+
+    Rank r owns the contiguous restarts `shard_bounds(R_total, r, world)` and runs them with `dcx_traj_adam_run`
+    (one persistent launch per <= 192 iterations when a path fits one tile); nothing is exchanged while iterating —
+    restarts are independent — and `finish()` gathers only the per-restart summaries (4 floats each) plus the candidate
+    paths.  `fused_adam_traj_optimize` and bench.py's config #5 are both built on this class."""
+
+    def __init__(self, model, limits, init_paths, lr, safety_margin, max_speed, valid_tol=None, grad_tol=None,
+                 group=None, sharded=None):
+        import torch.distributed as dist
+        from .sharded import shard_bounds
+        self.lib = _lib.require_gpu()
+        self.model, self.group = model, group
+        self.n_total = len(init_paths)
+        self.sharded = (group is not None or bool(sharded)) and dist.is_initialized()
+        self.rank, self.world = (dist.get_rank(group), dist.get_world_size(group)) if self.sharded else (0, 1)
+        lo, hi = shard_bounds(self.n_total, self.rank, self.world)
+        self.lo, self.hi, self.R = lo, hi, hi - lo
+        dev = model.dev
+        f32 = dict(device=dev, dtype=torch.float32)
+        W, dof = init_paths.shape[1], init_paths.shape[2]
+        self.W, self.dof = W, dof
+        path = init_paths[lo:hi].to(**f32).contiguous().clone() if self.R else torch.empty((0, W, dof), **f32)
+        R, inf = self.R, float('inf')
+        self.t = dict(path=path, adam_m=torch.zeros_like(path), adam_v=torch.zeros_like(path),
+                      limits=limits.to(**f32).contiguous(), col_score=torch.empty((R * W,), **f32),
+                      col_grad=torch.empty((R * W, dof), **f32), stats=torch.zeros((R, 8), **f32),
+                      lowest_loss=torch.full((R,), inf, **f32), lowest_obj=torch.full((R,), inf, **f32),
+                      lowest_path=path.clone(), best_valid_obj=torch.full((R,), inf, **f32),
+                      best_valid_path=path.clone(), done=torch.zeros((R,), device=dev, dtype=torch.int32),
+                      steps=torch.zeros((R,), device=dev, dtype=torch.int32))
+        self.st = _lib.TrajState(R, W, *(C.c_void_p(v.data_ptr() if v.numel() else 0) for v in self.t.values()))
+        self.opt = _lib.TrajOpts(lr, 0.9, 0.999, 1e-8, DIF_WEIGHT, COLLISION_WEIGHT, MAX_MOVE_WEIGHT, JOINT_LIMIT_WEIGHT,
+                                 float(safety_margin), float(max_speed),
+                                 VALID_CONSTRAINT_LOSS if valid_tol is None else float(valid_tol),
+                                 STATIONARY_GRAD_NORM if grad_tol is None else float(grad_tol))
+        self.it = 0
+
+    def run(self, n_iters):
+        """enqueue n_iters more iterations on torch's current stream (no host synchronisation)"""
+        if self.R and n_iters > 0:
+            dev = self.model.dev
+            with torch.cuda.device(dev):
+                stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+                _lib.check(self.lib.dcx_traj_adam_run(self.model._h, C.byref(self.st), C.byref(self.opt), self.it + 1,
+                                                      int(n_iters), stream))
+        self.it += n_iters
+
+    def all_done(self):
+        return self.R == 0 or bool(self.t['done'].all())
+
+    def finish(self):
+        """(summaries [R_total, 4] on the host: best_valid_obj, lowest_loss, lowest_obj, steps; best_valid_path,
+        lowest_path [R_total, W, dof] on the device) — identical on every rank"""
+        from .sharded import all_gather_rows
+        t = self.t
+        summ = torch.stack([t['best_valid_obj'], t['lowest_loss'], t['lowest_obj'], t['steps'].float()], dim=1)
+        bvp, lop = t['best_valid_path'], t['lowest_path']
+        if self.sharded and self.world > 1:
+            summ = all_gather_rows(summ, self.n_total, self.group)
+            bvp = all_gather_rows(bvp, self.n_total, self.group)
+            lop = all_gather_rows(lop, self.n_total, self.group)
+        return summ.cpu(), bvp, lop
+
+
 def fused_adam_traj_optimize(robot, dist_est, start_cfg, target_cfg, options, group=None):
     """Drop-in for `optim.adam_traj_optimize` with all restarts batched on the GPU.  With an initialised
     torch.distributed `group` (or the default group when options['distributed'] is true) the restarts are sharded
-    across ranks; every rank returns the same record."""
-    import torch.distributed as dist
-    lib = _lib.require_gpu()
+    across ranks (`ShardedAdamRun`); every rank returns the same record."""
     n_trials, max_iter = options['NUM_RE_TRIALS'], options['MAXITER']
     lr = options.get('extra_optimizer_options', {}).get('lr', 5e-1)
     seed = options['seed']
@@ -78,65 +143,31 @@ def fused_adam_traj_optimize(robot, dist_est, start_cfg, target_cfg, options, gr
     desc = robot.fk_desc()
     if desc.key() != model.desc.key():
         raise ValueError("the checker's transform is not this robot's fkine: the fused step shares one FK")
-    dev = model.dev
 
     # ---- initial paths, exactly as the reference's sequential trials would draw them ----------------------
     inits = [prob.make_init(t).clone() for t in range(n_trials)]
     W, dof = inits[0].shape
     if W == 2:  # nothing to optimise (reference: optim.py:61-72)
-        cp = robot.fkine(inits[0])
         return {'start_cfg': _np(start_cfg).tolist(), 'target_cfg': _np(target_cfg).tolist(), 'cnt_check': 0,
                 'cost': 0.0, 'time': time.time() - t0, 'success': True, 'seed': seed,
                 'solution': inits[0].numpy().tolist()}
     if any(p.shape != (W, dof) for p in inits):
         raise ValueError("all restarts must have the same number of waypoints (init_solution vs N_WAYPOINTS)")
 
-    sharded = (group is not None or options.get('distributed', False)) and dist.is_initialized()
-    rank, world = (dist.get_rank(group), dist.get_world_size(group)) if sharded else (0, 1)
-    from .sharded import all_gather_rows, shard_bounds
-    lo, hi = shard_bounds(n_trials, rank, world)
-    R = hi - lo
-
-    f32 = dict(device=dev, dtype=torch.float32)
-    path = torch.stack(inits[lo:hi]).to(**f32).contiguous() if R else torch.empty((0, W, dof), **f32)
-    adam_m, adam_v = torch.zeros_like(path), torch.zeros_like(path)
-    limits = robot.limits.to(**f32).contiguous()
-    col_score = torch.empty((R * W,), **f32)
-    col_grad = torch.empty((R * W, dof), **f32)
-    stats = torch.zeros((R, 8), **f32)
-    inf = float('inf')
-    lowest_loss, lowest_obj = torch.full((R,), inf, **f32), torch.full((R,), inf, **f32)
-    best_valid_obj = torch.full((R,), inf, **f32)
-    lowest_path, best_valid_path = path.clone(), path.clone()
-    done = torch.zeros((R,), device=dev, dtype=torch.int32)
-    steps = torch.zeros((R,), device=dev, dtype=torch.int32)
-
-    st = _lib.TrajState(R, W, *(C.c_void_p(t.data_ptr() if t.numel() else 0) for t in (
-        path, adam_m, adam_v, limits, col_score, col_grad, stats, lowest_loss, lowest_obj, lowest_path, best_valid_obj,
-        best_valid_path, done, steps)))
-    opt = _lib.TrajOpts(lr, 0.9, 0.999, 1e-8, DIF_WEIGHT, COLLISION_WEIGHT, MAX_MOVE_WEIGHT, JOINT_LIMIT_WEIGHT,
-                        float(prob.safety_margin), float(prob.max_speed), VALID_CONSTRAINT_LOSS, STATIONARY_GRAD_NORM)
+    run = ShardedAdamRun(model, robot.limits, torch.stack(inits), lr, prob.safety_margin, prob.max_speed,
+                         grad_tol=options.get('stationary_grad_norm'), group=group,
+                         sharded=options.get('distributed', False))
     chunk = int(options.get('fused_chunk', 50))  # iterations enqueued between two "all done?" checks
-    it = 0
-    with torch.cuda.device(dev):
-        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        while it < max_iter and R:
-            n = min(chunk, max_iter - it)
-            _lib.check(lib.dcx_traj_adam_run(model._h, C.byref(st), C.byref(opt), it + 1, n, stream))
-            it += n
-            if it < max_iter and bool(done.all()):
-                break
+    while run.it < max_iter:
+        run.run(min(chunk, max_iter - run.it))
+        if run.it < max_iter and run.all_done():  # this rank's restarts are all frozen (no collective inside the loop)
+            break
     # ---- gather the per-restart summaries (and paths) and apply the reference's selection policy ----------
-    summ = torch.stack([best_valid_obj, lowest_loss, lowest_obj, steps.float()], dim=1)
-    if sharded:
-        summ = all_gather_rows(summ, n_trials, group)
-        best_valid_path = all_gather_rows(best_valid_path, n_trials, group)
-        lowest_path = all_gather_rows(lowest_path, n_trials, group)
-    summ = summ.cpu()
+    summ, best_valid_path, lowest_path = run.finish()
     bvo, lol, loo, nst = summ[:, 0], summ[:, 1], summ[:, 2], summ[:, 3]
     t_win, found, cost, cnt = select_trial(bvo, lol, loo, nst, W)
     solution = (best_valid_path if found else lowest_path)[t_win]
     return {'start_cfg': _np(start_cfg).tolist(), 'target_cfg': _np(target_cfg).tolist(), 'cnt_check': cnt,
             'cost': cost, 'time': time.time() - t0, 'success': found, 'seed': seed,
             'solution': solution.double().cpu().numpy().tolist(),
-            'trial': t_win, 'cnt_check_batched': int(nst.sum().item()) * W, 'iterations_enqueued': it}
+            'trial': t_win, 'cnt_check_batched': int(nst.sum().item()) * W, 'iterations_enqueued': run.it}
