@@ -60,21 +60,19 @@ class CollisionChecker:
         raise NotImplementedError
 
     def _generate_dataset(self, q, labels, dists, num_samples, fix_joints=None, fix_joint_values=None, verbose=False):
-        if q is None:
-            q = self.robot.rand_configs(num_samples)
+        """(q, labels in {0, 1}, dists) for fit(): missing configurations are drawn from the joint limits, missing
+        labels come from the ground-truth callable, missing distances are zeros"""
+        q = self.robot.rand_configs(num_samples) if q is None else q
         if fix_joints is not None:
-            q[:, fix_joints] = torch.tensor(fix_joint_values, dtype=q.dtype, device=q.device)
-        num_samples = len(q)
-        if labels is None:
-            start_time = time.time()
+            q[:, fix_joints] = torch.as_tensor(fix_joint_values, dtype=q.dtype, device=q.device)
+        if labels is not None:
+            labels = labels.gt(0).to(q.dtype)
+        else:
+            t0 = time.perf_counter()
             labels = self._ground_truth(q)
             if verbose:
-                print(f'Labels generated in {time.time() - start_time:.2f}s')
-        else:
-            labels = (labels > 0).type(q.dtype)
-        if dists is None:
-            dists = torch.zeros(num_samples, dtype=q.dtype, device=q.device)
-        return q, labels, dists
+                print(f'Labels generated in {time.perf_counter() - t0:.2f}s')
+        return q, labels, (q.new_zeros(len(q)) if dists is None else dists)
 
 
 class RBFDiffCo(CollisionChecker):
@@ -162,15 +160,17 @@ class RBFDiffCo(CollisionChecker):
             exist_mask[-len(supports):] = True
         return self.fit(q, labels, dists, update=True, exist_mask=exist_mask, verify_ratio=verify, verbose=verbose)
 
+    def _verification_set(self, num_samples):
+        """a fresh random set of `num_samples` configurations (remembered), else the one kept from the last fit"""
+        if num_samples is None and self.q_verify is None:
+            raise ValueError('self.q_verify or num_samples should be provided')
+        if num_samples is not None:
+            self.q_verify = self.robot.rand_configs(num_samples)
+        return self.q_verify
+
     def verify(self, q_verify=None, labels_verify=None, num_samples=None, verbose=False):
         if q_verify is None:
-            if num_samples is not None:
-                q_verify = self.robot.rand_configs(num_samples)
-                self.q_verify = q_verify
-            elif self.q_verify is not None:
-                q_verify = self.q_verify
-            else:
-                raise ValueError('self.q_verify or num_samples should be provided')
+            q_verify = self._verification_set(num_samples)
         scores = self.perceptron.poly_score(q_verify)
         if labels_verify is None:
             labels_verify = (2 * self._ground_truth(q_verify) - 1).type(q_verify.dtype)
@@ -267,17 +267,13 @@ class ForwardKinematicsDiffCo(RBFDiffCo):
         return torch.cat(valid, dim=0)[:num_samples]
 
     def _generate_dataset(self, q, labels, dists, num_samples, verbose=False, sample_transform=None, **kwargs):
-        transform = None
-        if sample_transform == 'fkine':
-            transform = self.tensorized_fkine
-        elif callable(sample_transform):
-            transform = sample_transform
-        elif sample_transform is not None:
-            raise ValueError(f'Invalid sample_transform: {sample_transform}')
-        if transform is not None:
+        if sample_transform is not None:  # 'fkine' or any callable: sample uniformly on that map's image
+            named = {'fkine': self.tensorized_fkine}
+            transform = named.get(sample_transform) if isinstance(sample_transform, str) else sample_transform
+            if not callable(transform):
+                raise ValueError(f'Invalid sample_transform: {sample_transform}')
             q = self._uniform_sample_on_transformed_manifold(transform, num_samples)
-            num_samples = len(q)
-        return super()._generate_dataset(q, labels, dists, num_samples, verbose=verbose, **kwargs)
+        return super()._generate_dataset(q, labels, dists, len(q) if q is not None else num_samples, verbose=verbose, **kwargs)
 
     def collision_score(self, q=None, bias=None, q_link_pos=None):
         """q [..., dof], or q_link_pos [..., 3, L] link origins that bypass the forward kinematics"""

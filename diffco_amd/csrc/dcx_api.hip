@@ -219,7 +219,7 @@ int fk_device_copy(int device, const dcx_fk_desc& fk, FkProg** out) {
 // path calls getenv.  -1 = "use the rule".
 struct Knobs {
     std::atomic<int64_t> ys{-1}, nw{-1}, min_rows{-1}, split_finish_kernel{-1}, inlaunch_tiles{-1}, jac_per_class{-1},
-        mfma{-1}, traj_fused{-1};
+        mfma{-1}, traj_fused{-1}, xf{-1};
     Knobs() {
         auto rd = [](const char* name, std::atomic<int64_t>& dst, bool flag) {
             if (const char* e = std::getenv(name)) dst = flag ? 1 : std::atoll(e);
@@ -232,6 +232,7 @@ struct Knobs {
         rd("DCX_JAC_PER_CLASS", jac_per_class, true);
         rd("DCX_MFMA", mfma, false);
         rd("DCX_TRAJ_FUSED", traj_fused, false);
+        rd("DCX_XF", xf, false);
     }
 };
 Knobs& knobs() {
@@ -399,10 +400,12 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
     a.hinge = hinge.on;
     a.hinge_margin = hinge.margin;
     a.hinge_weight = hinge.weight;
+    a.xf = knobs().xf != 0 ? 1 : 0;  // expanded form wherever it exists (score_kernel.h); 0 only selects anything in DCX_BOTH_FORMS builds
     // MFMA form of the gradient fold: compiled for even D <= 16 with the two specialised kernel functions; needs every
     // wave to own a slice of the LDS reduction scratch (nw > 1, parallel fold)
     a.mfma = (mode != MODE_SCORE && m->Dt <= 16 && (m->Dt % 2) == 0 && m->kf != KF_GEN && g.nw > 1 && g.red_slots == g.nw &&
               knobs().mfma != 0 && knobs().mfma > 0) ? 1 : 0;
+    if (a.mfma) a.xf = 0;
 #ifdef DCX_TIMING
     if (!g_ts_dev && hipMalloc((void**)&g_ts_dev, sizeof(unsigned long long) * 16 * 8) == hipSuccess)
         (void)hipMemset(g_ts_dev, 0, sizeof(unsigned long long) * 16 * 8);
@@ -466,7 +469,7 @@ int dcx_debug_set(const char* name, int64_t value) {
     const std::string n(name);
     std::atomic<int64_t>* dst = n == "ys" ? &k.ys : n == "nw" ? &k.nw : n == "min_rows" ? &k.min_rows
         : n == "split_finish_kernel" ? &k.split_finish_kernel : n == "inlaunch_tiles" ? &k.inlaunch_tiles
-        : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : n == "traj_fused" ? &k.traj_fused : nullptr;
+        : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : n == "traj_fused" ? &k.traj_fused : n == "xf" ? &k.xf : nullptr;
     if (!dst) return fail(DCX_ERR_INVALID, "unknown knob: " + n);
     *dst = value;
     return DCX_OK;
@@ -539,7 +542,7 @@ int dcx_model_create(dcx_model** out, int device, const dcx_fk_desc* fk, int ker
             return fail_hip(e, "copy of supports/weights");
         }
     }
-    // support rows: [D coords | zero pad to Dt | C weights | (C>1) row sum | pad]; all-zero-weight rows dropped.
+    // support rows: [D coords | zero pad to Dt | C weights | (C>1) row sum | |s|^2 | pad]; all-zero-weight rows dropped.
     // Polyharmonic(k=1): the 1/eps factor is folded into the weights (score and gradient are linear in them).
     const float fold = (m->kf == KF_POLY1) ? 1.0f / m->kp1 : 1.0f;
     std::vector<float> rows;
@@ -559,6 +562,9 @@ int dcx_model_create(dcx_model** out, int device, const dcx_fk_desc* fk, int ker
             sum += v;
         }
         if (C > 1) rows[base + m->Dt + C] = sum;
+        double ss = 0.0;  // |s|^2 of the fp32 coordinates, rounded once (RowLayout::SS_OFF; the expanded-form sweep)
+        for (int k = 0; k < D; ++k) ss += (double)feat[j * D + k] * (double)feat[j * D + k];
+        rows[base + m->Dt + C + (C > 1 ? 1 : 0)] = (float)ss;
         ++kept;
     }
     m->S_active = kept;
@@ -712,6 +718,7 @@ int dcx_traj_adam_run(const dcx_model* m, const dcx_traj_state* st, const dcx_tr
             a.sc.kind = m->kind;
             a.sc.kp0 = m->kp0;
             a.sc.kp1 = m->kp1;
+            a.sc.xf = knobs().xf != 0 ? 1 : 0;
             a.st = *st;
             a.opt = *opt;
             a.n_points = m->fk.n_points;

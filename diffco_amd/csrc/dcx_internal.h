@@ -21,7 +21,7 @@ inline int template_d_for(int D) {
 // the ~3*D live registers of the sweep
 inline int max_threads_for(int Dt) { return Dt <= 16 ? 1024 : (Dt <= 48 ? 512 : 256); }
 
-inline int row_stride(int Dt, int C) { return (Dt + C + (C > 1 ? 1 : 0) + 3) / 4 * 4; }
+inline int row_stride(int Dt, int C) { return (Dt + C + (C > 1 ? 1 : 0) + 1 + 3) / 4 * 4; }  // RowLayout<Dt, C>::RS
 
 // one entry point per compiled D (score_inst.hip, built once per width)
 typedef hipError_t (*launch_fn)(int kf, int cc, int mode, int nw, size_t lds_bytes, int64_t n_blocks,

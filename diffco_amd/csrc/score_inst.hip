@@ -18,8 +18,23 @@ constexpr int kMaxT = kD <= 16 ? 1024 : (kD <= 48 ? 512 : 256);
 template <int KF, int MODE>
 constexpr bool kHasMfma = (kD <= 16) && (kD % 2 == 0) && (MODE != MODE_SCORE) && (KF != KF_GEN);
 
+// Shapes with an expanded form (score_kernel.h, XF) run it by default; -DDCX_BOTH_FORMS also compiles the direct form
+// for them (selected per launch by ScoreArgs::xf, for A/B tools and the cross-form parity tests).
+#ifdef DCX_BOTH_FORMS
+constexpr bool kBothForms = true;
+#else
+constexpr bool kBothForms = false;
+#endif
+
 template <int KF, int CC, int MODE>
 hipError_t go(int nw, size_t lds, int64_t nblk, const ScoreArgs& a, hipStream_t st) {
+    const dim3 grid((unsigned)nblk, (unsigned)(a.ys > 1 ? a.ys : 1), (unsigned)(a.nz > 1 ? a.nz : 1));
+    if constexpr (xf_applies(kD, CC)) {
+        if (!a.mfma && (a.xf || !kBothForms)) {
+            score_kernel<kD, KF, CC, MODE, kMaxT, false, true><<<grid, dim3(64 * nw), lds, st>>>(a);
+            return hipGetLastError();
+        }
+    }
     if constexpr (kHasMfma<KF, MODE>) {
         if (a.mfma) {
             score_kernel<kD, KF, CC, MODE, kMaxT, true><<<dim3((unsigned)nblk, (unsigned)(a.ys > 1 ? a.ys : 1), (unsigned)(a.nz > 1 ? a.nz : 1)), dim3(64 * nw), lds, st>>>(a);
@@ -80,6 +95,16 @@ hipError_t DCX_CAT(launch_traj_fused_D, DCX_INST_D)(int kf, int nw, size_t lds, 
         kern<<<dim3((unsigned)n_paths), dim3(64 * nw), lds, st>>>(a);
         return hipGetLastError();
     };
+    if constexpr (xf_applies(kD, 1)) {
+        if (a.sc.xf || !kBothForms) {
+            switch (kf) {
+            case KF_RQ2: return go_t(traj_fused_kernel<kD, KF_RQ2, kMaxT, true>);
+            case KF_POLY1: return go_t(traj_fused_kernel<kD, KF_POLY1, kMaxT, true>);
+            case KF_GEN: return go_t(traj_fused_kernel<kD, KF_GEN, kMaxT, true>);
+            default: return hipErrorInvalidValue;
+            }
+        }
+    }
     switch (kf) {
     case KF_RQ2: return go_t(traj_fused_kernel<kD, KF_RQ2, kMaxT>);
     case KF_POLY1: return go_t(traj_fused_kernel<kD, KF_POLY1, kMaxT>);

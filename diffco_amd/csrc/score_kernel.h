@@ -42,7 +42,7 @@ enum { MODE_SCORE = 0,    // score only
        MODE_GRAD_UP = 2 };// score + grad with an explicit upstream[b, :] (C > 1)
 
 struct ScoreArgs {
-    const float* rows;        // [S][RS] support rows: D coords, CC weights, (CC>1: sum of weights), pad
+    const float* rows;        // [S][RS] support rows: D coords, CC weights, (CC>1: sum of weights), |s|^2, pad
     const FkProg* fk;         // device copy of the compiled FK program
     const float* q;           // [B][dof]
     const float* upstream;    // [B][C] or null
@@ -73,6 +73,7 @@ struct ScoreArgs {
 #endif
     float kp0, kp1;           // kernel parameters
     int32_t mfma;             // 1: the launch uses the MFMA form of the gradient fold (score_kernel<..., MF = true>)
+    int32_t xf;               // 1: the launch uses the expanded form of the sweep (score_kernel<..., XF = true>)
     int32_t hinge;            // C == 1: gradient of weight * clamp(score - margin, 0) instead of the score's
     float hinge_margin, hinge_weight;
 };
@@ -80,8 +81,9 @@ struct ScoreArgs {
 template <int D, int CC>
 struct RowLayout {
     static constexpr int W_OFF = D;
-    static constexpr int WSUM_OFF = D + CC;  // only present when CC > 1
-    static constexpr int RS = (D + CC + (CC > 1 ? 1 : 0) + 3) / 4 * 4;
+    static constexpr int WSUM_OFF = D + CC;                   // only present when CC > 1
+    static constexpr int SS_OFF = D + CC + (CC > 1 ? 1 : 0);  // |s|^2 (float64 sum rounded once; the expanded-form sweep)
+    static constexpr int RS = (SS_OFF + 1 + 3) / 4 * 4;
 };
 
 typedef const __attribute__((address_space(4))) float* cfloat_ptr;
@@ -123,7 +125,8 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define DCX_D2_ACCS(D) (!DCX_D2_MULTI ? 1 : (D) >= 32 ? 4 : (D) >= 16 ? 2 : 1)
 
 // value K(d2) and g with dK/dx = g * (x - s)
-template <int KF>
+// CLAMPED: the caller guarantees d2 >= 1e-30 (the expanded-form sweep clamps at its near threshold)
+template <int KF, bool CLAMPED = false>
 __device__ __forceinline__ void kernel_eval(float d2, const ScoreArgs& a, float& val, float& g) {
     if constexpr (KF == KF_RQ2) {
         // (1 + gamma/2 d2)^-2 ;  dK/dd2 = -gamma (1 + gamma/2 d2)^-3
@@ -133,7 +136,7 @@ __device__ __forceinline__ void kernel_eval(float d2, const ScoreArgs& a, float&
         g = (-2.0f * a.kp0) * (val * u);
     } else if constexpr (KF == KF_POLY1) {
         // r (1/eps folded into the row weights); sub-gradient 0 at r == 0 because delta == 0 there
-        const float d2c = fmaxf(d2, 1e-30f);
+        const float d2c = CLAMPED ? d2 : fmaxf(d2, 1e-30f);
         const float ri = __builtin_amdgcn_rsqf(d2c);
         val = d2c * ri;
         g = ri;
@@ -206,7 +209,46 @@ constexpr int sweep_min_waves(int D, int CC, int KF) {
 // ---- the sweep: supports [j0, j1) against this lane's configuration, rows broadcast through SGPRs ---------------
 // Accumulates into sc[] (scores) and gx[] (feature gradient; untouched for MODE_SCORE).  A function of its own so that
 // kernel variants can share it (e.g. the two-tile helper-wave experiment of DESIGN.md 3.1).
-template <int D, int KF, int CC, int MODE>
+// ---- the expanded form (XF) ------------------------------------------------------------------------------------------
+// The direct form spends D/2 v_pk_add per pair on the differences x - s, which only exist to be squared and to be
+// scaled by the gradient coefficient.  Expanded,
+//     d2        = (|x|^2 + |s_j|^2) + sum_k (-2 x_k) s_jk            one v_add + D/2 v_pk_fma, s_jk straight from SGPRs
+//     gX[b, :]  = x_b * sum_j c_bj  -  sum_j c_bj s_j                D/2 v_pk_fma + one v_add per pair, s_jk from SGPRs
+// needs no difference at all: 21 instead of 24 VALU instructions per pair at D = 12 (the six dropped are the 4.4-cycle
+// packed adds: -17 % issue cycles), and D fewer live registers.  Both sums cancel when x is close to s_j, so:
+//   * a pair with d2 < thr = DCX_XF_TAU * |x|^2 (r below a tenth of |x|) is a NEAR pair.  The hot loop stays branch-free:
+//     every pair goes through the expanded form with d2 clamped at thr, so a near pair adds a bounded (wrong)
+//     term.  After each two-row stage of the pipeline one ballot asks whether any lane saw d2 <= thr; if so — rare — a
+//     correction block takes the expanded term of the near (lane, row) pairs out again (the same operations on the same
+//     operands reproduce it exactly; what is left is one rounding of a bounded number) and adds the DIRECT form:
+//     differences, squared distance and gradient term exactly as the direct sweep computes them (r = 0 stays exact).
+//     Lanes that are not near add +-0 in that block, so a configuration's result does not depend on which other
+//     configurations share its wave.
+//   * the expanded gradient lives in ONE accumulator set H = sum c s - (what has been folded so far); every DCX_XF_FLUSH
+//     rows the run's x * sum(c) is folded in place (H <- H - x A; A <- 0), which realises the cancellation while the
+//     run's sums are still small, so what H carries between runs is (minus) the true partial gradient.  No second
+//     accumulator set: the sweep holds -2x, H and a handful of temporaries — 12 VGPRs fewer than the direct form at
+//     D = 12 (with a second set the 64-register budget spilled long-lived values into scratch, and their reloads inside
+//     the single-wave FK / J^T code cost 2 us per block at small batches).
+// tools/split_numerics.py sizes the rounding error of exactly this arithmetic against float64: gradient 2e-7 .. 4e-6
+// relative (the direct form: 1e-6 .. 2e-6), score unchanged.  |s_j|^2 rides in the support row (RowLayout::SS_OFF).
+// Rows wider than 38 floats are consumed in parts whose SGPRs are gone when the coefficient is known: they keep the
+// direct form.
+#ifndef DCX_XF_TAU
+#define DCX_XF_TAU 0.01f
+#endif
+#ifndef DCX_XF_FLUSH
+#define DCX_XF_FLUSH 64
+#endif
+
+// does the expanded form exist for this shape?  (whole rows must sit in SGPRs when the coefficient is known)
+constexpr bool xf_applies(int D, int CC) {
+    const int used = D + CC + (CC > 1 ? 1 : 0);
+    const int parts = (4 * used <= (CC > 1 ? DCX_P0_MAX_MULTI : DCX_P0_MAX_SINGLE)) ? 0 : (used + 37) / 38;
+    return used + 1 <= 38 && parts <= 1;
+}
+
+template <int D, int KF, int CC, int MODE, bool XF = false>
 __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[D], const float (&up)[CC], int j0, int j1,
                                            float (&sc)[CC], float (&gx)[D]) {
     using L = RowLayout<D, CC>;
@@ -215,7 +257,136 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
 #pragma unroll
     for (int k = 0; k < D / 2 + 1; ++k) gx2[k] = v2f{0.0f, 0.0f};
     cfloat_ptr rows = (cfloat_ptr)(uintptr_t)a.rows;
+    // only the floats a row really carries are loaded (the tail of the padded stride is never touched)
+    constexpr int USED_DIRECT = D + CC + (CC > 1 ? 1 : 0);
+    constexpr bool XFA = XF && xf_applies(D, CC);
+    constexpr int USED = USED_DIRECT + (XFA ? 1 : 0);
 
+    // expanded-form state: -2 x (packed), |x|^2, the near threshold (also the hot path's clamp), H and the run's sum(c)
+    v2f xm[D / 2 + 1], ga[D / 2 + 1];
+    float xm_tail = 0.0f, ga_tail = 0.0f, xx = 0.0f, thr = 1e-30f, asum = 0.0f;
+    if constexpr (XFA) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) xx = fmaf(x[k], x[k], xx);
+        thr = fmaxf(DCX_XF_TAU * xx, 1e-30f);
+#pragma unroll
+        for (int k = 0; k + 1 < D; k += 2) {
+            xm[k / 2] = v2f{-2.0f * x[k], -2.0f * x[k + 1]};
+            ga[k / 2] = v2f{0.0f, 0.0f};
+        }
+        if constexpr (D & 1) xm_tail = -2.0f * x[D - 1];
+    }
+    // squared distance of one support row in the expanded form, clamped at thr (== thr marks a near pair)
+    auto d2_x = [&](const auto& r) __attribute__((always_inline)) -> float {
+        constexpr int NA = DCX_D2_ACCS(D);
+        v2f acc[NA];
+        acc[0] = v2f{xx + r[L::SS_OFF], 0.0f};
+#pragma unroll
+        for (int i = 1; i < NA; ++i) acc[i] = v2f{0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k + 1 < D; k += 2) {
+            const v2f rv = {r[k], r[k + 1]};
+            acc[(k / 2) % NA] = __builtin_elementwise_fma(xm[k / 2], rv, acc[(k / 2) % NA]);
+        }
+#pragma unroll
+        for (int i = 1; i < NA; ++i) acc[0] += acc[i];
+        float d2 = acc[0].x + acc[0].y;
+        if constexpr (D & 1) d2 = fmaf(xm_tail, r[D - 1], d2);
+        return fmaxf(d2, thr);
+    };
+    auto coef_of = [&](const auto& r, float g) __attribute__((always_inline)) -> float {
+        if constexpr (MODE == MODE_GRAD_ROW) {
+            return g * r[CC > 1 ? L::WSUM_OFF : L::W_OFF];
+        } else {
+            float wb = 0.0f;
+#pragma unroll
+            for (int c = 0; c < CC; ++c) wb = fmaf(up[c], r[L::W_OFF + c], wb);
+            return g * wb;
+        }
+    };
+    // SIGN = +1: the hot path's expanded term of one row;  SIGN = -1 with `keep`: the same term taken out again for the
+    // lanes in `keep` (others add -0)
+    auto apply_x = [&](const auto& r, float d2c, auto sign, bool keep) __attribute__((always_inline)) {
+        constexpr int SIGN = decltype(sign)::value;
+        float val, g;
+        kernel_eval<KF, true>(d2c, a, val, g);
+        if constexpr (SIGN < 0) val = keep ? -val : 0.0f;
+#pragma unroll
+        for (int c = 0; c < CC; ++c) sc[c] = fmaf(r[L::W_OFF + c], val, sc[c]);
+        if constexpr (GRAD) {
+            float coef = coef_of(r, g);
+            if constexpr (SIGN < 0) coef = keep ? -coef : 0.0f;
+            const v2f c2 = {coef, coef};
+#pragma unroll
+            for (int k = 0; k + 1 < D; k += 2) {
+                const v2f rv = {r[k], r[k + 1]};
+                ga[k / 2] = __builtin_elementwise_fma(c2, rv, ga[k / 2]);
+            }
+            if constexpr (D & 1) ga_tail = fmaf(coef, r[D - 1], ga_tail);
+            asum += coef;
+        }
+    };
+    auto pair_x = [&](const auto& r) __attribute__((always_inline)) -> float {
+        const float d2 = d2_x(r);
+        apply_x(r, d2, std::integral_constant<int, 1>{}, true);
+        return d2;
+    };
+    // the rare block: row `r` with raw expanded distance d2raw has near lanes -> out with their expanded term, in with
+    // the direct one
+    auto fix_near = [&](const auto& r, float d2c) __attribute__((always_inline)) {
+        const bool nr = d2c <= thr;
+        apply_x(r, d2c, std::integral_constant<int, -1>{}, nr);
+        v2f dp[D / 2 + 1];
+        v2f dacc = {0.0f, 0.0f};
+        const v2f mh = {-0.5f, -0.5f};  // x = -0.5 * (-2 x), exact: only the scaled copy stays in registers
+#pragma unroll
+        for (int k = 0; k + 1 < D; k += 2) {
+            const v2f rv = {r[k], r[k + 1]};
+            dp[k / 2] = xm[k / 2] * mh - rv;
+            dacc = __builtin_elementwise_fma(dp[k / 2], dp[k / 2], dacc);
+        }
+        float d2d = dacc.x + dacc.y;
+        float dl_tail = 0.0f;
+        if constexpr (D & 1) {
+            dl_tail = -0.5f * xm_tail - r[D - 1];
+            d2d = fmaf(dl_tail, dl_tail, d2d);
+        }
+        float val, g;
+        kernel_eval<KF>(d2d, a, val, g);
+        val = nr ? val : 0.0f;
+#pragma unroll
+        for (int c = 0; c < CC; ++c) sc[c] = fmaf(r[L::W_OFF + c], val, sc[c]);
+        if constexpr (GRAD) {
+            const float cd = nr ? -coef_of(r, g) : 0.0f;  // H carries MINUS the gradient
+            const v2f cd2 = {cd, cd};
+#pragma unroll
+            for (int k = 0; k + 1 < D; k += 2) ga[k / 2] = __builtin_elementwise_fma(cd2, dp[k / 2], ga[k / 2]);
+            if constexpr (D & 1) ga_tail = fmaf(cd, dl_tail, ga_tail);
+        }
+    };
+    // two rows of a pipeline stage in the expanded form + the near check
+    auto stage_x = [&](const auto& r0, const auto& r1) __attribute__((always_inline)) {
+        const float d0 = pair_x(r0);
+        const float d1 = pair_x(r1);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(fminf(d0, d1) <= thr) != 0, 0)) {
+            fix_near(r0, d0);
+            fix_near(r1, d1);
+        }
+    };
+    auto single_x = [&](const auto& r0) __attribute__((always_inline)) {
+        const float d0 = pair_x(r0);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(d0 <= thr) != 0, 0)) fix_near(r0, d0);
+    };
+    // fold the run's x * sum(c) into H in place: H <- H - x A = H + (-2 x) (A / 2), bit for bit the same product
+    auto flush_x = [&]() __attribute__((always_inline)) {
+        if constexpr (XFA && GRAD) {
+            const v2f ah = {0.5f * asum, 0.5f * asum};
+#pragma unroll
+            for (int k = 0; k + 1 < D; k += 2) ga[k / 2] = __builtin_elementwise_fma(xm[k / 2], ah, ga[k / 2]);
+            if constexpr (D & 1) ga_tail = fmaf(xm_tail, 0.5f * asum, ga_tail);
+            asum = 0.0f;
+        }
+    };
     // one support row against this lane's configuration; `r` is wave-uniform (SGPRs)
     auto pair = [&](const float (&r)[L::RS]) __attribute__((always_inline)) {
         float dl[D];
@@ -263,8 +434,6 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
             if constexpr (D & 1) gx[D - 1] = fmaf(coef, dl[D - 1], gx[D - 1]);
         }
     };
-    // only the floats a row really carries are loaded (the tail of the padded stride is never touched)
-    constexpr int USED = D + CC + (CC > 1 ? 1 : 0);
     auto load_row = [&](float (&dst)[L::RS], int j) __attribute__((always_inline)) {
         cfloat_ptr r = rows + (size_t)j * L::RS;
 #pragma unroll
@@ -277,6 +446,7 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
     // alive for every width by parking SGPRs in VGPR lanes: D=24 +37 %, D=42 +75 %, D=60 +97 % VALU instructions
     // (v_writelane / v_readlane) inside the sweep.
     constexpr int PARTS = (4 * USED <= (CC > 1 ? DCX_P0_MAX_MULTI : DCX_P0_MAX_SINGLE)) ? 0 : (USED + 37) / 38;  // parts of <= 38 floats
+    static_assert(!XFA || PARTS <= 1, "expanded form: whole rows only");
     if constexpr (PARTS == 0) {
     // Explicit software pipeline, two rows per stage (4 row buffers): the wait before a stage covers loads
     // issued TWO row bodies earlier, which is what hides an L2-latency scalar miss when only a few waves
@@ -293,24 +463,39 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
             load_row(rowC, j + 2);
             load_row(rowD, j + 3);
             __builtin_amdgcn_sched_barrier(0);
-            pair(rowA);
-            pair(rowB);
+            if constexpr (XFA) {
+                stage_x(rowA, rowB);
+            } else {
+                pair(rowA);
+                pair(rowB);
+            }
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_sched_barrier(0);
             load_row(rowA, (j + 4 < j1) ? j + 4 : jl);
             load_row(rowB, (j + 5 < j1) ? j + 5 : jl);
             __builtin_amdgcn_sched_barrier(0);
-            pair(rowC);
-            pair(rowD);
+            if constexpr (XFA) {
+                stage_x(rowC, rowD);
+            } else {
+                pair(rowC);
+                pair(rowD);
+            }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (XFA && GRAD) {
+                if ((j & (DCX_XF_FLUSH - 4)) == 0) flush_x();  // once per DCX_XF_FLUSH rows, whatever j0's alignment
+            }
         }
         // up to three rows left: rowA / rowB already hold rows j and j+1
-        if (j < j1) pair(rowA);
-        if (j + 1 < j1) pair(rowB);
+        auto one = [&](const float (&r)[L::RS]) __attribute__((always_inline)) {
+            if constexpr (XFA) single_x(r);
+            else pair(r);
+        };
+        if (j < j1) one(rowA);
+        if (j + 1 < j1) one(rowB);
         if (j + 2 < j1) {
             load_row(rowC, j + 2);
-            pair(rowC);
+            one(rowC);
         }
     }
     } else {
@@ -331,6 +516,10 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
             for (int e = 0; e < LEN; ++e) dst[e] = r[e];
         };
         auto consume = [&](const float (&b)[PS], auto pc) __attribute__((always_inline)) {
+            if constexpr (XFA) {  // whole rows (PARTS == 1)
+                single_x(b);
+                return;
+            }
             constexpr int P0 = decltype(pc)::value * PS;
             constexpr int LEN = (USED - P0 < PS) ? (USED - P0) : PS;
             if constexpr (decltype(pc)::value == 0) {
@@ -400,6 +589,9 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
                     __builtin_amdgcn_sched_barrier(0);
                     consume(bufB, P0c{});
                     __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (XFA && GRAD) {
+                        if ((j & (DCX_XF_FLUSH - 2)) == 0) flush_x();
+                    }
                 }
                 if (j < j1) consume(bufA, P0c{});  // bufA holds row j
             } else if constexpr (PARTS == 2) {
@@ -464,10 +656,20 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
         }
     }
 
+    if constexpr (XFA && GRAD) {
+        flush_x();
 #pragma unroll
-    for (int k = 0; k + 1 < D; k += 2) {
-        gx[k] += gx2[k / 2].x;
-        gx[k + 1] += gx2[k / 2].y;
+        for (int k = 0; k + 1 < D; k += 2) {
+            gx[k] -= ga[k / 2].x;
+            gx[k + 1] -= ga[k / 2].y;
+        }
+        if constexpr (D & 1) gx[D - 1] -= ga_tail;
+    } else {
+#pragma unroll
+        for (int k = 0; k + 1 < D; k += 2) {
+            gx[k] += gx2[k / 2].x;
+            gx[k + 1] += gx2[k / 2].y;
+        }
     }
 }
 
@@ -636,7 +838,7 @@ __device__ __forceinline__ void sweep_rows_mfma(const ScoreArgs& a, const float 
     }
 }
 
-template <int D, int KF, int CC, int MODE, int MAXT, bool MF = false>
+template <int D, int KF, int CC, int MODE, int MAXT, bool MF = false, bool XF = false>
 __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel(const ScoreArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr bool GRAD = (MODE != MODE_SCORE);
@@ -709,7 +911,7 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
         // this wave's slice of the reduction scratch doubles as its transpose buffer (X is dead, the fold comes later)
         sweep_rows_mfma<D, KF, CC, MODE>(a, x, up, j0, j1, sc, gx, sRed + (size_t)wave * ACC * 64, lane);
     } else {
-        sweep_rows<D, KF, CC, MODE>(a, x, up, j0, j1, sc, gx);
+        sweep_rows<D, KF, CC, MODE, XF>(a, x, up, j0, j1, sc, gx);
     }
     DCX_TS(3);
     // ---- meet the NW partial sums in LDS; wave 0 finishes --------------------------------

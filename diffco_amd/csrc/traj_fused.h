@@ -62,7 +62,7 @@ __device__ __forceinline__ float traj_wave_sum(float v) {
     return v;
 }
 
-template <int D, int KF, int MAXT>
+template <int D, int KF, int MAXT, bool XF = false>
 __global__ __launch_bounds__(MAXT, sweep_min_waves(D, 1, KF)) void traj_fused_kernel(const TrajFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int ACC = D + 1;
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, 1, KF)) void traj_fused_ke
         const float up[1] = {1.0f};
 #pragma unroll
         for (int k = 0; k < D; ++k) gx[k] = 0.0f;
-        sweep_rows<D, KF, 1, MODE_GRAD_ROW>(a.sc, x, up, j0, j1, sc, gx);
+        sweep_rows<D, KF, 1, MODE_GRAD_ROW, XF>(a.sc, x, up, j0, j1, sc, gx);
         if (nw > 1) {
             // the sweep's parallel cross-wave fold (score_kernel.h): row 0 first, then 1, 2, ...
             float* mine = sRed + (size_t)wave * ACC * 64 + lane;

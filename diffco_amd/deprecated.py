@@ -291,7 +291,7 @@ class DiffCoBeta(DiffCo):
         self.kernel_matrix = self.rbf_kernel(feats, feats)
         self.kernel_matrix = self.kernel_matrix + 0.1 * torch.eye(len(feats), dtype=self.kernel_matrix.dtype)
         self.gains = solve_system(self.rbf_kernel, self.kernel_matrix, da.reshape(-1, 1).to(self.kernel_matrix.dtype)).reshape(-1)
-        self.hypothesis = self.kernel_matrix @ self.gains
         self.rbf_nodes = self.gains
         self._reset_caches()
+        self.hypothesis = self.rbf_score(self.support_points)  # [N, 1], without the 0.1 I (deprecated/DiffCoBeta.py:109-110)
         print('DiffCo training done. {:.4f} secs cost'.format(time() - t0))

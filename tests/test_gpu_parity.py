@@ -27,10 +27,14 @@ def _n(t):
     return t.detach().cpu().numpy()
 
 
-@pytest.fixture(autouse=True, params=["valu", "mfma"])
+@pytest.fixture(autouse=True, params=["expanded", "direct", "mfma"])
 def fold_pipe(request, knob):
-    """every test of this file runs twice: gradient fold on the VALU (knob mfma = 0) and on the matrix cores
-    (v_mfma_f32_16x16x4_f32, knob mfma = 1; shapes without an MFMA instantiation take the VALU form either way)"""
+    """every test of this file runs three times: the sweep in its expanded form (score_kernel.h XF, the default; shapes
+    without one take the direct form), in its direct form (differences; only a libdcx built with
+    EXTRA=-DDCX_BOTH_FORMS carries it for the narrow shapes — otherwise this repeats "expanded"), and with the
+    gradient fold on the matrix cores (v_mfma_f32_16x16x4_f32, knob mfma = 1; shapes without an MFMA instantiation
+    take the default form)"""
+    knob("xf", 0 if request.param == "direct" else 1)
     knob("mfma", 1 if request.param == "mfma" else 0)
     yield request.param
 

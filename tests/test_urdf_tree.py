@@ -168,3 +168,50 @@ def test_undeclared_namespace_prefixes_are_tolerated():
     assert a.fk_desc().key() == b.fk_desc().key()
     with pytest.raises(Exception):
         URDFRobotFK("<robot><link name='a'></robot>")  # genuinely malformed XML still fails
+
+
+# ---- an independent pin for the URDF reader (tools/make_golden_urdf_pin.py: xml.etree + Rodrigues, no diffco_amd) ------
+def _pin():
+    import json
+    import os
+    from helpers import GOLDEN
+    return json.load(open(os.path.join(GOLDEN, "urdf_pin.json")))
+
+
+def _check_against_pin(rob, pin):
+    """feature-link origins of `rob` (diffco_amd's reader -> tree compiler -> C oracle, float64) against the hand-composed
+    link origins, joint values addressed by NAME"""
+    assert set(rob.joint_names) == set(pin["q"])                       # movable, non-mimic joints
+    assert set(rob.unique_position_link_names) <= set(pin["links"])
+    for key, qd in (("at_zero", {k: 0.0 for k in pin["q"]}), ("at_q", pin["q"])):
+        q = np.array([[qd[n] for n in rob.joint_names]], dtype=np.float64)
+        x = oracle.fkine(rob.fk_desc(), q, np.float64)[0]               # [3, L]
+        want = np.array([pin[key][ln] for ln in rob.unique_position_link_names]).T
+        assert x.shape == want.shape
+        assert np.abs(x - want).max() < 2e-7 * max(1.0, np.abs(want).max()), (key, np.abs(x - want).max())
+    # the pin moves: the two poses differ for every link behind a movable joint
+    moved = [ln for ln in rob.unique_position_link_names
+             if np.abs(np.array(pin["at_q"][ln]) - np.array(pin["at_zero"][ln])).max() > 1e-3]
+    assert len(moved) >= max(1, len(rob.unique_position_link_names) // 2)
+
+
+@pytest.mark.parametrize("name", URDF_NAMES)
+def test_reader_against_hand_composed_link_origins(name):
+    """the stored joint table (what diffco_amd.urdf.parse_urdf read from the reference's URDF when the fixtures were
+    made) reproduces link origins that were composed from the URDF text by another program"""
+    _check_against_pin(urdf_robot(name), _pin()[name])
+
+
+@pytest.mark.parametrize("name", ["urdf_panda", "urdf_allegro", "urdf_fetch", "urdf_trifinger"])
+def test_reader_on_the_original_urdf_text(name):
+    """the same, with the reader run on the ORIGINAL file (build container only: /root/reference is not on the GPU box)"""
+    import os
+    pin = _pin()[name]
+    path = None
+    for base, _, files in os.walk("/root/reference"):
+        if "2link_robot.urdf" in files:
+            path = os.path.join(base, pin["source"])
+    if path is None or not os.path.isfile(path):
+        pytest.skip("reference URDF files not present")
+    from diffco_amd.urdf import URDFRobotFK
+    _check_against_pin(URDFRobotFK(path), pin)

@@ -40,7 +40,7 @@ def import_reference():
     old = types.ModuleType("olddiffco")
     old.__path__ = [f"{REF}/diffco/deprecated", f"{REF}/diffco"]
     sys.modules["olddiffco"] = old
-    for m in ("kernel", "Obstacles", "DiffCo", "MultiDiffCo"):
+    for m in ("kernel", "Obstacles", "DiffCo", "MultiDiffCo", "DiffCoBeta"):
         mods["old_" + m] = importlib.import_module("olddiffco." + m)
     return types.SimpleNamespace(**mods)
 
@@ -459,6 +459,87 @@ def gen_trained(out, robots):
     return dc
 
 
+# ----------------------------------------------------------------------------- E2. old single-class API
+def gen_old_single(out, robots):
+    """deprecated/DiffCo.py through the exact call sequence of scripts/speed_compare.py:220-257 (FKKernel perceptron ->
+    score -> fit_poly(Polyharmonic(1, 1), 'label') WITHOUT fkine -> the spline score), the same with fkine, and
+    deprecated/DiffCoBeta.py: rbf_score on directly set state (:173-181) and its train() (:23-111).  DiffCoBeta.train
+    calls torch.solve, which torch >= 1.13 no longer has; for that one call this script binds the documented
+    replacement (torch.linalg.solve with the arguments swapped) to the old name — the routine itself runs unmodified."""
+    gen = torch.Generator().manual_seed(900)
+    rob = robots["baxter_left"]
+    n_train, n_test = 2000, 400
+    X = rand_cfgs(rob, n_train + n_test, gen)
+    centers = torch.tensor([[0.7, 0.3, 0.3], [0.4, -0.5, 0.0]])
+    dist = synth_labels(rob, X, centers, 0.25).max(dim=1).values
+    y = torch.where(dist > 0, 1.0, -1.0)
+    fkk = FKKernelRestated(rob.fkine, R.kernel.RQKernel(10.0))
+    ck = R.old_DiffCo.DiffCo(None, kernel_func=fkk, beta=1.0)
+    ck.train(X[:n_train], y[:n_train], max_iteration=n_train, distance=dist[:n_train])
+    qt = X[n_train:]
+
+    def with_grad(fn):
+        qv = qt.clone().requires_grad_(True)
+        sv = fn(qv)
+        (g,) = torch.autograd.grad(sv.sum(), qv)
+        return sv.detach(), g
+
+    arrs = dict(X=X[:n_train], y=y[:n_train], dist=dist[:n_train], q_test=qt, support_points=ck.support_points,
+                gains=ck.gains, hypothesis=ck.hypothesis, sup_y=ck.y, sup_dist=ck.distance)
+    arrs["score_test"], arrs["score_grad_test"] = with_grad(ck.score)
+    arrs["score_single"] = ck.score(qt[0])
+    ck.fit_poly(kernel_func=R.kernel.Polyharmonic(1, 1.0), target="label")        # speed_compare.py:236: no fkine
+    arrs["nodes_nofk"] = ck.rbf_nodes.clone()
+    arrs["poly_nofk_test"], arrs["poly_nofk_grad_test"] = with_grad(ck.poly_score)
+    for tgt in ("dist", "hypo"):
+        ck.fit_poly(kernel_func=R.kernel.Polyharmonic(1, 1.0), target=tgt)
+        arrs[f"nodes_nofk_{tgt}"] = ck.rbf_nodes.clone()
+    ck.fit_poly(kernel_func=R.kernel.Polyharmonic(1, 1.0), target="label", fkine=rob.fkine)
+    arrs["nodes_fk"] = ck.rbf_nodes.clone()
+    arrs["support_fkine"] = ck.support_fkine
+    arrs["poly_fk_test"], arrs["poly_fk_grad_test"] = with_grad(ck.poly_score)
+    print(f"  old DiffCo on Baxter: {len(ck.gains)} supports")
+    save(out, "old_single_baxter", **arrs)
+
+    # DiffCoBeta.rbf_score on directly set state, with and without fkine
+    Beta = R.old_DiffCoBeta.DiffCoBeta
+    S = 300
+    sup = rand_cfgs(rob, S, gen)
+    nodes = torch.randn(S, generator=gen)
+    b = Beta.__new__(Beta)
+    b.rbf_kernel = R.kernel.Polyharmonic(1, 1.0)
+    b.support_points, b.rbf_nodes = sup, nodes
+    b.fkine, b.support_fkine = rob.fkine, rob.fkine(sup).reshape(S, -1)
+    arrs = dict(support_points=sup, rbf_nodes=nodes, q_test=qt)
+    ck = b
+    arrs["rbf_fk_test"], arrs["rbf_fk_grad_test"] = with_grad(b.rbf_score)
+    b.fkine = None
+    b.rbf_kernel = R.kernel.MultiQuadratic(1.5)
+    arrs["rbf_nofk_mq_test"], arrs["rbf_nofk_mq_grad_test"] = with_grad(b.rbf_score)
+    arrs["rbf_single"] = b.rbf_score(qt[0])
+    # DiffCoBeta.train (perceptron on sign(d), then rbf_nodes = solve(K_rbf + 0.1 I, d) over supports + left-out samples)
+    import collections
+    Sol = collections.namedtuple("solve", ["solution", "LU"])
+    stub = getattr(torch, "solve", None)   # torch >= 1.13 keeps a stub that raises and names the replacement
+    torch.solve = lambda B, A: Sol(torch.linalg.solve(A, B), None)   # torch < 1.13 signature: solve(B, A)
+    try:
+        bt = Beta(None, kernel_func=fkk, beta=1.0)
+        nb = 800
+        bt.train(X[:nb], dist[:nb], fkine=rob.fkine, max_iteration=nb, n_left_out_points=100)
+    finally:
+        if stub is not None:
+            torch.solve = stub
+        else:
+            del torch.solve
+    ck = bt
+    arrs.update(train_X=X[:nb], train_d=dist[:nb], tr_support_points=bt.support_points, tr_gains=bt.gains,
+                tr_rbf_nodes=bt.rbf_nodes, tr_hypothesis=bt.hypothesis, tr_distance=bt.distance,
+                tr_num_origin_supports=np.array(bt.num_origin_supports))
+    arrs["tr_rbf_test"], arrs["tr_rbf_grad_test"] = with_grad(bt.rbf_score)
+    print(f"  DiffCoBeta on Baxter: {bt.num_origin_supports} perceptron supports + 100 left-out samples")
+    save(out, "old_beta_baxter", **arrs)
+
+
 # ----------------------------------------------------------------------------- F. optimiser records
 def gen_optim(out, robots):
     gen = torch.Generator().manual_seed(600)
@@ -501,18 +582,22 @@ def gen_optim(out, robots):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
+    ap.add_argument("--only", default=None, help="run one generator only (e.g. old_single); MANIFEST.json is rewritten")
     args = ap.parse_args()
     out = os.path.abspath(args.out)
     os.makedirs(out, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
     robots = make_robots()
-    print("FK");        gen_fk(out, robots)
-    print("kernels");   gen_kernels(out)
-    print("scores");    gen_scores(out, robots)
-    print("edges");     gen_edges(out, robots)
-    print("trained");   gen_trained(out, robots)
-    print("optim");     gen_optim(out, robots)
+    if args.only in (None, "all"):
+        print("FK");        gen_fk(out, robots)
+        print("kernels");   gen_kernels(out)
+        print("scores");    gen_scores(out, robots)
+        print("edges");     gen_edges(out, robots)
+        print("trained");   gen_trained(out, robots)
+        print("optim");     gen_optim(out, robots)
+    if args.only in (None, "all", "old_single"):   # last: the earlier fixtures do not depend on it
+        print("old single-class API"); gen_old_single(out, robots)
     with open(os.path.join(out, "MANIFEST.json"), "w") as f:
         json.dump({"generator": "tools/make_golden.py", "torch": torch.__version__, "numpy": np.__version__,
                    "reference": "ucsdarclab/diffco @ /root/reference (2025-03-21)",
