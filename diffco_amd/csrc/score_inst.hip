@@ -18,18 +18,19 @@ constexpr int kMaxT = kD <= 16 ? 1024 : (kD <= 48 ? 512 : 256);
 template <int KF, int MODE>
 constexpr bool kHasMfma = (kD <= 16) && (kD % 2 == 0) && (MODE != MODE_SCORE) && (KF != KF_GEN);
 
-// Shapes with an expanded form (score_kernel.h, XF) run it by default; -DDCX_BOTH_FORMS also compiles the direct form
-// for them (selected per launch by ScoreArgs::xf, for A/B tools and the cross-form parity tests).
-#ifdef DCX_BOTH_FORMS
-constexpr bool kBothForms = true;
-#else
+// Shapes with an expanded form (score_kernel.h, XF: Polyharmonic(1), rows of <= 37 floats) run it by default.  The
+// direct form is compiled for them as well and selected per launch by ScoreArgs::xf (dcx_debug_set("xf", 0)): the
+// parity tests run every case in both forms, tools/xf_probe.py times them side by side.  -DDCX_SINGLE_FORM drops it.
+#ifdef DCX_SINGLE_FORM
 constexpr bool kBothForms = false;
+#else
+constexpr bool kBothForms = true;
 #endif
 
 template <int KF, int CC, int MODE>
 hipError_t go(int nw, size_t lds, int64_t nblk, const ScoreArgs& a, hipStream_t st) {
     const dim3 grid((unsigned)nblk, (unsigned)(a.ys > 1 ? a.ys : 1), (unsigned)(a.nz > 1 ? a.nz : 1));
-    if constexpr (xf_applies(kD, CC)) {
+    if constexpr (xf_applies(kD, CC, KF)) {
         if (!a.mfma && (a.xf || !kBothForms)) {
             score_kernel<kD, KF, CC, MODE, kMaxT, false, true><<<grid, dim3(64 * nw), lds, st>>>(a);
             return hipGetLastError();
@@ -95,15 +96,8 @@ hipError_t DCX_CAT(launch_traj_fused_D, DCX_INST_D)(int kf, int nw, size_t lds, 
         kern<<<dim3((unsigned)n_paths), dim3(64 * nw), lds, st>>>(a);
         return hipGetLastError();
     };
-    if constexpr (xf_applies(kD, 1)) {
-        if (a.sc.xf || !kBothForms) {
-            switch (kf) {
-            case KF_RQ2: return go_t(traj_fused_kernel<kD, KF_RQ2, kMaxT, true>);
-            case KF_POLY1: return go_t(traj_fused_kernel<kD, KF_POLY1, kMaxT, true>);
-            case KF_GEN: return go_t(traj_fused_kernel<kD, KF_GEN, kMaxT, true>);
-            default: return hipErrorInvalidValue;
-            }
-        }
+    if constexpr (xf_applies(kD, 1, KF_POLY1)) {
+        if (kf == KF_POLY1 && (a.sc.xf || !kBothForms)) return go_t(traj_fused_kernel<kD, KF_POLY1, kMaxT, true>);
     }
     switch (kf) {
     case KF_RQ2: return go_t(traj_fused_kernel<kD, KF_RQ2, kMaxT>);

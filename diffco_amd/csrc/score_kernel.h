@@ -241,11 +241,17 @@ constexpr int sweep_min_waves(int D, int CC, int KF) {
 #define DCX_XF_FLUSH 64
 #endif
 
-// does the expanded form exist for this shape?  (whole rows must sit in SGPRs when the coefficient is known)
-constexpr bool xf_applies(int D, int CC) {
+// Does the expanded form exist for this shape?  Whole rows must sit in SGPRs when the coefficient is known, and the
+// kernel function must tolerate the expanded distance: its absolute error is ~ 2^-23 (|x|^2 + |s|^2) however small d2
+// is.  Polyharmonic(k = 1) — the reference's inference kernel, K = r — turns that into an absolute score error far
+// below the sum's own rounding (measured: the expanded form is as close to float64 as the direct one, gradient closer).
+// A sharp kernel does not: RQ(gamma = 10) weighs exactly the pairs with small d2, and on config #4's data (|x|^2 ~ 100)
+// the expanded form was 7e-6 from float64 where the direct form is 5e-7 — inside the 1e-5 bar but not by a margin
+// worth 3-7 %, so every kernel other than Polyharmonic(1) keeps the direct form.
+constexpr bool xf_applies(int D, int CC, int KF) {
     const int used = D + CC + (CC > 1 ? 1 : 0);
     const int parts = (4 * used <= (CC > 1 ? DCX_P0_MAX_MULTI : DCX_P0_MAX_SINGLE)) ? 0 : (used + 37) / 38;
-    return used + 1 <= 38 && parts <= 1;
+    return KF == KF_POLY1 && used + 1 <= 38 && parts <= 1;
 }
 
 template <int D, int KF, int CC, int MODE, bool XF = false>
@@ -259,7 +265,7 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
     cfloat_ptr rows = (cfloat_ptr)(uintptr_t)a.rows;
     // only the floats a row really carries are loaded (the tail of the padded stride is never touched)
     constexpr int USED_DIRECT = D + CC + (CC > 1 ? 1 : 0);
-    constexpr bool XFA = XF && xf_applies(D, CC);
+    constexpr bool XFA = XF && xf_applies(D, CC, KF);
     constexpr int USED = USED_DIRECT + (XFA ? 1 : 0);
 
     // expanded-form state: -2 x (packed), |x|^2, the near threshold (also the hot path's clamp), H and the run's sum(c)

@@ -185,12 +185,18 @@ class DiffCo(CollisionChecker):
         return self.score(point) > 0
 
     def rbf_score(self, point):
-        """K_rbf(fkine(point), support_fkine) @ rbf_nodes -> [N, 1]"""
+        """K_rbf(fkine(point), support_fkine) @ rbf_nodes -> [N, 1]; one query under an RQ / MultiQuadratic spline -> [1]
+        ([C] for MultiDiffCo): those kernels drop the row axis of a single query (kernel.py:26-27, 56-57) before the
+        reference's matmul with rbf_nodes[:, None], Polyharmonic does not"""
         if point.ndim == 1:
             point = point[None, :]
         if self.fkine is not None:
-            return self._rbf_fused.score(self.fkine, self.rbf_kernel, self.support_fkine, self.rbf_nodes, point)
-        return self._rbf_fused.score(None, self.rbf_kernel, self.support_points, self.rbf_nodes, point)
+            s = self._rbf_fused.score(self.fkine, self.rbf_kernel, self.support_fkine, self.rbf_nodes, point)
+        else:
+            s = self._rbf_fused.score(None, self.rbf_kernel, self.support_points, self.rbf_nodes, point)
+        if len(point) == 1 and isinstance(self.rbf_kernel, (kernel.RQKernel, kernel.MultiQuadratic)):
+            s = s.reshape(-1)
+        return s
 
     def poly_score(self, point):
         if point.ndim == 1:

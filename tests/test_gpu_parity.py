@@ -30,8 +30,8 @@ def _n(t):
 @pytest.fixture(autouse=True, params=["expanded", "direct", "mfma"])
 def fold_pipe(request, knob):
     """every test of this file runs three times: the sweep in its expanded form (score_kernel.h XF, the default; shapes
-    without one take the direct form), in its direct form (differences; only a libdcx built with
-    EXTRA=-DDCX_BOTH_FORMS carries it for the narrow shapes — otherwise this repeats "expanded"), and with the
+    without one — every kernel but Polyharmonic(1), rows wider than 37 floats — take the direct form), in its direct form
+    (differences), and with the
     gradient fold on the matrix cores (v_mfma_f32_16x16x4_f32, knob mfma = 1; shapes without an MFMA instantiation
     take the default form)"""
     knob("xf", 0 if request.param == "direct" else 1)
@@ -327,12 +327,12 @@ def test_full_size_properties(ops, B, S, C, kspec, knob):
 
 
 def test_config4_se3_streaming(ops):
-    """config #4: SE(3) configurations, RQ(10), 10k supports, no FK (D = 6), large batch"""
+    """config #4 at BASELINE size: 1 M SE(3) configurations, RQ(10), 10k supports, no FK (D = 6)"""
     from diffco_amd import _fkdesc
     from oracle import oracle
     g = torch.Generator().manual_seed(4)
     lo = torch.tensor([-10.0] * 3 + [-np.pi] * 3)
-    S, B = 10000, 1 << 18
+    S, B = 10000, 1 << 20
     sup = (torch.rand((S, 6), generator=g) * (-2 * lo) + lo).cuda()
     q = (torch.rand((B, 6), generator=g) * (-2 * lo) + lo).cuda()
     W = torch.randn((S, 1), generator=g).cuda()
@@ -344,8 +344,8 @@ def test_config4_se3_streaming(ops):
     assert relerr(_n(s[idx]), so) < TOL and relerr(_n(gr[idx]), go) < TOL
     half = ops.ScoreModel(desc, 0, 10.0, 2.0, sup[:5000], W[:5000]).score_grad_raw(q)
     rest = ops.ScoreModel(desc, 0, 10.0, 2.0, sup[5000:], W[5000:]).score_grad_raw(q)
-    assert float((half[0] + rest[0] - s).abs().max()) < 3e-6 * float(s.abs().max())
-    assert float((half[1] + rest[1] - gr).abs().max()) < 3e-6 * float(gr.abs().max())
+    assert float((half[0] + rest[0] - s).abs().max()) < 5e-6 * float(s.abs().max())
+    assert float((half[1] + rest[1] - gr).abs().max()) < 5e-6 * float(gr.abs().max())  # max over 1 M rows of a reassociated sum
 
 
 @pytest.mark.parametrize("B", [200, 5000])
