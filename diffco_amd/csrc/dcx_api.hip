@@ -219,7 +219,7 @@ int fk_device_copy(int device, const dcx_fk_desc& fk, FkProg** out) {
 // path calls getenv.  -1 = "use the rule".
 struct Knobs {
     std::atomic<int64_t> ys{-1}, nw{-1}, min_rows{-1}, split_finish_kernel{-1}, inlaunch_tiles{-1}, jac_per_class{-1},
-        mfma{-1}, traj_fused{-1}, xf{-1};
+        mfma{-1}, traj_fused{-1}, xf{-1}, mt{-1};
     Knobs() {
         auto rd = [](const char* name, std::atomic<int64_t>& dst, bool flag) {
             if (const char* e = std::getenv(name)) dst = flag ? 1 : std::atoll(e);
@@ -233,6 +233,7 @@ struct Knobs {
         rd("DCX_MFMA", mfma, false);
         rd("DCX_TRAJ_FUSED", traj_fused, false);
         rd("DCX_XF", xf, false);
+        rd("DCX_MT", mt, false);
     }
 };
 Knobs& knobs() {
@@ -412,8 +413,22 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
     a.ts = g_ts_dev;
     a.ts_block = std::getenv("DCX_TS_BLOCK") ? (unsigned)std::atoi(std::getenv("DCX_TS_BLOCK")) : 0u;
 #endif
-    const size_t lds = sizeof(float) * (lds_plan(a.dof, d_fk, m->frame_floats, g.nw > 1 ? g.red_slots : 0, acc, true).total + m->prog_floats);
+    size_t lds = sizeof(float) * (lds_plan(a.dof, d_fk, m->frame_floats, g.nw > 1 ? g.red_slots : 0, acc, true).total + m->prog_floats);
     if (g.ys == 1) {
+        // Several tiles per block (score_kernel_mt): built, bit-identical, and SLOWER than one tile per block at every
+        // batch (B = 65536: 104.4 -> 107.7 us, B = 1 M: 1320 -> 1426 us, profiles/r02_mt_probe.txt), so it is only
+        // compiled with EXTRA=-DDCX_WITH_MT and only taken when the developer knob asks for it.
+        int mt = 1;
+#ifdef DCX_WITH_MT
+        if (const int64_t v = knobs().mt; v >= 0) mt = (int)std::min<int64_t>(std::max<int64_t>(v, 1), kMtMaxTiles);
+#endif
+        if (mt >= 2 && nz == 1 && !a.mfma && g.red_slots == g.nw && g.nw >= mt && m->Dt <= kMtMaxD) {
+            const size_t lds_mt = sizeof(float) * (lds_plan_mt(a.dof, d_fk, m->frame_floats, g.nw, acc, mt).total + m->prog_floats);
+            if (lds_mt <= 80 * 1024) {
+                a.mt = mt;
+                lds = lds_mt;
+            }
+        }
         hipError_t e = m->launch(m->kf, m->C, mode, g.nw, lds, nblk, a, st);
         if (e != hipSuccess) return fail_hip(e, "score kernel launch");
         return DCX_OK;
@@ -469,8 +484,11 @@ int dcx_debug_set(const char* name, int64_t value) {
     const std::string n(name);
     std::atomic<int64_t>* dst = n == "ys" ? &k.ys : n == "nw" ? &k.nw : n == "min_rows" ? &k.min_rows
         : n == "split_finish_kernel" ? &k.split_finish_kernel : n == "inlaunch_tiles" ? &k.inlaunch_tiles
-        : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : n == "traj_fused" ? &k.traj_fused : n == "xf" ? &k.xf : nullptr;
+        : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : n == "traj_fused" ? &k.traj_fused : n == "xf" ? &k.xf : n == "mt" ? &k.mt : nullptr;
     if (!dst) return fail(DCX_ERR_INVALID, "unknown knob: " + n);
+#ifndef DCX_WITH_MT
+    if (dst == &k.mt && value >= 2) return fail(DCX_ERR_UNSUPPORTED, "this libdcx was built without score_kernel_mt (EXTRA=-DDCX_WITH_MT)");
+#endif
     *dst = value;
     return DCX_OK;
 }

@@ -30,6 +30,23 @@ constexpr bool kBothForms = true;
 template <int KF, int CC, int MODE>
 hipError_t go(int nw, size_t lds, int64_t nblk, const ScoreArgs& a, hipStream_t st) {
     const dim3 grid((unsigned)nblk, (unsigned)(a.ys > 1 ? a.ys : 1), (unsigned)(a.nz > 1 ? a.nz : 1));
+#ifdef DCX_WITH_MT
+    if constexpr (kD <= kMtMaxD) if (a.mt >= 2) {  // several tiles per block (score_kernel_mt); `lds` is lds_plan_mt's size, chosen by the caller
+        const dim3 grid_mt((unsigned)((nblk + a.mt - 1) / a.mt));
+        auto launch = [&](auto kern) {
+            if (lds > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return e;
+            }
+            kern<<<grid_mt, dim3(64 * nw), lds, st>>>(a, a.mt);
+            return hipGetLastError();
+        };
+        if constexpr (xf_applies(kD, CC, KF)) {
+            if (a.xf || !kBothForms) return launch(score_kernel_mt<kD, KF, CC, MODE, kMaxT, true>);
+        }
+        return launch(score_kernel_mt<kD, KF, CC, MODE, kMaxT, false>);
+    }
+#endif
     if constexpr (xf_applies(kD, CC, KF)) {
         if (!a.mfma && (a.xf || !kBothForms)) {
             score_kernel<kD, KF, CC, MODE, kMaxT, false, true><<<grid, dim3(64 * nw), lds, st>>>(a);

@@ -74,6 +74,7 @@ struct ScoreArgs {
     float kp0, kp1;           // kernel parameters
     int32_t mfma;             // 1: the launch uses the MFMA form of the gradient fold (score_kernel<..., MF = true>)
     int32_t xf;               // 1: the launch uses the expanded form of the sweep (score_kernel<..., XF = true>)
+    int32_t mt;               // >= 2: score_kernel_mt with this many tiles per block (unsplit launches only)
     int32_t hinge;            // C == 1: gradient of weight * clamp(score - margin, 0) instead of the score's
     float hinge_margin, hinge_weight;
 };
@@ -1081,6 +1082,172 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
             for (int i = lane; i < n; i += 64) gdst[i] = gq[i];
         } else {
             for (int i = lane; i < n; i += 64) gdst[(int64_t)(i / dof) * a.grad_stride + (i % dof)] = gq[i];
+        }
+    }
+}
+
+// ---- several tiles per block (MT) -------------------------------------------------------------------------------------
+// In score_kernel every 16-wave block spends ~25 % of its life with ONE wave working: the FK chain before the sweep,
+// the fold hand-over and J^T after it (profiles/r01_phase_timing.txt).  The two blocks that share a CU run in lock
+// step, so those phases coincide and the CU idles through them once per round of tiles.  Here a block owns NT <= 2
+// consecutive tiles: the chains of its tiles run side by side on waves 0 .. NT-1 (one lone wave each, on different
+// SIMDs), then all waves sweep tile 0, then tile 1 (each sweep ends in the same fixed-order cross-wave fold, into a
+// per-tile accumulator slab), then the J^T products run side by side again — half as many exposed single-wave phases
+// per CU for the same sweeps.  The arithmetic per configuration is exactly score_kernel's (same slices, same fold
+// order), so results are bit-identical to it.  Used for unsplit launches (ys == 1, one class per launch) with the
+// parallel fold; everything else stays on score_kernel.
+constexpr int kMtMaxTiles = 2;
+constexpr int kMtMaxD = 36;      // compiled for the narrow widths only (wider shapes fold through one LDS row anyway)
+constexpr int kMtFoldRows = 8;   // partial rows in LDS at a time: waves fold in rounds of 8 (keeps two blocks per CU)
+
+struct LdsPlanMT {
+    int q, f, x, acc, tile_stride, red, fk, total;
+};
+__host__ __device__ inline LdsPlanMT lds_plan_mt(int dof, int d_fk, int frame_floats, int nw, int acc_floats, int nt) {
+    LdsPlanMT p;
+    p.q = 0;
+    p.f = p.q + ((64 * dof + 3) & ~3);
+    p.x = p.f + 64 * frame_floats;
+    p.acc = p.x + 64 * d_fk;
+    p.tile_stride = p.acc + 64 * acc_floats;
+    p.red = nt * p.tile_stride;
+    const int rows = nw < kMtFoldRows ? nw : kMtFoldRows;
+    p.fk = p.red + rows * acc_floats * 64;
+    p.total = p.fk;
+    return p;
+}
+
+template <int D, int KF, int CC, int MODE, int MAXT, bool XF = false>
+__global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel_mt(const ScoreArgs a, const int nt_max) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr bool GRAD = (MODE != MODE_SCORE);
+    constexpr int ACC = (GRAD ? D : 0) + CC;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = blockDim.x >> 6;
+    const int dof = a.dof;
+    const int64_t n_tiles = (a.B + 63) / 64;
+    const int64_t t0 = (int64_t)blockIdx.x * nt_max;
+    const int nt = (int)((n_tiles - t0) < nt_max ? (n_tiles - t0) : nt_max);
+    const LdsPlanMT lp = lds_plan_mt(dof, a.d_fk, a.frame_floats, nw, ACC, nt_max);
+    float* sRed = smem + lp.red;
+    auto tile_q = [&](int i) { return smem + i * lp.tile_stride + lp.q; };
+    auto tile_f = [&](int i) { return smem + i * lp.tile_stride + lp.f; };
+    auto tile_x = [&](int i) { return smem + i * lp.tile_stride + lp.x; };
+    auto tile_a = [&](int i) { return smem + i * lp.tile_stride + lp.acc; };
+    auto tile_nb = [&](int i) {
+        const int64_t left = a.B - (t0 + i) * 64;
+        return (int)(left < 64 ? left : 64);
+    };
+
+    // ---- prologue: FK program and the q rows of every tile (coalesced) ----
+    const fk_cptr fk = stage_fk_prog(a.fk, smem + lp.fk, threadIdx.x, blockDim.x);
+    for (int i = 0; i < nt; ++i) {
+        const float* qsrc = a.q + (t0 + i) * 64 * dof;
+        const int nb = tile_nb(i), n = nb * dof;
+        float* sQ = tile_q(i);
+        for (int k = threadIdx.x; k < 64 * dof; k += blockDim.x) sQ[k] = qsrc[k < n ? k : (k % dof) + (nb - 1) * dof];
+    }
+    __syncthreads();
+    // sin / cos: the waves are dealt to the tiles (wave w -> tile w % nt, as worker w / nt of nw / nt)
+    {
+        const int i = wave % nt, sub = wave / nt, nsub = (nw - i + nt - 1) / nt;
+        fk_forward_trig(fk, tile_q(i) + lane * dof, tile_f(i) + lane, sub, nsub);
+    }
+    __syncthreads();
+    if (wave < nt) fk_forward_chain(fk, tile_q(wave) + lane * dof, tile_x(wave) + lane, tile_f(wave) + lane);
+    __syncthreads();
+
+    // ---- the sweeps, one tile after the other, all waves on each ----
+    const int j0 = (wave * a.s_chunk < a.S) ? wave * a.s_chunk : a.S;
+    const int j1 = (j0 + a.s_chunk < a.S) ? j0 + a.s_chunk : a.S;
+    for (int i = 0; i < nt; ++i) {
+        const float* sX = tile_x(i);
+        float x[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) x[k] = (k < a.d_fk) ? sX[k * 64 + lane] : 0.0f;
+        float up[CC];
+        if constexpr (MODE == MODE_GRAD_UP) {
+            const int nb = tile_nb(i);
+            const int64_t bl = (t0 + i) * 64 + (lane < nb ? lane : nb - 1);
+#pragma unroll
+            for (int c = 0; c < CC; ++c) up[c] = (a.one_hot >= 0) ? (c == a.one_hot ? 1.0f : 0.0f) : a.upstream[bl * CC + c];
+        }
+        float sc[CC];
+        float gx[D];
+#pragma unroll
+        for (int c = 0; c < CC; ++c) sc[c] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < D; ++k) gx[k] = 0.0f;
+        sweep_rows<D, KF, CC, MODE, XF>(a, x, up, j0, j1, sc, gx);
+        // fixed-order fold (row 0, 1, 2, ... as score_kernel adds them), kMtFoldRows partial rows in LDS at a time
+        float* sA = tile_a(i);
+        if (nw == 1) {
+#pragma unroll
+            for (int c = 0; c < CC; ++c) sA[c * 64 + lane] = sc[c];
+            if constexpr (GRAD) {
+#pragma unroll
+                for (int k = 0; k < D; ++k) sA[(CC + k) * 64 + lane] = gx[k];
+            }
+        } else {
+            for (int w0 = 0; w0 < nw; w0 += kMtFoldRows) {
+                __syncthreads();  // the previous round's (or tile's) fold has finished with sRed
+                if (wave >= w0 && wave < w0 + kMtFoldRows) {
+                    float* mine = sRed + (size_t)(wave - w0) * ACC * 64 + lane;
+#pragma unroll
+                    for (int c = 0; c < CC; ++c) mine[c * 64] = sc[c];
+                    if constexpr (GRAD) {
+#pragma unroll
+                        for (int k = 0; k < D; ++k) mine[(CC + k) * 64] = gx[k];
+                    }
+                }
+                __syncthreads();
+                const int rows = (nw - w0 < kMtFoldRows) ? (nw - w0) : kMtFoldRows;
+                for (int e = wave; e < ACC; e += nw) {
+                    float v = (w0 == 0) ? sRed[e * 64 + lane] : sA[e * 64 + lane];
+                    for (int r = (w0 == 0) ? 1 : 0; r < rows; ++r) v += sRed[((size_t)r * ACC + e) * 64 + lane];
+                    sA[e * 64 + lane] = v;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue: wave i finishes tile i (scores out, J^T, gradient rows out) ----
+    if (wave >= nt) return;
+    {
+        const int i = wave;
+        const int nb = tile_nb(i);
+        const int64_t b0 = (t0 + i) * 64;
+        float* sA = tile_a(i);
+        float sc[CC];
+#pragma unroll
+        for (int c = 0; c < CC; ++c) sc[c] = sA[c * 64 + lane];
+        if (a.score != nullptr && lane < nb) {
+#pragma unroll
+            for (int c = 0; c < CC; ++c) a.score[(b0 + lane) * CC + c] = sc[c];
+        }
+        if constexpr (GRAD) {
+            float scale = 1.0f;
+            if constexpr (CC == 1 && MODE == MODE_GRAD_ROW) {
+                if (a.upstream != nullptr) scale = a.upstream[b0 + (lane < nb ? lane : nb - 1)];
+                if (a.hinge) scale = (sc[0] - a.hinge_margin > 0.0f) ? a.hinge_weight : 0.0f;
+            }
+            float* sG = sA + CC * 64;  // the folded feature gradient, scaled in place: [k][64]
+#pragma unroll
+            for (int k = 0; k < D; ++k)
+                if (k < a.d_fk) sG[k * 64 + lane] = sG[k * 64 + lane] * scale;
+            float* gq = tile_q(i);      // the gradient row is built in place of the lane's own q row (as score_kernel does)
+            fk_vjp(fk, gq + lane * dof, tile_f(i) + lane, sG + lane, gq + lane * dof);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            float* gdst = a.grad + b0 * a.grad_stride;
+            const int n = nb * dof;
+            if (a.grad_stride == dof) {
+                for (int k = lane; k < n; k += 64) gdst[k] = gq[k];
+            } else {
+                for (int k = lane; k < n; k += 64) gdst[(int64_t)(k / dof) * a.grad_stride + (k % dof)] = gq[k];
+            }
         }
     }
 }

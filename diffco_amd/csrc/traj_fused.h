@@ -62,8 +62,11 @@ __device__ __forceinline__ float traj_wave_sum(float v) {
     return v;
 }
 
+// Register budget: ONE block per CU is the design point (256 restarts on 256 CUs; the LDS carve is ~90 KB), i.e.
+// MAXT / 256 waves per SIMD, so the allocator may use 512 / (MAXT / 256) VGPRs instead of the sweep kernel's 64: at
+// 64 the loop-carried state of the iteration (waypoint, moments, path terms) lived in scratch (236 B per lane).
 template <int D, int KF, int MAXT, bool XF = false>
-__global__ __launch_bounds__(MAXT, sweep_min_waves(D, 1, KF)) void traj_fused_kernel(const TrajFusedArgs a) {
+__global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_fused_kernel(const TrajFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int ACC = D + 1;
     const int r = blockIdx.x;

@@ -186,6 +186,40 @@ def test_split_launch_finish_modes_agree_bitwise(ops, name, knob):
     assert relerr(_n(s3), _n(s2)) < 3e-6 and relerr(_n(g3), _n(g2)) < 3e-6
 
 
+@pytest.mark.parametrize("name", ["cfg2_baxter_poly1", "cfg2_baxter_rq", "cfg2_panda_poly1", "cfg3_baxter_rq_c5", "cfg3_baxter_poly1_c5",
+                                  "misc_planar7_rq_p3", "cfg4_se3_keypts_rq"])
+@pytest.mark.parametrize("nw", [16, 8, 4, 1])
+def test_two_tiles_per_block_equals_one_tile_per_block_bitwise(ops, name, nw, knob):
+    """score_kernel_mt (two tiles per block: chains and J^T products of the block's tiles side by side, the sweeps one
+    after the other) against score_kernel with the same slicing: same arithmetic, same fold order -> identical bits;
+    odd tile counts, a ragged last tile, score-only, explicit upstream and the hinge entry point included.  The variant
+    is slower than one tile per block (profiles/r02_mt_probe.txt) and only compiled with EXTRA=-DDCX_WITH_MT."""
+    from diffco_amd import _lib
+    if _lib.load().dcx_debug_set(b"mt", 2) != 0:
+        pytest.skip("libdcx built without score_kernel_mt")
+    d = load(name)
+    m, _, _ = _model(ops, name, d)
+    reps = -(-461 // len(d["q"]))
+    q = _t(np.tile(d["q"], (reps, 1))[:461] if reps > 1 else d["q"][:461])       # 8 tiles, the last one ragged (13 rows)
+    q = q + 0.01 * torch.arange(len(q), device="cuda", dtype=torch.float32)[:, None] / len(q)
+    up = torch.randn((len(q), m.C), device="cuda") if m.C > 1 else None
+    knob("ys", 1)
+    knob("nw", nw)
+    knob("min_rows", 1)
+    for B in (461, 448, 129, 64):
+        knob("mt", 0)
+        s1, g1 = m.score_grad_raw(q[:B], None if up is None else up[:B])
+        so1 = m.score_raw(q[:B])
+        h1 = m.score_hinge_grad_raw(q[:B], 0.05, 3.0) if m.C == 1 else None
+        knob("mt", 2)
+        s2, g2 = m.score_grad_raw(q[:B], None if up is None else up[:B])
+        so2 = m.score_raw(q[:B])
+        assert torch.equal(s1, s2) and torch.equal(g1, g2) and torch.equal(so1, so2)
+        if h1 is not None:
+            h2 = m.score_hinge_grad_raw(q[:B], 0.05, 3.0)
+            assert torch.equal(h1[0], h2[0]) and torch.equal(h1[1], h2[1])
+
+
 @pytest.mark.parametrize("ys", [1, 4])
 def test_jacobian_rows_in_one_launch_equal_one_launch_per_class(ops, ys, knob):
     """C > 1: `dcx_score_jac` sends the C one-hot sweeps of a small batch out as ONE launch (grid z = class); with the
