@@ -219,7 +219,7 @@ int fk_device_copy(int device, const dcx_fk_desc& fk, FkProg** out) {
 // path calls getenv.  -1 = "use the rule".
 struct Knobs {
     std::atomic<int64_t> ys{-1}, nw{-1}, min_rows{-1}, split_finish_kernel{-1}, inlaunch_tiles{-1}, jac_per_class{-1},
-        mfma{-1}, traj_fused{-1}, xf{-1}, mt{-1};
+        mfma{-1}, traj_fused{-1}, xf{-1}, mt{-1}, prio{-1};
     Knobs() {
         auto rd = [](const char* name, std::atomic<int64_t>& dst, bool flag) {
             if (const char* e = std::getenv(name)) dst = flag ? 1 : std::atoll(e);
@@ -234,6 +234,7 @@ struct Knobs {
         rd("DCX_TRAJ_FUSED", traj_fused, false);
         rd("DCX_XF", xf, false);
         rd("DCX_MT", mt, false);
+        rd("DCX_PRIO", prio, false);
     }
 };
 Knobs& knobs() {
@@ -401,7 +402,10 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
     a.hinge = hinge.on;
     a.hinge_margin = hinge.margin;
     a.hinge_weight = hinge.weight;
-    a.xf = knobs().xf != 0 ? 1 : 0;  // expanded form wherever it exists (score_kernel.h); 0 only selects anything in DCX_BOTH_FORMS builds
+    a.prio = knobs().prio > 0 ? 1 : 0;
+    // Expanded form of the sweep (score_kernel.h XF) wherever it is compiled (Polyharmonic(1), rows <= 37 floats): 13-17 %
+    // faster for chip-filling batches, 1-3 % for split launches (profiles/r02_xf_probe.txt).  Knob xf = 0: direct form.
+    a.xf = knobs().xf != 0 ? 1 : 0;
     // MFMA form of the gradient fold: compiled for even D <= 16 with the two specialised kernel functions; needs every
     // wave to own a slice of the LDS reduction scratch (nw > 1, parallel fold)
     a.mfma = (mode != MODE_SCORE && m->Dt <= 16 && (m->Dt % 2) == 0 && m->kf != KF_GEN && g.nw > 1 && g.red_slots == g.nw &&
@@ -484,7 +488,7 @@ int dcx_debug_set(const char* name, int64_t value) {
     const std::string n(name);
     std::atomic<int64_t>* dst = n == "ys" ? &k.ys : n == "nw" ? &k.nw : n == "min_rows" ? &k.min_rows
         : n == "split_finish_kernel" ? &k.split_finish_kernel : n == "inlaunch_tiles" ? &k.inlaunch_tiles
-        : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : n == "traj_fused" ? &k.traj_fused : n == "xf" ? &k.xf : n == "mt" ? &k.mt : nullptr;
+        : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : n == "traj_fused" ? &k.traj_fused : n == "xf" ? &k.xf : n == "mt" ? &k.mt : n == "prio" ? &k.prio : nullptr;
     if (!dst) return fail(DCX_ERR_INVALID, "unknown knob: " + n);
 #ifndef DCX_WITH_MT
     if (dst == &k.mt && value >= 2) return fail(DCX_ERR_UNSUPPORTED, "this libdcx was built without score_kernel_mt (EXTRA=-DDCX_WITH_MT)");

@@ -74,6 +74,7 @@ struct ScoreArgs {
     float kp0, kp1;           // kernel parameters
     int32_t mfma;             // 1: the launch uses the MFMA form of the gradient fold (score_kernel<..., MF = true>)
     int32_t xf;               // 1: the launch uses the expanded form of the sweep (score_kernel<..., XF = true>)
+    int32_t prio;             // 1: raise the wave priority outside the sweep (the lone-wave FK / fold / J^T phases)
     int32_t mt;               // >= 2: score_kernel_mt with this many tiles per block (unsplit launches only)
     int32_t hinge;            // C == 1: gradient of weight * clamp(score - margin, 0) instead of the score's
     float hinge_margin, hinge_weight;
@@ -343,19 +344,20 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
     auto fix_near = [&](const auto& r, float d2c) __attribute__((always_inline)) {
         const bool nr = d2c <= thr;
         apply_x(r, d2c, std::integral_constant<int, -1>{}, nr);
-        v2f dp[D / 2 + 1];
-        v2f dacc = {0.0f, 0.0f};
+        // the differences are formed twice (once for the distance, once for the gradient term) rather than kept: this
+        // block sets the kernel's peak register pressure, and at 64 VGPRs every register held here is a long-lived
+        // value of the lone-wave code spilled to scratch
         const v2f mh = {-0.5f, -0.5f};  // x = -0.5 * (-2 x), exact: only the scaled copy stays in registers
+        v2f dacc = {0.0f, 0.0f};
 #pragma unroll
         for (int k = 0; k + 1 < D; k += 2) {
             const v2f rv = {r[k], r[k + 1]};
-            dp[k / 2] = xm[k / 2] * mh - rv;
-            dacc = __builtin_elementwise_fma(dp[k / 2], dp[k / 2], dacc);
+            const v2f dk = xm[k / 2] * mh - rv;
+            dacc = __builtin_elementwise_fma(dk, dk, dacc);
         }
         float d2d = dacc.x + dacc.y;
-        float dl_tail = 0.0f;
         if constexpr (D & 1) {
-            dl_tail = -0.5f * xm_tail - r[D - 1];
+            const float dl_tail = -0.5f * xm_tail - r[D - 1];
             d2d = fmaf(dl_tail, dl_tail, d2d);
         }
         float val, g;
@@ -367,22 +369,26 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
             const float cd = nr ? -coef_of(r, g) : 0.0f;  // H carries MINUS the gradient
             const v2f cd2 = {cd, cd};
 #pragma unroll
-            for (int k = 0; k + 1 < D; k += 2) ga[k / 2] = __builtin_elementwise_fma(cd2, dp[k / 2], ga[k / 2]);
-            if constexpr (D & 1) ga_tail = fmaf(cd, dl_tail, ga_tail);
+            for (int k = 0; k + 1 < D; k += 2) {
+                const v2f rv = {r[k], r[k + 1]};
+                ga[k / 2] = __builtin_elementwise_fma(cd2, xm[k / 2] * mh - rv, ga[k / 2]);
+            }
+            if constexpr (D & 1) ga_tail = fmaf(cd, -0.5f * xm_tail - r[D - 1], ga_tail);
         }
     };
-    // two rows of a pipeline stage in the expanded form + the near check
+    // two rows of a pipeline stage in the expanded form + the near check.  Each row's "any lane near?" goes to an SGPR
+    // mask straight away (the distances are not kept: the rare block recomputes them, bit for bit), one scalar branch
+    // per stage.
     auto stage_x = [&](const auto& r0, const auto& r1) __attribute__((always_inline)) {
-        const float d0 = pair_x(r0);
-        const float d1 = pair_x(r1);
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(fminf(d0, d1) <= thr) != 0, 0)) {
-            fix_near(r0, d0);
-            fix_near(r1, d1);
+        const auto m0 = __builtin_amdgcn_ballot_w64(pair_x(r0) <= thr);
+        const auto m1 = __builtin_amdgcn_ballot_w64(pair_x(r1) <= thr);
+        if (__builtin_expect((m0 | m1) != 0, 0)) {
+            fix_near(r0, d2_x(r0));
+            fix_near(r1, d2_x(r1));
         }
     };
     auto single_x = [&](const auto& r0) __attribute__((always_inline)) {
-        const float d0 = pair_x(r0);
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(d0 <= thr) != 0, 0)) fix_near(r0, d0);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(pair_x(r0) <= thr) != 0, 0)) fix_near(r0, d2_x(r0));
     };
     // fold the run's x * sum(c) into H in place: H <- H - x A = H + (-2 x) (A / 2), bit for bit the same product
     auto flush_x = [&]() __attribute__((always_inline)) {
@@ -845,13 +851,23 @@ __device__ __forceinline__ void sweep_rows_mfma(const ScoreArgs& a, const float 
     }
 }
 
+// The lane index, derived afresh from the execution mask (all lanes active) behind a compiler barrier.  The kernel
+// re-derives it after the sweep: everything computed from the prologue's copy (LDS column addresses, row offsets)
+// would otherwise stay live across the sweep, and at the sweep's 64-VGPR budget the allocator spilled exactly those
+// to scratch (8 B per lane per launch = 8 MB of HBM writes at B = 65536, and reloads inside the lone-wave FK code).
+__device__ __forceinline__ int fresh_lane() {
+    int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(l));
+    return l;
+}
+
 template <int D, int KF, int CC, int MODE, int MAXT, bool MF = false, bool XF = false>
 __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel(const ScoreArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr bool GRAD = (MODE != MODE_SCORE);
     constexpr int ACC = (GRAD ? D : 0) + CC;
 
-    const int lane = threadIdx.x & 63;
+    int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nw = blockDim.x >> 6;
     const int64_t b0 = (int64_t)blockIdx.x * 64;
@@ -866,6 +882,9 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
     float* sRed = smem + lp.red;
 
     DCX_TS(0);
+    // Issue arbitration is oldest-wave-first: a block that starts beside an older, sweeping block would crawl through its
+    // lone-wave phases.  They need few issue slots, so they run at raised priority; the sweep runs at the default.
+    if (a.prio) __builtin_amdgcn_s_setprio(3);
     // ---- prologue: stage the FK description and the q rows (coalesced), FK per lane on wave 0 ----
     const fk_cptr fk = stage_fk_prog(a.fk, smem + lp.fk, threadIdx.x, blockDim.x);
 #ifdef DCX_TIMING
@@ -914,6 +933,7 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
     const int j0 = (ybase + wave * a.s_chunk < yend) ? (ybase + wave * a.s_chunk) : yend;
     const int j1 = (j0 + a.s_chunk < yend) ? (j0 + a.s_chunk) : yend;
 
+    if (a.prio) __builtin_amdgcn_s_setprio(0);
     if constexpr (MF) {
         // this wave's slice of the reduction scratch doubles as its transpose buffer (X is dead, the fold comes later)
         sweep_rows_mfma<D, KF, CC, MODE>(a, x, up, j0, j1, sc, gx, sRed + (size_t)wave * ACC * 64, lane);
@@ -921,6 +941,8 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
         sweep_rows<D, KF, CC, MODE, XF>(a, x, up, j0, j1, sc, gx);
     }
     DCX_TS(3);
+    lane = fresh_lane();
+    if (a.prio) __builtin_amdgcn_s_setprio(3);
     // ---- meet the NW partial sums in LDS; wave 0 finishes --------------------------------
     if (nw > 1 && a.red_slots == 1) {
         // one LDS row: waves 1 .. nw-1 hand their partial sums to wave 0 in turn (same summation order as below)
