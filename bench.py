@@ -426,7 +426,11 @@ def main():
                          "traffic": None if pmc is None else pmc.get("hbm_bytes_per_launch"),
                          "traffic_source": None if pmc is None else f"profiles/pmc_{name}.json (rocprofv3 --pmc passes of an earlier run of "
                                                                      "this command, calibrated; a constant, not an observation of this run)",
-                         "kernel": "dcx::traj_fused_kernel<D,KF>" if is_traj else "dcx::score_kernel<D,KF,C,MODE>",
+                         "kernel": "dcx::traj_fused_kernel<D,KF,MAXT,XF>" if is_traj else "dcx::score_kernel<D,KF,C,MODE,MAXT,MF,XF>",
+                         "sweep_form": ("expanded (XF: d2 = |x|^2+|s|^2-2x.s, gX = x*sum(c)-sum(c s); 20 VALU/pair at D=12)"
+                                        if (w["kspec"][0] == 1 and w["kspec"][1] == 1.0 and w["D"] + C + (C > 1) + 1 <= 38
+                                            and os.environ.get("DCX_XF", "") != "0" and not mfma_on)
+                                        else "direct (differences; 24 VALU/pair at D=12)"),
                          "kernel_ms": round(kern_ms, 5), "flops_per_eval": F,
                          "note": "fp32 VALU bound (peak == fp32 MFMA peak 157.3 TFLOP/s); algorithmic flops "
                                  "S*(5D+4C+6)+800 per eval (SURVEY.md §8d)",

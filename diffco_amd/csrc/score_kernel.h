@@ -318,12 +318,17 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
         constexpr int SIGN = decltype(sign)::value;
         float val, g;
         kernel_eval<KF, true>(d2c, a, val, g);
-        if constexpr (SIGN < 0) val = keep ? -val : 0.0f;
+        // one class, row weight: w r = (w / r) d2 — the score rides on the gradient coefficient (one multiply fewer)
+        constexpr bool SCORE_BY_COEF = (KF == KF_POLY1 && CC == 1 && MODE == MODE_GRAD_ROW);
+        if constexpr (!SCORE_BY_COEF) {
+            if constexpr (SIGN < 0) val = keep ? -val : 0.0f;
 #pragma unroll
-        for (int c = 0; c < CC; ++c) sc[c] = fmaf(r[L::W_OFF + c], val, sc[c]);
+            for (int c = 0; c < CC; ++c) sc[c] = fmaf(r[L::W_OFF + c], val, sc[c]);
+        }
         if constexpr (GRAD) {
             float coef = coef_of(r, g);
             if constexpr (SIGN < 0) coef = keep ? -coef : 0.0f;
+            if constexpr (SCORE_BY_COEF) sc[0] = fmaf(coef, d2c, sc[0]);
             const v2f c2 = {coef, coef};
 #pragma unroll
             for (int k = 0; k + 1 < D; k += 2) {

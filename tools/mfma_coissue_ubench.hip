@@ -7,32 +7,51 @@
 //   M+V : the same number of each, interleaved in ONE wave's instruction stream (1 MFMA : R VALU)
 //   M|V : waves 0-3 of every 512-thread block MFMA only, waves 4-7 VALU only (each SIMD hosts one of each)
 // If the pipes overlap, M+V and M|V cost max(M, V); if they share one datapath they cost M + V.
-// Build: hipcc --offload-arch=gfx950 -O3 tools/mfma_coissue_ubench.hip -o build/mfma_coissue_ubench
+// Build: hipcc --offload-arch=gfx950 -O3 [-DBF16 [-DM32]] tools/mfma_coissue_ubench.hip -o tools/mfma_coissue_ubench
+//   default: v_mfma_f32_16x16x4_f32;  -DBF16: v_mfma_f32_16x16x32_bf16;  -DBF16 -DM32: v_mfma_f32_32x32x16_bf16
 #include <hip/hip_runtime.h>
 #include <cstdio>
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 
 // MODE 0: M, 1: V, 2: M+V interleaved, 3: M|V by wave parity.  PK: VALU op is v_pk_fma_f32 (else v_fma_f32).
 // R = VALU instructions per MFMA.
 template <int MODE, int PK, int R>
 __global__ __launch_bounds__(512) void k(float* out, int iters, float seed) {
+#ifdef M32
+    v16f acc[4];
+#else
     v4f acc[4];
+#endif
     float a[8];
     v2f p[8];
+#ifdef M32
+    for (int i = 0; i < 4; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = seed;
+#else
     for (int i = 0; i < 4; ++i) acc[i] = v4f{seed, seed, seed, seed};
+#endif
     for (int i = 0; i < 8; ++i) { a[i] = seed + i + threadIdx.x; p[i] = v2f{a[i], a[i] + 1.f}; }
     const float m = 1.0000001f, c = 1e-9f;
     const v2f m2 = {m, m}, c2 = {c, c};
     const float av = seed * 1e-3f, bv = seed * 2e-3f;
+    v8bf a8, b8;
+    for (int e = 0; e < 8; ++e) { a8[e] = (__bf16)(seed * 0.01f * e); b8[e] = (__bf16)(seed * 0.02f * e); }
     const int wave = threadIdx.x >> 8;  // M|V: a 512-thread block puts two waves on every SIMD, w and w + 4: one of each kind
     const bool do_m = MODE == 0 || MODE == 2 || (MODE == 3 && (wave & 1) == 0);
     const bool do_v = MODE == 1 || MODE == 2 || (MODE == 3 && (wave & 1) == 1);
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
+#ifdef M32
+            if (do_m) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[u]) : "v"(a8), "v"(b8));
+#elif defined(BF16)
+            if (do_m) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[u]) : "v"(a8), "v"(b8));
+#else
             if (do_m) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[u]) : "v"(av), "v"(bv));
+#endif
             if (do_v) {
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
@@ -83,7 +102,19 @@ void suite(int w) {
 int main() {
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
-    printf("device %s  CUs=%d  clock=%.0f MHz; MFMA = v_mfma_f32_16x16x4_f32 (2048 flop, 32 cycles/SIMD nominal)\n", prop.gcnArchName,
+    printf("device %s  CUs=%d  clock=%.0f MHz; MFMA = %s", prop.gcnArchName, prop.multiProcessorCount, prop.clockRate / 1e3,
+#ifdef BF16
+ #ifdef M32
+"v_mfma_f32_32x32x16_bf16 (32768 flop, 32 cycles/SIMD nominal)"
+#else
+"v_mfma_f32_16x16x32_bf16 (16384 flop, 16 cycles/SIMD nominal)"
+#endif
+
+#else
+ "v_mfma_f32_16x16x4_f32 (2048 flop, 32 cycles/SIMD nominal)"
+#endif
+);
+    if (0) printf("%s %d %f\n", prop.gcnArchName,
            prop.multiProcessorCount, prop.clockRate / 1e3);
     for (int w : {2, 4, 8}) {
         suite<0, 4>(w);
