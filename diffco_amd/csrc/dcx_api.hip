@@ -274,7 +274,9 @@ Geometry pick_geometry(const dcx_model* m, int64_t B, int acc_floats, bool allow
         g.ys = 3;
         g.nw = std::min(16, cap);
     } else {
-        g.nw = std::min((tiles <= 4 * (int64_t)m->n_cu) ? 16 : 8, cap);
+        // from four tiles per CU on, four 8-wave blocks per CU beat two 16-wave ones (expanded sweep, B = 65536: 98.8 -> 96.6 us,
+        // B = 262144: 364.6 -> 350.0 us; r01's direct sweep was level at B = 65536)
+        g.nw = std::min((tiles < 4 * (int64_t)m->n_cu) ? 16 : 8, cap);
     }
     const Knobs& kn = knobs();
     if (const int64_t v = kn.ys; v >= 1 && allow_split) g.ys = (int)std::min<int64_t>(v, 64);
