@@ -146,8 +146,12 @@ int dcx_device_count(void);
  * is split over blocks, never what is computed).  name: "ys" (support super-chunks per tile), "nw" (waves per
  * block), "min_rows" (supports per wave slice), "split_finish_kernel" (1 = finish split launches with a second
  * launch), "inlaunch_tiles", "jac_per_class" (1 = one launch per class in dcx_score_jac), "mfma" (0 = never use the
- * MFMA contraction, 1 = use it wherever it is compiled).  value < 0 restores the rule.  The initial values come
- * from the DCX_YS / DCX_NW / ... environment variables, read once at library load; no launch calls getenv.   */
+ * MFMA contraction, 1 = use it wherever it is compiled), "xf" (0 = the sweep in its direct form everywhere, 1 / rule =
+ * the expanded form wherever it is compiled: Polyharmonic(1), rows of <= 37 floats; the two forms agree to ~1e-6),
+ * "traj_fused" (0 = dcx_traj_adam_run as two launches per iteration), "prio" (1 = raised wave priority outside the
+ * sweep; measured: no effect), "mt" (2 = two tiles per block; only in EXTRA=-DDCX_WITH_MT builds, else
+ * DCX_ERR_UNSUPPORTED).  value < 0 restores the rule.  The initial values come from the DCX_YS / DCX_NW / DCX_XF / ...
+ * environment variables, read once at library load; no launch calls getenv.   */
 int dcx_debug_set(const char* name, int64_t value);
 
 /* ---- model = inference state of a kernel perceptron ------------------------------- */
