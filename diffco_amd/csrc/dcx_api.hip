@@ -783,8 +783,19 @@ int dcx_train_perceptron(int device, int kernel_kind, const float* kparams, floa
     if (!feats || !y || !gains || !hypothesis || !kernel_matrix || !info) return fail(DCX_ERR_INVALID, "a trainer pointer is NULL");
     if (int rc = check_kernel(kernel_kind, kparams)) return rc;
     if (int rc = set_device(device)) return rc;
+    // The register-resident kernel (one label column, N <= 10240) keeps a label as one sign bit; labels other than
+    // -1 / +1 (0 / 1 labels, y = 0) must take the generic kernel, which evaluates the reference's expressions on y itself.
+    // The check reads the labels back (<= 40 KB, on the caller's stream): the trainer is the one entry point that waits.
+    bool sign_labels = false;
+    if (C == 1 && N <= 512 * 20) {
+        std::vector<float> yh((size_t)N);
+        hipError_t ce = hipMemcpyAsync(yh.data(), y, yh.size() * sizeof(float), hipMemcpyDefault, (hipStream_t)stream);
+        if (ce == hipSuccess) ce = hipStreamSynchronize((hipStream_t)stream);
+        if (ce != hipSuccess) return fail_hip(ce, "perceptron trainer: reading the labels");
+        sign_labels = std::all_of(yh.begin(), yh.end(), [](float v) { return v == 1.0f || v == -1.0f; });
+    }
     hipError_t e = launch_perceptron(kernel_kind, kparams[0], kparams[1], beta, feats, y, gains, hypothesis, kernel_matrix,
-                                     info, (int)N, D, C, max_iteration, (hipStream_t)stream);
+                                     info, (int)N, D, C, max_iteration, sign_labels, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "perceptron trainer launch");
     return DCX_OK;
 }

@@ -57,7 +57,8 @@ hipError_t launch_kernel_matrix(int kind, float kp0, float kp1, const float* x, 
 
 // train_kernels.hip
 hipError_t launch_perceptron(int kind, float kp0, float kp1, float beta, const float* feats, const float* y, float* gains,
-                             float* hypo, float* K, int32_t* info, int N, int D, int C, int max_iter, hipStream_t st);
+                             float* hypo, float* K, int32_t* info, int N, int D, int C, int max_iter, bool sign_labels,
+                             hipStream_t st);
 
 // traj_kernels.hip
 hipError_t launch_traj_adam_step(const FkProg* fk_dev, const dcx_fk_desc& fk, const dcx_traj_state& st,

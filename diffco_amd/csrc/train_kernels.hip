@@ -332,14 +332,15 @@ __global__ __launch_bounds__(NT) void perceptron_reg_kernel(const TrainArgs a) {
 }  // namespace
 
 hipError_t launch_perceptron(int kind, float kp0, float kp1, float beta, const float* feats, const float* y, float* gains,
-                             float* hypo, float* K, int32_t* info, int N, int D, int C, int max_iter, hipStream_t st) {
+                             float* hypo, float* K, int32_t* info, int N, int D, int C, int max_iter, bool sign_labels,
+                             hipStream_t st) {
     TrainArgs a;
     a.feats = feats; a.y = y; a.gains = gains; a.hypo = hypo; a.K = K; a.info = info;
     a.N = N; a.D = D; a.C = C; a.max_iter = max_iter; a.kind = kind; a.kp0 = kp0; a.kp1 = kp1; a.beta = beta;
     const size_t lds = sizeof(float) * ((D + 3) & ~3) + 16 * sizeof(Best) + 16 * sizeof(int) + 4 * sizeof(float);
-    if (C == 1 && N <= 1024 * 4) {
+    if (sign_labels && C == 1 && N <= 1024 * 4) {
         perceptron_reg_kernel<4, 1024><<<dim3(1), dim3(1024), lds, st>>>(a);
-    } else if (C == 1 && N <= 512 * 20) {   // 8 waves = 2 per SIMD: 256 VGPRs per lane hold 20 samples' state
+    } else if (sign_labels && C == 1 && N <= 512 * 20) {   // 8 waves = 2 per SIMD: 256 VGPRs per lane hold 20 samples' state
         perceptron_reg_kernel<20, 512><<<dim3(1), dim3(512), lds, st>>>(a);
     } else {
         perceptron_kernel<<<dim3(1), dim3(1024), lds, st>>>(a);

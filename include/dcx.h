@@ -251,7 +251,9 @@ int dcx_traj_adam_run(const dcx_model* model, const dcx_traj_state* st, const dc
  *   kernel_matrix [N, N] dev in/out: zeros = "row not computed yet"; row i AND column i are filled when sample i
  *                 is first selected (K[i, :] = K[:, i] = k(x_i, X), kernel_perceptrons.py:117-119), so the sub-block
  *                 over the kept supports is complete even for a sample that was never selected itself
- *   info [2] dev out: iterations used, 1 if converged                                                    */
+ *   info [2] dev out: iterations used, 1 if converged
+ * For one label column and N <= 10240 the entry point reads the labels back once (a stream synchronisation) to decide
+ * whether the register-resident kernel, which keeps a label as its sign, may be used.                      */
 int dcx_train_perceptron(int device, int kernel_kind, const float* kparams, float beta, const float* feats, int64_t N,
                          int32_t D, const float* y, int32_t C, float* gains, float* hypothesis, float* kernel_matrix,
                          int32_t max_iteration, int32_t* info, void* stream);

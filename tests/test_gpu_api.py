@@ -332,6 +332,32 @@ def test_device_trainer_equals_host_trainer_and_reference(monkeypatch):
     assert float(((s > 0) == (yb[:4096] > 0)).float().mean()) > 0.99
 
 
+@pytest.mark.parametrize("n", [900, 6000])
+def test_device_trainer_with_labels_other_than_plus_minus_one(monkeypatch, n):
+    """the register-resident trainer keeps a label as its sign, which is only the reference's arithmetic for
+    labels in {-1, +1}.  Labels 0 / 0.5 / 2 (margin y*h, target beta^((1+y)/2)*y evaluated on y itself,
+    kernel_perceptrons.py:115-124) must give what the host loop gives, whatever N is (both register-resident sizes)."""
+    from diffco_amd import kernel
+    from diffco_amd.kernel_perceptrons import DiffCo
+    d = load("trained_baxter")
+    rob = make_robot("baxter_left")
+    X = torch.from_numpy(d["X"])
+    X = X.repeat(-(-n // len(X)), 1)[:n] + 0.001 * torch.arange(n)[:, None] / n
+    g = torch.Generator().manual_seed(7)
+    y = torch.tensor([-1.0, 0.0, 0.5, 1.0, 2.0])[torch.randint(0, 5, (n,), generator=g)]
+    runs = {}
+    for mode in ("device", "host"):
+        if mode == "host":
+            monkeypatch.setenv("DCX_HOST_TRAINER", "1")
+        dc = DiffCo(kernel_func=kernel.RQKernel(10.0), beta=0.7, transform=rob.fkine)
+        dc.train(X, y, max_iteration=400)
+        runs[mode] = dc
+    monkeypatch.delenv("DCX_HOST_TRAINER")
+    dev, host = runs["device"], runs["host"]
+    np.testing.assert_array_equal(_np(dev.support_points), _np(host.support_points))
+    assert relerr(_np(dev.gains), _np(host.gains)) < 1e-4 and relerr(_np(dev.hypothesis), _np(host.hypothesis)) < 1e-4
+
+
 @pytest.mark.parametrize("mns", [None, 16])
 @pytest.mark.parametrize("n", [60, 5000])
 def test_device_trainer_all_equal_labels_then_update(mns, n):
