@@ -256,7 +256,9 @@ constexpr bool xf_applies(int D, int CC, int KF) {
     return KF == KF_POLY1 && used + 1 <= 38 && parts <= 1;
 }
 
-template <int D, int KF, int CC, int MODE, bool XF = false>
+// NACC > 0 overrides the number of independent squared-distance accumulator pairs of the expanded form (callers that run
+// at few waves per SIMD trade one packed add per row for a shorter dependent chain)
+template <int D, int KF, int CC, int MODE, bool XF = false, int NACC = 0>
 __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[D], const float (&up)[CC], int j0, int j1,
                                            float (&sc)[CC], float (&gx)[D]) {
     using L = RowLayout<D, CC>;
@@ -286,7 +288,7 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
     }
     // squared distance of one support row in the expanded form, clamped at thr (== thr marks a near pair)
     auto d2_x = [&](const auto& r) __attribute__((always_inline)) -> float {
-        constexpr int NA = DCX_D2_ACCS(D);
+        constexpr int NA = NACC > 0 ? NACC : DCX_D2_ACCS(D);
         v2f acc[NA];
         acc[0] = v2f{xx + r[L::SS_OFF], 0.0f};
 #pragma unroll
@@ -1026,7 +1028,17 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
                 __hip_atomic_store(out + (CC + k) * 64, gx[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         DCX_FK_TS(7, 2);
+        // Every value of the row went out as an agent-scope atomic store (global_store sc1: written through to where the
+        // other XCDs see it), and this wave stored nothing else to global memory.  Waiting for those stores to be
+        // acknowledged therefore orders them before the counter increment below; the `buffer_wbl2 sc1` that a release
+        // fence adds writes back OTHER dirty L2 lines and has nothing of ours to do (LLVM AMDGPU memory model, gfx942:
+        // "fence release agent" = buffer_wbl2 sc1 + s_waitcnt vmcnt(0); "store atomic monotonic agent" = store sc1).
+        // Measured: config #2 17.8 -> 16.5 us, headline B = 4096 20.9 -> 19.6 us.  -DDCX_HANDOVER_FENCE restores the fence.
+#ifdef DCX_HANDOVER_FENCE
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         DCX_FK_TS(8, 2);
         unsigned int arrived = 0;
         if (lane == 0) arrived = __hip_atomic_fetch_add(a.tile_done + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -18,6 +18,14 @@
 #pragma once
 #include "score_kernel.h"
 
+// Squared-distance accumulator chains of the sweep inside the persistent kernel.  It runs at 4 waves per SIMD, where two
+// shorter dependent chains beat one by 2 % (36.0 -> 35.2 us per iteration with -DDCX_TRAJ_NACC=2), but a different
+// summation order gives up the bit-identity with the two-launch loop that tests/test_gpu_traj.py holds it to: default 0
+// (the sweep kernel's own rule).
+#ifndef DCX_TRAJ_NACC
+#define DCX_TRAJ_NACC 0
+#endif
+
 namespace dcx {
 
 constexpr int kTrajFusedMaxIters = 192;  // iterations per launch (the bias corrections travel as kernel arguments)
@@ -128,7 +136,7 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
         const float up[1] = {1.0f};
 #pragma unroll
         for (int k = 0; k < D; ++k) gx[k] = 0.0f;
-        sweep_rows<D, KF, 1, MODE_GRAD_ROW, XF>(a.sc, x, up, j0, j1, sc, gx);
+        sweep_rows<D, KF, 1, MODE_GRAD_ROW, XF, DCX_TRAJ_NACC>(a.sc, x, up, j0, j1, sc, gx);
         if (nw > 1) {
             // the sweep's parallel cross-wave fold (score_kernel.h): row 0 first, then 1, 2, ...
             float* mine = sRed + (size_t)wave * ACC * 64 + lane;
