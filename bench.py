@@ -44,6 +44,9 @@ WORKLOADS = {
     "cfg2_panda": ("panda", (1, 1.0, 1.0), 1000, 1, 4096, 4096, "config #2 with PandaFK (D=21)"),
     "cfg3": ("baxter", (0, 10.0, 2.0), 2000, 5, 8192, 65536,
              "BASELINE config #3: MultiDiffCo C=5, RQ(10), S=2000, batch 65536 over 8 GPUs = 8192 per GPU"),
+    "cfg3_poly": ("baxter", (1, 1.0, 1.0), 2000, 5, 8192, 65536,
+                  "config #3 with the Polyharmonic(1,1) spline nodes MultiDiffCo.rbf_score evaluates "
+                  "(deprecated/MultiDiffCo.py:156-169): C=5, S=2000, 8192 per GPU"),
     "cfg4": (None, (0, 10.0, 2.0), 10000, 1, 1 << 20, 1 << 20, "BASELINE config #4: SE(3) no-FK (D=6), RQ(10), S=10k, 1M configs"),
     # config #5: a "step" is ONE fused Adam iteration over R restarts x 50 waypoints (= 50 R score+grad evals)
     "cfg5": ("baxter", (1, 1.0, 1.0), 2000, 1, 256 * 50, 256 * 50,
@@ -81,7 +84,7 @@ def make_workload(name, batch, dev, seed=0):
         desc = rob.fk_desc()
     sup_q = torch.rand((S, len(lo)), generator=g) * (hi - lo) + lo
     W = torch.randn((S, C), generator=g)
-    if name == "cfg3":  # 40 % of the entries zeroed per class (mimics deprecated/MultiDiffCo.py:152-153)
+    if name in ("cfg3", "cfg3_poly"):  # 40 % of the entries zeroed per class (mimics deprecated/MultiDiffCo.py:152-153)
         W = W * (torch.rand((S, C), generator=g) >= 0.4)
     q = torch.rand((B, len(lo)), generator=gq) * (hi - lo) + lo
     sup = _ops.fkine(desc, sup_q.to(dev)).reshape(S, -1)

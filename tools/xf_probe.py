@@ -18,7 +18,7 @@ from oracle import oracle  # noqa: E402
 dev = torch.device("cuda", 0)
 lib = _lib.require_gpu()
 cases = [("headline", 65536), ("headline", 1 << 20), ("headline", 4096), ("cfg2", 4096), ("cfg2_panda", 4096), ("cfg3", 8192),
-         ("cfg3", 65536), ("cfg4", 1 << 18), ("cfg5", 12800)]
+         ("cfg3", 65536), ("cfg3_poly", 8192), ("cfg3_poly", 65536), ("cfg4", 1 << 18), ("cfg5", 12800)]
 if len(sys.argv) > 1:
     cases = [(a.split(":")[0], int(a.split(":")[1])) for a in sys.argv[1:]]
 for name, B in cases:
