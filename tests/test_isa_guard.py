@@ -1,0 +1,85 @@
+"""Code-generation guard (CPU only: hipcc cross-compiles): the hot loop of the fused sweep is hand-scheduled around the
+wave's ~100 SGPRs and a 64-VGPR budget, and small source changes have silently cost 30 % before (a scalar branch added to
+the loop made the allocator park row SGPRs in VGPR lanes; a second accumulator set spilled the lane index to scratch).
+This compiles the headline instantiations in both forms and checks what the profiles rely on:
+no v_readlane / v_writelane / scratch traffic inside the sweep loop, the expanded form's instruction count, no scratch
+beyond the FK tree's own frame."""
+import os
+import re
+import shutil
+import subprocess
+from collections import Counter
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "diffco_amd", "csrc")
+
+SRC = """#include "dcx_internal.h"
+namespace dcx {
+template __global__ void score_kernel<12, KF_POLY1, 1, MODE_GRAD_ROW, 1024, false, true>(const ScoreArgs);
+template __global__ void score_kernel<12, KF_POLY1, 1, MODE_GRAD_ROW, 1024, false, false>(const ScoreArgs);
+template __global__ void score_kernel<12, KF_RQ2, 5, MODE_GRAD_UP, 1024, false, false>(const ScoreArgs);
+template __global__ void score_kernel<6, KF_RQ2, 1, MODE_GRAD_ROW, 1024, false, false>(const ScoreArgs);
+}
+"""
+
+
+@pytest.fixture(scope="module")
+def isa(tmp_path_factory):
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    d = tmp_path_factory.mktemp("isa")
+    src, out = d / "k.hip", d / "k.s"
+    src.write_text(SRC)
+    subprocess.run(["hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I", CSRC, "-S", "--cuda-device-only",
+                    str(src), "-o", str(out)], check=True, stderr=subprocess.DEVNULL)
+    return out.read_text()
+
+
+def _kernels(txt):
+    for m in re.finditer(r"^(_ZN3dcx12score_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi1024ELb0ELb(\d)EEEvNS_9ScoreArgsE):", txt, re.M):
+        body = txt[m.end():txt.index(".Lfunc_end", m.end())].split("\n")
+        meta = txt[txt.index(".name:           " + m.group(1)):]
+        yield dict(D=int(m.group(2)), KF=int(m.group(3)), C=int(m.group(4)), MODE=int(m.group(5)), XF=int(m.group(6)), body=body,
+                   scratch_bytes=int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", meta).group(1)),
+                   vgpr=int(re.search(r"\.vgpr_count:\s+(\d+)", meta).group(1)))
+
+
+def _sweep_loop(body):
+    """the smallest backward-branch range that loads support rows through the scalar cache and holds at least two
+    quarter-rate ops (the two-row pipeline of wide rows; the four-row pipeline has four)"""
+    labels = {m.group(1): n for n, l in enumerate(body) if (m := re.match(r"^(\.LBB\d+_\d+):", l))}
+    best = None
+    for n, l in enumerate(body):
+        m = re.search(r"s_c?branch\w* (\.LBB\d+_\d+)", l)
+        if m and m.group(1) in labels and labels[m.group(1)] < n:
+            seg = body[labels[m.group(1)]:n + 1]
+            quarter = sum(("v_rsq_f32" in x) or ("v_rcp_f32" in x) for x in seg)
+            if quarter >= 2 and sum("s_load_dword" in x for x in seg) >= 2 and (best is None or len(seg) < len(best)):
+                best = seg
+    assert best is not None, "sweep loop not found"
+    return Counter(x.split()[0] for x in (y.strip() for y in best) if x and not x.startswith((".", ";")))
+
+
+def test_sweep_loops_have_no_lane_parking_and_no_scratch(isa):
+    seen = 0
+    for k in _kernels(isa):
+        c = _sweep_loop(k["body"])
+        tag = f"D={k['D']} KF={k['KF']} C={k['C']} MODE={k['MODE']} XF={k['XF']}"
+        assert c["v_readlane_b32"] + c["v_writelane_b32"] == 0, (tag, "SGPRs parked in VGPR lanes inside the sweep loop")
+        assert sum(v for op, v in c.items() if op.startswith("scratch_")) == 0, (tag, "scratch traffic inside the sweep loop")
+        assert k["vgpr"] <= 64, (tag, k["vgpr"])          # 8 waves per SIMD at the narrow shapes
+        assert k["scratch_bytes"] <= 44, (tag, k["scratch_bytes"])   # the noinline tree-FK frame and nothing else
+        seen += 1
+    assert seen == 4
+
+
+def test_expanded_form_instruction_count(isa):
+    """four rows per loop iteration: 12 v_pk_fma per row in the expanded form and no packed add on the hot path; the
+    direct form carries 6 v_pk_add + 12 v_pk_fma per row"""
+    ks = {k["XF"]: _sweep_loop(k["body"]) for k in _kernels(isa) if k["D"] == 12 and k["C"] == 1}
+    valu = {xf: sum(v for op, v in c.items() if op.startswith("v_")) for xf, c in ks.items()}
+    assert ks[0]["v_pk_add_f32"] == 24 and ks[0]["v_pk_fma_f32"] == 48 and valu[0] <= 100, (ks[0], valu[0])
+    # the expanded loop range also holds the flush block (6 v_pk_fma) and may hold one rare correction block
+    assert 48 <= ks[1]["v_pk_fma_f32"] <= 70 and ks[1]["v_rsq_f32"] <= 6 and valu[1] <= 135, (ks[1], valu[1])

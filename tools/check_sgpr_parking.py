@@ -39,8 +39,9 @@ def main():
     with ThreadPoolExecutor(8) as ex:
         for d, path in ex.map(compile_width, widths):
             txt = open(path).read()
-            for m in re.finditer(r"^(_ZN3dcx12score_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)EEEvNS_9ScoreArgsE):", txt, re.M):
+            for m in re.finditer(r"^(_ZN3dcx12score_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELb(\d)EEEvNS_9ScoreArgsE):", txt, re.M):
                 name, D, KF, CC, MODE = m.group(1), *map(int, m.group(2, 3, 4, 5))
+                MF, XF = int(m.group(7)), int(m.group(8))
                 body = txt[m.end():txt.index(".Lfunc_end", m.end())].split("\n")
                 best = None
                 for a, b in loops(body):
@@ -56,7 +57,7 @@ def main():
                 scratch = sum(v for k, v in c.items() if k.startswith("scratch_"))
                 if parked or scratch:
                     bad += 1
-                    print(f"D={D:<3} KF={KF} C={CC} MODE={MODE}: {parked} lane moves, {scratch} scratch ops among {valu} VALU "
+                    print(f"D={D:<3} KF={KF} C={CC} MODE={MODE} MF={MF} XF={XF}: {parked} lane moves, {scratch} scratch ops among {valu} VALU "
                           f"instructions of the sweep loop")
     print(f"{bad} instantiation(s) with SGPR parking or scratch inside the sweep loop")
 
