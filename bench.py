@@ -57,6 +57,27 @@ TRAJ_W = 50
 GATHER_EVERY = 4  # --gather bucketed: calls per all-gather
 
 
+SAME_GPU = os.environ.get("DCX_BENCH_SAME_GPU", "") not in ("", "0")
+"""Developer rehearsal of the N > 1 code path on a box with ONE GPU: every rank uses cuda:0 and the gloo backend (RCCL
+refuses two ranks on one device), the score gather goes through host buffers.  Timings are meaningless; shard
+arithmetic, the variants, the reductions and the JSON assembly are the real ones (tests/test_gpu_bench_contract.py)."""
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
+def gather_scores(full, local, async_op=False):
+    if not SAME_GPU:
+        return dist.all_gather_into_tensor(full, local, async_op=async_op)
+    torch.cuda.current_stream(local.device).synchronize()
+    host = torch.empty(full.shape, dtype=full.dtype)
+    dist.all_gather_into_tensor(host, local.cpu())
+    full.copy_(host)
+    return _Done() if async_op else None
+
+
 def flops_per_eval(D, C, S):
     """F_pair = 5D + 4C + 6, F_eval = S*F_pair + 800 (FK + J^T)"""
     return S * (5 * D + 4 * C + 6) + 800
@@ -217,7 +238,7 @@ class ScoreLoop:
             # the consumer needs the gathered scores before it issues the next call: same stream, strictly in order
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            dist.all_gather_into_tensor(self.full[0], self.local[0])
+            gather_scores(self.full[0], self.local[0])
             e1.record()
             self.gather_events.append((e0, e1))
             return
@@ -227,7 +248,7 @@ class ScoreLoop:
             self.comm.wait_event(ev)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            self.pending[b] = dist.all_gather_into_tensor(self.full[b], self.local[b], async_op=True)
+            self.pending[b] = gather_scores(self.full[b], self.local[b], async_op=True)
             e1.record()
             self.gather_events.append((e0, e1))
 
@@ -299,7 +320,7 @@ def measure(loop, steps, warmup, dev, multi):
     wall = time.perf_counter() - t0
     kern_ms = e0.elapsed_time(e1) / steps
     if multi:
-        tt = torch.tensor([wall, kern_ms], device=dev, dtype=torch.float64)
+        tt = torch.tensor([wall, kern_ms], device="cpu" if SAME_GPU else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall, kern_ms = float(tt[0]), float(tt[1])
     return wall, kern_ms
@@ -341,6 +362,8 @@ def main():
                  "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     from diffco_amd import _lib
     _lib.require_gpu()
+    if SAME_GPU:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     multi = world > 1 or args.force_dist
@@ -348,7 +371,10 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if SAME_GPU:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     ranks_reported = dist.get_world_size() if multi else 1
 
     name = args.workload
@@ -448,7 +474,7 @@ def main():
                                       "kernel_us_mfma_form", "kernel_us_valu_form", "verdict", "source")}}},
         }
         if multi:
-            out["multi"] = {"ranks": ranks_reported, "backend": "nccl (RCCL)", "gather": loop.gather,
+            out["multi"] = {"ranks": ranks_reported, "backend": "gloo, all ranks on cuda:0 (rehearsal)" if SAME_GPU else "nccl (RCCL)", "gather": loop.gather,
                             "gather_ms": None if gather_ms is None else round(gather_ms, 5),
                             "gather_bytes_per_call": None if is_traj else
                             world * B * C * 4 * (GATHER_EVERY if loop.gather == "bucketed" else 1)}

@@ -75,3 +75,33 @@ def test_cpu_baseline_leg():
     d = _run(["--batch", "4096"], steps=5, warmup=2)
     cb = d["cpu_baseline"]
     assert {"value", "unit", "cores", "kind", "sample"} <= set(cb) and cb["kind"] == "port" and cb["value"] > 0
+
+
+@pytest.mark.parametrize("extra", [["--scaling", "weak"], ["--scaling", "strong"], ["--workload", "cfg3", "--scaling", "strong"],
+                                   ["--workload", "cfg5", "--scaling", "strong"], ["--workload", "cfg5", "--scaling", "weak"]],
+                         ids=["headline-weak", "headline-strong", "cfg3-strong", "cfg5-strong", "cfg5-weak"])
+def test_two_rank_rehearsal_on_one_gpu(extra):
+    """world size 2 through torch.distributed.run exactly as the driver launches it, both ranks on cuda:0 with the gloo
+    backend (DCX_BENCH_SAME_GPU=1: RCCL refuses two ranks on one device, so the gather goes through host buffers).
+    Timings mean nothing here; the shard arithmetic, the barriers and reductions, the variants and the one JSON line of
+    rank 0 are the code the 2/4/8-GPU runs execute."""
+    env = dict(os.environ, DCX_BENCH_SAME_GPU="1")
+    port = str(29600 + (abs(hash(tuple(extra))) % 200))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12",
+                        "--warmup", "2"] + extra, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.split("\n") if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert (KEYS - {"cpu_baseline"}) <= set(d) and d["n_gpus"] == 2 and d["steps"] == 12 and d["value"] > 0
+    assert d["multi"]["ranks"] == 2 and d["scaling"] == extra[extra.index("--scaling") + 1]
+    cfg = d["config"]
+    if "cfg5" in extra:
+        assert d["multi"]["gather"] == "summaries"
+        assert cfg["global_batch"] == (256 * 50 if d["scaling"] == "strong" else 2 * 256 * 50)
+    elif d["scaling"] == "strong":
+        assert cfg["global_batch"] == 65536 and cfg["batch_per_gpu"] == 32768
+    else:
+        assert cfg["global_batch"] == 2 * cfg["batch_per_gpu"] == 2 * 65536
+    assert d["variants"]["other_scaling"]["value"] > 0
