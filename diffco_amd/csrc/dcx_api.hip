@@ -73,6 +73,17 @@ traj_fused_fn traj_fused_for(int Dt) {
     }
 }
 
+jac_fn jac_for(int Dt) {
+    switch (Dt) {
+#define DCX_CASE(D) case D: return launch_jac_D##D;
+        DCX_CASE(2) DCX_CASE(4) DCX_CASE(6) DCX_CASE(8) DCX_CASE(12) DCX_CASE(16) DCX_CASE(18) DCX_CASE(21)
+        DCX_CASE(24) DCX_CASE(27) DCX_CASE(30) DCX_CASE(32) DCX_CASE(36) DCX_CASE(42) DCX_CASE(48) DCX_CASE(54)
+        DCX_CASE(60) DCX_CASE(64) DCX_CASE(72) DCX_CASE(84) DCX_CASE(96)
+#undef DCX_CASE
+    default: return nullptr;
+    }
+}
+
 launch_fn launch_for(int Dt) {
     switch (Dt) {
 #define DCX_CASE(D) case D: return launch_score_D##D;
@@ -219,7 +230,7 @@ int fk_device_copy(int device, const dcx_fk_desc& fk, FkProg** out) {
 // path calls getenv.  -1 = "use the rule".
 struct Knobs {
     std::atomic<int64_t> ys{-1}, nw{-1}, min_rows{-1}, split_finish_kernel{-1}, inlaunch_tiles{-1}, jac_per_class{-1},
-        mfma{-1}, traj_fused{-1}, xf{-1}, mt{-1}, prio{-1};
+        mfma{-1}, traj_fused{-1}, xf{-1}, mt{-1}, prio{-1}, jac_one_sweep{-1};
     Knobs() {
         auto rd = [](const char* name, std::atomic<int64_t>& dst, bool flag) {
             if (const char* e = std::getenv(name)) dst = flag ? 1 : std::atoll(e);
@@ -235,6 +246,7 @@ struct Knobs {
         rd("DCX_XF", xf, false);
         rd("DCX_MT", mt, false);
         rd("DCX_PRIO", prio, false);
+        rd("DCX_JAC_ONE_SWEEP", jac_one_sweep, false);
     }
 };
 Knobs& knobs() {
@@ -490,7 +502,7 @@ int dcx_debug_set(const char* name, int64_t value) {
     const std::string n(name);
     std::atomic<int64_t>* dst = n == "ys" ? &k.ys : n == "nw" ? &k.nw : n == "min_rows" ? &k.min_rows
         : n == "split_finish_kernel" ? &k.split_finish_kernel : n == "inlaunch_tiles" ? &k.inlaunch_tiles
-        : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : n == "traj_fused" ? &k.traj_fused : n == "xf" ? &k.xf : n == "mt" ? &k.mt : n == "prio" ? &k.prio : nullptr;
+        : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : n == "traj_fused" ? &k.traj_fused : n == "xf" ? &k.xf : n == "mt" ? &k.mt : n == "prio" ? &k.prio : n == "jac_one_sweep" ? &k.jac_one_sweep : nullptr;
     if (!dst) return fail(DCX_ERR_INVALID, "unknown knob: " + n);
 #ifndef DCX_WITH_MT
     if (dst == &k.mt && value >= 2) return fail(DCX_ERR_UNSUPPORTED, "this libdcx was built without score_kernel_mt (EXTRA=-DDCX_WITH_MT)");
@@ -671,6 +683,44 @@ int dcx_score_jac(const dcx_model* m, const float* q, int64_t B, float* score, f
         int rc = run_score(m, q, B, nullptr, score, jac, MODE_GRAD_UP, -1, (int64_t)m->C * m->fk.dof, (hipStream_t)stream,
                            Hinge(), m->C);
         if (rc != DCX_ERR_UNSUPPORTED) return rc;
+    }
+    // A chip-filling batch: every class in ONE sweep (jac_kernel.h) where it is compiled (D * C + C <= 104 accumulators per
+    // lane).  Knob jac_one_sweep: 0 = never, 1 = also for small batches (tests).
+    const int64_t one_sweep = knobs().jac_one_sweep;
+    if (jac_applies(m->Dt, m->C) && B > 0 && one_sweep != 0 && !(knobs().jac_per_class > 0) &&
+        (one_sweep > 0 || (B + 63) / 64 * m->C > 2 * (int64_t)m->n_cu)) {
+        const int d_fk = m->fk.n_points * m->fk.point_dim;
+        int nw = std::min(16, m->max_threads / 64);
+        if (const int64_t v = knobs().nw; v >= 1) nw = (int)std::min<int64_t>(v, m->max_threads / 64);
+        int min_rows = 15;
+        if (const int64_t v = knobs().min_rows; v >= 1) min_rows = (int)v;
+        while (nw > 1 && m->S_active / nw < min_rows) nw /= 2;
+        ScoreArgs a{};
+        a.rows = m->rows_dev;
+        a.fk = m->fk_dev;
+        a.q = q;
+        a.score = score;
+        a.grad = jac;
+        a.B = B;
+        a.S = m->S_active;
+        a.ys = 1;
+        a.s_super = m->S_active;
+        a.s_chunk = (m->S_active + nw - 1) / nw;
+        a.dof = m->fk.dof;
+        a.d_fk = d_fk;
+        a.frame_floats = m->frame_floats;
+        a.kind = m->kind;
+        a.kp0 = m->kp0;
+        a.kp1 = m->kp1;
+        a.grad_stride = (int64_t)m->C * m->fk.dof;
+        const size_t lds = sizeof(float) * (size_t)(lds_plan_jac(a.dof, d_fk, m->frame_floats, m->C * m->Dt + m->C, m->C).total + m->prog_floats);
+        jac_fn fn = jac_for(m->Dt);
+        if (fn && lds <= 150 * 1024) {
+            hipError_t e = fn(m->kf, m->C, nw, lds, (B + 63) / 64, a, (hipStream_t)stream);
+            if (e == hipSuccess) return DCX_OK;
+            if (e != hipErrorNotSupported) return fail_hip(e, "Jacobian launch");
+            (void)hipGetLastError();
+        }
     }
     for (int c = 0; c < m->C; ++c) {
         int rc = run_score(m, q, B, nullptr, c == 0 ? score : nullptr, jac + (int64_t)c * m->fk.dof, MODE_GRAD_UP, c,

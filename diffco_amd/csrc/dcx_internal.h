@@ -5,6 +5,7 @@
 #include "../../include/dcx.h"
 #include "score_kernel.h"
 #include "traj_fused.h"
+#include "jac_kernel.h"
 
 namespace dcx {
 
@@ -35,6 +36,16 @@ DCX_DECLARE_LAUNCH(36) DCX_DECLARE_LAUNCH(42) DCX_DECLARE_LAUNCH(48) DCX_DECLARE
 DCX_DECLARE_LAUNCH(60) DCX_DECLARE_LAUNCH(64) DCX_DECLARE_LAUNCH(72) DCX_DECLARE_LAUNCH(84)
 DCX_DECLARE_LAUNCH(96)
 #undef DCX_DECLARE_LAUNCH
+// the one-sweep Jacobian (jac_kernel.h), one entry point per compiled D; hipErrorNotSupported where it is not instantiated
+typedef hipError_t (*jac_fn)(int kf, int cc, int nw, size_t lds_bytes, int64_t n_blocks, const ScoreArgs& args, hipStream_t stream);
+#define DCX_DECLARE_JAC(D) hipError_t launch_jac_D##D(int, int, int, size_t, int64_t, const ScoreArgs&, hipStream_t);
+DCX_DECLARE_JAC(2)  DCX_DECLARE_JAC(4)  DCX_DECLARE_JAC(6)  DCX_DECLARE_JAC(8)
+DCX_DECLARE_JAC(12) DCX_DECLARE_JAC(16) DCX_DECLARE_JAC(18) DCX_DECLARE_JAC(21)
+DCX_DECLARE_JAC(24) DCX_DECLARE_JAC(27) DCX_DECLARE_JAC(30) DCX_DECLARE_JAC(32)
+DCX_DECLARE_JAC(36) DCX_DECLARE_JAC(42) DCX_DECLARE_JAC(48) DCX_DECLARE_JAC(54)
+DCX_DECLARE_JAC(60) DCX_DECLARE_JAC(64) DCX_DECLARE_JAC(72) DCX_DECLARE_JAC(84)
+DCX_DECLARE_JAC(96)
+#undef DCX_DECLARE_JAC
 // config #5 as one persistent launch (traj_fused.h), one entry point per compiled D as well
 typedef hipError_t (*traj_fused_fn)(int kf, int nw, size_t lds_bytes, int n_paths, const TrajFusedArgs& args, hipStream_t stream);
 #define DCX_DECLARE_TRAJ(D) hipError_t launch_traj_fused_D##D(int, int, size_t, int, const TrajFusedArgs&, hipStream_t);

@@ -3,6 +3,7 @@
 // Built once per width so the widths compile in parallel (see Makefile).
 #include "dcx_internal.h"
 #include "traj_fused.h"
+#include "jac_kernel.h"
 
 #ifndef DCX_INST_D
 #error "compile with -DDCX_INST_D=<feature width>"
@@ -99,6 +100,47 @@ hipError_t DCX_CAT(launch_score_D, DCX_INST_D)(int kf, int cc, int mode, int nw,
     case KF_RQ2: return by_cc<KF_RQ2>(cc, mode, nw, lds, nblk, a, st);
     case KF_POLY1: return by_cc<KF_POLY1>(cc, mode, nw, lds, nblk, a, st);
     case KF_GEN: return by_cc<KF_GEN>(cc, mode, nw, lds, nblk, a, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+namespace {
+// the one-sweep Jacobian (jac_kernel.h); hipErrorNotSupported when this width / class count has no instantiation
+template <int KF, int CC>
+hipError_t jac_go(int nw, size_t lds, int64_t nblk, const ScoreArgs& a, hipStream_t st) {
+    if constexpr (jac_applies(kD, CC)) {
+        auto kern = score_jac_kernel<kD, KF, CC, kMaxT>;
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        kern<<<dim3((unsigned)nblk), dim3(64 * nw), lds, st>>>(a);
+        return hipGetLastError();
+    } else {
+        return hipErrorNotSupported;
+    }
+}
+template <int KF>
+hipError_t jac_by_cc(int cc, int nw, size_t lds, int64_t nblk, const ScoreArgs& a, hipStream_t st) {
+    switch (cc) {
+    case 2: return jac_go<KF, 2>(nw, lds, nblk, a, st);
+    case 3: return jac_go<KF, 3>(nw, lds, nblk, a, st);
+    case 4: return jac_go<KF, 4>(nw, lds, nblk, a, st);
+    case 5: return jac_go<KF, 5>(nw, lds, nblk, a, st);
+    case 6: return jac_go<KF, 6>(nw, lds, nblk, a, st);
+    case 7: return jac_go<KF, 7>(nw, lds, nblk, a, st);
+    case 8: return jac_go<KF, 8>(nw, lds, nblk, a, st);
+    default: return hipErrorNotSupported;
+    }
+}
+}  // namespace
+
+hipError_t DCX_CAT(launch_jac_D, DCX_INST_D)(int kf, int cc, int nw, size_t lds, int64_t nblk, const ScoreArgs& a,
+                                             hipStream_t st) {
+    switch (kf) {
+    case KF_RQ2: return jac_by_cc<KF_RQ2>(cc, nw, lds, nblk, a, st);
+    case KF_POLY1: return jac_by_cc<KF_POLY1>(cc, nw, lds, nblk, a, st);
+    case KF_GEN: return jac_by_cc<KF_GEN>(cc, nw, lds, nblk, a, st);
     default: return hipErrorInvalidValue;
     }
 }

@@ -150,7 +150,8 @@ int dcx_device_count(void);
  * the expanded form wherever it is compiled: Polyharmonic(1), rows of <= 37 floats; the two forms agree to ~1e-6),
  * "traj_fused" (0 = dcx_traj_adam_run as two launches per iteration), "prio" (1 = raised wave priority outside the
  * sweep; measured: no effect), "mt" (2 = two tiles per block; only in EXTRA=-DDCX_WITH_MT builds, else
- * DCX_ERR_UNSUPPORTED).  value < 0 restores the rule.  The initial values come from the DCX_YS / DCX_NW / DCX_XF / ...
+ * DCX_ERR_UNSUPPORTED), "jac_one_sweep" (0 = dcx_score_jac never takes the one-sweep kernel, 1 = whenever it is compiled
+ * and the batch is beyond the one-launch-per-all-classes regime).  value < 0 restores the rule.  The initial values come from the DCX_YS / DCX_NW / DCX_XF / ...
  * environment variables, read once at library load; no launch calls getenv.   */
 int dcx_debug_set(const char* name, int64_t value);
 

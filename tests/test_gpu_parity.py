@@ -220,6 +220,41 @@ def test_two_tiles_per_block_equals_one_tile_per_block_bitwise(ops, name, nw, kn
             assert torch.equal(h1[0], h2[0]) and torch.equal(h1[1], h2[1])
 
 
+@pytest.mark.parametrize("name", ["cfg3_baxter_rq_c5", "cfg3_baxter_poly1_c5", "misc_baxterR_mq_c2"])
+@pytest.mark.parametrize("nw", [16, 4, 1])
+def test_one_sweep_jacobian_equals_one_sweep_per_class(ops, name, nw, knob):
+    """jac_kernel.h (all classes of a pair in one sweep, C x D accumulators per lane, the C J^T products side by side)
+    against the one-hot sweeps of score_kernel in its direct form with the same slicing: same arithmetic per
+    (configuration, class), same fold order -> identical bits; ragged last tile, one tile, many tiles"""
+    d = load(name)
+    m, _, _ = _model(ops, name, d)
+    reps = -(-700 // len(d["q"]))
+    q = _t(np.tile(d["q"], (reps, 1))[:700])
+    q = q + 0.01 * torch.arange(len(q), device="cuda", dtype=torch.float32)[:, None] / len(q)
+    knob("nw", nw)
+    knob("ys", 1)
+    knob("min_rows", 1)
+    knob("xf", 0)
+    knob("mfma", 0)
+    for B in (700, 64, 5):
+        knob("jac_one_sweep", 0)
+        knob("jac_per_class", 1)
+        s1, j1 = m.score_jac_raw(q[:B])
+        knob("jac_per_class", -1)
+        knob("jac_one_sweep", 1)
+        s2, j2 = m.score_jac_raw(q[:B])
+        assert j2.shape == (B, m.C, q.shape[1])
+        assert torch.equal(s1, s2) and torch.equal(j1, j2), (B, float((j1 - j2).abs().max()))
+    # and against the float64 oracle's Jacobian
+    from oracle import oracle
+    kind, p0, p1 = case_kernel(d)
+    desc = desc_for(CASE_ROBOT[name], dof=d["q"].shape[1])
+    _, _, jo = oracle.score_grad(desc, kind, p0, p1, d["sup_x32"].reshape(len(d["sup_x32"]), -1).astype(np.float64),
+                                 d["weights"].astype(np.float64), _n(q[:64]).astype(np.float64), want_jac=True, dtype=np.float64)
+    s2, j2 = m.score_jac_raw(q[:64])
+    assert relerr(_n(j2), jo) < TOL
+
+
 @pytest.mark.parametrize("ys", [1, 4])
 def test_jacobian_rows_in_one_launch_equal_one_launch_per_class(ops, ys, knob):
     """C > 1: `dcx_score_jac` sends the C one-hot sweeps of a small batch out as ONE launch (grid z = class); with the
