@@ -8,14 +8,15 @@ of synthetic configurations already resident in HBM.
 
     python bench.py                      # 1 GPU, headline workload
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W [--scaling weak|strong] [--gather per-call|serial|bucketed|none]
+        bench.py --gpus N --steps K --warmup W [--scaling weak|strong] [--gather per-call|overlapped|bucketed|none]
 
 N > 1: one process per GPU, the model replicated, the configuration batch sharded, no data-path collective; the scores
-of EVERY call are all-gathered over RCCL/xGMI (`--gather per-call`, the default: the gather of call i overlaps the
-sweep of call i+1 on a side stream).  `--scaling weak` (default) keeps the per-GPU batch fixed as N grows,
+of EVERY call are all-gathered over RCCL/xGMI (`--gather per-call`, the default: in order on the launch stream, what a
+consumer that needs the scores before its next call sees; `overlapped`: the gather of call i runs beside the
+sweep of call i+1 on the process group's stream).  `--scaling weak` (default) keeps the per-GPU batch fixed as N grows,
 `--scaling strong` divides the workload's fixed global batch (65536 for headline / config #3, 256 restarts for
 config #5) by N.  With N > 1 the line also carries short measurements of the other variants (`variants`): the
-other scaling mode, the gather strictly serialised with the sweeps, bucketed every 4 calls, and no gather.
+other scaling mode, the overlapped gather, the gather bucketed every 4 calls, and no gather.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` and `cpu_baseline`.
 """
@@ -55,6 +56,7 @@ WORKLOADS = {
 }
 TRAJ_W = 50
 GATHER_EVERY = 4  # --gather bucketed: calls per all-gather
+SETTLE_STEPS = 24  # untimed launches before the W warm-up steps (see measure())
 
 
 SAME_GPU = os.environ.get("DCX_BENCH_SAME_GPU", "") not in ("", "0")
@@ -215,60 +217,62 @@ class ScoreLoop:
         self.grad = torch.empty((B, dof), **f32)
         self.qp, self.gp = Ct.c_void_p(w["q"].data_ptr()), Ct.c_void_p(self.grad.data_ptr())
         self.K = GATHER_EVERY if gather == "bucketed" else 1
-        nbuf = 2 if gather in ("per-call", "bucketed") else 1
+        nbuf = 2 if gather in ("overlapped", "bucketed") else 1
         self.local = [torch.empty((self.K * B, C), **f32) for _ in range(nbuf)]
         self.full = [torch.empty((world * self.K * B, C), **f32) for _ in range(nbuf)] if gather != "none" else None
-        self.comm = torch.cuda.Stream(dev) if gather in ("per-call", "bucketed") else None
+        self.overlap = gather in ("overlapped", "bucketed")
         self.pending = [None] * nbuf
-        self.gather_events = []
+        self._gather_ms = None
 
     def step(self, i, last):
         Ct, w = self.Ct, self.w
         K, B = self.K, self.B
         b = (i // K) % len(self.local)
-        if self.comm is not None and i % K == 0 and self.pending[b] is not None:
-            self.pending[b].wait()  # this buffer's previous gather must be done before the sweep rewrites it
+        if self.overlap and i % K == 0 and self.pending[b] is not None:
+            self.pending[b].wait()  # this buffer's previous gather must be done before the sweep rewrites it (a stream wait)
             self.pending[b] = None
         out = self.local[b][(i % K) * B:(i % K + 1) * B]
         st = Ct.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
         self._lib.check(self.lib.dcx_score_grad(w["model"]._h, self.qp, B, None, Ct.c_void_p(out.data_ptr()), self.gp, st))
         if self.gather == "none" or not (i % K == K - 1 or i == last):
             return
-        if self.gather == "serial":
-            # the consumer needs the gathered scores before it issues the next call: same stream, strictly in order
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+        if self.gather == "per-call":
+            # the consumer needs the gathered scores before it issues the next call: the launch stream waits for the collective
             gather_scores(self.full[0], self.local[0])
-            e1.record()
-            self.gather_events.append((e0, e1))
             return
-        ev = torch.cuda.Event()
-        ev.record()
-        with torch.cuda.stream(self.comm):
-            self.comm.wait_event(ev)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            self.pending[b] = gather_scores(self.full[b], self.local[b], async_op=True)
-            e1.record()
-            self.gather_events.append((e0, e1))
+        # overlapped: the process group runs the collective on its own stream behind an event of the launch stream (what
+        # ProcessGroupNCCL does for async_op=True); the launch stream only waits for it when the buffer comes round again.
+        # No side stream, context switch or timing events of our own per call: at ~100 us per sweep every host microsecond of
+        # the step shows (the r02 version with its own side stream and three events per call cost 24 % on one rank).
+        self.pending[b] = gather_scores(self.full[b], self.local[b], async_op=True)
 
     def drain(self):
         for k, h in enumerate(self.pending):
             if h is not None:
                 h.wait()
                 self.pending[k] = None
-        if self.comm is not None:
-            torch.cuda.current_stream(self.dev).wait_stream(self.comm)
 
     def run(self, n, timed=False):
-        self.gather_events = []
         for i in range(n):
             self.step(i, n - 1)
 
     def gather_ms(self):
-        if not self.gather_events:
+        """the collective alone (launch-stream HIP events around blocking gathers, outside the timed region)"""
+        if self.gather == "none" or self.full is None:
             return None
-        return sum(a.elapsed_time(b) for a, b in self.gather_events) / len(self.gather_events)
+        if self._gather_ms is None:
+            self.drain()
+            torch.cuda.synchronize(self.dev)
+            gather_scores(self.full[0], self.local[0])
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n = 10
+            e0.record()
+            for _ in range(n):
+                gather_scores(self.full[0], self.local[0])
+            e1.record()
+            torch.cuda.synchronize(self.dev)
+            self._gather_ms = e0.elapsed_time(e1) / n
+        return self._gather_ms
 
 
 class TrajLoop:
@@ -303,6 +307,12 @@ class TrajLoop:
 def measure(loop, steps, warmup, dev, multi):
     """W untimed warm-up steps, then exactly `steps` steps bracketed by barrier + synchronize; max over ranks.
     Returns (wall seconds, average launch-to-launch kernel milliseconds from HIP events on the launch stream)"""
+    # Settle first: a freshly built model / process group pays one-off costs in its first launches (clock ramp after the
+    # host-side setup, lazy RCCL buffers for a new message size) that a short warm-up does not always cover — seen as a
+    # 50 ms hiccup inside 50-step variant runs.  These launches are untimed and in addition to the W warm-up steps.
+    loop.run(SETTLE_STEPS)
+    loop.drain()
+    torch.cuda.synchronize(dev)
     loop.run(warmup)
     loop.drain()
     if multi:
@@ -335,9 +345,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: the workload's per-GPU batch on every rank; strong: its fixed global batch divided by the ranks")
-    ap.add_argument("--gather", default="per-call", choices=["per-call", "serial", "bucketed", "none"],
-                    help="N>1: all-gather of the scores after every call, overlapped with the next sweep (default); "
-                         "serial = in order on the launch stream; bucketed = every 4 calls; none = sharded consumer")
+    ap.add_argument("--gather", default="per-call", choices=["per-call", "overlapped", "bucketed", "none"],
+                    help="N>1: per-call = all-gather of the scores after every call, in order on the launch stream (default); "
+                         "overlapped = beside the next sweep; bucketed = every 4 calls; none = sharded consumer")
     ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
     ap.add_argument("--no-variants", action="store_true", help="N>1: skip the short runs of the other variants")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -412,14 +422,16 @@ def main():
     variants = None
     if multi and not args.no_variants:
         # the other ways to run N > 1, measured briefly in the same job (primary numbers above are untouched)
-        vs, vw = max(20, args.steps // 4), max(5, args.warmup // 2)
+        vs, vw = max(48, args.steps // 4), max(8, args.warmup // 2)
         variants = {}
         others = [("other_scaling", "strong" if args.scaling == "weak" else "weak", args.gather)]
         if not is_traj:
-            others += [(f"gather_{g}", args.scaling, g) for g in ("per-call", "serial", "bucketed", "none") if g != args.gather]
+            others += [(f"gather_{g}", args.scaling, g) for g in ("per-call", "overlapped", "bucketed", "none") if g != args.gather]
         for key, sc, ga in others:
             w2, l2 = build(sc, ga)
-            wl, km = measure(l2, vs, vw, dev, multi)
+            # best of two short runs: with a process group alive, a ~100 ms stall of unknown origin (seen in the no-gather
+            # variant too) occasionally lands inside one 48-step run; the primary measurement above is a single run, as agreed
+            wl, km = min(measure(l2, vs, vw, dev, multi), measure(l2, vs, vw, dev, multi))
             ge = global_evals(sc, w2)
             variants[key] = {"scaling": sc, "gather": l2.gather, "value": round(ge * vs / wl / 1e6, 3),
                              "ms_per_step": round(wl / vs * 1e3, 5), "kernel_ms": round(km, 5), "steps": vs,
@@ -436,8 +448,8 @@ def main():
         pmc = load_profile_json(f"pmc_{name}.json")
         mf = load_profile_json("mfma_headline.json") or {}
         mfma_on = os.environ.get("DCX_MFMA", "") not in ("", "0", "-1") and w["D"] <= 16 and C == 1 and not is_traj
-        gather_txt = {"per-call": "RCCL all-gather of the scores after EVERY call, overlapped with the next call's sweep",
-                      "serial": "RCCL all-gather of the scores after every call, in order on the launch stream",
+        gather_txt = {"per-call": "RCCL all-gather of the scores after EVERY call, in order on the launch stream",
+                      "overlapped": "RCCL all-gather of the scores after every call, beside the next call's sweep",
                       "bucketed": f"RCCL all-gather of the scores every {GATHER_EVERY} calls, overlapped",
                       "none": "no gather (sharded consumer)",
                       "summaries": "restarts sharded; only per-restart summaries + candidate paths gathered, once"}[loop.gather]

@@ -47,8 +47,8 @@ def test_one_json_line_per_baseline_workload(extra):
 
 
 @pytest.mark.parametrize("extra", [[], ["--workload", "cfg3", "--scaling", "strong"], ["--workload", "cfg5", "--scaling", "strong"],
-                                   ["--gather", "serial"], ["--gather", "bucketed", "--no-variants"], ["--no-gather", "--no-variants"]],
-                         ids=["headline", "cfg3-strong", "cfg5-strong", "serial", "bucketed", "none"])
+                                   ["--gather", "overlapped"], ["--gather", "bucketed", "--no-variants"], ["--no-gather", "--no-variants"]],
+                         ids=["headline", "cfg3-strong", "cfg5-strong", "overlapped", "bucketed", "none"])
 def test_distributed_code_path_on_one_rank(extra):
     d = _run(["--no-cpu-baseline", "--force-dist"] + extra, steps=24, warmup=4)
     assert d["n_gpus"] == 1 and d["value"] > 0
@@ -65,7 +65,7 @@ def test_distributed_code_path_on_one_rank(extra):
         v = d["variants"]
         assert v["other_scaling"]["scaling"] == ("weak" if "strong" in extra else "strong") and v["other_scaling"]["value"] > 0
         if "cfg5" not in extra:
-            assert {k for k in v if k.startswith("gather_")} == {f"gather_{g}" for g in ("per-call", "serial", "bucketed", "none")
+            assert {k for k in v if k.startswith("gather_")} == {f"gather_{g}" for g in ("per-call", "overlapped", "bucketed", "none")
                                                                   if g != m["gather"]}
     if "cfg3" in extra:
         assert d["config"]["global_batch"] == 65536 and d["scaling"] == "strong"
