@@ -727,9 +727,11 @@ __device__ __forceinline__ void sweep_rows_mfma(const ScoreArgs& a, const float 
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
     float asum = 0.0f;
-    float near2 = 1e-30f;  // pairs closer than 1e-3 |x| take the direct form (see pair)
+    float near2 = 1e-30f;  // pairs closer than 0.1 |x| take the direct form (see pair): the expanded sweep's threshold.  At the
+                           // first version's 1e-3 |x| the fold lost 2e-5 on queries planted 0.001-0.1 |x| from a support
+                           // (tests/test_gpu_parity.py::test_expanded_form_around_the_near_threshold)
 #pragma unroll
-    for (int k = 0; k < D; ++k) near2 = fmaf(1e-6f * x[k], x[k], near2);
+    for (int k = 0; k < D; ++k) near2 = fmaf(DCX_XF_TAU * x[k], x[k], near2);
 
     // one support row: score accumulation on the VALU, returns the gradient coefficient
     auto pair = [&](const float (&r)[L::RS]) __attribute__((always_inline)) -> float {

@@ -220,6 +220,45 @@ def test_two_tiles_per_block_equals_one_tile_per_block_bitwise(ops, name, nw, kn
             assert torch.equal(h1[0], h2[0]) and torch.equal(h1[1], h2[1])
 
 
+@pytest.mark.parametrize("D,C", [(12, 1), (12, 3), (7, 1), (21, 1), (6, 2)])
+def test_expanded_form_around_the_near_threshold(ops, knob, D, C):
+    """the expanded sweep's near-pair machinery under load: every query sits at a chosen relative distance
+    r / |x| in [1e-7, 1] from one support (the threshold is r / |x| = 0.1), many per wave, on both sides of it, plus exact
+    coincidences — score and gradient against the float64 oracle at the 1e-5 bar, in the expanded AND the direct form, and
+    a configuration's result must not depend on its wave-mates (shuffled batch, bit for bit).  The matrix-core fold
+    runs the same gauntlet through the file's third parametrisation."""
+    from diffco_amd import _fkdesc
+    from oracle import oracle
+    g = torch.Generator().manual_seed(100 * D + C)
+    S, B = 300, 4096
+    sup = (torch.rand((S, D), generator=g) * 2 - 1) * 1.5
+    W = torch.randn((S, C), generator=g)
+    j = torch.randint(0, S, (B,), generator=g)
+    u = torch.randn((B, D), generator=g)
+    u = u / u.norm(dim=1, keepdim=True)
+    rel = 10.0 ** (torch.rand((B, 1), generator=g) * 7 - 7)            # 1e-7 .. 1
+    rel[::97] = 0.0                                                     # exact coincidences
+    rel[1::53] = 0.1 * (1 + (torch.rand((len(rel[1::53]), 1), generator=g) - 0.5) * 1e-3)   # on the threshold
+    q = sup[j] + rel * sup[j].norm(dim=1, keepdim=True) * u
+    desc = _fkdesc.none_desc(D)
+    m = ops.ScoreModel(desc, 1, 1.0, 1.0, sup.cuda(), W.cuda())
+    up = torch.randn((B, C), generator=g).cuda() if C > 1 else None
+    so, go, _ = oracle.score_grad(desc, 1, 1.0, 1.0, sup.numpy().astype(np.float64), W.numpy().astype(np.float64),
+                                  q.numpy().astype(np.float64), upstream=None if up is None else _n(up).astype(np.float64),
+                                  dtype=np.float64)
+    res = {}
+    for form in (1, 0):   # under the "mfma" parametrisation form 0 is the matrix-core fold where it is compiled
+        knob("xf", form)
+        s, gr = m.score_grad_raw(q.cuda(), up)
+        assert torch.isfinite(s).all() and torch.isfinite(gr).all()
+        assert relerr(_n(s), so) < TOL and relerr(_n(gr), go) < TOL, (form, relerr(_n(s), so), relerr(_n(gr), go))
+        perm = torch.randperm(B, generator=g).cuda()
+        sp, gp = m.score_grad_raw(q.cuda()[perm].contiguous(), None if up is None else up[perm].contiguous())
+        assert torch.equal(sp, s[perm]) and torch.equal(gp, gr[perm]), form
+        res[form] = (s, gr)
+    assert relerr(_n(res[1][0]), _n(res[0][0])) < 6e-6 and relerr(_n(res[1][1]), _n(res[0][1])) < 6e-6
+
+
 @pytest.mark.parametrize("name", ["cfg3_baxter_rq_c5", "cfg3_baxter_poly1_c5", "misc_baxterR_mq_c2"])
 @pytest.mark.parametrize("nw", [16, 4, 1])
 def test_one_sweep_jacobian_equals_one_sweep_per_class(ops, name, nw, knob):
