@@ -31,6 +31,7 @@ SYMBOLS = {
     "dcx_score": (C.c_int, [C.c_void_p, _c_fp, C.c_int64, _c_fp, C.c_void_p]),
     "dcx_score_grad": (C.c_int, [C.c_void_p, _c_fp, C.c_int64, _c_fp, _c_fp, _c_fp, C.c_void_p]),
     "dcx_score_jac": (C.c_int, [C.c_void_p, _c_fp, C.c_int64, _c_fp, _c_fp, C.c_void_p]),
+    "dcx_score_hess": (C.c_int, [C.c_void_p, _c_fp, C.c_int64, _c_fp, _c_fp, _c_fp, C.c_void_p]),
     "dcx_score_hinge_grad": (C.c_int, [C.c_void_p, _c_fp, C.c_int64, C.c_float, C.c_float, _c_fp, _c_fp, C.c_void_p]),
     "dcx_traj_adam_step": (C.c_int, [C.c_int, C.POINTER(FkDesc), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "dcx_traj_adam_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
@@ -64,6 +65,10 @@ class DcxError(RuntimeError):
     pass
 
 
+class DcxUnsupported(DcxError):
+    """DCX_ERR_UNSUPPORTED: the shape / kind is outside what the library is compiled for"""
+
+
 def load():
     """Load libdcx.so (once) and bind every declared symbol.  Raises if it is not built."""
     global _lib
@@ -84,7 +89,7 @@ def load():
 def check(rc):
     if rc != 0:
         msg = load().dcx_last_error()
-        raise DcxError(f"libdcx error {rc}: {msg.decode() if msg else '?'}")
+        raise (DcxUnsupported if rc == 2 else DcxError)(f"libdcx error {rc}: {msg.decode() if msg else '?'}")
 
 
 def require_gpu():

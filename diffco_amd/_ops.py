@@ -181,6 +181,17 @@ class ScoreModel:
             _lib.check(self._lib.dcx_score_jac(self._h, _ptr(q32), B, _ptr(out), _ptr(jac), _stream(self.dev)))
         return out, jac
 
+    def score_hess_raw(self, q32, upstream32=None):
+        """(gradient [B, dof], Hessian [B, dof, dof]) of sum_c upstream * score w.r.t. q — analytic second derivatives
+        (dcx_score_hess; the reference double-backwards through dist_est, optim.py:380-391)"""
+        B = q32.shape[0]
+        grad = torch.empty((B, self.dof), device=self.dev, dtype=torch.float32)
+        hess = torch.empty((B, self.dof, self.dof), device=self.dev, dtype=torch.float32)
+        with torch.cuda.device(self.dev):
+            _lib.check(self._lib.dcx_score_hess(self._h, _ptr(q32), B, _ptr(upstream32), _ptr(grad), _ptr(hess),
+                                                _stream(self.dev)))
+        return grad, hess
+
     def score_hinge_grad_raw(self, q32, margin, weight):
         """(score [B,1], weight * 1[score > margin] * dscore/dq [B,dof]) — the optimisers' collision term, one launch"""
         B = q32.shape[0]

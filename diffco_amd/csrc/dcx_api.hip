@@ -671,6 +671,33 @@ int dcx_score_hinge_grad(const dcx_model* m, const float* q, int64_t B, float ma
     return run_score(m, q, B, nullptr, score, grad, MODE_GRAD_ROW, -1, m->fk.dof, (hipStream_t)stream, h);
 }
 
+int dcx_score_hess(const dcx_model* m, const float* q, int64_t B, const float* upstream, float* grad, float* hess,
+                   void* stream) {
+    if (!m) return fail(DCX_ERR_INVALID, "model is NULL");
+    if (B < 0 || (B > 0 && (!q || !hess))) return fail(DCX_ERR_INVALID, "q / hess is NULL or B < 0");
+    if (int rc = set_device(m->device)) return rc;
+    if (B == 0) return DCX_OK;
+    ModelView v{};
+    v.rows = m->rows_dev;
+    v.fk = m->fk_dev;
+    v.S = m->S_active;
+    v.Dt = m->Dt;
+    v.C = m->C;
+    v.RS = m->RS;
+    v.dof = m->fk.dof;
+    v.d_fk = m->fk.n_points * m->fk.point_dim;
+    v.frame_floats = m->frame_floats;
+    v.prog_floats = m->prog_floats;
+    v.kind = m->kind;
+    v.kf = m->kf;
+    v.kp0 = m->kp0;
+    v.kp1 = m->kp1;
+    const hipError_t e = launch_hess(v, q, B, upstream, grad, hess, (hipStream_t)stream);
+    if (e == hipErrorInvalidValue) return fail(DCX_ERR_UNSUPPORTED, "dcx_score_hess: the transform's frames do not fit the LDS in duals");
+    if (e != hipSuccess) return fail_hip(e, "dcx_score_hess");
+    return DCX_OK;
+}
+
 int dcx_score_jac(const dcx_model* m, const float* q, int64_t B, float* score, float* jac, void* stream) {
     if (!m) return fail(DCX_ERR_INVALID, "model is NULL");
     if (B < 0 || (B > 0 && (!q || !jac))) return fail(DCX_ERR_INVALID, "q / jac is NULL or B < 0");

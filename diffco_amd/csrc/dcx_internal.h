@@ -66,6 +66,16 @@ hipError_t launch_fkine_vjp(const FkProg* fk_dev, const dcx_fk_desc& fk_host, co
 hipError_t launch_kernel_matrix(int kind, float kp0, float kp1, const float* x, int64_t B, const float* s, int64_t S,
                                 int D, float* K, hipStream_t stream);
 
+// hess_kernel.hip: what the second-derivative kernel needs to know of a model
+struct ModelView {
+    const float* rows;
+    const FkProg* fk;
+    int32_t S, Dt, C, RS, dof, d_fk, frame_floats, prog_floats, kind, kf;
+    float kp0, kp1;
+};
+hipError_t launch_hess(const ModelView& m, const float* q, int64_t B, const float* upstream, float* grad, float* hess,
+                       hipStream_t stream);
+
 // train_kernels.hip
 hipError_t launch_perceptron(int kind, float kp0, float kp1, float beta, const float* feats, const float* y, float* gains,
                              float* hypo, float* K, int32_t* info, int N, int D, int C, int max_iter, bool sign_labels,

@@ -351,18 +351,58 @@ __device__ __forceinline__ void sincos_f32(float x, float* sn, float* cs) {
     *cs = ((q + 1) & 2) ? -c0 : c0;
 }
 
+__device__ __forceinline__ void sincos_t(float x, float* sn, float* cs) { sincos_f32(x, sn, cs); }
+// ---- scalar types of the FK walks ---------------------------------------------------------------------
+// The chain composition and the reverse sweep below are templates over their scalar: `float` in every launch of the
+// path, and `Dual` (value + one tangent) in dcx_score_hess, where forward-mode differentiation of the SAME code
+// yields the second derivatives of the transform (hess_kernel.hip).  With T = float every expression is the one the
+// functions held before they were templates: fma3 is fmaf.
+struct Dual {
+    float v, d;
+    Dual() = default;
+    __device__ __forceinline__ Dual(float a) : v(a), d(0.0f) {}
+    __device__ __forceinline__ Dual(float a, float b) : v(a), d(b) {}
+};
+__device__ __forceinline__ Dual operator+(Dual a, Dual b) { return Dual(a.v + b.v, a.d + b.d); }
+__device__ __forceinline__ Dual operator-(Dual a, Dual b) { return Dual(a.v - b.v, a.d - b.d); }
+__device__ __forceinline__ Dual operator-(Dual a) { return Dual(-a.v, -a.d); }
+__device__ __forceinline__ Dual operator*(Dual a, Dual b) { return Dual(a.v * b.v, fmaf(a.v, b.d, a.d * b.v)); }
+__device__ __forceinline__ Dual operator*(Dual a, float b) { return Dual(a.v * b, a.d * b); }
+__device__ __forceinline__ Dual operator*(float a, Dual b) { return Dual(a * b.v, a * b.d); }
+__device__ __forceinline__ Dual& operator+=(Dual& a, Dual b) { a.v += b.v; a.d += b.d; return a; }
+__device__ __forceinline__ float dual_v(float a) { return a; }
+__device__ __forceinline__ float dual_v(Dual a) { return a.v; }
+__device__ __forceinline__ float fma3(float a, float b, float c) { return fmaf(a, b, c); }
+template <class A, class B, class C>
+__device__ __forceinline__ Dual fma3(A a, B b, C c) {
+    float d = 0.0f;
+    bool first = true;
+    if constexpr (__is_same(C, Dual)) { d = c.d; first = false; }
+    if constexpr (__is_same(A, Dual)) { d = first ? a.d * dual_v(b) : fmaf(a.d, dual_v(b), d); first = false; }
+    if constexpr (__is_same(B, Dual)) { d = first ? dual_v(a) * b.d : fmaf(dual_v(a), b.d, d); }
+    return Dual(fmaf(dual_v(a), dual_v(b), dual_v(c)), d);
+}
+
+__device__ __forceinline__ void sincos_t(Dual x, Dual* sn, Dual* cs) {
+    float s0, c0;
+    sincos_f32(x.v, &s0, &c0);
+    *sn = Dual(s0, c0 * x.d);
+    *cs = Dual(c0, -s0 * x.d);
+}
+
 // ---- DCX_FK_TREE chain composition and reverse sweep ---------------------------------------------------
 // Deliberately NOT inlined: inside the fused kernel their register demand would otherwise be planned into every
 // robot's prologue / epilogue (the DH headline kernel went from 12 to 108 bytes of scratch per lane, doubling its
 // HBM writes, when these bodies were inlined).
-__device__ __attribute__((noinline)) void fk_tree_chain(fk_cptr fk, float* sXcol, float* sFcol) {
+template <class T>
+__device__ __attribute__((noinline)) void fk_tree_chain(fk_cptr fk, T* sXcol, T* sFcol) {
     // T_j = T_parent(j) * F_j * Motion_j over the tree in depth-first order (reference: RigidBody.forward_kinematics,
     // collision_interfaces/rigid_body.py:82-140); features = frame origins (+ constant offsets for links behind fixed
     // joints), collision_checkers.py:386-393
     const int stride = rfl(fk->out_stride) * 64, njt = rfl(fk->n_joints);
     const int f_leaf = rfl(fk->f_leaf), f_park = rfl(fk->f_park);
-    float r00 = 1.f, r01 = 0.f, r02 = 0.f, r10 = 0.f, r11 = 1.f, r12 = 0.f, r20 = 0.f, r21 = 0.f, r22 = 1.f;
-    float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+    T r00 = 1.f, r01 = 0.f, r02 = 0.f, r10 = 0.f, r11 = 1.f, r12 = 0.f, r20 = 0.f, r21 = 0.f, r22 = 1.f;
+    T t0 = 0.f, t1 = 0.f, t2 = 0.f;
     for (int j = 0; j < njt; ++j) {
         const int start = rfl(fk->tj[j].start);
         if (start <= -2) {  // a root: the frame is base[b]
@@ -371,7 +411,7 @@ __device__ __attribute__((noinline)) void fk_tree_chain(fk_cptr fk, float* sXcol
             r10 = Bm[4]; r11 = Bm[5]; r12 = Bm[6]; t1 = Bm[7];
             r20 = Bm[8]; r21 = Bm[9]; r22 = Bm[10]; t2 = Bm[11];
         } else if (start >= 0) {  // a later child of a branch node: its parent's frame was parked
-            const float* pk = sFcol + (f_park + 12 * start) * 64;
+            const T* pk = sFcol + (f_park + 12 * start) * 64;
             r00 = pk[0]; r01 = pk[64]; r02 = pk[128]; t0 = pk[192];
             r10 = pk[256]; r11 = pk[320]; r12 = pk[384]; t1 = pk[448];
             r20 = pk[512]; r21 = pk[576]; r22 = pk[640]; t2 = pk[704];
@@ -380,56 +420,57 @@ __device__ __attribute__((noinline)) void fk_tree_chain(fk_cptr fk, float* sXcol
         // N = T * F
         const float f00 = F[0], f01 = F[1], f02 = F[2], f03 = F[3], f10 = F[4], f11 = F[5], f12 = F[6], f13 = F[7];
         const float f20 = F[8], f21 = F[9], f22 = F[10], f23 = F[11];
-        t0 = fmaf(r00, f03, fmaf(r01, f13, fmaf(r02, f23, t0)));
-        t1 = fmaf(r10, f03, fmaf(r11, f13, fmaf(r12, f23, t1)));
-        t2 = fmaf(r20, f03, fmaf(r21, f13, fmaf(r22, f23, t2)));
-        float n00 = fmaf(r00, f00, fmaf(r01, f10, r02 * f20)), n01 = fmaf(r00, f01, fmaf(r01, f11, r02 * f21)),
-              n02 = fmaf(r00, f02, fmaf(r01, f12, r02 * f22));
-        float n10 = fmaf(r10, f00, fmaf(r11, f10, r12 * f20)), n11 = fmaf(r10, f01, fmaf(r11, f11, r12 * f21)),
-              n12 = fmaf(r10, f02, fmaf(r11, f12, r12 * f22));
-        float n20 = fmaf(r20, f00, fmaf(r21, f10, r22 * f20)), n21 = fmaf(r20, f01, fmaf(r21, f11, r22 * f21)),
-              n22 = fmaf(r20, f02, fmaf(r21, f12, r22 * f22));
+        t0 = fma3(r00, f03, fma3(r01, f13, fma3(r02, f23, t0)));
+        t1 = fma3(r10, f03, fma3(r11, f13, fma3(r12, f23, t1)));
+        t2 = fma3(r20, f03, fma3(r21, f13, fma3(r22, f23, t2)));
+        T n00 = fma3(r00, f00, fma3(r01, f10, r02 * f20)), n01 = fma3(r00, f01, fma3(r01, f11, r02 * f21)),
+              n02 = fma3(r00, f02, fma3(r01, f12, r02 * f22));
+        T n10 = fma3(r10, f00, fma3(r11, f10, r12 * f20)), n11 = fma3(r10, f01, fma3(r11, f11, r12 * f21)),
+              n12 = fma3(r10, f02, fma3(r11, f12, r12 * f22));
+        T n20 = fma3(r20, f00, fma3(r21, f10, r22 * f20)), n21 = fma3(r20, f01, fma3(r21, f11, r22 * f21)),
+              n22 = fma3(r20, f02, fma3(r21, f12, r22 * f22));
         const int type = rfl(fk->tj[j].type), slot = rfl(fk->tj[j].slot);
         if (type == TJ_REV) {
             // R <- N * Rz(v): columns 0, 1 rotate
-            const float s = sFcol[(2 * slot) * 64], c = sFcol[(2 * slot + 1) * 64];
-            r00 = fmaf(n00, c, n01 * s); r01 = fmaf(n01, c, -n00 * s); r02 = n02;
-            r10 = fmaf(n10, c, n11 * s); r11 = fmaf(n11, c, -n10 * s); r12 = n12;
-            r20 = fmaf(n20, c, n21 * s); r21 = fmaf(n21, c, -n20 * s); r22 = n22;
+            const T s = sFcol[(2 * slot) * 64], c = sFcol[(2 * slot + 1) * 64];
+            r00 = fma3(n00, c, n01 * s); r01 = fma3(n01, c, -n00 * s); r02 = n02;
+            r10 = fma3(n10, c, n11 * s); r11 = fma3(n11, c, -n10 * s); r12 = n12;
+            r20 = fma3(n20, c, n21 * s); r21 = fma3(n21, c, -n20 * s); r22 = n22;
         } else {
             r00 = n00; r01 = n01; r02 = n02; r10 = n10; r11 = n11; r12 = n12; r20 = n20; r21 = n21; r22 = n22;
             if (type == TJ_PRISM) {
-                const float v = sFcol[(2 * slot) * 64];
-                const float dx = fk->tj[j].ax * v, dy = fk->tj[j].ay * v, dz = fk->tj[j].az * v;
-                t0 = fmaf(r00, dx, fmaf(r01, dy, fmaf(r02, dz, t0)));
-                t1 = fmaf(r10, dx, fmaf(r11, dy, fmaf(r12, dz, t1)));
-                t2 = fmaf(r20, dx, fmaf(r21, dy, fmaf(r22, dz, t2)));
+                const T v = sFcol[(2 * slot) * 64];
+                const T dx = fk->tj[j].ax * v, dy = fk->tj[j].ay * v, dz = fk->tj[j].az * v;
+                t0 = fma3(r00, dx, fma3(r01, dy, fma3(r02, dz, t0)));
+                t1 = fma3(r10, dx, fma3(r11, dy, fma3(r12, dz, t1)));
+                t2 = fma3(r20, dx, fma3(r21, dy, fma3(r22, dz, t2)));
             }
         }
         const int pb = rfl(fk->tj[j].pt_begin), pe = rfl(fk->tj[j].pt_end);
         for (int p = pb; p < pe; ++p) {
             const float ox = fk->points[p].ox, oy = fk->points[p].oy, oz = fk->points[p].oz;
-            float* out = sXcol + rfl(fk->points[p].out_k) * 64;
-            out[0] = fmaf(r00, ox, fmaf(r01, oy, fmaf(r02, oz, t0)));
-            out[stride] = fmaf(r10, ox, fmaf(r11, oy, fmaf(r12, oz, t1)));
-            out[2 * stride] = fmaf(r20, ox, fmaf(r21, oy, fmaf(r22, oz, t2)));
+            T* out = sXcol + rfl(fk->points[p].out_k) * 64;
+            out[0] = fma3(r00, ox, fma3(r01, oy, fma3(r02, oz, t0)));
+            out[stride] = fma3(r10, ox, fma3(r11, oy, fma3(r12, oz, t1)));
+            out[2 * stride] = fma3(r20, ox, fma3(r21, oy, fma3(r22, oz, t2)));
         }
         const int park = rfl(fk->tj[j].park), leaf = rfl(fk->tj[j].leaf);
         if (park >= 0) {  // further children start from this frame
-            float* pk = sFcol + (f_park + 12 * park) * 64;
+            T* pk = sFcol + (f_park + 12 * park) * 64;
             pk[0] = r00; pk[64] = r01; pk[128] = r02; pk[192] = t0;
             pk[256] = r10; pk[320] = r11; pk[384] = r12; pk[448] = t1;
             pk[512] = r20; pk[576] = r21; pk[640] = r22; pk[704] = t2;
         }
         if (leaf >= 0) {  // nothing continues from here in registers: the reverse sweep restarts from this rotation
-            float* fr = sFcol + (f_leaf + 9 * leaf) * 64;
+            T* fr = sFcol + (f_leaf + 9 * leaf) * 64;
             fr[0] = r00; fr[64] = r01; fr[128] = r02; fr[192] = r10; fr[256] = r11; fr[320] = r12;
             fr[384] = r20; fr[448] = r21; fr[512] = r22;
         }
     }
 }
 
-__device__ __attribute__((noinline)) void fk_tree_vjp(fk_cptr fk, const float* sFcol, const float* sGcol, float* gqRow) {
+template <class T>
+__device__ __attribute__((noinline)) void fk_tree_vjp(fk_cptr fk, const T* sFcol, const T* sGcol, T* gqRow) {
     const int dof = rfl(fk->dof);
     // Reverse-mode sweep through T_j = T_parent(j) F_j M_j(v_j) over the tree; joints driven by the same q (mimic)
     // simply accumulate.  With N = T_parent F_j:
@@ -439,92 +480,92 @@ __device__ __attribute__((noinline)) void fk_tree_vjp(fk_cptr fk, const float* s
     for (int i = 0; i < dof; ++i) gqRow[i] = 0.f;  // the sweep reads frames, not q
     const int stride = rfl(fk->out_stride) * 64, njt = rfl(fk->n_joints);
     const int f_leaf = rfl(fk->f_leaf), f_adj = rfl(fk->f_adj), n_branch = rfl(fk->n_branch);
-    float* sFw = const_cast<float*>(sFcol);  // the adjoint sums of branch nodes live in the frames area
+    T* sFw = const_cast<T*>(sFcol);  // the adjoint sums of branch nodes live in the frames area
     for (int e = 0; e < 12 * n_branch; ++e) sFw[(f_adj + e) * 64] = 0.f;
-    float r00 = 1.f, r01 = 0.f, r02 = 0.f, r10 = 0.f, r11 = 1.f, r12 = 0.f, r20 = 0.f, r21 = 0.f, r22 = 1.f;
-    float G00 = 0.f, G01 = 0.f, G02 = 0.f, G10 = 0.f, G11 = 0.f, G12 = 0.f, G20 = 0.f, G21 = 0.f, G22 = 0.f;
-    float T0 = 0.f, T1 = 0.f, T2 = 0.f;
+    T r00 = 1.f, r01 = 0.f, r02 = 0.f, r10 = 0.f, r11 = 1.f, r12 = 0.f, r20 = 0.f, r21 = 0.f, r22 = 1.f;
+    T G00 = 0.f, G01 = 0.f, G02 = 0.f, G10 = 0.f, G11 = 0.f, G12 = 0.f, G20 = 0.f, G21 = 0.f, G22 = 0.f;
+    T T0 = 0.f, T1 = 0.f, T2 = 0.f;
     // nodes in reverse depth-first order: every child has been processed before its parent
     for (int j = njt - 1; j >= 0; --j) {
         const int leaf = rfl(fk->tj[j].leaf), park = rfl(fk->tj[j].park);
         if (leaf >= 0) {  // no child handed its state over in registers: restart from this node's own rotation
-            const float* fr = sFcol + (f_leaf + 9 * leaf) * 64;
+            const T* fr = sFcol + (f_leaf + 9 * leaf) * 64;
             r00 = fr[0]; r01 = fr[64]; r02 = fr[128]; r10 = fr[192]; r11 = fr[256]; r12 = fr[320];
             r20 = fr[384]; r21 = fr[448]; r22 = fr[512];
             G00 = G01 = G02 = G10 = G11 = G12 = G20 = G21 = G22 = 0.f;
             T0 = T1 = T2 = 0.f;
         }
         if (park >= 0) {  // plus what the children that started from the parked frame sent back
-            const float* ad = sFcol + (f_adj + 12 * park) * 64;
+            const T* ad = sFcol + (f_adj + 12 * park) * 64;
             G00 += ad[0]; G01 += ad[64]; G02 += ad[128]; T0 += ad[192];
             G10 += ad[256]; G11 += ad[320]; G12 += ad[384]; T1 += ad[448];
             G20 += ad[512]; G21 += ad[576]; G22 += ad[640]; T2 += ad[704];
         }
         const int pb = rfl(fk->tj[j].pt_begin), pe = rfl(fk->tj[j].pt_end);
         for (int p = pb; p < pe; ++p) {
-            const float* gin = sGcol + rfl(fk->points[p].out_k) * 64;
-            const float g0 = gin[0], g1 = gin[stride], g2 = gin[2 * stride];
+            const T* gin = sGcol + rfl(fk->points[p].out_k) * 64;
+            const T g0 = gin[0], g1 = gin[stride], g2 = gin[2 * stride];
             const float ox = fk->points[p].ox, oy = fk->points[p].oy, oz = fk->points[p].oz;
             T0 += g0; T1 += g1; T2 += g2;
-            G00 = fmaf(g0, ox, G00); G01 = fmaf(g0, oy, G01); G02 = fmaf(g0, oz, G02);
-            G10 = fmaf(g1, ox, G10); G11 = fmaf(g1, oy, G11); G12 = fmaf(g1, oz, G12);
-            G20 = fmaf(g2, ox, G20); G21 = fmaf(g2, oy, G21); G22 = fmaf(g2, oz, G22);
+            G00 = fma3(g0, ox, G00); G01 = fma3(g0, oy, G01); G02 = fma3(g0, oz, G02);
+            G10 = fma3(g1, ox, G10); G11 = fma3(g1, oy, G11); G12 = fma3(g1, oz, G12);
+            G20 = fma3(g2, ox, G20); G21 = fma3(g2, oy, G21); G22 = fma3(g2, oz, G22);
         }
         const int type = rfl(fk->tj[j].type), slot = rfl(fk->tj[j].slot);
         if (type == TJ_REV) {
-            const float s = sFcol[(2 * slot) * 64], c = sFcol[(2 * slot + 1) * 64];
+            const T s = sFcol[(2 * slot) * 64], c = sFcol[(2 * slot + 1) * 64];
             // R_N = R_j Rz^T: columns 0, 1 rotate back
-            const float p00 = fmaf(r00, c, -r01 * s), p01 = fmaf(r01, c, r00 * s);
-            const float p10 = fmaf(r10, c, -r11 * s), p11 = fmaf(r11, c, r10 * s);
-            const float p20 = fmaf(r20, c, -r21 * s), p21 = fmaf(r21, c, r20 * s);
+            const T p00 = fma3(r00, c, -r01 * s), p01 = fma3(r01, c, r00 * s);
+            const T p10 = fma3(r10, c, -r11 * s), p11 = fma3(r11, c, r10 * s);
+            const T p20 = fma3(r20, c, -r21 * s), p21 = fma3(r21, c, r20 * s);
             // A = R_N^T GR, rows 0 and 1, columns 0 and 1 (dRz/dv = [[-s, -c, 0], [c, -s, 0], [0, 0, 0]])
-            const float A00 = fmaf(p00, G00, fmaf(p10, G10, p20 * G20)), A01 = fmaf(p00, G01, fmaf(p10, G11, p20 * G21));
-            const float A10 = fmaf(p01, G00, fmaf(p11, G10, p21 * G20)), A11 = fmaf(p01, G01, fmaf(p11, G11, p21 * G21));
-            const float dv = (c * A10 - s * A11) - (s * A00 + c * A01);
+            const T A00 = fma3(p00, G00, fma3(p10, G10, p20 * G20)), A01 = fma3(p00, G01, fma3(p10, G11, p20 * G21));
+            const T A10 = fma3(p01, G00, fma3(p11, G10, p21 * G20)), A11 = fma3(p01, G01, fma3(p11, G11, p21 * G21));
+            const T dv = (c * A10 - s * A11) - (s * A00 + c * A01);
             gqRow[rfl(fk->tj[j].q_index)] += fk->tj[j].scale * dv;
             // G_RN = GR Rz^T
-            const float h00 = fmaf(G00, c, -G01 * s), h01 = fmaf(G01, c, G00 * s);
-            const float h10 = fmaf(G10, c, -G11 * s), h11 = fmaf(G11, c, G10 * s);
-            const float h20 = fmaf(G20, c, -G21 * s), h21 = fmaf(G21, c, G20 * s);
+            const T h00 = fma3(G00, c, -G01 * s), h01 = fma3(G01, c, G00 * s);
+            const T h10 = fma3(G10, c, -G11 * s), h11 = fma3(G11, c, G10 * s);
+            const T h20 = fma3(G20, c, -G21 * s), h21 = fma3(G21, c, G20 * s);
             G00 = h00; G01 = h01; G10 = h10; G11 = h11; G20 = h20; G21 = h21;
             r00 = p00; r01 = p01; r10 = p10; r11 = p11; r20 = p20; r21 = p21;
         } else if (type == TJ_PRISM) {
-            const float v = sFcol[(2 * slot) * 64];
+            const T v = sFcol[(2 * slot) * 64];
             const float ax = fk->tj[j].ax, ay = fk->tj[j].ay, az = fk->tj[j].az;
-            const float w0 = fmaf(r00, ax, fmaf(r01, ay, r02 * az)), w1 = fmaf(r10, ax, fmaf(r11, ay, r12 * az)),
-                        w2 = fmaf(r20, ax, fmaf(r21, ay, r22 * az));
-            gqRow[rfl(fk->tj[j].q_index)] += fk->tj[j].scale * fmaf(T0, w0, fmaf(T1, w1, T2 * w2));
-            const float dx = ax * v, dy = ay * v, dz = az * v;
-            G00 = fmaf(T0, dx, G00); G01 = fmaf(T0, dy, G01); G02 = fmaf(T0, dz, G02);
-            G10 = fmaf(T1, dx, G10); G11 = fmaf(T1, dy, G11); G12 = fmaf(T1, dz, G12);
-            G20 = fmaf(T2, dx, G20); G21 = fmaf(T2, dy, G21); G22 = fmaf(T2, dz, G22);
+            const T w0 = fma3(r00, ax, fma3(r01, ay, r02 * az)), w1 = fma3(r10, ax, fma3(r11, ay, r12 * az)),
+                        w2 = fma3(r20, ax, fma3(r21, ay, r22 * az));
+            gqRow[rfl(fk->tj[j].q_index)] += fk->tj[j].scale * fma3(T0, w0, fma3(T1, w1, T2 * w2));
+            const T dx = ax * v, dy = ay * v, dz = az * v;
+            G00 = fma3(T0, dx, G00); G01 = fma3(T0, dy, G01); G02 = fma3(T0, dz, G02);
+            G10 = fma3(T1, dx, G10); G11 = fma3(T1, dy, G11); G12 = fma3(T1, dz, G12);
+            G20 = fma3(T2, dx, G20); G21 = fma3(T2, dy, G21); G22 = fma3(T2, dz, G22);
         }
         // back through the constant transform F
         const auto* F = fk->tj[j].F;
         const float f00 = F[0], f01 = F[1], f02 = F[2], f03 = F[3], f10 = F[4], f11 = F[5], f12 = F[6], f13 = F[7];
         const float f20 = F[8], f21 = F[9], f22 = F[10], f23 = F[11];
-        const float n00 = fmaf(G00, f00, fmaf(G01, f01, fmaf(G02, f02, T0 * f03)));
-        const float n01 = fmaf(G00, f10, fmaf(G01, f11, fmaf(G02, f12, T0 * f13)));
-        const float n02 = fmaf(G00, f20, fmaf(G01, f21, fmaf(G02, f22, T0 * f23)));
-        const float n10 = fmaf(G10, f00, fmaf(G11, f01, fmaf(G12, f02, T1 * f03)));
-        const float n11 = fmaf(G10, f10, fmaf(G11, f11, fmaf(G12, f12, T1 * f13)));
-        const float n12 = fmaf(G10, f20, fmaf(G11, f21, fmaf(G12, f22, T1 * f23)));
-        const float n20 = fmaf(G20, f00, fmaf(G21, f01, fmaf(G22, f02, T2 * f03)));
-        const float n21 = fmaf(G20, f10, fmaf(G21, f11, fmaf(G22, f12, T2 * f13)));
-        const float n22 = fmaf(G20, f20, fmaf(G21, f21, fmaf(G22, f22, T2 * f23)));
+        const T n00 = fma3(G00, f00, fma3(G01, f01, fma3(G02, f02, T0 * f03)));
+        const T n01 = fma3(G00, f10, fma3(G01, f11, fma3(G02, f12, T0 * f13)));
+        const T n02 = fma3(G00, f20, fma3(G01, f21, fma3(G02, f22, T0 * f23)));
+        const T n10 = fma3(G10, f00, fma3(G11, f01, fma3(G12, f02, T1 * f03)));
+        const T n11 = fma3(G10, f10, fma3(G11, f11, fma3(G12, f12, T1 * f13)));
+        const T n12 = fma3(G10, f20, fma3(G11, f21, fma3(G12, f22, T1 * f23)));
+        const T n20 = fma3(G20, f00, fma3(G21, f01, fma3(G22, f02, T2 * f03)));
+        const T n21 = fma3(G20, f10, fma3(G21, f11, fma3(G22, f12, T2 * f13)));
+        const T n22 = fma3(G20, f20, fma3(G21, f21, fma3(G22, f22, T2 * f23)));
         G00 = n00; G01 = n01; G02 = n02; G10 = n10; G11 = n11; G12 = n12; G20 = n20; G21 = n21; G22 = n22;
-        const float q00 = fmaf(r00, f00, fmaf(r01, f01, r02 * f02)), q01 = fmaf(r00, f10, fmaf(r01, f11, r02 * f12)),
-                    q02 = fmaf(r00, f20, fmaf(r01, f21, r02 * f22));
-        const float q10 = fmaf(r10, f00, fmaf(r11, f01, r12 * f02)), q11 = fmaf(r10, f10, fmaf(r11, f11, r12 * f12)),
-                    q12 = fmaf(r10, f20, fmaf(r11, f21, r12 * f22));
-        const float q20 = fmaf(r20, f00, fmaf(r21, f01, r22 * f02)), q21 = fmaf(r20, f10, fmaf(r21, f11, r22 * f12)),
-                    q22 = fmaf(r20, f20, fmaf(r21, f21, r22 * f22));
+        const T q00 = fma3(r00, f00, fma3(r01, f01, r02 * f02)), q01 = fma3(r00, f10, fma3(r01, f11, r02 * f12)),
+                    q02 = fma3(r00, f20, fma3(r01, f21, r02 * f22));
+        const T q10 = fma3(r10, f00, fma3(r11, f01, r12 * f02)), q11 = fma3(r10, f10, fma3(r11, f11, r12 * f12)),
+                    q12 = fma3(r10, f20, fma3(r11, f21, r12 * f22));
+        const T q20 = fma3(r20, f00, fma3(r21, f01, r22 * f02)), q21 = fma3(r20, f10, fma3(r21, f11, r22 * f12)),
+                    q22 = fma3(r20, f20, fma3(r21, f21, r22 * f22));
         r00 = q00; r01 = q01; r02 = q02; r10 = q10; r11 = q11; r12 = q12; r20 = q20; r21 = q21; r22 = q22;
         // (R, GR, Gt) now refer to the parent frame.  A child that started from a parked frame adds its adjoint to the
         // parent's sum; a child that continued in registers just carries on; a root's parent adjoint is dropped.
         const int start = rfl(fk->tj[j].start);
         if (start >= 0) {
-            float* ad = sFw + (f_adj + 12 * start) * 64;
+            T* ad = sFw + (f_adj + 12 * start) * 64;
             ad[0] += G00; ad[64] += G01; ad[128] += G02; ad[192] += T0;
             ad[256] += G10; ad[320] += G11; ad[384] += G12; ad[448] += T1;
             ad[512] += G20; ad[576] += G21; ad[640] += G22; ad[704] += T2;
@@ -534,14 +575,15 @@ __device__ __attribute__((noinline)) void fk_tree_vjp(fk_cptr fk, const float* s
 
 // ---- forward, phase A (every wave of the block): sin/cos of the joint angles -> frames ---------------
 // wave w of nw takes joints w, w+nw, ...   Caller synchronises the block afterwards.
-__device__ inline void fk_forward_trig(fk_cptr fk, const float* sQrow, float* sFcol, int wave, int nw) {
+template <class T>
+__device__ inline void fk_forward_trig(fk_cptr fk, const T* sQrow, T* sFcol, int wave, int nw) {
     const int kind = rfl(fk->kind);
     if (kind == DCX_FK_DH) {
         const int nj = rfl(fk->n_joints);
         for (int j = wave; j < nj; j += nw) {
-            const float th = sQrow[rfl(fk->joints[j].q_index)] + fk->joints[j].theta0;
-            float s, c;
-            sincos_f32(th, &s, &c);
+            const T th = sQrow[rfl(fk->joints[j].q_index)] + fk->joints[j].theta0;
+            T s, c;
+            sincos_t(th, &s, &c);
             sFcol[(2 * j) * 64] = s;
             sFcol[(2 * j + 1) * 64] = c;
         }
@@ -550,11 +592,11 @@ __device__ inline void fk_forward_trig(fk_cptr fk, const float* sQrow, float* sF
         for (int j = wave; j < nj; j += nw) {
             const int type = rfl(fk->tj[j].type);
             if (type == TJ_FIXED || !rfl(fk->tj[j].slot_owner)) continue;
-            const float v = fmaf(fk->tj[j].scale, sQrow[rfl(fk->tj[j].q_index)], fk->tj[j].offset);
+            const T v = fma3(fk->tj[j].scale, sQrow[rfl(fk->tj[j].q_index)], fk->tj[j].offset);
             const int slot = rfl(fk->tj[j].slot);
             if (type == TJ_REV) {
-                float s, c;
-                sincos_f32(v, &s, &c);
+                T s, c;
+                sincos_t(v, &s, &c);
                 sFcol[(2 * slot) * 64] = s;
                 sFcol[(2 * slot + 1) * 64] = c;
             } else {
@@ -564,10 +606,10 @@ __device__ inline void fk_forward_trig(fk_cptr fk, const float* sQrow, float* sF
     } else if (kind == DCX_FK_PLANAR) {
         const int dof = rfl(fk->dof);
         for (int j = wave; j < dof; j += nw) {
-            float phi = 0.f;
+            T phi = 0.f;
             for (int i = 0; i <= j; ++i) phi += sQrow[i];  // same left-to-right sum as cumsum
-            float s, c;
-            sincos_f32(phi, &s, &c);
+            T s, c;
+            sincos_t(phi, &s, &c);
             sFcol[(2 * j) * 64] = c;
             sFcol[(2 * j + 1) * 64] = s;
         }
@@ -575,88 +617,89 @@ __device__ inline void fk_forward_trig(fk_cptr fk, const float* sQrow, float* sF
 }
 
 // ---- forward, phase B (one wave): compose the chain -> X (LDS column) --------------------------------
-__device__ inline void fk_forward_chain(fk_cptr fk, const float* sQrow, float* sXcol, float* sFcol) {
+template <class T>
+__device__ inline void fk_forward_chain(fk_cptr fk, const T* sQrow, T* sXcol, T* sFcol) {
     const int kind = rfl(fk->kind);
     if (kind == DCX_FK_NONE) {
         const int dof = rfl(fk->dof);
         for (int i = 0; i < dof; ++i) sXcol[i * 64] = sQrow[i];
     } else if (kind == DCX_FK_PLANAR) {
         const int dof = rfl(fk->dof);
-        float x = 0.f, y = 0.f;
+        T x = 0.f, y = 0.f;
         for (int i = 0; i < dof; ++i) {
             const float l = fk->link_length[i];
-            x = fmaf(l, sFcol[(2 * i) * 64], x);
-            y = fmaf(l, sFcol[(2 * i + 1) * 64], y);
+            x = fma3(l, sFcol[(2 * i) * 64], x);
+            y = fma3(l, sFcol[(2 * i + 1) * 64], y);
             sXcol[(2 * i) * 64] = x;
             sXcol[(2 * i + 1) * 64] = y;
         }
     } else if (kind == DCX_FK_DH) {
         const int nch = rfl(fk->n_chains), njt = rfl(fk->n_joints);
         for (int ch = 0; ch < nch; ++ch) {
-            float r00 = fk->base[ch][0], r01 = fk->base[ch][1], r02 = fk->base[ch][2], t0 = fk->base[ch][3];
-            float r10 = fk->base[ch][4], r11 = fk->base[ch][5], r12 = fk->base[ch][6], t1 = fk->base[ch][7];
-            float r20 = fk->base[ch][8], r21 = fk->base[ch][9], r22 = fk->base[ch][10], t2 = fk->base[ch][11];
+            T r00 = fk->base[ch][0], r01 = fk->base[ch][1], r02 = fk->base[ch][2], t0 = fk->base[ch][3];
+            T r10 = fk->base[ch][4], r11 = fk->base[ch][5], r12 = fk->base[ch][6], t1 = fk->base[ch][7];
+            T r20 = fk->base[ch][8], r21 = fk->base[ch][9], r22 = fk->base[ch][10], t2 = fk->base[ch][11];
             const int jb = rfl(fk->chain_begin[ch]), je = rfl(fk->chain_end[ch]);
             for (int j = jb; j < je; ++j) {
-                const float s = sFcol[(2 * j) * 64], c = sFcol[(2 * j + 1) * 64];
+                const T s = sFcol[(2 * j) * 64], c = sFcol[(2 * j + 1) * 64];
                 const float a = fk->joints[j].a, d = fk->joints[j].d;
                 const float sa = fk->joints[j].sin_alpha, ca = fk->joints[j].cos_alpha;
                 // T <- T * [[c, -s ca,  s sa, a c], [s, c ca, -c sa, a s], [0, sa, ca, d]]   (utils.DH2mat)
-                const float m01 = -s * ca, m02 = s * sa, m11 = c * ca, m12 = -c * sa;
-                const float ac = a * c, as = a * s;
-                t0 = fmaf(r00, ac, fmaf(r01, as, fmaf(r02, d, t0)));
-                t1 = fmaf(r10, ac, fmaf(r11, as, fmaf(r12, d, t1)));
-                t2 = fmaf(r20, ac, fmaf(r21, as, fmaf(r22, d, t2)));
-                const float n00 = fmaf(r00, c, r01 * s), n10 = fmaf(r10, c, r11 * s), n20 = fmaf(r20, c, r21 * s);
-                const float n01 = fmaf(r00, m01, fmaf(r01, m11, r02 * sa));
-                const float n11 = fmaf(r10, m01, fmaf(r11, m11, r12 * sa));
-                const float n21 = fmaf(r20, m01, fmaf(r21, m11, r22 * sa));
-                const float n02 = fmaf(r00, m02, fmaf(r01, m12, r02 * ca));
-                const float n12 = fmaf(r10, m02, fmaf(r11, m12, r12 * ca));
-                const float n22 = fmaf(r20, m02, fmaf(r21, m12, r22 * ca));
+                const T m01 = -s * ca, m02 = s * sa, m11 = c * ca, m12 = -c * sa;
+                const T ac = a * c, as = a * s;
+                t0 = fma3(r00, ac, fma3(r01, as, fma3(r02, d, t0)));
+                t1 = fma3(r10, ac, fma3(r11, as, fma3(r12, d, t1)));
+                t2 = fma3(r20, ac, fma3(r21, as, fma3(r22, d, t2)));
+                const T n00 = fma3(r00, c, r01 * s), n10 = fma3(r10, c, r11 * s), n20 = fma3(r20, c, r21 * s);
+                const T n01 = fma3(r00, m01, fma3(r01, m11, r02 * sa));
+                const T n11 = fma3(r10, m01, fma3(r11, m11, r12 * sa));
+                const T n21 = fma3(r20, m01, fma3(r21, m11, r22 * sa));
+                const T n02 = fma3(r00, m02, fma3(r01, m12, r02 * ca));
+                const T n12 = fma3(r10, m02, fma3(r11, m12, r12 * ca));
+                const T n22 = fma3(r20, m02, fma3(r21, m12, r22 * ca));
                 r00 = n00; r01 = n01; r02 = n02; r10 = n10; r11 = n11; r12 = n12; r20 = n20; r21 = n21; r22 = n22;
                 const int pb = rfl(fk->joints[j].pt_begin), pe = rfl(fk->joints[j].pt_end);
                 for (int p = pb; p < pe; ++p) {
                     const float ox = fk->points[p].ox, oy = fk->points[p].oy, oz = fk->points[p].oz;
-                    float* out = sXcol + rfl(fk->points[p].out_k) * 64;
-                    out[0] = fmaf(r00, ox, fmaf(r01, oy, fmaf(r02, oz, t0)));
-                    out[64] = fmaf(r10, ox, fmaf(r11, oy, fmaf(r12, oz, t1)));
-                    out[128] = fmaf(r20, ox, fmaf(r21, oy, fmaf(r22, oz, t2)));
+                    T* out = sXcol + rfl(fk->points[p].out_k) * 64;
+                    out[0] = fma3(r00, ox, fma3(r01, oy, fma3(r02, oz, t0)));
+                    out[64] = fma3(r10, ox, fma3(r11, oy, fma3(r12, oz, t1)));
+                    out[128] = fma3(r20, ox, fma3(r21, oy, fma3(r22, oz, t2)));
                 }
                 DCX_FK_TS(7 + (j < 8 ? j : 8), 0);
             }
-            float* fr = sFcol + (2 * njt + 9 * ch) * 64;  // final rotation of this chain (for the reverse sweep)
+            T* fr = sFcol + (2 * njt + 9 * ch) * 64;  // final rotation of this chain (for the reverse sweep)
             fr[0] = r00; fr[64] = r01; fr[128] = r02; fr[192] = r10; fr[256] = r11; fr[320] = r12;
             fr[384] = r20; fr[448] = r21; fr[512] = r22;
         }
     } else if (kind == DCX_FK_TREE) {
         fk_tree_chain(fk, sXcol, sFcol);
     } else if (kind == DCX_FK_SE2) {
-        const float x = sQrow[0], y = sQrow[1];
-        float s, c;
-        sincos_f32(sQrow[2], &s, &c);
+        const T x = sQrow[0], y = sQrow[1];
+        T s, c;
+        sincos_t(sQrow[2], &s, &c);
         const int n_pts = rfl(fk->n_points);
         for (int k = 0; k < n_pts; ++k) {
             const float kx = fk->keypoints[k][0], ky = fk->keypoints[k][1];
-            sXcol[(2 * k) * 64] = fmaf(c, kx, fmaf(-s, ky, x));
-            sXcol[(2 * k + 1) * 64] = fmaf(s, kx, fmaf(c, ky, y));
+            sXcol[(2 * k) * 64] = fma3(c, kx, fma3(-s, ky, x));
+            sXcol[(2 * k + 1) * 64] = fma3(s, kx, fma3(c, ky, y));
         }
     } else if (kind == DCX_FK_SE3) {
-        float sx, cx, sy, cy, sz, cz;
-        sincos_f32(sQrow[3], &sx, &cx);
-        sincos_f32(sQrow[4], &sy, &cy);
-        sincos_f32(sQrow[5], &sz, &cz);
+        T sx, cx, sy, cy, sz, cz;
+        sincos_t(sQrow[3], &sx, &cx);
+        sincos_t(sQrow[4], &sy, &cy);
+        sincos_t(sQrow[5], &sz, &cz);
         // R = Rz(yaw) Ry(pitch) Rx(roll)
-        const float r00 = cz * cy, r01 = cz * sy * sx - sz * cx, r02 = cz * sy * cx + sz * sx;
-        const float r10 = sz * cy, r11 = sz * sy * sx + cz * cx, r12 = sz * sy * cx - cz * sx;
-        const float r20 = -sy, r21 = cy * sx, r22 = cy * cx;
-        const float x = sQrow[0], y = sQrow[1], z = sQrow[2];
+        const T r00 = cz * cy, r01 = cz * sy * sx - sz * cx, r02 = cz * sy * cx + sz * sx;
+        const T r10 = sz * cy, r11 = sz * sy * sx + cz * cx, r12 = sz * sy * cx - cz * sx;
+        const T r20 = -sy, r21 = cy * sx, r22 = cy * cx;
+        const T x = sQrow[0], y = sQrow[1], z = sQrow[2];
         const int n_pts = rfl(fk->n_points);
         for (int k = 0; k < n_pts; ++k) {
             const float kx = fk->keypoints[k][0], ky = fk->keypoints[k][1], kz = fk->keypoints[k][2];
-            sXcol[(3 * k) * 64] = fmaf(r00, kx, fmaf(r01, ky, fmaf(r02, kz, x)));
-            sXcol[(3 * k + 1) * 64] = fmaf(r10, kx, fmaf(r11, ky, fmaf(r12, kz, y)));
-            sXcol[(3 * k + 2) * 64] = fmaf(r20, kx, fmaf(r21, ky, fmaf(r22, kz, z)));
+            sXcol[(3 * k) * 64] = fma3(r00, kx, fma3(r01, ky, fma3(r02, kz, x)));
+            sXcol[(3 * k + 1) * 64] = fma3(r10, kx, fma3(r11, ky, fma3(r12, kz, y)));
+            sXcol[(3 * k + 2) * 64] = fma3(r20, kx, fma3(r21, ky, fma3(r22, kz, z)));
         }
     }
 }
@@ -664,7 +707,8 @@ __device__ inline void fk_forward_chain(fk_cptr fk, const float* sQrow, float* s
 // ---- vjp (one wave): gq (LDS row, dof floats) = J(q)^T gX, using the frames the forward left ------------
 // NOTE: gqRow may alias sQrow (callers build the gradient row in place of the q row), so every branch must
 // finish reading sQrow before its first write to gqRow.
-__device__ inline void fk_vjp(fk_cptr fk, const float* sQrow, const float* sFcol, const float* sGcol, float* gqRow) {
+template <class T>
+__device__ inline void fk_vjp(fk_cptr fk, const T* sQrow, const T* sFcol, const T* sGcol, T* gqRow) {
     const int kind = rfl(fk->kind);
     const int dof = rfl(fk->dof);
     if (kind == DCX_FK_NONE) {
@@ -673,12 +717,12 @@ __device__ inline void fk_vjp(fk_cptr fk, const float* sQrow, const float* sFcol
     }
     if (kind == DCX_FK_PLANAR) {
         // gq_i = sum_{j>=i} l_j (-sin phi_j * GX_j + cos phi_j * GY_j),  GX_j = sum_{k>=j} gx_k
-        float GX = 0.f, GY = 0.f, acc = 0.f;
+        T GX = 0.f, GY = 0.f, acc = 0.f;
         for (int j = dof - 1; j >= 0; --j) {
             GX += sGcol[(2 * j) * 64];
             GY += sGcol[(2 * j + 1) * 64];
-            const float c = sFcol[(2 * j) * 64], s = sFcol[(2 * j + 1) * 64];
-            acc = fmaf(fk->link_length[j], fmaf(c, GY, -s * GX), acc);
+            const T c = sFcol[(2 * j) * 64], s = sFcol[(2 * j + 1) * 64];
+            acc = fma3(fk->link_length[j], fma3(c, GY, -s * GX), acc);
             gqRow[j] = acc;
         }
         return;
@@ -694,57 +738,57 @@ __device__ inline void fk_vjp(fk_cptr fk, const float* sQrow, const float* sFcol
         for (int i = 0; i < dof; ++i) gqRow[i] = 0.f;  // DH reads frames, not q
         const int nch = rfl(fk->n_chains), njt = rfl(fk->n_joints);
         for (int ch = 0; ch < nch; ++ch) {
-            const float* fr = sFcol + (2 * njt + 9 * ch) * 64;
-            float r00 = fr[0], r01 = fr[64], r02 = fr[128], r10 = fr[192], r11 = fr[256], r12 = fr[320];
-            float r20 = fr[384], r21 = fr[448], r22 = fr[512];
-            float G00 = 0.f, G01 = 0.f, G02 = 0.f, G10 = 0.f, G11 = 0.f, G12 = 0.f, G20 = 0.f, G21 = 0.f, G22 = 0.f;
-            float T0 = 0.f, T1 = 0.f, T2 = 0.f;
+            const T* fr = sFcol + (2 * njt + 9 * ch) * 64;
+            T r00 = fr[0], r01 = fr[64], r02 = fr[128], r10 = fr[192], r11 = fr[256], r12 = fr[320];
+            T r20 = fr[384], r21 = fr[448], r22 = fr[512];
+            T G00 = 0.f, G01 = 0.f, G02 = 0.f, G10 = 0.f, G11 = 0.f, G12 = 0.f, G20 = 0.f, G21 = 0.f, G22 = 0.f;
+            T T0 = 0.f, T1 = 0.f, T2 = 0.f;
             const int jb = rfl(fk->chain_begin[ch]), je = rfl(fk->chain_end[ch]);
             for (int j = je - 1; j >= jb; --j) {
                 const int pb = rfl(fk->joints[j].pt_begin), pe = rfl(fk->joints[j].pt_end);
                 for (int p = pb; p < pe; ++p) {
-                    const float* gin = sGcol + rfl(fk->points[p].out_k) * 64;
-                    const float g0 = gin[0], g1 = gin[64], g2 = gin[128];
+                    const T* gin = sGcol + rfl(fk->points[p].out_k) * 64;
+                    const T g0 = gin[0], g1 = gin[64], g2 = gin[128];
                     const float ox = fk->points[p].ox, oy = fk->points[p].oy, oz = fk->points[p].oz;
                     T0 += g0; T1 += g1; T2 += g2;
-                    G00 = fmaf(g0, ox, G00); G01 = fmaf(g0, oy, G01); G02 = fmaf(g0, oz, G02);
-                    G10 = fmaf(g1, ox, G10); G11 = fmaf(g1, oy, G11); G12 = fmaf(g1, oz, G12);
-                    G20 = fmaf(g2, ox, G20); G21 = fmaf(g2, oy, G21); G22 = fmaf(g2, oz, G22);
+                    G00 = fma3(g0, ox, G00); G01 = fma3(g0, oy, G01); G02 = fma3(g0, oz, G02);
+                    G10 = fma3(g1, ox, G10); G11 = fma3(g1, oy, G11); G12 = fma3(g1, oz, G12);
+                    G20 = fma3(g2, ox, G20); G21 = fma3(g2, oy, G21); G22 = fma3(g2, oz, G22);
                 }
-                const float s = sFcol[(2 * j) * 64], c = sFcol[(2 * j + 1) * 64];
+                const T s = sFcol[(2 * j) * 64], c = sFcol[(2 * j + 1) * 64];
                 const float a = fk->joints[j].a, d = fk->joints[j].d;
                 const float sa = fk->joints[j].sin_alpha, ca = fk->joints[j].cos_alpha;
                 // A_R = [[c, -s ca, s sa], [s, c ca, -c sa], [0, sa, ca]],  a_t = (a c, a s, d)
-                const float a00 = c, a01 = -s * ca, a02 = s * sa, a10 = s, a11 = c * ca, a12 = -c * sa;
-                const float at0 = a * c, at1 = a * s;
+                const T a00 = c, a01 = -s * ca, a02 = s * sa, a10 = s, a11 = c * ca, a12 = -c * sa;
+                const T at0 = a * c, at1 = a * s;
                 // R_{i-1} = R_i A_R^T
-                const float p00 = fmaf(r00, a00, fmaf(r01, a01, r02 * a02)), p01 = fmaf(r00, a10, fmaf(r01, a11, r02 * a12)),
-                            p02 = fmaf(r01, sa, r02 * ca);
-                const float p10 = fmaf(r10, a00, fmaf(r11, a01, r12 * a02)), p11 = fmaf(r10, a10, fmaf(r11, a11, r12 * a12)),
-                            p12 = fmaf(r11, sa, r12 * ca);
-                const float p20 = fmaf(r20, a00, fmaf(r21, a01, r22 * a02)), p21 = fmaf(r20, a10, fmaf(r21, a11, r22 * a12)),
-                            p22 = fmaf(r21, sa, r22 * ca);
+                const T p00 = fma3(r00, a00, fma3(r01, a01, r02 * a02)), p01 = fma3(r00, a10, fma3(r01, a11, r02 * a12)),
+                            p02 = fma3(r01, sa, r02 * ca);
+                const T p10 = fma3(r10, a00, fma3(r11, a01, r12 * a02)), p11 = fma3(r10, a10, fma3(r11, a11, r12 * a12)),
+                            p12 = fma3(r11, sa, r12 * ca);
+                const T p20 = fma3(r20, a00, fma3(r21, a01, r22 * a02)), p21 = fma3(r20, a10, fma3(r21, a11, r22 * a12)),
+                            p22 = fma3(r21, sa, r22 * ca);
                 // M = R_{i-1}^T GR (rows 0,1 only: dA_R/dtheta has a zero third row), u = R_{i-1}^T Gt
-                const float M00 = fmaf(p00, G00, fmaf(p10, G10, p20 * G20)), M01 = fmaf(p00, G01, fmaf(p10, G11, p20 * G21)),
-                            M02 = fmaf(p00, G02, fmaf(p10, G12, p20 * G22));
-                const float M10 = fmaf(p01, G00, fmaf(p11, G10, p21 * G20)), M11 = fmaf(p01, G01, fmaf(p11, G11, p21 * G21)),
-                            M12 = fmaf(p01, G02, fmaf(p11, G12, p21 * G22));
-                const float u0 = fmaf(p00, T0, fmaf(p10, T1, p20 * T2)), u1 = fmaf(p01, T0, fmaf(p11, T1, p21 * T2));
+                const T M00 = fma3(p00, G00, fma3(p10, G10, p20 * G20)), M01 = fma3(p00, G01, fma3(p10, G11, p20 * G21)),
+                            M02 = fma3(p00, G02, fma3(p10, G12, p20 * G22));
+                const T M10 = fma3(p01, G00, fma3(p11, G10, p21 * G20)), M11 = fma3(p01, G01, fma3(p11, G11, p21 * G21)),
+                            M12 = fma3(p01, G02, fma3(p11, G12, p21 * G22));
+                const T u0 = fma3(p00, T0, fma3(p10, T1, p20 * T2)), u1 = fma3(p01, T0, fma3(p11, T1, p21 * T2));
                 // dA_R/dtheta = [[-s, -c ca, c sa], [c, -s ca, s sa], [0,0,0]] = [[-a10, -a11, -a12], [a00, a01, a02], 0]
                 // da_t/dtheta = (-a s, a c, 0)
-                const float dth = (M10 * a00 + M11 * a01 + M12 * a02) - (M00 * a10 + M01 * a11 + M02 * a12)
+                const T dth = (M10 * a00 + M11 * a01 + M12 * a02) - (M00 * a10 + M01 * a11 + M02 * a12)
                                   + (u1 * at0 - u0 * at1);
                 gqRow[rfl(fk->joints[j].q_index)] += dth;
                 // GR <- GR A_R^T + Gt a_t^T
-                const float n00 = fmaf(G00, a00, fmaf(G01, a01, fmaf(G02, a02, T0 * at0)));
-                const float n01 = fmaf(G00, a10, fmaf(G01, a11, fmaf(G02, a12, T0 * at1)));
-                const float n02 = fmaf(G01, sa, fmaf(G02, ca, T0 * d));
-                const float n10 = fmaf(G10, a00, fmaf(G11, a01, fmaf(G12, a02, T1 * at0)));
-                const float n11 = fmaf(G10, a10, fmaf(G11, a11, fmaf(G12, a12, T1 * at1)));
-                const float n12 = fmaf(G11, sa, fmaf(G12, ca, T1 * d));
-                const float n20 = fmaf(G20, a00, fmaf(G21, a01, fmaf(G22, a02, T2 * at0)));
-                const float n21 = fmaf(G20, a10, fmaf(G21, a11, fmaf(G22, a12, T2 * at1)));
-                const float n22 = fmaf(G21, sa, fmaf(G22, ca, T2 * d));
+                const T n00 = fma3(G00, a00, fma3(G01, a01, fma3(G02, a02, T0 * at0)));
+                const T n01 = fma3(G00, a10, fma3(G01, a11, fma3(G02, a12, T0 * at1)));
+                const T n02 = fma3(G01, sa, fma3(G02, ca, T0 * d));
+                const T n10 = fma3(G10, a00, fma3(G11, a01, fma3(G12, a02, T1 * at0)));
+                const T n11 = fma3(G10, a10, fma3(G11, a11, fma3(G12, a12, T1 * at1)));
+                const T n12 = fma3(G11, sa, fma3(G12, ca, T1 * d));
+                const T n20 = fma3(G20, a00, fma3(G21, a01, fma3(G22, a02, T2 * at0)));
+                const T n21 = fma3(G20, a10, fma3(G21, a11, fma3(G22, a12, T2 * at1)));
+                const T n22 = fma3(G21, sa, fma3(G22, ca, T2 * d));
                 G00 = n00; G01 = n01; G02 = n02; G10 = n10; G11 = n11; G12 = n12; G20 = n20; G21 = n21; G22 = n22;
                 r00 = p00; r01 = p01; r02 = p02; r10 = p10; r11 = p11; r12 = p12; r20 = p20; r21 = p21; r22 = p22;
                 DCX_FK_TS(7 + (j < 8 ? j : 8), 1);
@@ -753,46 +797,46 @@ __device__ inline void fk_vjp(fk_cptr fk, const float* sQrow, const float* sFcol
     } else if (kind == DCX_FK_TREE) {
         fk_tree_vjp(fk, sFcol, sGcol, gqRow);
     } else if (kind == DCX_FK_SE2) {
-        float s, c;
-        sincos_f32(sQrow[2], &s, &c);
-        float gx = 0.f, gy = 0.f, gt = 0.f;
+        T s, c;
+        sincos_t(sQrow[2], &s, &c);
+        T gx = 0.f, gy = 0.f, gt = 0.f;
         const int n_pts = rfl(fk->n_points);
         for (int k = 0; k < n_pts; ++k) {
             const float kx = fk->keypoints[k][0], ky = fk->keypoints[k][1];
-            const float a = sGcol[(2 * k) * 64], b = sGcol[(2 * k + 1) * 64];
+            const T a = sGcol[(2 * k) * 64], b = sGcol[(2 * k + 1) * 64];
             gx += a;
             gy += b;
             gt += a * (-s * kx - c * ky) + b * (c * kx - s * ky);
         }
         gqRow[0] = gx; gqRow[1] = gy; gqRow[2] = gt;
     } else if (kind == DCX_FK_SE3) {
-        float sx, cx, sy, cy, sz, cz;
-        sincos_f32(sQrow[3], &sx, &cx);
-        sincos_f32(sQrow[4], &sy, &cy);
-        sincos_f32(sQrow[5], &sz, &cz);
+        T sx, cx, sy, cy, sz, cz;
+        sincos_t(sQrow[3], &sx, &cx);
+        sincos_t(sQrow[4], &sy, &cy);
+        sincos_t(sQrow[5], &sz, &cz);
         // M = sum_k g_k k_k^T (3x3); d/dangle = <dR/dangle, M>
-        float m00 = 0, m01 = 0, m02 = 0, m10 = 0, m11 = 0, m12 = 0, m20 = 0, m21 = 0, m22 = 0;
-        float g0s = 0, g1s = 0, g2s = 0;
+        T m00 = 0, m01 = 0, m02 = 0, m10 = 0, m11 = 0, m12 = 0, m20 = 0, m21 = 0, m22 = 0;
+        T g0s = 0, g1s = 0, g2s = 0;
         const int n_pts = rfl(fk->n_points);
         for (int k = 0; k < n_pts; ++k) {
             const float kx = fk->keypoints[k][0], ky = fk->keypoints[k][1], kz = fk->keypoints[k][2];
-            const float g0 = sGcol[(3 * k) * 64], g1 = sGcol[(3 * k + 1) * 64], g2 = sGcol[(3 * k + 2) * 64];
+            const T g0 = sGcol[(3 * k) * 64], g1 = sGcol[(3 * k + 1) * 64], g2 = sGcol[(3 * k + 2) * 64];
             g0s += g0; g1s += g1; g2s += g2;
             m00 += g0 * kx; m01 += g0 * ky; m02 += g0 * kz;
             m10 += g1 * kx; m11 += g1 * ky; m12 += g1 * kz;
             m20 += g2 * kx; m21 += g2 * ky; m22 += g2 * kz;
         }
         // dR/droll  (d/dx of Rx): columns 1,2 change
-        const float a01 = cz * sy * cx + sz * sx, a02 = -cz * sy * sx + sz * cx;
-        const float a11 = sz * sy * cx - cz * sx, a12 = -sz * sy * sx - cz * cx;
-        const float a21 = cy * cx, a22 = -cy * sx;
+        const T a01 = cz * sy * cx + sz * sx, a02 = -cz * sy * sx + sz * cx;
+        const T a11 = sz * sy * cx - cz * sx, a12 = -sz * sy * sx - cz * cx;
+        const T a21 = cy * cx, a22 = -cy * sx;
         // dR/dpitch
-        const float b00 = -cz * sy, b01 = cz * cy * sx, b02 = cz * cy * cx;
-        const float b10 = -sz * sy, b11 = sz * cy * sx, b12 = sz * cy * cx;
-        const float b20 = -cy, b21 = -sy * sx, b22 = -sy * cx;
+        const T b00 = -cz * sy, b01 = cz * cy * sx, b02 = cz * cy * cx;
+        const T b10 = -sz * sy, b11 = sz * cy * sx, b12 = sz * cy * cx;
+        const T b20 = -cy, b21 = -sy * sx, b22 = -sy * cx;
         // dR/dyaw
-        const float c00 = -sz * cy, c01 = -sz * sy * sx - cz * cx, c02 = -sz * sy * cx + cz * sx;
-        const float c10 = cz * cy, c11 = cz * sy * sx - sz * cx, c12 = cz * sy * cx + sz * sx;
+        const T c00 = -sz * cy, c01 = -sz * sy * sx - cz * cx, c02 = -sz * sy * cx + cz * sx;
+        const T c10 = cz * cy, c11 = cz * sy * sx - sz * cx, c12 = cz * sy * cx + sz * sx;
         gqRow[0] = g0s; gqRow[1] = g1s; gqRow[2] = g2s;
         gqRow[3] = a01 * m01 + a02 * m02 + a11 * m11 + a12 * m12 + a21 * m21 + a22 * m22;
         gqRow[4] = b00 * m00 + b01 * m01 + b02 * m02 + b10 * m10 + b11 * m11 + b12 * m12 + b20 * m20 + b21 * m21 + b22 * m22;

@@ -1,0 +1,265 @@
+// hess_kernel.hip — analytic second derivatives of the score: dcx_score_hess.
+//
+// Replaces the double backward the reference runs through dist_est for trust-constr's constraint Hessian
+// (diffco/optim.py:380-391, torch.autograd.functional.hessian over DiffCo.score / poly_score).  For
+//     f(q) = sum_c up_c * sum_j W[j, c] K(|x(q) - s_j|^2),       x = T(q) (the FK control points)
+// row i of the Hessian is the directional derivative of the gradient along e_i.  One lane takes one
+// (configuration, direction) pair and pushes a value + tangent pair (fk_device.h `Dual`) through the SAME three phases
+// as the fused gradient kernel:
+//   1. forward FK in duals:           x,  dx = J e_i
+//   2. the sweep over the supports:   gX  = sum_j c_j delta_j,                 c_j = w_j g(d2_j), delta_j = x - s_j
+//                                     dgX = sum_j c_j dx + e_j delta_j,        e_j = w_j h(d2_j) (delta_j . dx)
+//      with g = 2 K'(d2) (the gradient coefficient of score_kernel.h kernel_eval) and h = 2 dg/dd2 in closed form
+//   3. the reverse FK sweep in duals: the tangent of J^T gX is  J^T dgX + (dJ/dq_i)^T gX  = H[i, :]
+// so the second derivatives of the transform come from forward-mode differentiation of the code that produces the first
+// ones — no finite differences anywhere (the previous route took central differences of the analytic gradient: 2e-3 of
+// the float64 Hessian; this one is fp32 round-off, ~1e-6).
+//
+// This is a callers'-side kernel (hundreds to thousands of dense-path points per trust-constr iteration), written for
+// exactness and generality — any feature width, every kernel function and transform — not for the instruction-rate
+// roofline of the sweep: for D <= 32 x, dx and the sums sit in registers, beyond that in LDS (4 D ds operations per pair
+// and lane).
+#include "dcx_internal.h"
+
+namespace dcx {
+
+struct HessArgs {
+    const float* rows;      // model rows [S][RS]
+    const FkProg* fk;
+    const float* q;         // [B][dof]
+    const float* upstream;  // [B][C] or null (= all ones)
+    float* grad;            // [B][dof] or null
+    float* hess;            // [B][dof][dof]
+    int64_t n_lanes;        // B * dof
+    int32_t S, D, C, RS, w_off, wsum_off;
+    int32_t dof, d_fk, frame_floats;
+    int32_t kind, kf;
+    float kp0, kp1;
+    int32_t s_chunk;
+    // LDS plan, in Dual elements (8 bytes)
+    int32_t o_q, o_f, o_x, o_acc, o_fk_floats;
+};
+
+// value, gradient coefficient g (dK/dx = g * delta) and h = 2 dg/dd2 (d2K/dx2 = g I + h delta delta^T)
+__device__ __forceinline__ void kernel_eval_h(const HessArgs& a, float d2, float& g, float& h) {
+    if (a.kf == KF_RQ2 || (a.kf == KF_GEN && a.kind == DCX_K_RQ)) {
+        // K = t^-p, t = 1 + gamma/p d2:  g = -2 gamma t^(-p-1),  h = 4 gamma^2 (p+1)/p t^(-p-2)
+        const float p = (a.kf == KF_RQ2) ? 2.0f : a.kp1;
+        const float t = fmaf(a.kp0 / p, d2, 1.0f);
+        const float u = 1.0f / t;
+        const float tp1 = (p == 2.0f) ? u * u * u : powf(t, -p - 1.0f);
+        g = -2.0f * a.kp0 * tp1;
+        h = 4.0f * a.kp0 * a.kp0 * (p + 1.0f) / p * tp1 / t;
+    } else if (a.kf == KF_POLY1 || a.kind == DCX_K_POLY) {
+        // K = r^k / eps (k odd) or r^k log r / eps (k even).  KF_POLY1 rows carry 1/eps in the weights.
+        const int k = (a.kf == KF_POLY1) ? 1 : (int)a.kp0;
+        const float ie = (a.kf == KF_POLY1) ? 1.0f : 1.0f / a.kp1;
+        if (d2 < 1e-20f) {  // on a support the kernel is not twice differentiable (k <= 2); the pair contributes nothing
+            g = 0.0f;
+            h = 0.0f;
+            return;
+        }
+        const float r = sqrtf(d2);
+        const float i2 = 1.0f / d2;
+        float rk4 = i2 * i2;  // r^(k-4)
+        for (int i = 0; i < k; ++i) rk4 *= r;
+        if (k & 1) {
+            g = (float)k * rk4 * d2 * ie;
+            h = (float)(k * (k - 2)) * rk4 * ie;
+        } else {
+            const float lg = logf(r);
+            g = rk4 * d2 * fmaf((float)k, lg, 1.0f) * ie;
+            h = rk4 * ((float)(k - 2) * fmaf((float)k, lg, 1.0f) + (float)k) * ie;
+        }
+    } else {  // DCX_K_MQ: K = sqrt(1 + d2 / eps^2)
+        const float ie2 = 1.0f / (a.kp0 * a.kp0);
+        const float rv = 1.0f / sqrtf(fmaf(d2, ie2, 1.0f));
+        g = rv * ie2;
+        h = -rv * rv * rv * ie2 * ie2;
+    }
+}
+
+__device__ __forceinline__ float pair_weight(const HessArgs& a, const float* r, const float* up) {
+    if (!up) return r[a.C > 1 ? a.wsum_off : a.w_off];
+    float w = 0.0f;
+    for (int c = 0; c < a.C; ++c) w = fmaf(up[c], r[a.w_off + c], w);
+    return w;
+}
+
+// supports [j0, j1) of one wave, any width: x, dx and the sums stay in LDS
+__device__ __forceinline__ void sweep_hess_lds(const HessArgs& a, const Dual* sX, Dual* sAcc, const float* up, int j0, int j1) {
+    for (int j = j0; j < j1; ++j) {
+        const float* r = a.rows + (size_t)j * a.RS;  // uniform address: scalar loads
+        float d2 = 0.0f, dd = 0.0f;
+        for (int k = 0; k < a.D; ++k) {
+            const Dual xk = sX[k * 64];
+            const float dl = xk.v - r[k];
+            d2 = fmaf(dl, dl, d2);
+            dd = fmaf(dl, xk.d, dd);
+        }
+        const float w = pair_weight(a, r, up);
+        float g, h;
+        kernel_eval_h(a, d2, g, h);
+        const float cf = w * g, ef = w * h * dd;
+        for (int k = 0; k < a.D; ++k) {
+            const Dual xk = sX[k * 64];
+            const float dl = xk.v - r[k];
+            Dual acc = sAcc[k * 64];
+            acc.v = fmaf(cf, dl, acc.v);
+            acc.d = fmaf(cf, xk.d, fmaf(ef, dl, acc.d));
+            sAcc[k * 64] = acc;
+        }
+    }
+}
+
+// the same for one of the compiled widths D <= 32 with x, dx and the sums in registers and the rows read through the
+// scalar cache (constant address space, like the sweep of score_kernel.h)
+template <int D>
+__device__ __forceinline__ void sweep_hess_regs(const HessArgs& a, const Dual* sX, Dual* sAcc, const float* up, int j0, int j1) {
+    float xv[D], xd[D], av[D], ad[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const Dual t = sX[k * 64];
+        xv[k] = t.v; xd[k] = t.d; av[k] = 0.0f; ad[k] = 0.0f;
+    }
+    cfloat_ptr rows = (cfloat_ptr)(uintptr_t)a.rows;
+    const int C = a.C, w_off = a.w_off;
+    for (int j = j0; j < j1; ++j) {
+        cfloat_ptr r = rows + (size_t)j * a.RS;
+        float rr[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) rr[k] = r[k];
+        float w;
+        if (up) {
+            w = 0.0f;
+            for (int c = 0; c < C; ++c) w = fmaf(up[c], r[w_off + c], w);
+        } else {
+            w = r[C > 1 ? a.wsum_off : w_off];
+        }
+        float d2 = 0.0f, dd = 0.0f;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const float dl = xv[k] - rr[k];
+            d2 = fmaf(dl, dl, d2);
+            dd = fmaf(dl, xd[k], dd);
+        }
+        float g, h;
+        kernel_eval_h(a, d2, g, h);
+        const float cf = w * g, ef = w * h * dd;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const float dl = xv[k] - rr[k];
+            av[k] = fmaf(cf, dl, av[k]);
+            ad[k] = fmaf(cf, xd[k], fmaf(ef, dl, ad[k]));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < D; ++k) sAcc[k * 64] = Dual(av[k], ad[k]);
+}
+
+__global__ __launch_bounds__(512) void score_hess_kernel(const HessArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    Dual* sd = reinterpret_cast<Dual*>(smem);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = blockDim.x >> 6;
+    const int dof = a.dof;
+    int64_t gl = (int64_t)blockIdx.x * 64 + lane;
+    const bool live = gl < a.n_lanes;
+    if (!live) gl = a.n_lanes - 1;  // surplus lanes repeat the last pair and store nothing
+    const int64_t b = gl / dof;
+    const int dir = (int)(gl - b * dof);
+    Dual* sQ = sd + a.o_q + lane * dof;  // this lane's row
+    Dual* sF = sd + a.o_f + lane;        // columns, stride 64
+    Dual* sX = sd + a.o_x + lane;
+    Dual* sAcc = sd + a.o_acc + (size_t)wave * a.D * 64 + lane;
+
+    const fk_cptr fk = stage_fk_prog(a.fk, smem + a.o_fk_floats, threadIdx.x, blockDim.x);
+    if (wave == 0)
+        for (int k = 0; k < dof; ++k) sQ[k] = Dual(a.q[b * dof + k], k == dir ? 1.0f : 0.0f);
+    __syncthreads();
+    fk_forward_trig<Dual>(fk, sQ, sF, wave, nw);
+    __syncthreads();
+    if (wave == 0) {
+        fk_forward_chain<Dual>(fk, sQ, sX, sF);
+        for (int k = a.d_fk; k < a.D; ++k) sX[k * 64] = Dual(0.0f, 0.0f);  // zero padding up to the compiled width
+    }
+    for (int k = 0; k < a.D; ++k) sAcc[k * 64] = Dual(0.0f, 0.0f);
+    __syncthreads();
+
+    // ---- the sweep: this wave's slice of the supports ----
+    const int j0 = (wave * a.s_chunk < a.S) ? wave * a.s_chunk : a.S;
+    const int j1 = (j0 + a.s_chunk < a.S) ? j0 + a.s_chunk : a.S;
+    const float* up = a.upstream ? a.upstream + b * a.C : nullptr;
+    switch (a.D) {  // a.D is one of the compiled widths (dcx_internal.h kTemplateD)
+#define DCX_HESS_CASE(W) case W: sweep_hess_regs<W>(a, sX, sAcc, up, j0, j1); break;
+        DCX_HESS_CASE(2) DCX_HESS_CASE(4) DCX_HESS_CASE(6) DCX_HESS_CASE(8) DCX_HESS_CASE(12) DCX_HESS_CASE(16)
+        DCX_HESS_CASE(18) DCX_HESS_CASE(21) DCX_HESS_CASE(24) DCX_HESS_CASE(27) DCX_HESS_CASE(30) DCX_HESS_CASE(32)
+#undef DCX_HESS_CASE
+        default: sweep_hess_lds(a, sX, sAcc, up, j0, j1);
+    }
+    __syncthreads();
+    // ---- wave 0: add the other waves' sums in wave order, then the reverse sweep in duals ----
+    if (wave == 0) {
+        for (int k = 0; k < a.D; ++k) {
+            Dual t = sAcc[k * 64];
+            for (int w = 1; w < nw; ++w) t += sAcc[((size_t)w * a.D + k) * 64];
+            sAcc[k * 64] = t;
+        }
+        fk_vjp<Dual>(fk, sQ, sF, sAcc, sQ);  // the gradient row is built in place of the q row
+        if (live) {
+            float* hrow = a.hess + gl * dof;
+            for (int k = 0; k < dof; ++k) hrow[k] = sQ[k].d;
+            if (a.grad && dir == 0)
+                for (int k = 0; k < dof; ++k) a.grad[b * dof + k] = sQ[k].v;
+        }
+    }
+}
+
+hipError_t launch_hess(const ModelView& m, const float* q, int64_t B, const float* upstream, float* grad, float* hess,
+                       hipStream_t stream) {
+    HessArgs a{};
+    a.rows = m.rows;
+    a.fk = m.fk;
+    a.q = q;
+    a.upstream = upstream;
+    a.grad = grad;
+    a.hess = hess;
+    a.n_lanes = B * m.dof;
+    a.S = m.S;
+    a.D = m.Dt;
+    a.C = m.C;
+    a.RS = m.RS;
+    a.w_off = m.Dt;
+    a.wsum_off = m.Dt + m.C;
+    a.dof = m.dof;
+    a.d_fk = m.d_fk;
+    a.frame_floats = m.frame_floats;
+    a.kind = m.kind;
+    a.kf = m.kf;
+    a.kp0 = m.kp0;
+    a.kp1 = m.kp1;
+    // waves per block: as many support slices as the LDS allows (Dual = 8 bytes; 64 lanes per column)
+    const int fixed = m.dof + m.frame_floats + m.Dt;               // q row, frames, x
+    const int budget = (int)((150 * 1024 - 4 * (size_t)m.prog_floats) / 512);  // Dual columns that fit
+    int nw = (budget - fixed) / m.Dt;
+    if (nw < 1) return hipErrorInvalidValue;
+    if (nw > 8) nw = 8;
+    a.s_chunk = (m.S + nw - 1) / nw;
+    a.o_q = 0;
+    a.o_f = a.o_q + 64 * m.dof;
+    a.o_x = a.o_f + 64 * m.frame_floats;
+    a.o_acc = a.o_x + 64 * m.Dt;
+    a.o_fk_floats = 2 * (a.o_acc + nw * 64 * m.Dt);
+    const size_t lds = sizeof(float) * ((size_t)a.o_fk_floats + m.prog_floats);
+    if (lds > 64 * 1024) {
+        if (hipError_t e = hipFuncSetAttribute((const void*)score_hess_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
+            return e;
+    }
+    const int64_t nblk = (a.n_lanes + 63) / 64;
+    if (nblk > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(score_hess_kernel, dim3((unsigned)nblk), dim3(64 * nw), lds, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace dcx

@@ -21,7 +21,7 @@ import numpy as np
 import torch
 from scipy.optimize import BFGS, NonlinearConstraint, minimize
 
-from . import utils
+from . import _lib, utils
 
 DIF_WEIGHT = 1           # path-length term; fixed by the reference ("should NOT be changed")
 MAX_MOVE_WEIGHT = 10
@@ -250,16 +250,16 @@ class _ScipyTerms:
             J.index_put_((row, seg + 1), a, accumulate=True)
         return J[:, 1:-1].numpy().reshape(n_seg, -1)
 
-    HESS_FD_STEP = 4e-3  # rad (or m): fp32 gradient noise ~1e-6 / step against step^2 truncation
+    HESS_FD_STEP = 4e-3  # rad (or m); only where dcx_score_hess reports DCX_ERR_UNSUPPORTED
 
     def hess_collision(self, x, v):
         """[(W-2)*dof, (W-2)*dof] Hessian of v . collision(x), the `hess` of the reference's trust-constr constraint
         (optim.py:380-391, a double backward through dist_est).  With a fusable dist_est the per-point score
-        Hessians are central differences of the ANALYTIC fused gradient — all 2*dof probes of every dense point in
-        one `dcx_score_grad` launch — and the dense-path geometry is chained exactly: the second-order Taylor
-        model of hinge(score) around each dense point, composed with dense_n(p), has the same Hessian in p as the
-        constraint itself, and autograd differentiates that small fp64 surrogate twice on the host.
-        Otherwise: the reference's route (needs a twice-differentiable dist_est)."""
+        Hessians are ANALYTIC (`dcx_score_hess`: forward-mode tangents through the FK, the sweep and the reverse FK
+        sweep, one launch for every dense point and direction) and the dense-path geometry is chained exactly: the
+        second-order Taylor model of hinge(score) around each dense point, composed with dense_n(p), has the same
+        Hessian in p as the constraint itself, and autograd differentiates that small fp64 surrogate twice on the
+        host.  Otherwise: the reference's route (needs a twice-differentiable dist_est)."""
         v = torch.as_tensor(np.asarray(v), dtype=torch.float64)
         m = self._fused_model()
         if m is not None and self.dense_cap is None:
@@ -283,16 +283,24 @@ class _ScipyTerms:
         if n_pt == 0:
             return np.zeros(((W - 2) * dof, (W - 2) * dof))
         per = -(-n_pt // n_seg)
-        eps = self.HESS_FD_STEP
-        probes = pts[:, None, None, :] + eps * torch.stack([torch.eye(dof), -torch.eye(dof)]).to(pts.dtype)[None]
-        q32 = torch.cat([pts, probes.reshape(-1, dof)]).to(device=model.dev, dtype=torch.float32).contiguous()
+        q32 = pts.to(device=model.dev, dtype=torch.float32).contiguous()
         s, g = model.score_grad_raw(q32)
-        s, g = s.double().cpu()[:n_pt, 0], g.double().cpu()
+        try:
+            _, S = model.score_hess_raw(q32)
+            S = S.double().cpu()
+        except _lib.DcxUnsupported:
+            # a transform whose frames do not fit the LDS as (value, tangent) pairs (of the reference's robots: the
+            # 23-joint iiwa7 + Allegro tree): central differences of the analytic fused gradient, all 2 * dof probes
+            # of every dense point in one launch (step: fp32 gradient noise ~1e-6 / step against step^2 truncation)
+            eps = self.HESS_FD_STEP
+            probes = pts[:, None, None, :] + eps * torch.stack([torch.eye(dof), -torch.eye(dof)]).to(pts.dtype)[None]
+            _, gp = model.score_grad_raw(probes.reshape(-1, dof).to(device=model.dev, dtype=torch.float32).contiguous())
+            gp = gp.double().cpu().reshape(n_pt, 2, dof, dof)
+            S = (gp[:, 0] - gp[:, 1]) / (2 * eps)
+        s, g = s.double().cpu()[:, 0], g.double().cpu()
         active = -((s - prob.safety_margin) > 0).double() * v[torch.arange(n_pt) // per]  # d(v.c)/d score_n
-        gp = g[n_pt:].reshape(n_pt, 2, dof, dof)
-        S = (gp[:, 0] - gp[:, 1]) / (2 * eps)
         S = 0.5 * (S + S.transpose(1, 2)) * active[:, None, None]
-        h = g[:n_pt] * active[:, None]
+        h = g * active[:, None]
 
         def taylor(z):
             delta = z[1:] - z[:-1]
@@ -351,8 +359,8 @@ def givengrad_traj_optimize(robot, dist_est, start_cfg, target_cfg, options):
 
 def trustconstr_traj_optimize(robot, dist_est, start_cfg, target_cfg, options):
     """trust-constr with analytic first derivatives and a Hessian of the collision constraint (reference
-    optim.py:486-492).  options['constraint_hessian']: 'auto' (default) = the fused finite-difference-of-analytic-
-    gradient Hessian when dist_est is a fusable diffco_amd score, else a BFGS model; 'fused' / 'autograd' (the
+    optim.py:486-492).  options['constraint_hessian']: 'auto' (default) = the fused analytic Hessian
+    (dcx_score_hess) when dist_est is a fusable diffco_amd score, else a BFGS model; 'fused' / 'autograd' (the
     reference's double backward through dist_est) / 'bfgs' force one."""
     max_iter = options['MAXITER']
     mode = options.get('constraint_hessian', 'auto')

@@ -191,6 +191,15 @@ int dcx_score_grad(const dcx_model* m, const float* q, int64_t B, const float* u
 int dcx_score_jac(const dcx_model* m, const float* q, int64_t B, float* score, float* jac,
                   void* stream);
 
+/* Second derivatives: hess[b, i, k] = d2( sum_c upstream[b,c] * score[b,c] ) / d q_b[i] d q_b[k]   ([B, dof, dof] dev),
+ * analytic (forward-mode tangents through the FK, the sweep and the reverse FK sweep: hess_kernel.hip) — what the
+ * reference obtains by a double backward through dist_est for trust-constr's constraint Hessian (optim.py:380-391,
+ * torch.autograd.functional.hessian).  upstream [B, C] dev or NULL (= all ones); grad [B, dof] dev or NULL receives
+ * the gradient of the same function.  A configuration that sits exactly on a support (|x - s| = 0) takes no
+ * contribution from that support for Polyharmonic kernels (the kernel is not twice differentiable there).    */
+int dcx_score_hess(const dcx_model* m, const float* q, int64_t B, const float* upstream, float* grad, float* hess,
+                   void* stream);
+
 /* score as above (C == 1 models only) and the gradient of the hinge penalty the optimisers build on it:
  *   grad[b, :] = weight * 1[score_b - margin > 0] * d score_b / d q_b
  * i.e. d/dq of  weight * clamp(dist_est(q) - safety_margin, min=0).sum()  (optim.py:88-89, 97-101) in the

@@ -277,10 +277,10 @@ def test_analytic_constraint_jacobian_matches_autograd():
     assert np.abs(Ja - Jb).max() < 1e-6 * np.abs(Jb).max()  # the fused route evaluates the points in fp32
 
 
-def test_constraint_hessian_from_gradient_differences_matches_double_backward():
-    """trust-constr's `hess`: central differences of the (stand-in) analytic gradient at the dense points, chained
-    through the dense-path geometry by autograd on the Taylor surrogate, equal the reference's double backward
-    through dist_est (optim.py:380-391)"""
+def test_constraint_hessian_from_point_hessians_matches_double_backward():
+    """trust-constr's `hess`: the (stand-in) analytic per-point Hessians at the dense points, chained through the
+    dense-path geometry by autograd on the Taylor surrogate, equal the reference's double backward through dist_est
+    (optim.py:380-391)"""
     from diffco_amd import optim
     g = torch.Generator().manual_seed(1)
     p = torch.randn((6, 3), generator=g, dtype=torch.float64)
@@ -290,6 +290,9 @@ def test_constraint_hessian_from_gradient_differences_matches_double_backward():
 
         def score_grad_raw(self, q, upstream=None, want_score=True):
             return torch.sin(q.double()).sum(1, keepdim=True), torch.cos(q.double())
+
+        def score_hess_raw(self, q, upstream=None):
+            return torch.cos(q.double()), torch.diag_embed(-torch.sin(q.double()))
 
     class Rob:
         dof, limits = 3, torch.tensor([[-3.0, 3.0]] * 3)
@@ -303,4 +306,13 @@ def test_constraint_hessian_from_gradient_differences_matches_double_backward():
     Hb = terms.hess_collision(x, v)
     assert Ha.shape == Hb.shape == (12, 12) and np.abs(Hb).max() > 0.5
     assert np.abs(Ha - Ha.T).max() < 1e-12
-    assert np.abs(Ha - Hb).max() < 1e-5 * np.abs(Hb).max()  # step^2 / 6 truncation of the central difference
+    assert np.abs(Ha - Hb).max() < 1e-6 * np.abs(Hb).max()  # the dense points go through fp32 on the fused route
+
+    # a transform dcx_score_hess cannot hold: differences of the analytic gradient instead
+    from diffco_amd import _lib
+
+    class NoHess(FakeModel):
+        def score_hess_raw(self, q, upstream=None):
+            raise _lib.DcxUnsupported("frames do not fit")
+    Hc = terms._hess_collision_fused(x, torch.from_numpy(v), NoHess())
+    assert np.abs(Hc - Hb).max() < 1e-5 * np.abs(Hb).max()  # step^2 / 6 truncation of the central difference

@@ -541,6 +541,60 @@ def gen_old_single(out, robots):
 
 
 # ----------------------------------------------------------------------------- F. optimiser records
+HESS_CASES = {  # fixture -> (robot, kind, params, which); inputs are the ones the score fixture already holds
+    "cfg1_planar2_rq": ("planar2", "rq", (10.0, 2), "score"), "cfg2_baxter_poly1": ("baxter_left", "poly", (1, 1.0), "poly"),
+    "cfg2_baxter_rq": ("baxter_left", "rq", (10.0, 2), "score"), "cfg2_panda_rq": ("panda", "rq", (10.0, 2), "score"),
+    "cfg3_baxter_rq_c5": ("baxter_left", "rq", (10.0, 2), "multi"), "cfg4_se3_nofk_rq": (None, "rq", (10.0, 2), "score"),
+    "cfg4_se3_keypts_rq": ("se3", "rq", (10.0, 2), "score"), "misc_dualbaxter_poly1": ("baxter_dual", "poly", (1, 1.0), "poly"),
+    "misc_dualpanda_rq": ("dual_panda", "rq", (10.0, 2), "score"), "misc_panda5_mq": ("panda5", "mq", (1.0,), "multi"),
+    "misc_se2_poly3": ("se2", "poly", (3, 2.0), "multi"), "misc_planar3_poly2": ("planar3", "poly", (2, 1.0), "poly"),
+    "misc_planar7_rq_p3": ("planar7", "rq", (3.0, 3), "score"), "misc_baxterR_mq_c2": ("baxter_right", "mq", (0.5,), "multi"),
+}
+
+
+def gen_hess(out, robots):
+    """Second derivatives of the score at the first 6 configurations of existing score fixtures, the way the reference
+    obtains them for trust-constr's constraint Hessian (optim.py:383-388): torch.autograd.functional.hessian over
+    the reference's own dist_est (fp32, `hess32`; skipped where its graph is not twice differentiable) and over the
+    float64 referee of score_case (`hess64`).  For C > 1 the function is sum_c upstream[b, c] * score[b, c]."""
+    n = 6
+    arrs = {}
+    for name, (rname, kind, params, which) in HESS_CASES.items():
+        d = np.load(os.path.join(out, name + ".npz"))
+        rob = None if rname is None else robots[rname]
+        q, sup_q, W = (torch.from_numpy(d[k]) for k in ("q", "sup_q", "weights"))
+        sup_x32 = torch.from_numpy(d["sup_x32"])
+        S, C = W.shape
+        up = torch.from_numpy(d["upstream"])[:n] if "upstream" in d.files else torch.ones((n, C))
+        T = (lambda t: t) if rob is None else fk64_fn(rob)
+        Sd = sup_q.double() if rob is None else fk64(rob, sup_q)
+
+        def f64(qb, b):
+            return (k64(kind, params, T(qb[None]), Sd) @ W.double() * up[b].double()).sum()
+        arrs[name + "/hess64"] = torch.stack([torch.autograd.functional.hessian(lambda z, b=b: f64(z, b), q[b].double())
+                                              for b in range(n)])
+        if which != "multi":
+            dc = new_diffco(rob, kind, params, sup_q, W[:, 0].clone(), which)
+            dist_est = dc.score if which == "score" else dc.poly_score
+        else:
+            md = R.old_MultiDiffCo.MultiDiffCo.__new__(R.old_MultiDiffCo.MultiDiffCo)
+            md.fkine = None if rob is None else rob.fkine
+            md.support_points, md.support_fkine = sup_q, sup_x32.reshape(S, -1)
+            md.rbf_kernel, md.rbf_nodes, md.num_class = make_kernel(kind, params), W, C
+            dist_est = md.rbf_score
+        try:
+            h32 = torch.stack([torch.autograd.functional.hessian(
+                lambda z, b=b: (dist_est(z[None]).reshape(1, -1) * up[b]).sum(), q[b]) for b in range(n)])
+            if torch.isfinite(h32).all():
+                arrs[name + "/hess32"] = h32
+        except RuntimeError as e:
+            print(f"  {name}: the reference's fp32 graph is not twice differentiable here ({str(e)[:60]})")
+        rel = (arrs[name + "/hess32"].double() - arrs[name + "/hess64"]).abs().max() / arrs[name + "/hess64"].abs().max() \
+            if name + "/hess32" in arrs else float("nan")
+        print(f"  {name}: |H|max {float(arrs[name + '/hess64'].abs().max()):.3g}, fp32 reference vs fp64 referee {float(rel):.1e}")
+    save(out, "hess_points", n=np.array(n), **arrs)
+
+
 def gen_optim(out, robots):
     gen = torch.Generator().manual_seed(600)
     rob = robots["baxter_left"]
@@ -598,6 +652,8 @@ def main():
         print("optim");     gen_optim(out, robots)
     if args.only in (None, "all", "old_single"):   # last: the earlier fixtures do not depend on it
         print("old single-class API"); gen_old_single(out, robots)
+    if args.only in (None, "all", "hess"):
+        print("second derivatives"); gen_hess(out, robots)
     with open(os.path.join(out, "MANIFEST.json"), "w") as f:
         json.dump({"generator": "tools/make_golden.py", "torch": torch.__version__, "numpy": np.__version__,
                    "reference": "ucsdarclab/diffco @ /root/reference (2025-03-21)",
