@@ -122,6 +122,9 @@ def train_perceptron_device(kind, p0, p1, beta, feats, y, gains, hypo, K, max_it
         _lib.check(lib.dcx_train_perceptron(dev.index, kind, _kparams(p0, p1), float(beta), _ptr(f), N, D, _ptr(yy), Cn,
                                             _ptr(g), _ptr(h), _ptr(Kd), int(max_iteration), _ptr(info), _stream(dev)))
     it, conv = (int(v) for v in info.tolist())
+    if conv < 0:
+        raise _lib.DcxError("dcx_train_perceptron: a grid-wide barrier of the multi-workgroup trainer did not complete "
+                            "(another kernel holding CUs for seconds?); set DCX_TRAIN_GRID=0 for the one-workgroup kernel")
     return g.reshape(shape), h.reshape(shape), Kd, it, bool(conv)
 
 

@@ -230,7 +230,7 @@ int fk_device_copy(int device, const dcx_fk_desc& fk, FkProg** out) {
 // path calls getenv.  -1 = "use the rule".
 struct Knobs {
     std::atomic<int64_t> ys{-1}, nw{-1}, min_rows{-1}, split_finish_kernel{-1}, inlaunch_tiles{-1}, jac_per_class{-1},
-        mfma{-1}, traj_fused{-1}, xf{-1}, mt{-1}, prio{-1}, jac_one_sweep{-1};
+        mfma{-1}, traj_fused{-1}, xf{-1}, mt{-1}, prio{-1}, jac_one_sweep{-1}, train_grid{-1};
     Knobs() {
         auto rd = [](const char* name, std::atomic<int64_t>& dst, bool flag) {
             if (const char* e = std::getenv(name)) dst = flag ? 1 : std::atoll(e);
@@ -247,6 +247,7 @@ struct Knobs {
         rd("DCX_MT", mt, false);
         rd("DCX_PRIO", prio, false);
         rd("DCX_JAC_ONE_SWEEP", jac_one_sweep, false);
+        rd("DCX_TRAIN_GRID", train_grid, false);
     }
 };
 Knobs& knobs() {
@@ -502,7 +503,7 @@ int dcx_debug_set(const char* name, int64_t value) {
     const std::string n(name);
     std::atomic<int64_t>* dst = n == "ys" ? &k.ys : n == "nw" ? &k.nw : n == "min_rows" ? &k.min_rows
         : n == "split_finish_kernel" ? &k.split_finish_kernel : n == "inlaunch_tiles" ? &k.inlaunch_tiles
-        : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : n == "traj_fused" ? &k.traj_fused : n == "xf" ? &k.xf : n == "mt" ? &k.mt : n == "prio" ? &k.prio : n == "jac_one_sweep" ? &k.jac_one_sweep : nullptr;
+        : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : n == "traj_fused" ? &k.traj_fused : n == "xf" ? &k.xf : n == "mt" ? &k.mt : n == "prio" ? &k.prio : n == "jac_one_sweep" ? &k.jac_one_sweep : n == "train_grid" ? &k.train_grid : nullptr;
     if (!dst) return fail(DCX_ERR_INVALID, "unknown knob: " + n);
 #ifndef DCX_WITH_MT
     if (dst == &k.mt && value >= 2) return fail(DCX_ERR_UNSUPPORTED, "this libdcx was built without score_kernel_mt (EXTRA=-DDCX_WITH_MT)");
@@ -860,19 +861,26 @@ int dcx_train_perceptron(int device, int kernel_kind, const float* kparams, floa
     if (!feats || !y || !gains || !hypothesis || !kernel_matrix || !info) return fail(DCX_ERR_INVALID, "a trainer pointer is NULL");
     if (int rc = check_kernel(kernel_kind, kparams)) return rc;
     if (int rc = set_device(device)) return rc;
-    // The register-resident kernel (one label column, N <= 10240) keeps a label as one sign bit; labels other than
-    // -1 / +1 (0 / 1 labels, y = 0) must take the generic kernel, which evaluates the reference's expressions on y itself.
-    // The check reads the labels back (<= 40 KB, on the caller's stream): the trainer is the one entry point that waits.
+    // The register-resident kernels (one label column; one workgroup up to N = 10240, several up to 131072) keep a label as
+    // one sign bit; labels other than -1 / +1 (0 / 1 labels, y = 0) must take the generic kernel, which evaluates the
+    // reference's expressions on y itself.  The check reads the labels back (<= 512 KB, on the caller's stream): the
+    // trainer is the one entry point that waits.
     bool sign_labels = false;
-    if (C == 1 && N <= 512 * 20) {
+    if (C == 1 && N <= kTrainGridMaxN) {
         std::vector<float> yh((size_t)N);
         hipError_t ce = hipMemcpyAsync(yh.data(), y, yh.size() * sizeof(float), hipMemcpyDefault, (hipStream_t)stream);
         if (ce == hipSuccess) ce = hipStreamSynchronize((hipStream_t)stream);
         if (ce != hipSuccess) return fail_hip(ce, "perceptron trainer: reading the labels");
         sign_labels = std::all_of(yh.begin(), yh.end(), [](float v) { return v == 1.0f || v == -1.0f; });
     }
+    // Several workgroups (one grid barrier per iteration) pay once a single workgroup would hold more than four samples
+    // per thread.  Knob train_grid: 0 = never, 1 = whenever N >= 2048,
+    // 2 = the generic kernel whatever the labels.
+    const int64_t tg = knobs().train_grid;
+    const bool grid = tg == 0 ? false : (tg > 0 ? N >= 2048 : N > 4096);
+    if (tg == 2) sign_labels = false;  // tests: the generic one-workgroup kernel as the referee
     hipError_t e = launch_perceptron(kernel_kind, kparams[0], kparams[1], beta, feats, y, gains, hypothesis, kernel_matrix,
-                                     info, (int)N, D, C, max_iteration, sign_labels, (hipStream_t)stream);
+                                     info, (int)N, D, C, max_iteration, sign_labels, grid, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "perceptron trainer launch");
     return DCX_OK;
 }

@@ -79,7 +79,8 @@ hipError_t launch_hess(const ModelView& m, const float* q, int64_t B, const floa
 // train_kernels.hip
 hipError_t launch_perceptron(int kind, float kp0, float kp1, float beta, const float* feats, const float* y, float* gains,
                              float* hypo, float* K, int32_t* info, int N, int D, int C, int max_iter, bool sign_labels,
-                             hipStream_t st);
+                             bool grid, hipStream_t st);
+constexpr int kTrainGridMaxN = 128 * 1024;  // 128 workgroups x 1024 samples (train_kernels.hip perceptron_grid_kernel)
 
 // traj_kernels.hip
 hipError_t launch_traj_adam_step(const FkProg* fk_dev, const dcx_fk_desc& fk, const dcx_traj_state& st,

@@ -13,6 +13,22 @@
 // sequence of argmin choices, and therefore the support set, matches the reference's.
 #include "dcx_internal.h"
 
+// The reference's updates are separate torch ops (hypothesis += delta * K[i]: one rounding for the product, one for the
+// sum), and the argmin sequence depends on those roundings.  HIP's __fmul_rn / __fadd_rn are plain operators compiled
+// with the header's contraction state, so hipcc still fuses them into an fma (the generic kernel did, until round 2:
+// its hypothesis differed from the register-resident kernels' in the last bit).  Contraction is therefore switched off
+// for this translation unit and the updates use the helpers below; the kernel functions' own fmaf calls are explicit
+// and stay.
+#pragma clang fp contract(off)
+namespace dcx {
+namespace {
+__device__ __forceinline__ float add_rn(float a, float b) { return a + b; }
+__device__ __forceinline__ float sub_rn(float a, float b) { return a - b; }
+__device__ __forceinline__ float mul_rn(float a, float b) { return a * b; }
+__device__ __forceinline__ float div_rn(float a, float b) { return a / b; }
+}  // namespace
+}  // namespace dcx
+
 namespace dcx {
 namespace {
 
@@ -32,8 +48,18 @@ struct Best {
     float v;
     int i;
 };
-__device__ __forceinline__ Best better_min(Best a, Best b) { return (b.v < a.v || (b.v == a.v && b.i < a.i)) ? b : a; }
-__device__ __forceinline__ Best better_max(Best a, Best b) { return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a; }
+// torch.min / torch.max semantics: a NaN wins over every number (a diverged run keeps walking like the reference's does,
+// instead of leaving the search without a valid index), the first index wins among equals
+__device__ __forceinline__ bool takes_min(float bv, int bi, float av, int ai) {
+    const bool bn = bv != bv, an = av != av;
+    return (bn && !an) || (bn == an && (bv < av || ((bv == av || bn) && bi < ai)));
+}
+__device__ __forceinline__ bool takes_max(float bv, int bi, float av, int ai) {
+    const bool bn = bv != bv, an = av != av;
+    return (bn && !an) || (bn == an && (bv > av || ((bv == av || bn) && bi < ai)));
+}
+__device__ __forceinline__ Best better_min(Best a, Best b) { return takes_min(b.v, b.i, a.v, a.i) ? b : a; }
+__device__ __forceinline__ Best better_max(Best a, Best b) { return takes_max(b.v, b.i, a.v, a.i) ? b : a; }
 
 template <bool IS_MIN>
 __device__ Best block_best(Best mine, Best* sB, int tid) {
@@ -103,13 +129,13 @@ __device__ bool class_step(const TrainArgs& a, int c, float* sX, Best* sB, int* 
         const float yi = a.y[(size_t)i * C + c], hi = a.hypo[(size_t)i * C + c];
         // beta^((1+y)/2) * y (kernel_perceptrons.py:121); exact shortcuts for the usual +-1 labels
         const float target = (yi == 1.0f ? a.beta : yi == -1.0f ? 1.0f : powf(a.beta, 0.5f * (1.0f + yi))) * yi;
-        const float step = __fdiv_rn(__fsub_rn(target, hi), kii);
+        const float step = div_rn(sub_rn(target, hi), kii);
         __syncthreads();  // everyone has read hypo[i] before it changes
         for (int j = tid; j < N; j += NT) {
             const size_t o = (size_t)j * C + c;
-            a.hypo[o] = __fadd_rn(a.hypo[o], __fmul_rn(step, Ki[j]));
+            a.hypo[o] = add_rn(a.hypo[o], mul_rn(step, Ki[j]));
         }
-        if (tid == 0) a.gains[(size_t)i * C + c] = __fadd_rn(a.gains[(size_t)i * C + c], step);
+        if (tid == 0) a.gains[(size_t)i * C + c] = add_rn(a.gains[(size_t)i * C + c], step);
         __syncthreads();
         return false;
     }
@@ -122,7 +148,7 @@ __device__ bool class_step(const TrainArgs& a, int c, float* sX, Best* sB, int* 
         float mm = 0.0f;
         if (g != 0.0f) {
             ++nnz;
-            mm = __fmul_rn(a.y[o], __fsub_rn(a.hypo[o], __fmul_rn(g, a.K[(size_t)j * N + j])));
+            mm = mul_rn(a.y[o], sub_rn(a.hypo[o], mul_rn(g, a.K[(size_t)j * N + j])));
         }
         cand = better_max(cand, Best{mm, j});
     }
@@ -141,7 +167,7 @@ __device__ bool class_step(const TrainArgs& a, int c, float* sX, Best* sB, int* 
         __syncthreads();
         for (int j = tid; j < N; j += NT) {
             const size_t o = (size_t)j * C + c;
-            a.hypo[o] = __fsub_rn(a.hypo[o], __fmul_rn(gj, Kj[j]));
+            a.hypo[o] = sub_rn(a.hypo[o], mul_rn(gj, Kj[j]));
         }
         if (tid == 0) a.gains[(size_t)jx * C + c] = 0.0f;
         __syncthreads();
@@ -266,12 +292,12 @@ __global__ __launch_bounds__(NT) void perceptron_reg_kernel(const TrainArgs a) {
         if (violated) {
             // 3. margin violated: move sample i onto its target:  h += step * K_i,  g_i += step
             const float target = (yi > 0.f ? a.beta : 1.0f) * yi;
-            const float step = __fdiv_rn(__fsub_rn(target, hi), kii);
+            const float step = div_rn(sub_rn(target, hi), kii);
 #pragma unroll
             for (int e = 0; e < EPT; ++e) {
                 const int j = tid + e * NT;
-                if (j < N) m[e] = __fadd_rn(m[e], ysign(e) * __fmul_rn(step, Ki[j]));
-                if (j == i) yg[e] = __fadd_rn(yg[e], ysign(e) * step);
+                if (j < N) m[e] = add_rn(m[e], ysign(e) * mul_rn(step, Ki[j]));
+                if (j == i) yg[e] = add_rn(yg[e], ysign(e) * step);
             }
             __syncthreads();  // sS is rewritten next iteration
             continue;
@@ -286,7 +312,7 @@ __global__ __launch_bounds__(NT) void perceptron_reg_kernel(const TrainArgs a) {
                 float mm = 0.0f;
                 if (yg[e] != 0.0f) {
                     ++nnz;
-                    mm = __fsub_rn(m[e], __fmul_rn(yg[e], dg[e]));
+                    mm = sub_rn(m[e], mul_rn(yg[e], dg[e]));
                 }
                 cand = better_max(cand, Best{mm, j});
             }
@@ -309,7 +335,7 @@ __global__ __launch_bounds__(NT) void perceptron_reg_kernel(const TrainArgs a) {
 #pragma unroll
             for (int e = 0; e < EPT; ++e) {
                 const int j = tid + e * NT;
-                if (j < N) m[e] = __fsub_rn(m[e], ysign(e) * __fmul_rn(gj, Kj[j]));
+                if (j < N) m[e] = sub_rn(m[e], ysign(e) * mul_rn(gj, Kj[j]));
                 if (j == jx) yg[e] = 0.0f;
             }
             __syncthreads();
@@ -329,15 +355,259 @@ __global__ __launch_bounds__(NT) void perceptron_reg_kernel(const TrainArgs a) {
     }
 }
 
+// ---- several workgroups (single class, -1 / +1 labels, N beyond one workgroup's registers) -----------------------
+// The register-resident loop spread over G workgroups on G CUs.  Workgroup g owns samples j = g * NT + tid + e * G * NT
+// and keeps their margin, signed gain and kernel diagonal in registers; per iteration each workgroup reduces its own
+// candidates, posts one 16-byte record, and a grid-wide barrier (arrival counter in device memory, agent-scope release /
+// acquire) turns the G records into the same global choice everywhere — the argmin with the lowest index on ties, i.e.
+// exactly the sequence of the one-workgroup kernel.  The kernel matrix needs no cross-workgroup visibility: when
+// sample i is first selected every workgroup fills ITS part of row i (and of column i), and later only reads entries it
+// wrote itself.  One barrier per violated-margin iteration, two per retire iteration.
+// The launch is cooperative (all G workgroups resident), and a barrier that does not complete within ~2 s sets an abort
+// flag that every workgroup honours (info[1] = -1) instead of hanging the device.
+struct GridRec {
+    float v;
+    int i;
+    float a0, a1;
+};
+struct GridSync {
+    unsigned int counter;   // arrivals, monotonically increasing
+    unsigned int abort;
+    unsigned int pad[2];
+    GridRec rec[2][128];    // double-buffered by barrier parity
+};
+constexpr int kGridMaxWg = 128;
+constexpr int kGridNT = 256, kGridEPT = 4;  // 1024 samples per workgroup
+
+// every thread calls; returns false when the run was aborted
+__device__ __forceinline__ bool grid_barrier(GridSync* gs, unsigned& n_done, int tid) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    ++n_done;
+    if (tid == 0) {
+        const unsigned target = n_done * gridDim.x;
+        __hip_atomic_fetch_add(&gs->counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t0 = wall_clock64();  // 100 MHz
+        while (__hip_atomic_load(&gs->counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (__hip_atomic_load(&gs->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+            if (wall_clock64() - t0 > 200000000ull) {
+                __hip_atomic_store(&gs->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return __hip_atomic_load(&gs->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+}
+
+__device__ __forceinline__ void post_rec(GridRec* slot, float v, int i, float a0, float a1) {
+    __hip_atomic_store(&slot->v, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&slot->i, i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&slot->a0, a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&slot->a1, a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// wave 0 folds the G records (best by v with the lowest index on ties; a1 summed when SUM_A1) -> sR[0]; caller syncs
+template <bool IS_MIN, bool SUM_A1>
+__device__ __forceinline__ void fold_recs(const GridRec* recs, int G, GridRec* sR, int tid) {
+    if (tid < 64) {
+        GridRec best{IS_MIN ? INFINITY : -INFINITY, 0x7fffffff, 0.f, 0.f};
+        float sum = 0.f;
+        for (int g = tid; g < G; g += 64) {
+            GridRec r;
+            r.v = __hip_atomic_load(&recs[g].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            r.i = __hip_atomic_load(&recs[g].i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            r.a0 = __hip_atomic_load(&recs[g].a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            r.a1 = __hip_atomic_load(&recs[g].a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sum += r.a1;
+            const bool take = IS_MIN ? takes_min(r.v, r.i, best.v, best.i) : takes_max(r.v, r.i, best.v, best.i);
+            if (take) best = r;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            GridRec r{__shfl_xor(best.v, o, 64), __shfl_xor(best.i, o, 64), __shfl_xor(best.a0, o, 64), __shfl_xor(best.a1, o, 64)};
+            sum += __shfl_xor(sum, o, 64);
+            const bool take = IS_MIN ? takes_min(r.v, r.i, best.v, best.i) : takes_max(r.v, r.i, best.v, best.i);
+            if (take) best = r;
+        }
+        if (SUM_A1) best.a1 = sum;
+        if (tid == 0) sR[0] = best;
+    }
+}
+
+template <int EPT, int NT>
+__global__ __launch_bounds__(NT) void perceptron_grid_kernel(const TrainArgs a, GridSync* gs) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sX = smem;                                           // [D]
+    Best* sB = reinterpret_cast<Best*>(sX + ((a.D + 3) & ~3));  // [16]
+    int* sCnt = reinterpret_cast<int*>(sB + 16);                // [16]
+    GridRec* sR = reinterpret_cast<GridRec*>(sCnt + 16);        // [1]
+    const int tid = threadIdx.x, N = a.N, G = gridDim.x;
+    const int base = blockIdx.x * NT + tid, stride = G * NT;
+    float m[EPT], yg[EPT], dg[EPT];
+    unsigned ypos = 0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int j = base + e * stride;
+        const bool in = j < N;
+        const float yj = in ? a.y[j] : 1.0f;
+        if (yj > 0.f) ypos |= 1u << e;
+        m[e] = in ? yj * a.hypo[j] : INFINITY;
+        yg[e] = in ? yj * a.gains[j] : 0.0f;
+        dg[e] = in ? a.K[(size_t)j * N + j] : 0.0f;
+    }
+    auto ysign = [&](int e) { return (ypos >> e) & 1u ? 1.0f : -1.0f; };
+    unsigned n_bar = 0;
+    int it = 0;
+    int converged = 0;
+    for (; it < a.max_iter; ++it) {
+        // 1. worst margin: this workgroup's, then everyone's
+        Best mine{INFINITY, 0x7fffffff};
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int j = base + e * stride;
+            if (j < N) mine = better_min(mine, Best{m[e], j});
+        }
+        const Best wg = block_best<true>(mine, sB, tid);
+        GridRec* recs = gs->rec[n_bar & 1];
+        if (wg.i == 0x7fffffff) {
+            if (tid == 0) post_rec(&recs[blockIdx.x], INFINITY, 0x7fffffff, 0.f, 0.f);
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPT; ++e)
+                if (base + e * stride == wg.i) post_rec(&recs[blockIdx.x], wg.v, wg.i, ysign(e), dg[e]);  // the owner posts y_i, K_ii
+        }
+        if (!grid_barrier(gs, n_bar, tid)) { converged = -1; break; }
+        fold_recs<true, false>(recs, G, sR, tid);
+        __syncthreads();
+        const GridRec worst = sR[0];
+        const int i = worst.i;
+        const float yi = worst.a0, hi = yi * worst.v;
+        float kii = worst.a1;
+        float* Ki = a.K + (size_t)i * N;
+        const bool violated = worst.v <= 0.0f;
+        if (kii == 0.0f) {
+            // 2. first use of row i: every workgroup fills its own part of the row and of the column
+            for (int k = tid; k < a.D; k += NT) sX[k] = a.feats[(size_t)i * a.D + k];
+            __syncthreads();
+#pragma unroll 1
+            for (int e = 0; e < EPT; ++e) {
+                const int j = base + e * stride;
+                if (j < N) {
+                    const float* xj = a.feats + (size_t)j * a.D;
+                    float d2 = 0.f;
+                    for (int k = 0; k < a.D; ++k) {
+                        const float dl = sX[k] - xj[k];
+                        d2 = fmaf(dl, dl, d2);
+                    }
+                    const float kv = kernel_value(a, d2);
+                    Ki[j] = kv;
+                    a.K[(size_t)j * N + i] = kv;
+                }
+            }
+            kii = kernel_value(a, 0.0f);  // d2 of sample i against itself is an exact zero
+#pragma unroll
+            for (int e = 0; e < EPT; ++e)
+                if (base + e * stride == i) dg[e] = kii;
+        }
+        if (violated) {
+            // 3. margin violated: h += step * K_i, g_i += step
+            const float target = (yi > 0.f ? a.beta : 1.0f) * yi;
+            const float step = div_rn(sub_rn(target, hi), kii);
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                const int j = base + e * stride;
+                if (j < N) m[e] = add_rn(m[e], ysign(e) * mul_rn(step, Ki[j]));
+                if (j == i) yg[e] = add_rn(yg[e], ysign(e) * step);
+            }
+            __syncthreads();  // sR / sX are rewritten next iteration
+            continue;
+        }
+        // 4. all margins positive: retire a support that is classified correctly without its own contribution
+        Best cand{-INFINITY, 0x7fffffff};
+        int nnz = 0;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int j = base + e * stride;
+            if (j < N) {
+                float mm = 0.0f;
+                if (yg[e] != 0.0f) {
+                    ++nnz;
+                    mm = sub_rn(m[e], mul_rn(yg[e], dg[e]));
+                }
+                cand = better_max(cand, Best{mm, j});
+            }
+        }
+        const Best top = block_best<false>(cand, sB, tid);
+        for (int o = 32; o > 0; o >>= 1) nnz += __shfl_xor(nnz, o, 64);
+        __syncthreads();
+        if ((tid & 63) == 0) sCnt[tid >> 6] = nnz;
+        __syncthreads();
+        int wg_nnz = 0;
+        for (int w = 0; w < NT / 64; ++w) wg_nnz += sCnt[w];
+        recs = gs->rec[n_bar & 1];
+        if (top.i == 0x7fffffff) {
+            if (tid == 0) post_rec(&recs[blockIdx.x], -INFINITY, 0x7fffffff, 0.f, 0.f);
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPT; ++e)
+                if (base + e * stride == top.i) post_rec(&recs[blockIdx.x], top.v, top.i, ysign(e) * yg[e], (float)wg_nnz);  // g_jx, count
+        }
+        if (!grid_barrier(gs, n_bar, tid)) { converged = -1; break; }
+        fold_recs<false, true>(recs, G, sR, tid);
+        __syncthreads();
+        const GridRec best = sR[0];
+        if (best.v > 0.0f && best.a1 > 1.0f) {
+            const int jx = best.i;
+            const float gj = best.a0;
+            const float* Kj = a.K + (size_t)jx * N;
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                const int j = base + e * stride;
+                if (j < N) m[e] = sub_rn(m[e], ysign(e) * mul_rn(gj, Kj[j]));
+                if (j == jx) yg[e] = 0.0f;
+            }
+            __syncthreads();
+            continue;
+        }
+        converged = 1;
+        break;
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int j = base + e * stride;
+        if (j < N) { a.hypo[j] = ysign(e) * m[e]; a.gains[j] = ysign(e) * yg[e]; }
+    }
+    if (tid == 0 && blockIdx.x == 0) {
+        a.info[0] = it;
+        a.info[1] = converged;
+    }
+}
+
 }  // namespace
+
+int perceptron_grid_workgroups(int N) { return (N + kGridNT * kGridEPT - 1) / (kGridNT * kGridEPT); }
 
 hipError_t launch_perceptron(int kind, float kp0, float kp1, float beta, const float* feats, const float* y, float* gains,
                              float* hypo, float* K, int32_t* info, int N, int D, int C, int max_iter, bool sign_labels,
-                             hipStream_t st) {
+                             bool grid, hipStream_t st) {
     TrainArgs a;
     a.feats = feats; a.y = y; a.gains = gains; a.hypo = hypo; a.K = K; a.info = info;
     a.N = N; a.D = D; a.C = C; a.max_iter = max_iter; a.kind = kind; a.kp0 = kp0; a.kp1 = kp1; a.beta = beta;
-    const size_t lds = sizeof(float) * ((D + 3) & ~3) + 16 * sizeof(Best) + 16 * sizeof(int) + 4 * sizeof(float);
+    const size_t lds = sizeof(float) * ((D + 3) & ~3) + 16 * sizeof(Best) + 16 * sizeof(int) + 4 * sizeof(float) + sizeof(GridRec);
+    if (grid && sign_labels && C == 1 && perceptron_grid_workgroups(N) <= kGridMaxWg) {
+        // several workgroups: a stream-ordered scratch for the records and the arrival counter, a cooperative launch
+        GridSync* gs = nullptr;
+        if (hipError_t e = hipMallocAsync((void**)&gs, sizeof(GridSync), st)) return e;
+        if (hipError_t e = hipMemsetAsync(gs, 0, sizeof(GridSync), st)) return e;
+        void* params[] = {(void*)&a, (void*)&gs};
+        hipError_t e = hipLaunchCooperativeKernel((const void*)perceptron_grid_kernel<kGridEPT, kGridNT>,
+                                                  dim3(perceptron_grid_workgroups(N)), dim3(kGridNT), params, (unsigned)lds, st);
+        const hipError_t f = hipFreeAsync(gs, st);
+        return e != hipSuccess ? e : f;
+    }
     if (sign_labels && C == 1 && N <= 1024 * 4) {
         perceptron_reg_kernel<4, 1024><<<dim3(1), dim3(1024), lds, st>>>(a);
     } else if (sign_labels && C == 1 && N <= 512 * 20) {   // 8 waves = 2 per SIMD: 256 VGPRs per lane hold 20 samples' state

@@ -151,7 +151,7 @@ int dcx_device_count(void);
  * "traj_fused" (0 = dcx_traj_adam_run as two launches per iteration), "prio" (1 = raised wave priority outside the
  * sweep; measured: no effect), "mt" (2 = two tiles per block; only in EXTRA=-DDCX_WITH_MT builds, else
  * DCX_ERR_UNSUPPORTED), "jac_one_sweep" (0 = dcx_score_jac never takes the one-sweep kernel, 1 = whenever it is compiled
- * and the batch is beyond the one-launch-per-all-classes regime).  value < 0 restores the rule.  The initial values come from the DCX_YS / DCX_NW / DCX_XF / ...
+ * and the batch is beyond the one-launch-per-all-classes regime), "train_grid" (see dcx_train_perceptron).  value < 0 restores the rule.  The initial values come from the DCX_YS / DCX_NW / DCX_XF / ...
  * environment variables, read once at library load; no launch calls getenv.   */
 int dcx_debug_set(const char* name, int64_t value);
 
@@ -261,9 +261,13 @@ int dcx_traj_adam_run(const dcx_model* model, const dcx_traj_state* st, const dc
  *   kernel_matrix [N, N] dev in/out: zeros = "row not computed yet"; row i AND column i are filled when sample i
  *                 is first selected (K[i, :] = K[:, i] = k(x_i, X), kernel_perceptrons.py:117-119), so the sub-block
  *                 over the kept supports is complete even for a sample that was never selected itself
- *   info [2] dev out: iterations used, 1 if converged
- * For one label column and N <= 10240 the entry point reads the labels back once (a stream synchronisation) to decide
- * whether the register-resident kernel, which keeps a label as its sign, may be used.                      */
+ *   info [2] dev out: iterations used; 1 if converged, 0 if not, -1 if the multi-workgroup form gave up on a
+ *                 grid barrier (another kernel kept its workgroups from running for seconds)
+ * For one label column and N <= 131072 the entry point reads the labels back once (a stream synchronisation) to decide
+ * whether a register-resident kernel, which keeps a label as its sign, may be used: one workgroup up to N = 4096,
+ * beyond that N / 1024 workgroups on as many CUs (a cooperative launch, one grid-wide barrier per iteration; the same
+ * argmin sequence, bit for bit).  Debug knob "train_grid": 0 = one workgroup only, 1 = several from N = 2048,
+ * 2 = the generic one-workgroup kernel whatever the labels.                                                 */
 int dcx_train_perceptron(int device, int kernel_kind, const float* kparams, float beta, const float* feats, int64_t N,
                          int32_t D, const float* y, int32_t C, float* gains, float* hypothesis, float* kernel_matrix,
                          int32_t max_iteration, int32_t* info, void* stream);

@@ -412,3 +412,57 @@ def test_device_trainer_labels_outside_plus_minus_one():
     assert it_d in (it_h, it_h + 1)
     np.testing.assert_array_equal(_np(gd) != 0, gh.numpy() != 0)
     assert relerr(_np(gd), gh.numpy()) < 1e-4 and relerr(_np(hd), hh.numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("n,kind", [(3000, 0), (7000, 0), (20000, 0), (5000, 3)])
+def test_trainer_on_several_workgroups_equals_one_workgroup_bitwise(n, kind, knob):
+    """the register-resident perceptron loop on G workgroups with a grid-wide barrier per
+    iteration (train_kernels.hip perceptron_grid_kernel) takes the same argmin at every iteration as one workgroup:
+    identical gains, hypothesis, kernel matrix and iteration count — cold start, then a jump start from that state
+    with flipped labels.  n = 20000 has no register-resident one-workgroup form: the generic kernel is the referee."""
+    from diffco_amd import _ops
+    rob = make_robot("baxter_left")
+    g = torch.Generator().manual_seed(n)
+    lim = rob.limits
+    q = torch.rand((n, 7), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]
+    feats = rob.fkine(q.cuda()).reshape(n, -1)
+    y = torch.where(feats[:, -1] + 0.3 * feats[:, -2] > 0.2, 1.0, -1.0)
+    p0, p1 = (10.0, 2.0) if kind == 0 else (3.0, 3.0)  # kind 3 here: RQ with p = 3, the generic kernel function
+    kind = 0
+    zeros = torch.zeros(n, device="cuda")
+    runs = {}
+    for mode in (0, 1, 2) if n <= 7000 else (0, 1):  # 2 = the generic one-workgroup kernel
+        knob("train_grid", mode)
+        g1, h1, K1, it1, c1 = _ops.train_perceptron_device(kind, p0, p1, 0.8, feats, y, zeros, zeros, None, 300)
+        y2 = y.clone()
+        y2[::97] *= -1
+        g2, h2, K2, it2, c2 = _ops.train_perceptron_device(kind, p0, p1, 0.8, feats, y2, g1, h1, K1, 200)
+        runs[mode] = (g1, h1, K1, it1, c1, g2, h2, K2, it2, c2)
+    a = runs[0]
+    assert a[3] > 50 and int((a[0] != 0).sum()) > 5  # the loop did run
+    for b in list(runs.values())[1:]:
+        assert a[3] == b[3] and a[4] == b[4] and a[8] == b[8] and a[9] == b[9], (a[3], b[3], a[8], b[8])
+        for k in (0, 1, 2, 5, 6, 7):
+            assert torch.equal(a[k], b[k]), k
+
+
+def test_trainer_survives_a_diverging_run(knob):
+    """MultiQuadratic is not positive definite: the perceptron's margins overflow to inf / NaN.  The reference keeps
+    walking (torch.min returns a NaN's index); so must every device kernel — a NaN wins the argmin instead of leaving
+    it without a valid index (which used to send the row pointer out of bounds)."""
+    from diffco_amd import _ops
+    rob = make_robot("baxter_left")
+    n = 5000
+    g = torch.Generator().manual_seed(2)
+    lim = rob.limits
+    q = torch.rand((n, 7), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]
+    feats = rob.fkine(q.cuda()).reshape(n, -1)
+    y = torch.where(feats[:, -1] + 0.3 * feats[:, -2] > 0.2, 1.0, -1.0)
+    zeros = torch.zeros(n, device="cuda")
+    its = []
+    for mode in (0, 1, 2):
+        knob("train_grid", mode)
+        out = _ops.train_perceptron_device(2, 0.7, 0.0, 0.8, feats, y, zeros, zeros, None, 300)
+        torch.cuda.synchronize()
+        its.append(out[3])
+    assert its[0] == its[1] == its[2]
