@@ -42,6 +42,20 @@ struct HessArgs {
 
 // value, gradient coefficient g (dK/dx = g * delta) and h = 2 dg/dd2 (d2K/dx2 = g I + h delta delta^T)
 __device__ __forceinline__ void kernel_eval_h(const HessArgs& a, float d2, float& g, float& h) {
+    if (a.kf == KF_POLY1) {  // r / eps with 1 / eps in the row weights: g = 1 / r, h = -1 / r^3 (v_rsq, like the sweep's kernel_eval)
+        const float ri = __builtin_amdgcn_rsqf(fmaxf(d2, 1e-30f));
+        const bool on = d2 >= 1e-20f;  // on a support the kernel is not twice differentiable: the pair contributes nothing
+        g = on ? ri : 0.0f;
+        h = on ? -(ri * ri) * ri : 0.0f;
+        return;
+    }
+    if (a.kf == KF_RQ2) {  // (1 + gamma/2 d2)^-2: g = -2 gamma u^3, h = 6 gamma^2 u^4 with u = 1 / t (v_rcp)
+        const float u = __builtin_amdgcn_rcpf(fmaf(0.5f * a.kp0, d2, 1.0f));
+        const float u3 = (u * u) * u;
+        g = -2.0f * a.kp0 * u3;
+        h = 6.0f * a.kp0 * a.kp0 * (u3 * u);
+        return;
+    }
     if (a.kf == KF_RQ2 || (a.kf == KF_GEN && a.kind == DCX_K_RQ)) {
         // K = t^-p, t = 1 + gamma/p d2:  g = -2 gamma t^(-p-1),  h = 4 gamma^2 (p+1)/p t^(-p-2)
         const float p = (a.kf == KF_RQ2) ? 2.0f : a.kp1;
@@ -112,52 +126,63 @@ __device__ __forceinline__ void sweep_hess_lds(const HessArgs& a, const Dual* sX
     }
 }
 
-// the same for one of the compiled widths D <= 32 with x, dx and the sums in registers and the rows read through the
-// scalar cache (constant address space, like the sweep of score_kernel.h)
+// the same for one of the compiled widths D <= 32 with x, dx and the sums in registers as packed pairs (v_pk_add /
+// v_pk_fma: 3 D instructions per pair for the differences, d2, delta . dx and the two accumulations) and the rows read
+// through the scalar cache (constant address space, like the sweep of score_kernel.h)
 template <int D>
 __device__ __forceinline__ void sweep_hess_regs(const HessArgs& a, const Dual* sX, Dual* sAcc, const float* up, int j0, int j1) {
-    float xv[D], xd[D], av[D], ad[D];
+    constexpr int NP = D / 2;
+    constexpr bool ODD = (D & 1) != 0;
+    v2f xv[NP + 1], xd[NP + 1], av[NP + 1], ad[NP + 1];  // [NP] holds the odd last feature in .x
 #pragma unroll
-    for (int k = 0; k < D; ++k) {
-        const Dual t = sX[k * 64];
-        xv[k] = t.v; xd[k] = t.d; av[k] = 0.0f; ad[k] = 0.0f;
+    for (int k = 0; k <= NP; ++k) {
+        const bool two = k < NP;
+        const Dual t0 = (two || ODD) ? sX[(2 * k) * 64] : Dual(0.0f, 0.0f);
+        const Dual t1 = two ? sX[(2 * k + 1) * 64] : Dual(0.0f, 0.0f);
+        xv[k] = v2f{t0.v, t1.v}; xd[k] = v2f{t0.d, t1.d}; av[k] = v2f{0.0f, 0.0f}; ad[k] = v2f{0.0f, 0.0f};
     }
     cfloat_ptr rows = (cfloat_ptr)(uintptr_t)a.rows;
     const int C = a.C, w_off = a.w_off;
-    for (int j = j0; j < j1; ++j) {
-        cfloat_ptr r = rows + (size_t)j * a.RS;
-        float rr[D];
+    auto weight = [&](cfloat_ptr r) __attribute__((always_inline)) {
+        if (!up) return r[C > 1 ? a.wsum_off : w_off];
+        float w = 0.0f;
+        for (int c = 0; c < C; ++c) w = fmaf(up[c], r[w_off + c], w);
+        return w;
+    };
+    constexpr int NV = NP + (ODD ? 1 : 0);
+    auto pair = [&](cfloat_ptr r) __attribute__((always_inline)) {
+        v2f dl[NV], s2a = {0.0f, 0.0f}, s2b = {0.0f, 0.0f}, sda = {0.0f, 0.0f}, sdb = {0.0f, 0.0f};
 #pragma unroll
-        for (int k = 0; k < D; ++k) rr[k] = r[k];
-        float w;
-        if (up) {
-            w = 0.0f;
-            for (int c = 0; c < C; ++c) w = fmaf(up[c], r[w_off + c], w);
-        } else {
-            w = r[C > 1 ? a.wsum_off : w_off];
+        for (int k = 0; k < NV; ++k) {
+            const v2f rv = (k < NP) ? v2f{r[2 * k], r[2 * k + 1]} : v2f{r[D - 1], 0.0f};
+            dl[k] = xv[k] - rv;
+            if (k & 1) { s2b = __builtin_elementwise_fma(dl[k], dl[k], s2b); sdb = __builtin_elementwise_fma(dl[k], xd[k], sdb); }
+            else       { s2a = __builtin_elementwise_fma(dl[k], dl[k], s2a); sda = __builtin_elementwise_fma(dl[k], xd[k], sda); }
         }
-        float d2 = 0.0f, dd = 0.0f;
-#pragma unroll
-        for (int k = 0; k < D; ++k) {
-            const float dl = xv[k] - rr[k];
-            d2 = fmaf(dl, dl, d2);
-            dd = fmaf(dl, xd[k], dd);
-        }
+        s2a += s2b;
+        sda += sdb;
+        const float w = weight(r);
         float g, h;
-        kernel_eval_h(a, d2, g, h);
-        const float cf = w * g, ef = w * h * dd;
+        kernel_eval_h(a, s2a.x + s2a.y, g, h);
+        const float cf = w * g, ef = w * h * (sda.x + sda.y);
+        const v2f c2 = {cf, cf}, e2 = {ef, ef};
 #pragma unroll
-        for (int k = 0; k < D; ++k) {
-            const float dl = xv[k] - rr[k];
-            av[k] = fmaf(cf, dl, av[k]);
-            ad[k] = fmaf(cf, xd[k], fmaf(ef, dl, ad[k]));
+        for (int k = 0; k < NV; ++k) {
+            av[k] = __builtin_elementwise_fma(c2, dl[k], av[k]);
+            ad[k] = __builtin_elementwise_fma(c2, xd[k], __builtin_elementwise_fma(e2, dl[k], ad[k]));
         }
-    }
+    };
+    for (int j = j0; j < j1; ++j) pair(rows + (size_t)j * a.RS);
 #pragma unroll
-    for (int k = 0; k < D; ++k) sAcc[k * 64] = Dual(av[k], ad[k]);
+    for (int k = 0; k < NV; ++k) {
+        sAcc[(2 * k) * 64] = Dual(av[k].x, ad[k].x);
+        if (k < NP) sAcc[(2 * k + 1) * 64] = Dual(av[k].y, ad[k].y);
+    }
 }
 
-__global__ __launch_bounds__(512) void score_hess_kernel(const HessArgs a) {
+// SMALL: compiled widths <= 16 only, up to 16 waves per block (128 VGPRs); otherwise every width, up to 8 waves
+template <bool SMALL>
+__global__ __launch_bounds__(SMALL ? 1024 : 512) void score_hess_kernel(const HessArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     Dual* sd = reinterpret_cast<Dual*>(smem);
     const int lane = threadIdx.x & 63;
@@ -191,13 +216,19 @@ __global__ __launch_bounds__(512) void score_hess_kernel(const HessArgs a) {
     const int j0 = (wave * a.s_chunk < a.S) ? wave * a.s_chunk : a.S;
     const int j1 = (j0 + a.s_chunk < a.S) ? j0 + a.s_chunk : a.S;
     const float* up = a.upstream ? a.upstream + b * a.C : nullptr;
-    switch (a.D) {  // a.D is one of the compiled widths (dcx_internal.h kTemplateD)
 #define DCX_HESS_CASE(W) case W: sweep_hess_regs<W>(a, sX, sAcc, up, j0, j1); break;
-        DCX_HESS_CASE(2) DCX_HESS_CASE(4) DCX_HESS_CASE(6) DCX_HESS_CASE(8) DCX_HESS_CASE(12) DCX_HESS_CASE(16)
-        DCX_HESS_CASE(18) DCX_HESS_CASE(21) DCX_HESS_CASE(24) DCX_HESS_CASE(27) DCX_HESS_CASE(30) DCX_HESS_CASE(32)
-#undef DCX_HESS_CASE
-        default: sweep_hess_lds(a, sX, sAcc, up, j0, j1);
+    if constexpr (SMALL) {
+        switch (a.D) {  // a.D is one of the compiled widths (dcx_internal.h kTemplateD)
+            DCX_HESS_CASE(2) DCX_HESS_CASE(4) DCX_HESS_CASE(6) DCX_HESS_CASE(8) DCX_HESS_CASE(12) DCX_HESS_CASE(16)
+            default: break;
+        }
+    } else {
+        switch (a.D) {
+            DCX_HESS_CASE(18) DCX_HESS_CASE(21) DCX_HESS_CASE(24) DCX_HESS_CASE(27) DCX_HESS_CASE(30) DCX_HESS_CASE(32)
+            default: sweep_hess_lds(a, sX, sAcc, up, j0, j1);
+        }
     }
+#undef DCX_HESS_CASE
     __syncthreads();
     // ---- wave 0: add the other waves' sums in wave order, then the reverse sweep in duals ----
     if (wave == 0) {
@@ -244,7 +275,10 @@ hipError_t launch_hess(const ModelView& m, const float* q, int64_t B, const floa
     const int budget = (int)((150 * 1024 - 4 * (size_t)m.prog_floats) / 512);  // Dual columns that fit
     int nw = (budget - fixed) / m.Dt;
     if (nw < 1) return hipErrorInvalidValue;
-    if (nw > 8) nw = 8;
+    const bool small = m.Dt <= 16;
+    const int nw_max = small ? 16 : 8;
+    if (nw > nw_max) nw = nw_max;
+    while (nw > 1 && (m.S + nw - 1) / nw < 32) nw >>= 1;  // a slice shorter than 32 supports is all FK and fold
     a.s_chunk = (m.S + nw - 1) / nw;
     a.o_q = 0;
     a.o_f = a.o_q + 64 * m.dof;
@@ -253,12 +287,15 @@ hipError_t launch_hess(const ModelView& m, const float* q, int64_t B, const floa
     a.o_fk_floats = 2 * (a.o_acc + nw * 64 * m.Dt);
     const size_t lds = sizeof(float) * ((size_t)a.o_fk_floats + m.prog_floats);
     if (lds > 64 * 1024) {
-        if (hipError_t e = hipFuncSetAttribute((const void*)score_hess_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
-            return e;
+        const void* fn = small ? (const void*)score_hess_kernel<true> : (const void*)score_hess_kernel<false>;
+        if (hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return e;
     }
     const int64_t nblk = (a.n_lanes + 63) / 64;
     if (nblk > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(score_hess_kernel, dim3((unsigned)nblk), dim3(64 * nw), lds, stream, a);
+    if (small)
+        hipLaunchKernelGGL(score_hess_kernel<true>, dim3((unsigned)nblk), dim3(64 * nw), lds, stream, a);
+    else
+        hipLaunchKernelGGL(score_hess_kernel<false>, dim3((unsigned)nblk), dim3(64 * nw), lds, stream, a);
     return hipGetLastError();
 }
 
