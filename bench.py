@@ -428,16 +428,21 @@ def main():
         if not is_traj:
             others += [(f"gather_{g}", args.scaling, g) for g in ("per-call", "overlapped", "bucketed", "none") if g != args.gather]
         for key, sc, ga in others:
-            w2, l2 = build(sc, ga)
-            # best of two short runs: with a process group alive, a ~100 ms stall of unknown origin (seen in the no-gather
-            # variant too) occasionally lands inside one 48-step run; the primary measurement above is a single run, as agreed
-            wl, km = min(measure(l2, vs, vw, dev, multi), measure(l2, vs, vw, dev, multi))
-            ge = global_evals(sc, w2)
-            variants[key] = {"scaling": sc, "gather": l2.gather, "value": round(ge * vs / wl / 1e6, 3),
-                             "ms_per_step": round(wl / vs * 1e3, 5), "kernel_ms": round(km, 5), "steps": vs,
-                             "global_batch": ge, "batch_per_gpu": w2["B"],
-                             "gather_ms": None if l2.gather_ms() is None else round(l2.gather_ms(), 5)}
-            del w2, l2
+            # A variant is a side measurement: if one fails (the same way on every rank: an allocation, an argument), it
+            # is recorded as failed and the primary line above still goes out.
+            try:
+                w2, l2 = build(sc, ga)
+                # best of two short runs: with a process group alive, a ~100 ms stall of unknown origin (seen in the no-gather
+                # variant too) occasionally lands inside one 48-step run; the primary measurement above is a single run, as agreed
+                wl, km = min(measure(l2, vs, vw, dev, multi), measure(l2, vs, vw, dev, multi))
+                ge = global_evals(sc, w2)
+                variants[key] = {"scaling": sc, "gather": l2.gather, "value": round(ge * vs / wl / 1e6, 3),
+                                 "ms_per_step": round(wl / vs * 1e3, 5), "kernel_ms": round(km, 5), "steps": vs,
+                                 "global_batch": ge, "batch_per_gpu": w2["B"],
+                                 "gather_ms": None if l2.gather_ms() is None else round(l2.gather_ms(), 5)}
+                del w2, l2
+            except Exception as exc:  # noqa: BLE001
+                variants[key] = {"scaling": sc, "gather": ga, "error": f"{type(exc).__name__}: {exc}"[:200]}
 
     if rank == 0:
         ge = global_evals(args.scaling, w)

@@ -62,8 +62,11 @@ struct FkProgTreeJoint {
 };
 struct FkProgPoint {  // 4 dwords
     float ox, oy, oz;
-    int32_t out_k;  // feature slot: coordinate r goes to X[out_k + r * out_stride]
+    int32_t out_k;  // feature slot: coordinate r goes to X[out_k + r * out_stride]; DH: | kPointBare
 };
+// DCX_FK_DH: the control point IS the frame origin (offset 0: every Baxter point, Panda's five frame points).  The walks
+// then skip R*o and o x l - the same values (a zero offset adds +-0), 9 + 6 operations fewer per point on the lone wave.
+constexpr int32_t kPointBare = 1 << 30;
 struct FkProg {
     int32_t kind, dof, n_points, point_dim;
     int32_t n_chains, n_joints, out_stride, n_dwords;  // n_dwords: how much of this struct the kind uses
@@ -277,7 +280,8 @@ inline void build_fk_prog(const dcx_fk_desc& fk, FkProg& p) {
                 p.points[np].ox = fk.pt_off[k][0];
                 p.points[np].oy = fk.pt_off[k][1];
                 p.points[np].oz = fk.pt_off[k][2];
-                p.points[np].out_k = 3 * k;
+                const bool bare = fk.pt_off[k][0] == 0.0f && fk.pt_off[k][1] == 0.0f && fk.pt_off[k][2] == 0.0f;
+                p.points[np].out_k = 3 * k | (bare ? kPointBare : 0);
                 ++np;
             }
             J.pt_end = np;
@@ -644,6 +648,19 @@ __device__ inline void fk_forward_chain(fk_cptr fk, const T* sQrow, T* sXcol, T*
                 const T s = sFcol[(2 * j) * 64], c = sFcol[(2 * j + 1) * 64];
                 const float a = fk->joints[j].a, d = fk->joints[j].d;
                 const float sa = fk->joints[j].sin_alpha, ca = fk->joints[j].cos_alpha;
+#ifndef DCX_FK_DH_MATRIX
+                // T <- T * Rz(theta) * Trans(a, 0, d) * Rx(alpha)   (utils.DH2mat, factor by factor: columns 0, 1 of R mix by
+                // theta, the origin moves by a along the new column 0 and by d along column 2, columns 1, 2 mix by alpha):
+                // 30 operations per joint where the product with the assembled 3x4 block takes 39 - the chain is a lone
+                // wave's phase, bound by its instruction count.  -DDCX_FK_DH_MATRIX restores the block form.
+                const T n00 = fma3(r00, c, r01 * s), n10 = fma3(r10, c, r11 * s), n20 = fma3(r20, c, r21 * s);
+                const T u0 = fma3(r01, c, -(r00 * s)), u1 = fma3(r11, c, -(r10 * s)), u2 = fma3(r21, c, -(r20 * s));
+                t0 = fma3(n00, a, fma3(r02, d, t0));
+                t1 = fma3(n10, a, fma3(r12, d, t1));
+                t2 = fma3(n20, a, fma3(r22, d, t2));
+                const T n01 = fma3(u0, ca, r02 * sa), n11 = fma3(u1, ca, r12 * sa), n21 = fma3(u2, ca, r22 * sa);
+                const T n02 = fma3(r02, ca, -(u0 * sa)), n12 = fma3(r12, ca, -(u1 * sa)), n22 = fma3(r22, ca, -(u2 * sa));
+#else
                 // T <- T * [[c, -s ca,  s sa, a c], [s, c ca, -c sa, a s], [0, sa, ca, d]]   (utils.DH2mat)
                 const T m01 = -s * ca, m02 = s * sa, m11 = c * ca, m12 = -c * sa;
                 const T ac = a * c, as = a * s;
@@ -657,11 +674,17 @@ __device__ inline void fk_forward_chain(fk_cptr fk, const T* sQrow, T* sXcol, T*
                 const T n02 = fma3(r00, m02, fma3(r01, m12, r02 * ca));
                 const T n12 = fma3(r10, m02, fma3(r11, m12, r12 * ca));
                 const T n22 = fma3(r20, m02, fma3(r21, m12, r22 * ca));
+#endif
                 r00 = n00; r01 = n01; r02 = n02; r10 = n10; r11 = n11; r12 = n12; r20 = n20; r21 = n21; r22 = n22;
                 const int pb = rfl(fk->joints[j].pt_begin), pe = rfl(fk->joints[j].pt_end);
                 for (int p = pb; p < pe; ++p) {
+                    const int ok = rfl(fk->points[p].out_k);
+                    T* out = sXcol + (ok & (kPointBare - 1)) * 64;
+                    if (ok & kPointBare) {
+                        out[0] = t0; out[64] = t1; out[128] = t2;
+                        continue;
+                    }
                     const float ox = fk->points[p].ox, oy = fk->points[p].oy, oz = fk->points[p].oz;
-                    T* out = sXcol + rfl(fk->points[p].out_k) * 64;
                     out[0] = fma3(r00, ox, fma3(r01, oy, fma3(r02, oz, t0)));
                     out[64] = fma3(r10, ox, fma3(r11, oy, fma3(r12, oz, t1)));
                     out[128] = fma3(r20, ox, fma3(r21, oy, fma3(r22, oz, t2)));
@@ -728,6 +751,70 @@ __device__ inline void fk_vjp(fk_cptr fk, const T* sQrow, const T* sFcol, const 
         return;
     }
     if (kind == DCX_FK_DH) {
+        for (int i = 0; i < dof; ++i) gqRow[i] = 0.f;  // DH reads frames, not q
+        const int nch = rfl(fk->n_chains), njt = rfl(fk->n_joints);
+#ifndef DCX_VJP_MATRIX_ADJOINT
+        // Reverse sweep of a WRENCH (force f, moment n about the frame origin) expressed in the coordinates of the current
+        // frame, from the tip of the chain to its base.  With A_j = Rz(theta_j) Trans(a, 0, d) Rx(alpha):
+        //   points of frame j (offset o, upstream g):  l = R_j^T g ;  f += l ;  n += o x l
+        //   through Rx(alpha) and the translation:     f1 = Rx f ;  n1 = Rx n + (a, 0, d) x f1
+        //   dL/dtheta_j = n1.z                         (the moment about frame j-1's z axis; Rz(theta) leaves z alone)
+        //   through Rz(theta):                         f <- Rz f1 ;  n <- Rz n1 ;  R_{j-1} = R_j Rx^T Rz^T (recomputed)
+        // Six adjoint components instead of the twelve (GR 3x3, Gt) of the matrix chain rule, and the joint derivative
+        // costs nothing: ~44 instead of ~100 operations per joint (the lone wave's J^T phase of a block).
+        // Like the matrix form - and unlike the world-frame z x (p - o), which differences accumulated positions - the
+        // STRUCTURAL zeros come out exactly: they live in the DH constants (Baxter's last joint, a = 0 with the control
+        // point on the joint axis: n stays 0 and n1.z = sa*0 + ca*0 + 0*f1.y = 0), so an optimiser such as Adam is not
+        // handed 1e-8 of round-off to normalise into full-size steps.  -DDCX_VJP_MATRIX_ADJOINT restores the matrix form.
+        for (int ch = 0; ch < nch; ++ch) {
+            const T* fr = sFcol + (2 * njt + 9 * ch) * 64;
+            T r00 = fr[0], r01 = fr[64], r02 = fr[128], r10 = fr[192], r11 = fr[256], r12 = fr[320];
+            T r20 = fr[384], r21 = fr[448], r22 = fr[512];
+            T f0 = 0.f, f1 = 0.f, f2 = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
+            const int jb = rfl(fk->chain_begin[ch]), je = rfl(fk->chain_end[ch]);
+            for (int j = je - 1; j >= jb; --j) {
+                const int pb = rfl(fk->joints[j].pt_begin), pe = rfl(fk->joints[j].pt_end);
+                for (int p = pb; p < pe; ++p) {
+                    const int ok = rfl(fk->points[p].out_k);
+                    const T* gin = sGcol + (ok & (kPointBare - 1)) * 64;
+                    const T g0 = gin[0], g1 = gin[64], g2 = gin[128];
+                    const T l0 = fma3(r00, g0, fma3(r10, g1, r20 * g2));
+                    const T l1 = fma3(r01, g0, fma3(r11, g1, r21 * g2));
+                    const T l2 = fma3(r02, g0, fma3(r12, g1, r22 * g2));
+                    f0 += l0; f1 += l1; f2 += l2;
+                    if (ok & kPointBare) continue;  // o = 0: no moment about the frame origin
+                    const float ox = fk->points[p].ox, oy = fk->points[p].oy, oz = fk->points[p].oz;
+                    n0 = fma3(oy, l2, fma3(-oz, l1, n0));
+                    n1 = fma3(oz, l0, fma3(-ox, l2, n1));
+                    n2 = fma3(ox, l1, fma3(-oy, l0, n2));
+                }
+                const T s = sFcol[(2 * j) * 64], c = sFcol[(2 * j + 1) * 64];
+                const float a = fk->joints[j].a, d = fk->joints[j].d;
+                const float sa = fk->joints[j].sin_alpha, ca = fk->joints[j].cos_alpha;
+                // Rx(alpha), then the moment arm (a, 0, d)
+                const T fy = fma3(ca, f1, -(sa * f2)), fz = fma3(sa, f1, ca * f2);
+                const T mx = fma3(-d, fy, n0);
+                const T my = fma3(d, f0, fma3(-a, fz, fma3(ca, n1, -(sa * n2))));
+                const T mz = fma3(a, fy, fma3(sa, n1, ca * n2));
+                gqRow[rfl(fk->joints[j].q_index)] += mz;
+                if (j > jb) {
+                    // Rz(theta)
+                    f1 = fma3(s, f0, c * fy);
+                    f0 = fma3(c, f0, -(s * fy));
+                    f2 = fz;
+                    n0 = fma3(c, mx, -(s * my));
+                    n1 = fma3(s, mx, c * my);
+                    n2 = mz;
+                    // R_{j-1} = R_j Rx(alpha)^T Rz(theta)^T : columns 1, 2 mix by alpha, then columns 0, 1 by theta
+                    const T u0 = fma3(ca, r01, -(sa * r02)), u1 = fma3(ca, r11, -(sa * r12)), u2 = fma3(ca, r21, -(sa * r22));
+                    r02 = fma3(sa, r01, ca * r02); r12 = fma3(sa, r11, ca * r12); r22 = fma3(sa, r21, ca * r22);
+                    r01 = fma3(s, r00, c * u0); r11 = fma3(s, r10, c * u1); r21 = fma3(s, r20, c * u2);
+                    r00 = fma3(c, r00, -(s * u0)); r10 = fma3(c, r10, -(s * u1)); r20 = fma3(c, r20, -(s * u2));
+                }
+                DCX_FK_TS(7 + (j < 8 ? j : 8), 1);
+            }
+        }
+#else
         // Reverse-mode sweep through T_j = T_{j-1} A_j(theta_j), exactly the chain rule autograd applies to
         // the reference's bmm chain.  Unlike the geometric form z x (p - o) it reproduces STRUCTURAL zeros
         // exactly (e.g. Baxter's last joint, a = 0 and the control point on the joint axis): an optimiser
@@ -735,8 +822,6 @@ __device__ inline void fk_vjp(fk_cptr fk, const T* sQrow, const T* sFcol, const 
         //   GR, Gt : adjoints of the current frame's rotation / translation
         //   dL/dtheta_j = <R_{j-1}^T GR, dA_R/dtheta> + <R_{j-1}^T Gt, da_t/dtheta>
         //   GR <- GR A_R^T + Gt a_t^T ;  Gt unchanged ;  R_{j-1} = R_j A_R^T (recomputed, not stored)
-        for (int i = 0; i < dof; ++i) gqRow[i] = 0.f;  // DH reads frames, not q
-        const int nch = rfl(fk->n_chains), njt = rfl(fk->n_joints);
         for (int ch = 0; ch < nch; ++ch) {
             const T* fr = sFcol + (2 * njt + 9 * ch) * 64;
             T r00 = fr[0], r01 = fr[64], r02 = fr[128], r10 = fr[192], r11 = fr[256], r12 = fr[320];
@@ -747,7 +832,7 @@ __device__ inline void fk_vjp(fk_cptr fk, const T* sQrow, const T* sFcol, const 
             for (int j = je - 1; j >= jb; --j) {
                 const int pb = rfl(fk->joints[j].pt_begin), pe = rfl(fk->joints[j].pt_end);
                 for (int p = pb; p < pe; ++p) {
-                    const T* gin = sGcol + rfl(fk->points[p].out_k) * 64;
+                    const T* gin = sGcol + (rfl(fk->points[p].out_k) & (kPointBare - 1)) * 64;
                     const T g0 = gin[0], g1 = gin[64], g2 = gin[128];
                     const float ox = fk->points[p].ox, oy = fk->points[p].oy, oz = fk->points[p].oz;
                     T0 += g0; T1 += g1; T2 += g2;
@@ -794,6 +879,7 @@ __device__ inline void fk_vjp(fk_cptr fk, const T* sQrow, const T* sFcol, const 
                 DCX_FK_TS(7 + (j < 8 ? j : 8), 1);
             }
         }
+#endif
     } else if (kind == DCX_FK_TREE) {
         fk_tree_vjp(fk, sFcol, sGcol, gqRow);
     } else if (kind == DCX_FK_SE2) {
