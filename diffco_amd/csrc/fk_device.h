@@ -473,6 +473,105 @@ __device__ __attribute__((noinline)) void fk_tree_chain(fk_cptr fk, T* sXcol, T*
     }
 }
 
+#ifndef DCX_VJP_MATRIX_ADJOINT
+template <class T>
+__device__ __attribute__((noinline)) void fk_tree_vjp(fk_cptr fk, const T* sFcol, const T* sGcol, T* gqRow) {
+    const int dof = rfl(fk->dof);
+    // Reverse sweep of a wrench through T_j = T_parent(j) F_j M_j(v_j) over the tree (the DH branch of fk_vjp explains the
+    // form): force f and moment n about the origin of the current node's frame, in that frame's coordinates; joints
+    // driven by the same q (mimic) simply accumulate.  With N = T_parent F_j:
+    //   points of node j (offset o, upstream g):  l = R_j^T g ;  f += l ;  n += o x l
+    //   revolute : T_j = N Rz(v)         ->  dL/dv = n.z ;  f <- Rz f, n <- Rz n ;  R_N = R_j Rz^T
+    //   prismatic: t_j = t_N + R_N a v   ->  dL/dv = f . a ;  n <- n + (a v) x f
+    //   through F: f_parent = F_R f ;  n_parent = F_R n + F_t x f_parent ;  R_parent = R_N F_R^T
+    // A branch node's later children leave their wrench (6 floats, in the branch node's coordinates) in its adjoint slot.
+    for (int i = 0; i < dof; ++i) gqRow[i] = 0.f;  // the sweep reads frames, not q
+    const int stride = rfl(fk->out_stride) * 64, njt = rfl(fk->n_joints);
+    const int f_leaf = rfl(fk->f_leaf), f_adj = rfl(fk->f_adj), n_branch = rfl(fk->n_branch);
+    T* sFw = const_cast<T*>(sFcol);  // the adjoint sums of branch nodes live in the frames area (12 floats apart, 6 used)
+    for (int b = 0; b < n_branch; ++b)
+        for (int e = 0; e < 6; ++e) sFw[(f_adj + 12 * b + e) * 64] = 0.f;
+    T r00 = 1.f, r01 = 0.f, r02 = 0.f, r10 = 0.f, r11 = 1.f, r12 = 0.f, r20 = 0.f, r21 = 0.f, r22 = 1.f;
+    T f0 = 0.f, f1 = 0.f, f2 = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
+    // nodes in reverse depth-first order: every child has been processed before its parent
+    for (int j = njt - 1; j >= 0; --j) {
+        const int leaf = rfl(fk->tj[j].leaf), park = rfl(fk->tj[j].park);
+        if (leaf >= 0) {  // no child handed its state over in registers: restart from this node's own rotation
+            const T* fr = sFcol + (f_leaf + 9 * leaf) * 64;
+            r00 = fr[0]; r01 = fr[64]; r02 = fr[128]; r10 = fr[192]; r11 = fr[256]; r12 = fr[320];
+            r20 = fr[384]; r21 = fr[448]; r22 = fr[512];
+            f0 = f1 = f2 = 0.f;
+            n0 = n1 = n2 = 0.f;
+        }
+        if (park >= 0) {  // plus what the children that started from the parked frame sent back
+            const T* ad = sFcol + (f_adj + 12 * park) * 64;
+            f0 += ad[0]; f1 += ad[64]; f2 += ad[128];
+            n0 += ad[192]; n1 += ad[256]; n2 += ad[320];
+        }
+        const int pb = rfl(fk->tj[j].pt_begin), pe = rfl(fk->tj[j].pt_end);
+        for (int p = pb; p < pe; ++p) {
+            const T* gin = sGcol + rfl(fk->points[p].out_k) * 64;
+            const T g0 = gin[0], g1 = gin[stride], g2 = gin[2 * stride];
+            const float ox = fk->points[p].ox, oy = fk->points[p].oy, oz = fk->points[p].oz;
+            const T l0 = fma3(r00, g0, fma3(r10, g1, r20 * g2));
+            const T l1 = fma3(r01, g0, fma3(r11, g1, r21 * g2));
+            const T l2 = fma3(r02, g0, fma3(r12, g1, r22 * g2));
+            f0 += l0; f1 += l1; f2 += l2;
+            n0 = fma3(oy, l2, fma3(-oz, l1, n0));
+            n1 = fma3(oz, l0, fma3(-ox, l2, n1));
+            n2 = fma3(ox, l1, fma3(-oy, l0, n2));
+        }
+        const int type = rfl(fk->tj[j].type), slot = rfl(fk->tj[j].slot);
+        if (type == TJ_REV) {
+            const T s = sFcol[(2 * slot) * 64], c = sFcol[(2 * slot + 1) * 64];
+            gqRow[rfl(fk->tj[j].q_index)] += fk->tj[j].scale * n2;
+            // into N's coordinates: Rz(v) on f and n; R_N = R_j Rz^T (columns 0, 1 rotate back)
+            const T g0 = fma3(c, f0, -(s * f1)), g1 = fma3(s, f0, c * f1);
+            const T m0 = fma3(c, n0, -(s * n1)), m1 = fma3(s, n0, c * n1);
+            f0 = g0; f1 = g1; n0 = m0; n1 = m1;
+            const T p00 = fma3(r00, c, -r01 * s), p01 = fma3(r01, c, r00 * s);
+            const T p10 = fma3(r10, c, -r11 * s), p11 = fma3(r11, c, r10 * s);
+            const T p20 = fma3(r20, c, -r21 * s), p21 = fma3(r21, c, r20 * s);
+            r00 = p00; r01 = p01; r10 = p10; r11 = p11; r20 = p20; r21 = p21;
+        } else if (type == TJ_PRISM) {
+            const T v = sFcol[(2 * slot) * 64];
+            const float ax = fk->tj[j].ax, ay = fk->tj[j].ay, az = fk->tj[j].az;
+            gqRow[rfl(fk->tj[j].q_index)] += fk->tj[j].scale * fma3(ax, f0, fma3(ay, f1, az * f2));
+            const T dx = ax * v, dy = ay * v, dz = az * v;
+            n0 = fma3(dy, f2, fma3(-dz, f1, n0));
+            n1 = fma3(dz, f0, fma3(-dx, f2, n1));
+            n2 = fma3(dx, f1, fma3(-dy, f0, n2));
+        }
+        // back through the constant transform F
+        const auto* F = fk->tj[j].F;
+        const float f00 = F[0], f01 = F[1], f02 = F[2], f03 = F[3], f10 = F[4], f11 = F[5], f12 = F[6], f13 = F[7];
+        const float f20 = F[8], f21 = F[9], f22 = F[10], f23 = F[11];
+        const T h0 = fma3(f00, f0, fma3(f01, f1, f02 * f2)), h1 = fma3(f10, f0, fma3(f11, f1, f12 * f2)),
+                    h2 = fma3(f20, f0, fma3(f21, f1, f22 * f2));
+        const T k0 = fma3(f00, n0, fma3(f01, n1, f02 * n2)), k1 = fma3(f10, n0, fma3(f11, n1, f12 * n2)),
+                    k2 = fma3(f20, n0, fma3(f21, n1, f22 * n2));
+        f0 = h0; f1 = h1; f2 = h2;
+        n0 = fma3(f13, h2, fma3(-f23, h1, k0));
+        n1 = fma3(f23, h0, fma3(-f03, h2, k1));
+        n2 = fma3(f03, h1, fma3(-f13, h0, k2));
+        const T q00 = fma3(r00, f00, fma3(r01, f01, r02 * f02)), q01 = fma3(r00, f10, fma3(r01, f11, r02 * f12)),
+                    q02 = fma3(r00, f20, fma3(r01, f21, r02 * f22));
+        const T q10 = fma3(r10, f00, fma3(r11, f01, r12 * f02)), q11 = fma3(r10, f10, fma3(r11, f11, r12 * f12)),
+                    q12 = fma3(r10, f20, fma3(r11, f21, r12 * f22));
+        const T q20 = fma3(r20, f00, fma3(r21, f01, r22 * f02)), q21 = fma3(r20, f10, fma3(r21, f11, r22 * f12)),
+                    q22 = fma3(r20, f20, fma3(r21, f21, r22 * f22));
+        r00 = q00; r01 = q01; r02 = q02; r10 = q10; r11 = q11; r12 = q12; r20 = q20; r21 = q21; r22 = q22;
+        // (R, f, n) now refer to the parent frame.  A child that started from a parked frame adds its wrench to the
+        // parent's sum; a child that continued in registers just carries on; a root's parent wrench is dropped.
+        const int start = rfl(fk->tj[j].start);
+        if (start >= 0) {
+            T* ad = sFw + (f_adj + 12 * start) * 64;
+            ad[0] += f0; ad[64] += f1; ad[128] += f2;
+            ad[192] += n0; ad[256] += n1; ad[320] += n2;
+        }
+    }
+}
+#else
 template <class T>
 __device__ __attribute__((noinline)) void fk_tree_vjp(fk_cptr fk, const T* sFcol, const T* sGcol, T* gqRow) {
     const int dof = rfl(fk->dof);
@@ -576,6 +675,8 @@ __device__ __attribute__((noinline)) void fk_tree_vjp(fk_cptr fk, const T* sFcol
         }
     }
 }
+
+#endif
 
 // ---- forward, phase A (every wave of the block): sin/cos of the joint angles -> frames ---------------
 // wave w of nw takes joints w, w+nw, ...   Caller synchronises the block afterwards.
