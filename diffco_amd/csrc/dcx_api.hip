@@ -230,7 +230,7 @@ int fk_device_copy(int device, const dcx_fk_desc& fk, FkProg** out) {
 // path calls getenv.  -1 = "use the rule".
 struct Knobs {
     std::atomic<int64_t> ys{-1}, nw{-1}, min_rows{-1}, split_finish_kernel{-1}, inlaunch_tiles{-1}, jac_per_class{-1},
-        mfma{-1}, traj_fused{-1}, xf{-1}, mt{-1}, prio{-1}, jac_one_sweep{-1}, train_grid{-1};
+        mfma{-1}, traj_fused{-1}, xf{-1}, mt{-1}, prio{-1}, jac_one_sweep{-1}, train_grid{-1}, fkk{-1};
     Knobs() {
         auto rd = [](const char* name, std::atomic<int64_t>& dst, bool flag) {
             if (const char* e = std::getenv(name)) dst = flag ? 1 : std::atoll(e);
@@ -248,6 +248,7 @@ struct Knobs {
         rd("DCX_PRIO", prio, false);
         rd("DCX_JAC_ONE_SWEEP", jac_one_sweep, false);
         rd("DCX_TRAIN_GRID", train_grid, false);
+        rd("DCX_FKK", fkk, false);
     }
 };
 Knobs& knobs() {
@@ -418,6 +419,8 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
     a.hinge_margin = hinge.margin;
     a.hinge_weight = hinge.weight;
     a.prio = knobs().prio > 0 ? 1 : 0;
+    // DH arms: the lone-wave FK walks read the program with scalar loads (fk_device.h fk_*_dh_k); knob fkk = 0: from LDS
+    a.fkk = (m->fk.kind == DCX_FK_DH && knobs().fkk != 0) ? 1 : 0;
     // Expanded form of the sweep (score_kernel.h XF) wherever it is compiled (Polyharmonic(1), rows <= 37 floats): 13-17 %
     // faster for chip-filling batches, 1-3 % for split launches (profiles/r02_xf_probe.txt).  Knob xf = 0: direct form.
     a.xf = knobs().xf != 0 ? 1 : 0;
@@ -503,7 +506,7 @@ int dcx_debug_set(const char* name, int64_t value) {
     const std::string n(name);
     std::atomic<int64_t>* dst = n == "ys" ? &k.ys : n == "nw" ? &k.nw : n == "min_rows" ? &k.min_rows
         : n == "split_finish_kernel" ? &k.split_finish_kernel : n == "inlaunch_tiles" ? &k.inlaunch_tiles
-        : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : n == "traj_fused" ? &k.traj_fused : n == "xf" ? &k.xf : n == "mt" ? &k.mt : n == "prio" ? &k.prio : n == "jac_one_sweep" ? &k.jac_one_sweep : n == "train_grid" ? &k.train_grid : nullptr;
+        : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : n == "traj_fused" ? &k.traj_fused : n == "xf" ? &k.xf : n == "mt" ? &k.mt : n == "prio" ? &k.prio : n == "jac_one_sweep" ? &k.jac_one_sweep : n == "train_grid" ? &k.train_grid : n == "fkk" ? &k.fkk : nullptr;
     if (!dst) return fail(DCX_ERR_INVALID, "unknown knob: " + n);
 #ifndef DCX_WITH_MT
     if (dst == &k.mt && value >= 2) return fail(DCX_ERR_UNSUPPORTED, "this libdcx was built without score_kernel_mt (EXTRA=-DDCX_WITH_MT)");

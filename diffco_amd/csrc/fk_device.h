@@ -36,10 +36,14 @@ constexpr int kMaxProgJoints = DCX_MAX_CHAINS * DCX_MAX_JOINTS;
 // base transforms the program carries: one per DH chain, one per DISTINCT base of a tree's chains
 constexpr int kMaxProgChains = DCX_MAX_TREE_BASES > DCX_MAX_CHAINS ? DCX_MAX_TREE_BASES : DCX_MAX_CHAINS;
 
-struct FkProgJoint {  // DCX_FK_DH, 8 dwords
+struct FkProgJoint {  // DCX_FK_DH, 12 dwords
     int32_t q_index;
     float theta0, a, d, sin_alpha, cos_alpha;
     int32_t pt_begin, pt_end;  // control points attached to this joint's frame: points[pt_begin .. pt_end)
+    // a copy of points[pt_begin] (p0_k = its out_k with the kPointBare flag; -1: the frame carries no control point): the
+    // scalar-load walks (fk_*_dh_k) get a joint and its usual single point from one record
+    int32_t p0_k;
+    float p0x, p0y, p0z;
 };
 // DCX_FK_TREE node, 28 dwords:  T <- T_parent * [F] * Motion.  The root-to-leaf chains of the public description
 // are merged back into a tree on the host (a joint repeated on several chains becomes ONE node), nodes are stored in
@@ -285,6 +289,14 @@ inline void build_fk_prog(const dcx_fk_desc& fk, FkProg& p) {
                 ++np;
             }
             J.pt_end = np;
+            J.p0_k = -1;
+            J.p0x = J.p0y = J.p0z = 0.0f;
+            if (J.pt_end > J.pt_begin) {
+                J.p0_k = p.points[J.pt_begin].out_k;
+                J.p0x = p.points[J.pt_begin].ox;
+                J.p0y = p.points[J.pt_begin].oy;
+                J.p0z = p.points[J.pt_begin].oz;
+            }
         }
         p.chain_end[c] = nj;
     }
@@ -677,6 +689,139 @@ __device__ __attribute__((noinline)) void fk_tree_vjp(fk_cptr fk, const T* sFcol
 }
 
 #endif
+
+// ---- DCX_FK_DH walks that read the program with SCALAR loads -------------------------------------------------------------
+// fk_forward_chain / fk_vjp interpret the program from its LDS copy: every wave-uniform field arrives in a VGPR and goes
+// through v_readfirstlane before it can steer a branch or an address, and a lone wave pays ~10 cycles for each of those
+// instructions (profiles/r02_vjp_ab.txt: 680-960 cycles per joint for ~45 FMAs).  Here the same program is read from global
+// memory through the constant address space: one s_load per joint record lands in SGPRs, ready to be VALU operands, loop
+// bounds and LDS offsets; the record of the NEXT joint is requested before the current one is composed, so the scalar
+// cache / L2 latency hides behind a joint's arithmetic.  The arithmetic is the LDS walks', expression for expression:
+// results are bit-identical (tests/test_gpu_parity.py).
+typedef const __attribute__((address_space(4))) FkProg* fk_kptr;
+struct FkJointRec {
+    int32_t q_index, pt_begin, pt_end, p0_k;
+    float a, d, sa, ca, p0x, p0y, p0z;
+};
+__device__ __forceinline__ FkJointRec fk_load_joint(fk_kptr gk, int j) {
+    FkJointRec r;
+    r.q_index = gk->joints[j].q_index;
+    r.a = gk->joints[j].a;
+    r.d = gk->joints[j].d;
+    r.sa = gk->joints[j].sin_alpha;
+    r.ca = gk->joints[j].cos_alpha;
+    r.pt_begin = gk->joints[j].pt_begin;
+    r.pt_end = gk->joints[j].pt_end;
+    r.p0_k = gk->joints[j].p0_k;
+    r.p0x = gk->joints[j].p0x;
+    r.p0y = gk->joints[j].p0y;
+    r.p0z = gk->joints[j].p0z;
+    return r;
+}
+
+template <class T>
+__device__ inline void fk_forward_chain_dh_k(fk_kptr gk, T* sXcol, T* sFcol) {
+    const int nch = gk->n_chains, njt = gk->n_joints;
+    for (int ch = 0; ch < nch; ++ch) {
+        T r00 = gk->base[ch][0], r01 = gk->base[ch][1], r02 = gk->base[ch][2], t0 = gk->base[ch][3];
+        T r10 = gk->base[ch][4], r11 = gk->base[ch][5], r12 = gk->base[ch][6], t1 = gk->base[ch][7];
+        T r20 = gk->base[ch][8], r21 = gk->base[ch][9], r22 = gk->base[ch][10], t2 = gk->base[ch][11];
+        const int jb = gk->chain_begin[ch], je = gk->chain_end[ch];
+        FkJointRec nx = fk_load_joint(gk, jb);
+        for (int j = jb; j < je; ++j) {
+            const FkJointRec cu = nx;
+            nx = fk_load_joint(gk, j + 1 < je ? j + 1 : j);
+            const T s = sFcol[(2 * j) * 64], c = sFcol[(2 * j + 1) * 64];
+            const float a = cu.a, d = cu.d, sa = cu.sa, ca = cu.ca;
+            const T n00 = fma3(r00, c, r01 * s), n10 = fma3(r10, c, r11 * s), n20 = fma3(r20, c, r21 * s);
+            const T u0 = fma3(r01, c, -(r00 * s)), u1 = fma3(r11, c, -(r10 * s)), u2 = fma3(r21, c, -(r20 * s));
+            t0 = fma3(n00, a, fma3(r02, d, t0));
+            t1 = fma3(n10, a, fma3(r12, d, t1));
+            t2 = fma3(n20, a, fma3(r22, d, t2));
+            const T n01 = fma3(u0, ca, r02 * sa), n11 = fma3(u1, ca, r12 * sa), n21 = fma3(u2, ca, r22 * sa);
+            const T n02 = fma3(r02, ca, -(u0 * sa)), n12 = fma3(r12, ca, -(u1 * sa)), n22 = fma3(r22, ca, -(u2 * sa));
+            r00 = n00; r01 = n01; r02 = n02; r10 = n10; r11 = n11; r12 = n12; r20 = n20; r21 = n21; r22 = n22;
+            if (cu.p0_k >= 0) {
+                T* out = sXcol + (cu.p0_k & (kPointBare - 1)) * 64;
+                if (cu.p0_k & kPointBare) {
+                    out[0] = t0; out[64] = t1; out[128] = t2;
+                } else {
+                    out[0] = fma3(r00, cu.p0x, fma3(r01, cu.p0y, fma3(r02, cu.p0z, t0)));
+                    out[64] = fma3(r10, cu.p0x, fma3(r11, cu.p0y, fma3(r12, cu.p0z, t1)));
+                    out[128] = fma3(r20, cu.p0x, fma3(r21, cu.p0y, fma3(r22, cu.p0z, t2)));
+                }
+                for (int p = cu.pt_begin + 1; p < cu.pt_end; ++p) {  // further points of this frame (Panda's fingers)
+                    const int ok = gk->points[p].out_k;
+                    const float ox = gk->points[p].ox, oy = gk->points[p].oy, oz = gk->points[p].oz;
+                    T* o2 = sXcol + (ok & (kPointBare - 1)) * 64;
+                    o2[0] = fma3(r00, ox, fma3(r01, oy, fma3(r02, oz, t0)));
+                    o2[64] = fma3(r10, ox, fma3(r11, oy, fma3(r12, oz, t1)));
+                    o2[128] = fma3(r20, ox, fma3(r21, oy, fma3(r22, oz, t2)));
+                }
+            }
+            DCX_FK_TS(7 + (j < 8 ? j : 8), 0);
+        }
+        T* fr = sFcol + (2 * njt + 9 * ch) * 64;  // final rotation of this chain (for the reverse sweep)
+        fr[0] = r00; fr[64] = r01; fr[128] = r02; fr[192] = r10; fr[256] = r11; fr[320] = r12;
+        fr[384] = r20; fr[448] = r21; fr[512] = r22;
+    }
+}
+
+template <class T>
+__device__ inline void fk_vjp_dh_k(fk_kptr gk, const T* sFcol, const T* sGcol, T* gqRow) {
+    const int dof = gk->dof;
+    for (int i = 0; i < dof; ++i) gqRow[i] = 0.f;
+    const int nch = gk->n_chains, njt = gk->n_joints;
+    for (int ch = 0; ch < nch; ++ch) {
+        const int jb = gk->chain_begin[ch], je = gk->chain_end[ch];
+        FkJointRec nx = fk_load_joint(gk, je - 1);
+        const T* fr = sFcol + (2 * njt + 9 * ch) * 64;
+        T r00 = fr[0], r01 = fr[64], r02 = fr[128], r10 = fr[192], r11 = fr[256], r12 = fr[320];
+        T r20 = fr[384], r21 = fr[448], r22 = fr[512];
+        T f0 = 0.f, f1 = 0.f, f2 = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
+        for (int j = je - 1; j >= jb; --j) {
+            const FkJointRec cu = nx;
+            nx = fk_load_joint(gk, j > jb ? j - 1 : j);
+            // same order as fk_vjp: points[pt_begin], then the further points of the frame
+            for (int p = cu.pt_begin; p < cu.pt_end; ++p) {
+                const bool first = (p == cu.pt_begin);
+                const int ok = first ? cu.p0_k : gk->points[p].out_k;
+                const T* gin = sGcol + (ok & (kPointBare - 1)) * 64;
+                const T g0 = gin[0], g1 = gin[64], g2 = gin[128];
+                const T l0 = fma3(r00, g0, fma3(r10, g1, r20 * g2));
+                const T l1 = fma3(r01, g0, fma3(r11, g1, r21 * g2));
+                const T l2 = fma3(r02, g0, fma3(r12, g1, r22 * g2));
+                f0 += l0; f1 += l1; f2 += l2;
+                if (ok & kPointBare) continue;
+                const float ox = first ? cu.p0x : gk->points[p].ox, oy = first ? cu.p0y : gk->points[p].oy,
+                            oz = first ? cu.p0z : gk->points[p].oz;
+                n0 = fma3(oy, l2, fma3(-oz, l1, n0));
+                n1 = fma3(oz, l0, fma3(-ox, l2, n1));
+                n2 = fma3(ox, l1, fma3(-oy, l0, n2));
+            }
+            const T s = sFcol[(2 * j) * 64], c = sFcol[(2 * j + 1) * 64];
+            const float a = cu.a, d = cu.d, sa = cu.sa, ca = cu.ca;
+            const T fy = fma3(ca, f1, -(sa * f2)), fz = fma3(sa, f1, ca * f2);
+            const T mx = fma3(-d, fy, n0);
+            const T my = fma3(d, f0, fma3(-a, fz, fma3(ca, n1, -(sa * n2))));
+            const T mz = fma3(a, fy, fma3(sa, n1, ca * n2));
+            gqRow[cu.q_index] += mz;
+            if (j > jb) {
+                f1 = fma3(s, f0, c * fy);
+                f0 = fma3(c, f0, -(s * fy));
+                f2 = fz;
+                n0 = fma3(c, mx, -(s * my));
+                n1 = fma3(s, mx, c * my);
+                n2 = mz;
+                const T u0 = fma3(ca, r01, -(sa * r02)), u1 = fma3(ca, r11, -(sa * r12)), u2 = fma3(ca, r21, -(sa * r22));
+                r02 = fma3(sa, r01, ca * r02); r12 = fma3(sa, r11, ca * r12); r22 = fma3(sa, r21, ca * r22);
+                r01 = fma3(s, r00, c * u0); r11 = fma3(s, r10, c * u1); r21 = fma3(s, r20, c * u2);
+                r00 = fma3(c, r00, -(s * u0)); r10 = fma3(c, r10, -(s * u1)); r20 = fma3(c, r20, -(s * u2));
+            }
+            DCX_FK_TS(7 + (j < 8 ? j : 8), 1);
+        }
+    }
+}
 
 // ---- forward, phase A (every wave of the block): sin/cos of the joint angles -> frames ---------------
 // wave w of nw takes joints w, w+nw, ...   Caller synchronises the block afterwards.

@@ -76,6 +76,7 @@ struct ScoreArgs {
     int32_t xf;               // 1: the launch uses the expanded form of the sweep (score_kernel<..., XF = true>)
     int32_t prio;             // 1: raise the wave priority outside the sweep (the lone-wave FK / fold / J^T phases)
     int32_t mt;               // >= 2: score_kernel_mt with this many tiles per block (unsplit launches only)
+    int32_t fkk;              // 1 (DCX_FK_DH only): the FK walks read the program with scalar loads (fk_*_dh_k)
     int32_t hinge;            // C == 1: gradient of weight * clamp(score - margin, 0) instead of the score's
     float hinge_margin, hinge_weight;
 };
@@ -912,7 +913,10 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
     fk_forward_trig(fk, sQ + lane * dof, sF + lane, wave, nw);   // all waves: sin/cos of the joint angles
     __syncthreads();
     DCX_TS(6);
-    if (wave == 0) fk_forward_chain(fk, sQ + lane * dof, sX + lane, sF + lane);
+    if (wave == 0) {
+        if (a.fkk) fk_forward_chain_dh_k((fk_kptr)(uintptr_t)a.fk, sX + lane, sF + lane);
+        else fk_forward_chain(fk, sQ + lane * dof, sX + lane, sF + lane);
+    }
 #endif
     __syncthreads();
 
@@ -1111,7 +1115,8 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
 #if defined(DCX_ABLATE) && (DCX_ABLATE & 1)  // timing ablation only (wrong results): no J^T
         for (int i = 0; i < dof; ++i) gq[lane * dof + i] = sG[(i % a.d_fk) * 64 + lane];
 #else
-        fk_vjp(fk, sQ + lane * dof, sF + lane, sG + lane, gq + lane * dof);
+        if (a.fkk) fk_vjp_dh_k((fk_kptr)(uintptr_t)a.fk, sF + lane, sG + lane, gq + lane * dof);
+        else fk_vjp(fk, sQ + lane * dof, sF + lane, sG + lane, gq + lane * dof);
 #endif
         DCX_TS(5);
         // rows -> HBM, coalesced (LDS ops of one wave complete in order; no other wave is alive)
