@@ -729,6 +729,7 @@ int dcx_score_jac(const dcx_model* m, const float* q, int64_t B, float* score, f
         ScoreArgs a{};
         a.rows = m->rows_dev;
         a.fk = m->fk_dev;
+        a.fkk = (m->fk.kind == DCX_FK_DH && knobs().fkk != 0) ? 1 : 0;
         a.q = q;
         a.score = score;
         a.grad = jac;
@@ -815,6 +816,7 @@ int dcx_traj_adam_run(const dcx_model* m, const dcx_traj_state* st, const dcx_tr
             TrajFusedArgs a{};
             a.sc.rows = m->rows_dev;
             a.sc.fk = m->fk_dev;
+            a.sc.fkk = (m->fk.kind == DCX_FK_DH && knobs().fkk != 0) ? 1 : 0;
             a.sc.S = m->S_active;
             a.sc.s_chunk = (m->S_active + nw - 1) / nw;
             a.sc.dof = m->fk.dof;

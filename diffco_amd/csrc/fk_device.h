@@ -1176,4 +1176,17 @@ __device__ inline void fk_vjp(fk_cptr fk, const T* sQrow, const T* sFcol, const 
     }
 }
 
+// the chain / J^T of one wave, by whichever walk the launch selected (fkk: scalar-load walks, DCX_FK_DH only)
+template <class T>
+__device__ __forceinline__ void fk_chain_sel(int fkk, const FkProg* gfk, fk_cptr fk, const T* sQrow, T* sXcol, T* sFcol) {
+    if (fkk) fk_forward_chain_dh_k((fk_kptr)(uintptr_t)gfk, sXcol, sFcol);
+    else fk_forward_chain(fk, sQrow, sXcol, sFcol);
+}
+template <class T>
+__device__ __forceinline__ void fk_vjp_sel(int fkk, const FkProg* gfk, fk_cptr fk, const T* sQrow, const T* sFcol, const T* sGcol,
+                                           T* gqRow) {
+    if (fkk) fk_vjp_dh_k((fk_kptr)(uintptr_t)gfk, sFcol, sGcol, gqRow);
+    else fk_vjp(fk, sQrow, sFcol, sGcol, gqRow);
+}
+
 }  // namespace dcx

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void score
     __syncthreads();
     fk_forward_trig(fk, sQ + lane * dof, sF + lane, wave, nw);
     __syncthreads();
-    if (wave == 0) fk_forward_chain(fk, sQ + lane * dof, sX + lane, sF + lane);
+    if (wave == 0) fk_chain_sel(a.fkk, a.fk, fk, sQ + lane * dof, sX + lane, sF + lane);
     __syncthreads();
     float x[D];
 #pragma unroll
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void score
     auto finish_class = [&](int c) __attribute__((always_inline)) {
         float* gq = smem + lp.gq + c * lp.gq_stride;
         for (int i = 0; i < dof; ++i) gq[lane * dof + i] = sQ[lane * dof + i];   // the row is built in place of a copy of q
-        fk_vjp(fk, gq + lane * dof, sF + lane, sG + (size_t)c * a.d_fk * 64 + lane, gq + lane * dof);
+        fk_vjp_sel(a.fkk, a.fk, fk, gq + lane * dof, sF + lane, sG + (size_t)c * a.d_fk * 64 + lane, gq + lane * dof);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
         float* gdst = a.grad + b0 * a.grad_stride + (size_t)c * dof;

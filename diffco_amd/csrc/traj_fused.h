@@ -124,7 +124,7 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
         // ---- forward kinematics of the current waypoints (once per iteration) -----------------------------------
         fk_forward_trig(fk, sQ + lane * dof, sF + lane, wave, nw);
         __syncthreads();
-        if (wave == 0) fk_forward_chain(fk, sQ + lane * dof, sX + lane, sF + lane);
+        if (wave == 0) fk_chain_sel(a.sc.fkk, a.sc.fk, fk, sQ + lane * dof, sX + lane, sF + lane);
         __syncthreads();
         float x[D];
 #pragma unroll
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
                 if (k < d_fk) sGc[k * 64 + lane] = gx[k] * scale;
             // q row -> gq row in a separate buffer (the two-launch form overwrites the q row; same arithmetic)
             for (int i = 0; i < dof; ++i) sGQc[lane * dof + i] = sQ[lane * dof + i];
-            fk_vjp(fk, sGQc + lane * dof, sF + lane, sGc + lane, sGQc + lane * dof);
+            fk_vjp_sel(a.sc.fkk, a.sc.fk, fk, sGQc + lane * dof, sF + lane, sGc + lane, sGQc + lane * dof);
             const float s0 = sc[0] - a.opt.safety_margin;
             if (live && s0 > 0.f) col = s0;
         }
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
                 const float cp = 2.f * (a.opt.w_diff + (mp > 0.f ? a.opt.w_max_move : 0.f));
                 for (int c = 0; c < pd; ++c) sGp[(a.coord_major ? c * a.n_points + p : p * pd + c) * 64 + lane] = cp * dp[c] - cn * dn[c];
             }
-            fk_vjp(fk, sQ + lane * dof, sF + lane, sGp + lane, sGQp + lane * dof);
+            fk_vjp_sel(a.sc.fkk, a.sc.fk, fk, sQ + lane * dof, sF + lane, sGp + lane, sGQp + lane * dof);
             const float so = traj_wave_sum(obj), sm = traj_wave_sum(mmv);
             if (lane == 0) { sR[0] = so; sR[16] = sm; }
         }
