@@ -151,7 +151,8 @@ int dcx_device_count(void);
  * "traj_fused" (0 = dcx_traj_adam_run as two launches per iteration), "prio" (1 = raised wave priority outside the
  * sweep; measured: no effect), "mt" (2 = two tiles per block; only in EXTRA=-DDCX_WITH_MT builds, else
  * DCX_ERR_UNSUPPORTED), "jac_one_sweep" (0 = dcx_score_jac never takes the one-sweep kernel, 1 = whenever it is compiled
- * and the batch is beyond the one-launch-per-all-classes regime), "train_grid" (see dcx_train_perceptron).  value < 0 restores the rule.  The initial values come from the DCX_YS / DCX_NW / DCX_XF / ...
+ * and the batch is beyond the one-launch-per-all-classes regime), "train_grid" (see dcx_train_perceptron), "fkk" (0 = DH arms walk the FK program from its LDS copy instead of
+ * with scalar loads; bit-identical results).  value < 0 restores the rule.  The initial values come from the DCX_YS / DCX_NW / DCX_XF / ...
  * environment variables, read once at library load; no launch calls getenv.   */
 int dcx_debug_set(const char* name, int64_t value);
 
