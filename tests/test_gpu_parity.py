@@ -508,3 +508,33 @@ def test_concurrent_streams_share_a_model(ops):
     for i, (s0, g0) in enumerate(want):
         for s, g in got[i]:
             assert torch.equal(s, s0) and torch.equal(g, g0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["baxter_left", "panda", "panda5", "baxter_dual", "dual_panda"])
+@pytest.mark.parametrize("B", [1, 200, 4096, 20000])
+def test_scalar_load_fk_walks_equal_lds_walks_bitwise(ops, knob, name, B):
+    """DH arms walk their FK program with scalar loads (fk_device.h fk_forward_chain_dh_k / fk_vjp_dh_k, knob fkk, the
+    default) or from its LDS copy (fkk = 0): the same arithmetic, so score, gradient and the one-sweep Jacobian must agree bit
+    for bit — for one and two chains, frames with no / one / three control points (Panda's fingers), unsplit and split
+    launches"""
+    rob = make_robot(name)
+    g = torch.Generator().manual_seed(len(name) * 1000 + B)
+    lim = rob.limits.float()
+    S, C = 300, 3
+    rnd = lambda n: torch.rand((n, rob.dof), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]
+    sup = rob.fkine(rnd(S).cuda()).reshape(S, -1)
+    q = rnd(B).cuda()
+    out = {}
+    for fkk in (1, 0):
+        knob("fkk", fkk)
+        m1 = ops.ScoreModel(rob.fk_desc(), 1, 1.0, 1.0, sup, torch.randn((S, 1), generator=torch.Generator().manual_seed(3)).cuda())
+        mc = ops.ScoreModel(rob.fk_desc(), 0, 10.0, 2.0, sup, torch.randn((S, C), generator=torch.Generator().manual_seed(4)).cuda())
+        s1, g1 = m1.score_grad_raw(q)
+        up = torch.randn((B, C), generator=torch.Generator().manual_seed(5)).cuda()
+        sc, gc = mc.score_grad_raw(q, up)
+        sj, jj = mc.score_jac_raw(q)
+        out[fkk] = [_n(t).copy() for t in (s1, g1, sc, gc, sj, jj)]
+    knob("fkk", -1)
+    for a, b in zip(out[1], out[0]):
+        assert np.isfinite(a).all() and np.array_equal(a, b)
