@@ -351,6 +351,8 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
     ap.add_argument("--no-variants", action="store_true", help="N>1: skip the short runs of the other variants")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="headline, N=1: skip the short measurements of the other BASELINE configurations (`configs` in the line)")
     ap.add_argument("--force-dist", action="store_true",
                     help="exercise the N>1 code path (process group + all-gather) even with one rank")
     args = ap.parse_args()
@@ -444,6 +446,29 @@ def main():
             except Exception as exc:  # noqa: BLE001
                 variants[key] = {"scaling": sc, "gather": ga, "error": f"{type(exc).__name__}: {exc}"[:200]}
 
+    # The other BASELINE configurations, measured briefly in the same job on the same box (N = 1, headline run only): the
+    # driver's bench line then carries a number for every entry of BASELINE.json.configs that runs on a GPU.
+    configs = None
+    if world == 1 and not multi and name == "headline" and not args.batch and not args.no_configs:
+        configs = {}
+        for cname, csteps in (("cfg2", 200), ("cfg2_panda", 200), ("cfg3", 200), ("cfg3_poly", 200), ("cfg4", 12), ("cfg5", 200)):
+            try:
+                cw = make_workload(cname, WORKLOADS[cname][4], dev, seed=rank)
+                if cname == "cfg5":
+                    cl = TrajLoop(cw, dev, 1, WORKLOADS[cname][4] // TRAJ_W, None)
+                else:
+                    cl = ScoreLoop(cw, dev, 1, "none")
+                cwall, ckm = measure(cl, csteps, 10, dev, False)
+                cF = flops_per_eval(cw["D"], cw["C"], cw["S"])
+                ctf = cF * cw["B"] / (ckm * 1e-3) / 1e12
+                configs[cname] = {"workload": cw["text"], "batch": cw["B"], "steps": csteps,
+                                  "value": round(cw["B"] * csteps / cwall / 1e6, 3), "unit": "M evals/s",
+                                  "ms_per_step": round(cwall / csteps * 1e3, 5), "kernel_ms": round(ckm, 5),
+                                  "flops_per_eval": cF, "frac": round(ctf / PEAK_FP32_TFLOPS, 4)}
+                del cw, cl
+            except Exception as exc:  # noqa: BLE001  (a side measurement never takes the primary line down)
+                configs[cname] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+
     if rank == 0:
         ge = global_evals(args.scaling, w)
         value = ge * args.steps / wall / 1e6
@@ -497,9 +522,13 @@ def main():
                             world * B * C * 4 * (GATHER_EVERY if loop.gather == "bucketed" else 1)}
             if variants is not None:
                 out["variants"] = variants
-        if world == 1 and not args.no_cpu_baseline:
+        if configs is not None:
+            out["configs"] = configs
+        # the CPU port beside the GPU number, on rank 0's host cores, for every N (after the timed region and the closing
+        # barrier: the other ranks only wait in destroy_process_group)
+        if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w)
-            tb = torch_cpu_baseline(w)
+            tb = torch_cpu_baseline(w) if world == 1 else None
             if tb:
                 out["cpu_baseline_torch"] = tb
         else:

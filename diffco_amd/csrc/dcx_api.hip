@@ -19,6 +19,9 @@ struct dcx_model {
     int device = 0;
     dcx_fk_desc fk{};              // host copy
     FkProg* fk_dev = nullptr;      // device copy of the compiled program
+    DhProg* dh_dev = nullptr;      // DCX_FK_DH: device copy of the step table (fk_device.h), null when the robot has none
+    DhArgs dh{};                   // its control part, copied into every launch's arguments
+    int32_t fk_dwords = 0;         // dwords of FkProg the transform uses
     float* rows_dev = nullptr;     // [S_active][RS]
     int64_t S_in = 0;
     int32_t S_active = 0;
@@ -230,7 +233,7 @@ int fk_device_copy(int device, const dcx_fk_desc& fk, FkProg** out) {
 // path calls getenv.  -1 = "use the rule".
 struct Knobs {
     std::atomic<int64_t> ys{-1}, nw{-1}, min_rows{-1}, split_finish_kernel{-1}, inlaunch_tiles{-1}, jac_per_class{-1},
-        mfma{-1}, traj_fused{-1}, xf{-1}, mt{-1}, prio{-1}, jac_one_sweep{-1}, train_grid{-1}, fkk{-1};
+        mfma{-1}, traj_fused{-1}, xf{-1}, jac_one_sweep{-1}, train_grid{-1}, fkk{-1}, jt_waves{-1};
     Knobs() {
         auto rd = [](const char* name, std::atomic<int64_t>& dst, bool flag) {
             if (const char* e = std::getenv(name)) dst = flag ? 1 : std::atoll(e);
@@ -244,11 +247,10 @@ struct Knobs {
         rd("DCX_MFMA", mfma, false);
         rd("DCX_TRAJ_FUSED", traj_fused, false);
         rd("DCX_XF", xf, false);
-        rd("DCX_MT", mt, false);
-        rd("DCX_PRIO", prio, false);
         rd("DCX_JAC_ONE_SWEEP", jac_one_sweep, false);
         rd("DCX_TRAIN_GRID", train_grid, false);
         rd("DCX_FKK", fkk, false);
+        rd("DCX_JT_WAVES", jt_waves, false);
     }
 };
 Knobs& knobs() {
@@ -360,6 +362,19 @@ float* split_scratch(const dcx_model* m, hipStream_t st, size_t bytes) {
     return p;
 }
 
+// Which FK walk a launch of this model uses (fk_device.h FkWalk).  DH arms: the step table where the model has one, else
+// the FkProg through scalar loads; knob fkk = 0 / 1 / 2 forces a walk for tests (0: the LDS walks every other kind uses).
+void set_fk_walk(const dcx_model* m, ScoreArgs& a) {
+    a.fk = m->fk_dev;
+    a.fk_dwords = m->fk_dwords;
+    a.dh = m->dh;
+    a.fkk = 0;
+    if (m->fk.kind == DCX_FK_DH) {
+        const int64_t k = knobs().fkk;
+        a.fkk = (k == 0) ? 0 : (k == 1) ? 1 : (m->dh_dev ? 2 : 1);
+    }
+}
+
 struct Hinge {
     int on = 0;
     float margin = 0.f, weight = 0.f;
@@ -395,7 +410,7 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
     if (nblk > 0x7fffffffLL) return fail(DCX_ERR_UNSUPPORTED, "batch too large for one launch");
     ScoreArgs a{};
     a.rows = m->rows_dev;
-    a.fk = m->fk_dev;
+    set_fk_walk(m, a);
     a.q = q;
     a.upstream = upstream;
     a.score = score;
@@ -418,9 +433,6 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
     a.hinge = hinge.on;
     a.hinge_margin = hinge.margin;
     a.hinge_weight = hinge.weight;
-    a.prio = knobs().prio > 0 ? 1 : 0;
-    // DH arms: the lone-wave FK walks read the program with scalar loads (fk_device.h fk_*_dh_k); knob fkk = 0: from LDS
-    a.fkk = (m->fk.kind == DCX_FK_DH && knobs().fkk != 0) ? 1 : 0;
     // Expanded form of the sweep (score_kernel.h XF) wherever it is compiled (Polyharmonic(1), rows <= 37 floats): 13-17 %
     // faster for chip-filling batches, 1-3 % for split launches (profiles/r02_xf_probe.txt).  Knob xf = 0: direct form.
     a.xf = knobs().xf != 0 ? 1 : 0;
@@ -429,28 +441,18 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
     a.mfma = (mode != MODE_SCORE && m->Dt <= 16 && (m->Dt % 2) == 0 && m->kf != KF_GEN && g.nw > 1 && g.red_slots == g.nw &&
               knobs().mfma != 0 && knobs().mfma > 0) ? 1 : 0;
     if (a.mfma) a.xf = 0;
+    // J^T on several waves (fk_device.h dh2_vjp_waves): the step table, a parallel fold (its scratch rows 1 .. nw-1 hold 12
+    // columns per point step), and not the finish-kernel mode.  Knob jt_waves = 0: wave 0 alone (tests: identical bits).
+    a.jt_waves = (a.fkk == 2 && mode != MODE_SCORE && g.nw > 1 && g.red_slots == g.nw && (g.nw - 1) * acc >= 12 * m->dh.n_pt &&
+                  (g.ys == 1 || counters != nullptr) && knobs().jt_waves != 0) ? 1 : 0;
 #ifdef DCX_TIMING
-    if (!g_ts_dev && hipMalloc((void**)&g_ts_dev, sizeof(unsigned long long) * 16 * 8) == hipSuccess)
-        (void)hipMemset(g_ts_dev, 0, sizeof(unsigned long long) * 16 * 8);
+    if (!g_ts_dev && hipMalloc((void**)&g_ts_dev, sizeof(unsigned long long) * 32 * 16) == hipSuccess)
+        (void)hipMemset(g_ts_dev, 0, sizeof(unsigned long long) * 32 * 16);
     a.ts = g_ts_dev;
     a.ts_block = std::getenv("DCX_TS_BLOCK") ? (unsigned)std::atoi(std::getenv("DCX_TS_BLOCK")) : 0u;
 #endif
     size_t lds = sizeof(float) * (lds_plan(a.dof, d_fk, m->frame_floats, g.nw > 1 ? g.red_slots : 0, acc, true).total + m->prog_floats);
     if (g.ys == 1) {
-        // Several tiles per block (score_kernel_mt): built, bit-identical, and SLOWER than one tile per block at every
-        // batch (B = 65536: 104.4 -> 107.7 us, B = 1 M: 1320 -> 1426 us, profiles/r02_mt_probe.txt), so it is only
-        // compiled with EXTRA=-DDCX_WITH_MT and only taken when the developer knob asks for it.
-        int mt = 1;
-#ifdef DCX_WITH_MT
-        if (const int64_t v = knobs().mt; v >= 0) mt = (int)std::min<int64_t>(std::max<int64_t>(v, 1), kMtMaxTiles);
-#endif
-        if (mt >= 2 && nz == 1 && !a.mfma && g.red_slots == g.nw && g.nw >= mt && m->Dt <= kMtMaxD) {
-            const size_t lds_mt = sizeof(float) * (lds_plan_mt(a.dof, d_fk, m->frame_floats, g.nw, acc, mt).total + m->prog_floats);
-            if (lds_mt <= 80 * 1024) {
-                a.mt = mt;
-                lds = lds_mt;
-            }
-        }
         hipError_t e = m->launch(m->kf, m->C, mode, g.nw, lds, nblk, a, st);
         if (e != hipSuccess) return fail_hip(e, "score kernel launch");
         return DCX_OK;
@@ -494,7 +496,7 @@ extern "C" {
 int dcx_debug_read_ts(unsigned long long* out) {  // developer builds only
     if (!g_ts_dev) return 1;
     (void)hipDeviceSynchronize();
-    return hipMemcpy(out, g_ts_dev, sizeof(unsigned long long) * 16 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 3;
+    return hipMemcpy(out, g_ts_dev, sizeof(unsigned long long) * 32 * 16, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 3;
 }
 #endif
 
@@ -506,11 +508,8 @@ int dcx_debug_set(const char* name, int64_t value) {
     const std::string n(name);
     std::atomic<int64_t>* dst = n == "ys" ? &k.ys : n == "nw" ? &k.nw : n == "min_rows" ? &k.min_rows
         : n == "split_finish_kernel" ? &k.split_finish_kernel : n == "inlaunch_tiles" ? &k.inlaunch_tiles
-        : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : n == "traj_fused" ? &k.traj_fused : n == "xf" ? &k.xf : n == "mt" ? &k.mt : n == "prio" ? &k.prio : n == "jac_one_sweep" ? &k.jac_one_sweep : n == "train_grid" ? &k.train_grid : n == "fkk" ? &k.fkk : nullptr;
+        : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : n == "traj_fused" ? &k.traj_fused : n == "xf" ? &k.xf : n == "jac_one_sweep" ? &k.jac_one_sweep : n == "train_grid" ? &k.train_grid : n == "fkk" ? &k.fkk : n == "jt_waves" ? &k.jt_waves : nullptr;
     if (!dst) return fail(DCX_ERR_INVALID, "unknown knob: " + n);
-#ifndef DCX_WITH_MT
-    if (dst == &k.mt && value >= 2) return fail(DCX_ERR_UNSUPPORTED, "this libdcx was built without score_kernel_mt (EXTRA=-DDCX_WITH_MT)");
-#endif
     *dst = value;
     return DCX_OK;
 }
@@ -612,6 +611,21 @@ int dcx_model_create(dcx_model** out, int device, const dcx_fk_desc* fk, int ker
         dcx_model_destroy(m);
         return rc;
     }
+    {
+        FkProg prog;
+        build_fk_prog(m->fk, prog);
+        m->fk_dwords = prog.n_dwords;
+        DhProg dh;
+        if (build_dh_prog(m->fk, dh)) {
+            hipError_t de = hipMalloc((void**)&m->dh_dev, sizeof(DhProg));
+            if (de == hipSuccess) de = hipMemcpy(m->dh_dev, &dh, sizeof(DhProg), hipMemcpyHostToDevice);
+            if (de != hipSuccess) {
+                dcx_model_destroy(m);
+                return fail_hip(de, "upload of the DH step table");
+            }
+            m->dh = dh_args_of(dh, m->dh_dev);
+        }
+    }
     hipError_t e = hipSuccess;
     if (kept > 0) {
         rows.resize(rows.size() + 8 * (size_t)m->RS + 16, 0.0f);  // the MFMA B-operand loads run up to 7 rows + 15 floats ahead
@@ -630,6 +644,7 @@ void dcx_model_destroy(dcx_model* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
     if (m->fk_dev) (void)hipFree(m->fk_dev);
+    if (m->dh_dev) (void)hipFree(m->dh_dev);
     if (m->rows_dev) (void)hipFree(m->rows_dev);
     for (auto& sc : m->scratch)
         if (sc.ptr) (void)hipFree(sc.ptr);
@@ -728,8 +743,7 @@ int dcx_score_jac(const dcx_model* m, const float* q, int64_t B, float* score, f
         while (nw > 1 && m->S_active / nw < min_rows) nw /= 2;
         ScoreArgs a{};
         a.rows = m->rows_dev;
-        a.fk = m->fk_dev;
-        a.fkk = (m->fk.kind == DCX_FK_DH && knobs().fkk != 0) ? 1 : 0;
+        set_fk_walk(m, a);
         a.q = q;
         a.score = score;
         a.grad = jac;
@@ -815,8 +829,7 @@ int dcx_traj_adam_run(const dcx_model* m, const dcx_traj_state* st, const dcx_tr
         if (fn && lds_of(nw) <= 150 * 1024) {
             TrajFusedArgs a{};
             a.sc.rows = m->rows_dev;
-            a.sc.fk = m->fk_dev;
-            a.sc.fkk = (m->fk.kind == DCX_FK_DH && knobs().fkk != 0) ? 1 : 0;
+            set_fk_walk(m, a.sc);
             a.sc.S = m->S_active;
             a.sc.s_chunk = (m->S_active + nw - 1) / nw;
             a.sc.dof = m->fk.dof;

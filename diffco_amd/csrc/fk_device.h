@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
+#include <type_traits>
 #include "../../include/dcx.h"
 
 namespace dcx {
@@ -303,12 +304,124 @@ inline void build_fk_prog(const dcx_fk_desc& fk, FkProg& p) {
     p.n_joints = nj;
 }
 
+
+// ---- DCX_FK_DH as a STEP TABLE (round 3; the fused kernels' default walk for DH arms, ScoreArgs::fkk == 2) --------------
+// The walks above interpret FkProg: per joint a record fetched through the scalar cache (fk_*_dh_k) or LDS -> VGPR ->
+// v_readfirstlane (fk_forward_chain / fk_vjp), loop bounds for the joint's points, flags.  On the lone wave that runs the
+// chain and J^T of a block every one of those is a dependent round trip: a scalar load and an LDS read share lgkmcnt and
+// scalar loads return out of order, so each joint's `s_waitcnt lgkmcnt(0)` waited for the NEXT joint's record as well
+// (profiles/r02_phase_fkk.txt: 480-560 cycles per joint for 30 FMAs, 560-920 in the reverse sweep).
+// Here the host flattens the robot into at most 32 STEPS of one shape - "compose one DH joint, then place at most one
+// control point" - 12 dwords each:
+//   * a joint with several control points becomes the joint plus identity steps (theta = a = d = alpha = 0, exact in fp32)
+//     that carry the further points, ordered so that the reverse sweep adds the points of a frame in the old order;
+//   * everything that steers control flow is a KERNEL ARGUMENT (step counts per chain, bit masks "step has a point",
+//     "point sits at the frame origin", "step is a real joint"): SGPRs from the first instruction on, tested with
+//     s_bitcmp - no load, no v_readfirstlane;
+//   * everything else (DH constants, point offset, feature column, q index) is read from the LDS copy of the table at a
+//     wave-uniform address straight into VGPRs, where the VALU wants its operands, one step AHEAD of its use; with no
+//     scalar load in flight the LDS counter is in order and the waits are exact.
+// Same expressions in the same order as the walks above: bit-identical results (tests/test_gpu_parity.py).
+constexpr int kMaxDhSteps = 32;
+struct alignas(16) DhStep {  // 12 dwords
+    float a, d, sa, ca;
+    float ox, oy, oz;
+    int32_t meta;     // feature column of the point's x (bits 0-7) | q index (8-15) | feature column of step j-1's point (16-23)
+    float theta0;
+    int32_t pad[3];
+};
+struct alignas(16) DhProg {
+    int32_t n_chains, n_steps, end0, n_dwords;  // chain 0 = steps [0, end0), chain 1 = [end0, n_steps)
+    uint32_t pt_mask, bare_mask, real_mask;
+    int32_t n_pt;                               // steps that carry a control point ("point steps", numbered in step order)
+    float base[DCX_MAX_CHAINS][12];
+    int32_t ps_col[kMaxDhSteps];                // feature column of point step ps (the several-wave J^T, dh2_vjp_waves)
+    DhStep steps[kMaxDhSteps];
+};
+struct DhArgs {  // the part of the table that travels as kernel arguments
+    const DhProg* prog;  // device copy; null: this model has no step table (not DCX_FK_DH, or more than kMaxDhSteps steps)
+    int32_t n_dwords, n_steps, end0, n_chains;
+    uint32_t pt, bare, real;
+    int32_t n_pt;
+};
+inline int dh_step_count(const dcx_fk_desc& fk) {
+    if (fk.kind != DCX_FK_DH) return 0;
+    int steps = 0;
+    for (int c = 0; c < fk.n_chains; ++c)
+        for (int i = 0; i < fk.chain_len[c]; ++i) {
+            int pts = 0;
+            for (int k = 0; k < fk.n_points; ++k) pts += (fk.pt_chain[k] == c && fk.pt_frame[k] == i);
+            steps += pts > 1 ? pts : 1;
+        }
+    return steps;
+}
+// host: description -> step table; false when the robot does not fit (the fused kernels then keep the FkProg walks)
+inline bool build_dh_prog(const dcx_fk_desc& fk, DhProg& p) {
+    memset(&p, 0, sizeof(p));
+    if (fk.kind != DCX_FK_DH || dh_step_count(fk) > kMaxDhSteps || fk.n_points * 3 > 255 || fk.dof > 255) return false;
+    p.n_chains = fk.n_chains;
+    int ns = 0;
+    for (int c = 0; c < fk.n_chains; ++c) {
+        for (int e = 0; e < 12; ++e) p.base[c][e] = fk.base[c][e];
+        for (int i = 0; i < fk.chain_len[c]; ++i) {
+            int pts[DCX_MAX_POINTS], np = 0;
+            for (int k = 0; k < fk.n_points; ++k)
+                if (fk.pt_chain[k] == c && fk.pt_frame[k] == i) pts[np++] = k;
+            // the joint carries the frame's LAST point, identity steps the earlier ones in descending order: the reverse
+            // sweep (steps in descending order) then meets them as points[pt_begin], points[pt_begin + 1], ... like fk_vjp
+            const int n_here = np > 1 ? np : 1;
+            for (int u = 0; u < n_here; ++u, ++ns) {
+                DhStep& st = p.steps[ns];
+                const bool real = (u == 0);
+                st.a = real ? fk.a[c][i] : 0.0f;
+                st.d = real ? fk.d[c][i] : 0.0f;
+                st.sa = real ? fk.sin_alpha[c][i] : 0.0f;
+                st.ca = real ? fk.cos_alpha[c][i] : 1.0f;
+                st.theta0 = real ? fk.theta0[c][i] : 0.0f;
+                int col = 0;
+                if (np > 0) {
+                    const int k = pts[np - 1 - u];
+                    st.ox = fk.pt_off[k][0];
+                    st.oy = fk.pt_off[k][1];
+                    st.oz = fk.pt_off[k][2];
+                    col = 3 * k;
+                    p.ps_col[p.n_pt++] = col;
+                    p.pt_mask |= 1u << ns;
+                    if (st.ox == 0.0f && st.oy == 0.0f && st.oz == 0.0f) p.bare_mask |= 1u << ns;
+                }
+                if (real) p.real_mask |= 1u << ns;
+                st.meta = col | (fk.joint_q[c][i] << 8);
+            }
+        }
+        if (c == 0) p.end0 = ns;
+    }
+    p.n_steps = ns;
+    if (fk.n_chains == 1) p.end0 = ns;
+    for (int j = 1; j < ns; ++j) p.steps[j].meta |= (p.steps[j - 1].meta & 0xff) << 16;
+    p.n_dwords = (int)(offsetof(DhProg, steps) / 4) + 12 * ns;
+    return true;
+}
+inline DhArgs dh_args_of(const DhProg& p, const DhProg* dev) {
+    DhArgs a;
+    a.prog = dev;
+    a.n_dwords = p.n_dwords;
+    a.n_steps = p.n_steps;
+    a.end0 = p.end0;
+    a.n_chains = p.n_chains;
+    a.pt = p.pt_mask;
+    a.bare = p.bare_mask;
+    a.real = p.real_mask;
+    a.n_pt = p.n_pt;
+    return a;
+}
+
 // LDS floats per lane the FK needs for its frames.
 inline int fk_frame_floats(const dcx_fk_desc& fk) {
     if (fk.kind == DCX_FK_DH) {
         int j = 0;
         for (int c = 0; c < fk.n_chains; ++c) j += fk.chain_len[c];
-        return 2 * j + 9 * fk.n_chains;
+        const int steps = dh_step_count(fk);  // the step-table walks keep (sin, cos) per step
+        return 2 * (steps > j ? steps : j) + 9 * fk.n_chains;
     }
     if (fk.kind == DCX_FK_PLANAR) return 2 * fk.dof;
     if (fk.kind == DCX_FK_TREE) {
@@ -326,7 +439,7 @@ typedef const __attribute__((address_space(3))) FkProg* fk_cptr;
 static __shared__ unsigned long long* dcx_fk_ts;
 #define DCX_FK_TS(slot, col)                                                                     \
     do {                                                                                         \
-        if (dcx_fk_ts && (threadIdx.x & 63) == 0) dcx_fk_ts[(slot) * 8 + (col)] = __builtin_readcyclecounter(); \
+        if (dcx_fk_ts && (threadIdx.x & 63) == 0) dcx_fk_ts[(slot) * 16 + (col)] = __builtin_readcyclecounter(); \
     } while (0)
 #else
 #define DCX_FK_TS(slot, col) do { } while (0)
@@ -335,10 +448,11 @@ static __shared__ unsigned long long* dcx_fk_ts;
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // all threads of the block copy the program global -> LDS (coalesced); caller synchronises
-__device__ __forceinline__ fk_cptr stage_fk_prog(const FkProg* g, float* lds, int tid, int nthreads) {
+// n_known > 0: the program's size travels as a kernel argument (no dependent load in front of the copy)
+__device__ __forceinline__ fk_cptr stage_fk_prog(const FkProg* g, float* lds, int tid, int nthreads, int n_known = 0) {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(g);
     uint32_t* dst = reinterpret_cast<uint32_t*>(lds);
-    const int n = rfl(g->n_dwords);
+    const int n = n_known > 0 ? n_known : rfl(g->n_dwords);
     for (int i = tid; i < n; i += nthreads) dst[i] = src[i];
 #ifdef DCX_TIMING
     if (tid == 0) dcx_fk_ts = nullptr;  // the fused kernel points it at its stamp buffer afterwards
@@ -1176,17 +1290,546 @@ __device__ inline void fk_vjp(fk_cptr fk, const T* sQrow, const T* sFcol, const 
     }
 }
 
-// the chain / J^T of one wave, by whichever walk the launch selected (fkk: scalar-load walks, DCX_FK_DH only)
-template <class T>
-__device__ __forceinline__ void fk_chain_sel(int fkk, const FkProg* gfk, fk_cptr fk, const T* sQrow, T* sXcol, T* sFcol) {
-    if (fkk) fk_forward_chain_dh_k((fk_kptr)(uintptr_t)gfk, sXcol, sFcol);
-    else fk_forward_chain(fk, sQrow, sXcol, sFcol);
+// ---- the step-table walks (device) ------------------------------------------------------------------------------------
+typedef const __attribute__((address_space(3))) DhProg* dh_cptr;
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) f4v* lds_f4;
+
+// all threads of the block copy the used part of the table global -> LDS, 16 bytes per thread; caller synchronises
+__device__ __forceinline__ dh_cptr stage_dh_prog(const DhArgs& c, float* lds, int tid, int nthreads) {
+    const f4v* src = reinterpret_cast<const f4v*>(c.prog);
+    f4v* dst = reinterpret_cast<f4v*>(lds);
+    const int n = c.n_dwords >> 2;
+    for (int i = tid; i < n; i += nthreads) dst[i] = src[i];
+    return (dh_cptr)(uintptr_t)(uint32_t)(uintptr_t)lds;
 }
-template <class T>
-__device__ __forceinline__ void fk_vjp_sel(int fkk, const FkProg* gfk, fk_cptr fk, const T* sQrow, const T* sFcol, const T* sGcol,
-                                           T* gqRow) {
-    if (fkk) fk_vjp_dh_k((fk_kptr)(uintptr_t)gfk, sFcol, sGcol, gqRow);
-    else fk_vjp(fk, sQrow, sFcol, sGcol, gqRow);
+__device__ __forceinline__ bool dh_bit(uint32_t mask, int j) { return (mask >> j) & 1u; }
+
+// sin / cos per step (every wave of the block: wave w takes steps w, w + nw, ...); identity steps get (0, 1)
+__device__ inline void dh2_trig(dh_cptr p, const DhArgs& c, const float* sQrow, float* sFcol, int wave, int nw) {
+    for (int j = wave; j < c.n_steps; j += nw) {
+        float s = 0.0f, co = 1.0f;
+        if (dh_bit(c.real, j)) {
+            const int qi = (p->steps[j].meta >> 8) & 0xff;
+            sincos_f32(sQrow[qi] + p->steps[j].theta0, &s, &co);
+        }
+        sFcol[(2 * j) * 64] = s;
+        sFcol[(2 * j + 1) * 64] = co;
+    }
+}
+
+// chain composition (one wave): T <- T * Rz(theta) * Trans(a, 0, d) * Rx(alpha) per step, the step's control point out
+__device__ inline void dh2_chain(dh_cptr p, const DhArgs& c, float* sXcol, float* sFcol) {
+    int jb = 0;
+    for (int ch = 0; ch < c.n_chains; ++ch) {
+        const int je = ch == 0 ? c.end0 : c.n_steps;
+        const f4v b0 = *(lds_f4)&p->base[ch][0], b1 = *(lds_f4)&p->base[ch][4], b2 = *(lds_f4)&p->base[ch][8];
+        float r00 = b0.x, r01 = b0.y, r02 = b0.z, t0 = b0.w;
+        float r10 = b1.x, r11 = b1.y, r12 = b1.z, t1 = b1.w;
+        float r20 = b2.x, r21 = b2.y, r22 = b2.z, t2 = b2.w;
+        f4v nk = *(lds_f4)&p->steps[jb].a, no = *(lds_f4)&p->steps[jb].ox;
+        float ns = sFcol[(2 * jb) * 64], nc = sFcol[(2 * jb + 1) * 64];
+        for (int j = jb; j < je; ++j) {
+            const f4v k = nk, o = no;
+            const float s = ns, co = nc;
+            const int jn = j + 1 < je ? j + 1 : j;  // the next step's operands are requested before this one is composed
+            nk = *(lds_f4)&p->steps[jn].a;
+            no = *(lds_f4)&p->steps[jn].ox;
+            ns = sFcol[(2 * jn) * 64];
+            nc = sFcol[(2 * jn + 1) * 64];
+            const float a = k.x, d = k.y, sa = k.z, ca = k.w;
+            const float n00 = fmaf(r00, co, r01 * s), n10 = fmaf(r10, co, r11 * s), n20 = fmaf(r20, co, r21 * s);
+            const float u0 = fmaf(r01, co, -(r00 * s)), u1 = fmaf(r11, co, -(r10 * s)), u2 = fmaf(r21, co, -(r20 * s));
+            t0 = fmaf(n00, a, fmaf(r02, d, t0));
+            t1 = fmaf(n10, a, fmaf(r12, d, t1));
+            t2 = fmaf(n20, a, fmaf(r22, d, t2));
+            const float n01 = fmaf(u0, ca, r02 * sa), n11 = fmaf(u1, ca, r12 * sa), n21 = fmaf(u2, ca, r22 * sa);
+            const float n02 = fmaf(r02, ca, -(u0 * sa)), n12 = fmaf(r12, ca, -(u1 * sa)), n22 = fmaf(r22, ca, -(u2 * sa));
+            r00 = n00; r01 = n01; r02 = n02; r10 = n10; r11 = n11; r12 = n12; r20 = n20; r21 = n21; r22 = n22;
+            if (dh_bit(c.pt, j)) {
+                float* out = sXcol + (__float_as_int(o.w) & 0xff) * 64;
+                if (dh_bit(c.bare, j)) {
+                    out[0] = t0; out[64] = t1; out[128] = t2;
+                } else {
+                    out[0] = fmaf(r00, o.x, fmaf(r01, o.y, fmaf(r02, o.z, t0)));
+                    out[64] = fmaf(r10, o.x, fmaf(r11, o.y, fmaf(r12, o.z, t1)));
+                    out[128] = fmaf(r20, o.x, fmaf(r21, o.y, fmaf(r22, o.z, t2)));
+                }
+            }
+            DCX_FK_TS(7 + (j < 8 ? j : 8), 0);
+        }
+        float* fr = sFcol + (2 * c.n_steps + 9 * ch) * 64;  // final rotation of this chain (for the reverse sweep)
+        fr[0] = r00; fr[64] = r01; fr[128] = r02; fr[192] = r10; fr[256] = r11; fr[320] = r12;
+        fr[384] = r20; fr[448] = r21; fr[512] = r22;
+        jb = je;
+    }
+}
+
+// J^T (one wave): the reverse sweep of a wrench of fk_vjp (see there), step by step from the tip of each chain
+__device__ inline void dh2_vjp(dh_cptr p, const DhArgs& c, const float* sFcol, const float* sGcol, float* gqRow, int dof) {
+    for (int i = 0; i < dof; ++i) gqRow[i] = 0.f;
+    int jb = 0;
+    for (int ch = 0; ch < c.n_chains; ++ch) {
+        const int je = ch == 0 ? c.end0 : c.n_steps;
+        const float* fr = sFcol + (2 * c.n_steps + 9 * ch) * 64;
+        float r00 = fr[0], r01 = fr[64], r02 = fr[128], r10 = fr[192], r11 = fr[256], r12 = fr[320];
+        float r20 = fr[384], r21 = fr[448], r22 = fr[512];
+        float f0 = 0.f, f1 = 0.f, f2 = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
+        const int jl = je - 1;
+        f4v nk = *(lds_f4)&p->steps[jl].a, no = *(lds_f4)&p->steps[jl].ox;
+        float ns = sFcol[(2 * jl) * 64], nc = sFcol[(2 * jl + 1) * 64];
+        float ng0 = 0.f, ng1 = 0.f, ng2 = 0.f;
+        if (dh_bit(c.pt, jl)) {
+            const float* gin = sGcol + (__float_as_int(no.w) & 0xff) * 64;
+            ng0 = gin[0]; ng1 = gin[64]; ng2 = gin[128];
+        }
+        for (int j = jl; j >= jb; --j) {
+            const f4v k = nk, o = no;
+            const float s = ns, co = nc, g0 = ng0, g1 = ng1, g2 = ng2;
+            const int meta = __float_as_int(o.w);
+            if (j > jb) {  // step j - 1's operands, its point's upstream gradient included, are requested now
+                const int jn = j - 1;
+                nk = *(lds_f4)&p->steps[jn].a;
+                no = *(lds_f4)&p->steps[jn].ox;
+                ns = sFcol[(2 * jn) * 64];
+                nc = sFcol[(2 * jn + 1) * 64];
+                if (dh_bit(c.pt, jn)) {
+                    const float* gin = sGcol + ((meta >> 16) & 0xff) * 64;
+                    ng0 = gin[0]; ng1 = gin[64]; ng2 = gin[128];
+                }
+            }
+            if (dh_bit(c.pt, j)) {
+                const float l0 = fmaf(r00, g0, fmaf(r10, g1, r20 * g2));
+                const float l1 = fmaf(r01, g0, fmaf(r11, g1, r21 * g2));
+                const float l2 = fmaf(r02, g0, fmaf(r12, g1, r22 * g2));
+                f0 += l0; f1 += l1; f2 += l2;
+                if (!dh_bit(c.bare, j)) {
+                    n0 = fmaf(o.y, l2, fmaf(-o.z, l1, n0));
+                    n1 = fmaf(o.z, l0, fmaf(-o.x, l2, n1));
+                    n2 = fmaf(o.x, l1, fmaf(-o.y, l0, n2));
+                }
+            }
+            const float a = k.x, d = k.y, sa = k.z, ca = k.w;
+            const float fy = fmaf(ca, f1, -(sa * f2)), fz = fmaf(sa, f1, ca * f2);
+            const float mx = fmaf(-d, fy, n0);
+            const float my = fmaf(d, f0, fmaf(-a, fz, fmaf(ca, n1, -(sa * n2))));
+            const float mz = fmaf(a, fy, fmaf(sa, n1, ca * n2));
+            if (dh_bit(c.real, j)) gqRow[(meta >> 8) & 0xff] += mz;
+            if (j > jb) {
+                f1 = fmaf(s, f0, co * fy);
+                f0 = fmaf(co, f0, -(s * fy));
+                f2 = fz;
+                n0 = fmaf(co, mx, -(s * my));
+                n1 = fmaf(s, mx, co * my);
+                n2 = mz;
+                const float u0 = fmaf(ca, r01, -(sa * r02)), u1 = fmaf(ca, r11, -(sa * r12)), u2 = fmaf(ca, r21, -(sa * r22));
+                r02 = fmaf(sa, r01, ca * r02); r12 = fmaf(sa, r11, ca * r12); r22 = fmaf(sa, r21, ca * r22);
+                r01 = fmaf(s, r00, co * u0); r11 = fmaf(s, r10, co * u1); r21 = fmaf(s, r20, co * u2);
+                r00 = fmaf(co, r00, -(s * u0)); r10 = fmaf(co, r10, -(s * u1)); r20 = fmaf(co, r20, -(s * u2));
+            }
+            DCX_FK_TS(7 + (j < 8 ? j : 8), 1);
+        }
+        jb = je;
+    }
+}
+
+// ---- the step-table walks on SEVERAL waves (round 3) --------------------------------------------------------------------
+// A lone wave issues one instruction per ~5.5 cycles however simple (independent v_fma_f32; ~10 when dependent; an LDS
+// round trip 66, a taken branch ~30: tools/lone_wave_ubench.hip, profiles/r03_lone_wave.txt), so the chain and J^T phases
+// are priced by the instructions ONE wave executes, not by flops.  Under T <- T * A the rows of [R | t] never mix: the
+// chain is split by rows over two waves - role 0 carries rows 0 and 1 as PACKED pairs (v_pk_fma_f32: two rows for the
+// issue slots of one), role 1 carries row 2 - ten arithmetic instructions per step and wave instead of thirty.  Same
+// expressions per entry as dh2_chain (v_pk_fma_f32 is fmaf per half): bit-identical.
+template <class V>
+__device__ __forceinline__ V dh_splat(float x) {
+    if constexpr (__is_same(V, float)) return x;
+    else return V{x, x};
+}
+// Scalar results are made opaque to the optimiser where they are produced: the SLP vectoriser otherwise pairs the row-2 /
+// wrench arithmetic into v_pk_* with a v_mov per operand half (+8 instructions per step on the wave that can least afford
+// them), while the rest of the translation unit - the C > 1 sweeps - gains from it (profiles/r03_dev_d_bench.txt).
+__device__ __forceinline__ float dh_opaque(float x) {
+    asm("" : "+v"(x));
+    return x;
+}
+template <class V>
+__device__ __forceinline__ V dh_fma(V a, V b, V c) {
+    if constexpr (__is_same(V, float)) return dh_opaque(fmaf(a, b, c));
+    else return __builtin_elementwise_fma(a, b, c);
+}
+// ROLE 0: V = f2v, rows 0 and 1;  ROLE 1: V = float, row 2.  Caller: waves 0 and 1 of the block, then a block barrier.
+template <int ROLE>
+__device__ __forceinline__ void dh2_chain_rows(dh_cptr p, const DhArgs& c, float* sXcol, float* sFcol) {
+    using V = typename std::conditional<ROLE == 0, f2v, float>::type;
+    auto row = [](f4v b0, f4v b1, f4v b2, int k) -> V {  // entry k of this role's rows of the base transform
+        if constexpr (ROLE == 0) return V{b0[k], b1[k]};
+        else return b2[k];
+    };
+    int jb = 0;
+    for (int ch = 0; ch < c.n_chains; ++ch) {
+        const int je = ch == 0 ? c.end0 : c.n_steps;
+        const f4v b0 = *(lds_f4)&p->base[ch][0], b1 = *(lds_f4)&p->base[ch][4], b2 = *(lds_f4)&p->base[ch][8];
+        V r0 = row(b0, b1, b2, 0), r1 = row(b0, b1, b2, 1), r2 = row(b0, b1, b2, 2), t = row(b0, b1, b2, 3);
+        f4v nk = *(lds_f4)&p->steps[jb].a, no = *(lds_f4)&p->steps[jb].ox;
+        float ns = sFcol[(2 * jb) * 64], nc = sFcol[(2 * jb + 1) * 64];
+        for (int j = jb; j < je; ++j) {
+            const f4v k = nk, o = no;
+            const V s = dh_splat<V>(ns), co = dh_splat<V>(nc);
+            const int jn = j + 1 < je ? j + 1 : j;
+            nk = *(lds_f4)&p->steps[jn].a;
+            no = *(lds_f4)&p->steps[jn].ox;
+            ns = sFcol[(2 * jn) * 64];
+            nc = sFcol[(2 * jn + 1) * 64];
+            const V a = dh_splat<V>(k.x), d = dh_splat<V>(k.y), sa = dh_splat<V>(k.z), ca = dh_splat<V>(k.w);
+            const V n0 = dh_fma<V>(r0, co, r1 * s);
+            const V u = dh_fma<V>(r1, co, -(r0 * s));
+            t = dh_fma<V>(n0, a, dh_fma<V>(r2, d, t));
+            const V n1 = dh_fma<V>(u, ca, r2 * sa);
+            const V n2 = dh_fma<V>(r2, ca, -(u * sa));
+            r0 = n0; r1 = n1; r2 = n2;
+            if (dh_bit(c.pt, j)) {
+                V pt = t;
+                if (!dh_bit(c.bare, j)) pt = dh_fma<V>(r0, dh_splat<V>(o.x), dh_fma<V>(r1, dh_splat<V>(o.y), dh_fma<V>(r2, dh_splat<V>(o.z), t)));
+                float* out = sXcol + (__float_as_int(o.w) & 0xff) * 64;
+                if constexpr (ROLE == 0) { out[0] = pt.x; out[64] = pt.y; }
+                else out[128] = pt;
+            }
+        }
+        float* fr = sFcol + (2 * c.n_steps + 9 * ch) * 64;  // final rotation of this chain, this role's rows
+        if constexpr (ROLE == 0) {
+            fr[0] = r0.x; fr[64] = r1.x; fr[128] = r2.x; fr[192] = r0.y; fr[256] = r1.y; fr[320] = r2.y;
+        } else {
+            fr[384] = r0; fr[448] = r1; fr[512] = r2;
+        }
+        jb = je;
+    }
+}
+
+// ---- the same walks UNROLLED for one chain of at most kDhUnroll steps (every single arm the reference ships) ---------------
+// The loops above still spend three instructions of bookkeeping (register rotation of the prefetched operands, table
+// address arithmetic, loop control) for every one of arithmetic.  With the step index a compile-time constant the table
+// reads become immediate offsets, the masks are tested with s_bitcmp on an immediate bit, and nothing rotates.  Steps
+// past n_steps are skipped by one scalar compare each.  Same expressions, same order: bit-identical to the loops.
+constexpr int kDhUnroll = 8;
+template <int I, int N, class F>
+__device__ __forceinline__ void dh_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        dh_static_for<I + 1, N>(f);
+    }
+}
+__device__ __forceinline__ bool dh2_unrollable(const DhArgs& c) { return c.n_chains == 1 && c.n_steps <= kDhUnroll; }
+
+// one step's operands, requested one step ahead of their use, unconditionally (reads past n_steps stay inside the staged
+// table's LDS allocation and inside the frames: the values are never used)
+struct DhOps {
+    f4v k, o;
+    float s, co;
+};
+template <bool WITH_O>
+__device__ __forceinline__ DhOps dh_load_ops(dh_cptr p, const float* sFcol, int j) {
+    DhOps r;
+    r.k = *(lds_f4)&p->steps[j].a;
+    if constexpr (WITH_O) r.o = *(lds_f4)&p->steps[j].ox;
+    r.s = sFcol[(2 * j) * 64];
+    r.co = sFcol[(2 * j + 1) * 64];
+    return r;
+}
+
+template <int ROLE>
+__device__ __forceinline__ void dh2_chain_rows_u(dh_cptr p, const DhArgs& c, float* sXcol, float* sFcol) {
+    using V = typename std::conditional<ROLE == 0, f2v, float>::type;
+    const f4v b0 = *(lds_f4)&p->base[0][0], b1 = *(lds_f4)&p->base[0][4], b2 = *(lds_f4)&p->base[0][8];
+    V r0, r1, r2, t;
+    if constexpr (ROLE == 0) { r0 = V{b0.x, b1.x}; r1 = V{b0.y, b1.y}; r2 = V{b0.z, b1.z}; t = V{b0.w, b1.w}; }
+    else { r0 = b2.x; r1 = b2.y; r2 = b2.z; t = b2.w; }
+    DhOps nx = dh_load_ops<true>(p, sFcol, 0);
+    dh_static_for<0, kDhUnroll>([&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        const DhOps cu = nx;
+        if constexpr (j + 1 < kDhUnroll) nx = dh_load_ops<true>(p, sFcol, j + 1);
+        if (j < c.n_steps) {
+            const V s = dh_splat<V>(cu.s), co = dh_splat<V>(cu.co);
+            const V a = dh_splat<V>(cu.k.x), d = dh_splat<V>(cu.k.y), sa = dh_splat<V>(cu.k.z), ca = dh_splat<V>(cu.k.w);
+            const V n0 = dh_fma<V>(r0, co, r1 * s);
+            const V u = dh_fma<V>(r1, co, -(r0 * s));
+            t = dh_fma<V>(n0, a, dh_fma<V>(r2, d, t));
+            const V n1 = dh_fma<V>(u, ca, r2 * sa);
+            const V n2 = dh_fma<V>(r2, ca, -(u * sa));
+            r0 = n0; r1 = n1; r2 = n2;
+            if (dh_bit(c.pt, j)) {
+                V pt = t;
+                if (!dh_bit(c.bare, j))
+                    pt = dh_fma<V>(r0, dh_splat<V>(cu.o.x), dh_fma<V>(r1, dh_splat<V>(cu.o.y), dh_fma<V>(r2, dh_splat<V>(cu.o.z), t)));
+                float* out = sXcol + (__float_as_int(cu.o.w) & 0xff) * 64;
+                if constexpr (ROLE == 0) { out[0] = pt.x; out[64] = pt.y; }
+                else out[128] = pt;
+            }
+        }
+    });
+    float* fr = sFcol + (2 * c.n_steps) * 64;
+    if constexpr (ROLE == 0) {
+        fr[0] = r0.x; fr[64] = r1.x; fr[128] = r2.x; fr[192] = r0.y; fr[256] = r1.y; fr[320] = r2.y;
+    } else {
+        fr[384] = r0; fr[448] = r1; fr[512] = r2;
+    }
+}
+
+// phase R1 of dh2_vjp_waves, unrolled (steps in descending order; ps = point steps below the current one)
+template <int ROLE>
+__device__ __forceinline__ void dh2_vjp_r1_u(dh_cptr p, const DhArgs& c, const float* sFcol, float* scr) {
+    using V = typename std::conditional<ROLE == 0, f2v, float>::type;
+    const float* fr = sFcol + (2 * c.n_steps) * 64;
+    V r0, r1, r2;
+    if constexpr (ROLE == 0) { r0 = V{fr[0], fr[192]}; r1 = V{fr[64], fr[256]}; r2 = V{fr[128], fr[320]}; }
+    else { r0 = fr[384]; r1 = fr[448]; r2 = fr[512]; }
+    DhOps nx = dh_load_ops<false>(p, sFcol, kDhUnroll - 1);
+    dh_static_for<0, kDhUnroll>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int j = kDhUnroll - 1 - decltype(ic)::value;
+        const DhOps cu = nx;
+        if constexpr (j > 0) nx = dh_load_ops<false>(p, sFcol, j - 1);
+        if (j < c.n_steps) {
+            if (dh_bit(c.pt, j)) {
+                const int ps = __builtin_popcount(c.pt & ((1u << j) - 1u));
+                float* o = scr + (12 * ps) * 64;
+                if constexpr (ROLE == 0) {
+                    o[0] = r0.x; o[64] = r1.x; o[128] = r2.x; o[192] = r0.y; o[256] = r1.y; o[320] = r2.y;
+                } else {
+                    o[384] = r0; o[448] = r1; o[512] = r2;
+                }
+            }
+            if constexpr (j > 0) {
+                const V s = dh_splat<V>(cu.s), co = dh_splat<V>(cu.co);
+                const V sa = dh_splat<V>(cu.k.z), ca = dh_splat<V>(cu.k.w);
+                const V u = dh_fma<V>(ca, r1, -(sa * r2));
+                r2 = dh_fma<V>(sa, r1, ca * r2);
+                r1 = dh_fma<V>(s, r0, co * u);
+                r0 = dh_fma<V>(co, r0, -(s * u));
+            }
+        }
+    });
+}
+
+// phase R2 of dh2_vjp_waves, unrolled (wave 0)
+__device__ __forceinline__ void dh2_vjp_r2_u(dh_cptr p, const DhArgs& c, const float* sFcol, const float* scr, float* gqRow, int dof) {
+    for (int i = 0; i < dof; ++i) gqRow[i] = 0.f;
+    float f0 = 0.f, f1 = 0.f, f2 = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
+    DhOps nx = dh_load_ops<true>(p, sFcol, kDhUnroll - 1);
+    dh_static_for<0, kDhUnroll>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int j = kDhUnroll - 1 - decltype(ic)::value;
+        const DhOps cu = nx;
+        if constexpr (j > 0) nx = dh_load_ops<true>(p, sFcol, j - 1);
+        if (j < c.n_steps) {
+            const float s = cu.s, co = cu.co;
+            const int meta = __float_as_int(cu.o.w);
+            if (dh_bit(c.pt, j)) {
+                const int ps = __builtin_popcount(c.pt & ((1u << j) - 1u));
+                const float* l = scr + (12 * ps + 9) * 64;
+                const float l0 = l[0], l1 = l[64], l2 = l[128];
+                f0 = dh_opaque(f0 + l0); f1 = dh_opaque(f1 + l1); f2 = dh_opaque(f2 + l2);
+                if (!dh_bit(c.bare, j)) {
+                    n0 = dh_opaque(fmaf(cu.o.y, l2, fmaf(-cu.o.z, l1, n0)));
+                    n1 = dh_opaque(fmaf(cu.o.z, l0, fmaf(-cu.o.x, l2, n1)));
+                    n2 = dh_opaque(fmaf(cu.o.x, l1, fmaf(-cu.o.y, l0, n2)));
+                }
+            }
+            const float a = cu.k.x, d = cu.k.y, sa = cu.k.z, ca = cu.k.w;
+            const f2v y1 = {f1, n1}, y2 = {f2, n2}, sa2 = {sa, sa}, ca2 = {ca, ca};
+            const f2v yy = __builtin_elementwise_fma(ca2, y1, -(sa2 * y2));
+            const f2v zz = __builtin_elementwise_fma(sa2, y1, ca2 * y2);
+            const float fy = yy.x, fz = zz.x;
+            const float mx = dh_opaque(fmaf(-d, fy, n0));
+            const float my = dh_opaque(fmaf(d, f0, fmaf(-a, fz, yy.y)));
+            const float mz = dh_opaque(fmaf(a, fy, zz.y));
+            if (dh_bit(c.real, j)) gqRow[(meta >> 8) & 0xff] += mz;
+            if constexpr (j > 0) {
+                const f2v x0 = {f0, mx}, x1 = {fy, my}, s2 = {s, s}, c2 = {co, co};
+                const f2v w1 = __builtin_elementwise_fma(s2, x0, c2 * x1);
+                const f2v w0 = __builtin_elementwise_fma(c2, x0, -(s2 * x1));
+                f0 = w0.x; n0 = w0.y; f1 = w1.x; n1 = w1.y;
+                f2 = fz; n2 = mz;
+            }
+        }
+    });
+}
+
+// J^T on several waves, three phases with block barriers between them (every wave of the block calls this):
+//   R1  (waves 0, 1): the rotations R_j are recomputed from each chain's tip backwards, row-split like the chain above
+//        (R_{j-1} = R_j Rx^T Rz^T row by row), and the rows of every POINT step's R_j are left in `scr`;
+//   R1b (wave ps, ps + nw, ...): l = R_j^T (scale * g) of point step ps - the nine FMAs per point that need the rotation;
+//   R2  (wave 0): the wrench recurrence itself (fk_vjp's expressions), which now only reads l: ~25 instructions per step.
+// scr: 12 columns per point step ([9] rotation, row-major, [3] l), per lane.  sGtot: the UNSCALED feature gradient columns;
+// `scale` is this lane's factor (what the one-wave epilogue multiplies in while staging G).  Bit-identical to dh2_vjp.
+__device__ __forceinline__ void dh2_vjp_waves(dh_cptr p, const DhArgs& c, const float* sFcol, const float* sGtot, float scale,
+                                              float* scr, float* gqRow, int dof, int wave, int nw) {
+    // ---- R1 ----
+    auto r1_rows = [&](auto rolec) __attribute__((always_inline)) {
+        constexpr int ROLE = decltype(rolec)::value;
+        using V = typename std::conditional<ROLE == 0, f2v, float>::type;
+        int jb = 0;
+        for (int ch = 0; ch < c.n_chains; ++ch) {
+            const int je = ch == 0 ? c.end0 : c.n_steps;
+            const float* fr = sFcol + (2 * c.n_steps + 9 * ch) * 64;
+            V r0, r1, r2;
+            if constexpr (ROLE == 0) { r0 = V{fr[0], fr[192]}; r1 = V{fr[64], fr[256]}; r2 = V{fr[128], fr[320]}; }
+            else { r0 = fr[384]; r1 = fr[448]; r2 = fr[512]; }
+            const int jl = je - 1;
+            f4v nk = *(lds_f4)&p->steps[jl].a;
+            float ns = sFcol[(2 * jl) * 64], nc = sFcol[(2 * jl + 1) * 64];
+            int ps = __builtin_popcount(c.pt & ((je >= 32 ? 0u : (1u << je)) - 1u));  // point steps below je
+            for (int j = jl; j >= jb; --j) {
+                const f4v k = nk;
+                const V s = dh_splat<V>(ns), co = dh_splat<V>(nc);
+                if (j > jb) {
+                    nk = *(lds_f4)&p->steps[j - 1].a;
+                    ns = sFcol[(2 * (j - 1)) * 64];
+                    nc = sFcol[(2 * (j - 1) + 1) * 64];
+                }
+                if (dh_bit(c.pt, j)) {
+                    --ps;
+                    float* o = scr + (12 * ps) * 64;
+                    if constexpr (ROLE == 0) {
+                        o[0] = r0.x; o[64] = r1.x; o[128] = r2.x; o[192] = r0.y; o[256] = r1.y; o[320] = r2.y;
+                    } else {
+                        o[384] = r0; o[448] = r1; o[512] = r2;
+                    }
+                }
+                if (j > jb) {
+                    const V sa = dh_splat<V>(k.z), ca = dh_splat<V>(k.w);
+                    const V u = dh_fma<V>(ca, r1, -(sa * r2));
+                    r2 = dh_fma<V>(sa, r1, ca * r2);
+                    r1 = dh_fma<V>(s, r0, co * u);
+                    r0 = dh_fma<V>(co, r0, -(s * u));
+                }
+            }
+            jb = je;
+        }
+    };
+    const bool unrolled = dh2_unrollable(c);
+    if (unrolled) {
+        if (wave == 0) dh2_vjp_r1_u<0>(p, c, sFcol, scr);
+        else if (wave == 1) dh2_vjp_r1_u<1>(p, c, sFcol, scr);
+    } else {
+        if (wave == 0) r1_rows(std::integral_constant<int, 0>{});
+        else if (wave == 1) r1_rows(std::integral_constant<int, 1>{});
+    }
+    __syncthreads();
+    // ---- R1b ----
+    for (int ps = wave; ps < c.n_pt; ps += nw) {
+        const float* R = scr + (12 * ps) * 64;
+        const float* gin = sGtot + p->ps_col[ps] * 64;
+        const float g0 = gin[0] * scale, g1 = gin[64] * scale, g2 = gin[128] * scale;
+        const float r00 = R[0], r01 = R[64], r02 = R[128], r10 = R[192], r11 = R[256], r12 = R[320];
+        const float r20 = R[384], r21 = R[448], r22 = R[512];
+        float* l = scr + (12 * ps + 9) * 64;
+        l[0] = fmaf(r00, g0, fmaf(r10, g1, r20 * g2));
+        l[64] = fmaf(r01, g0, fmaf(r11, g1, r21 * g2));
+        l[128] = fmaf(r02, g0, fmaf(r12, g1, r22 * g2));
+    }
+    __syncthreads();
+    // ---- R2 ----
+    if (wave != 0) return;
+    if (unrolled) {
+        dh2_vjp_r2_u(p, c, sFcol, scr, gqRow, dof);
+        return;
+    }
+    for (int i = 0; i < dof; ++i) gqRow[i] = 0.f;
+    int jb = 0;
+    for (int ch = 0; ch < c.n_chains; ++ch) {
+        const int je = ch == 0 ? c.end0 : c.n_steps;
+        float f0 = 0.f, f1 = 0.f, f2 = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
+        const int jl = je - 1;
+        int ps = __builtin_popcount(c.pt & ((je >= 32 ? 0u : (1u << je)) - 1u));
+        f4v nk = *(lds_f4)&p->steps[jl].a, no = *(lds_f4)&p->steps[jl].ox;
+        float ns = sFcol[(2 * jl) * 64], nc = sFcol[(2 * jl + 1) * 64];
+        float nl0 = 0.f, nl1 = 0.f, nl2 = 0.f;
+        if (dh_bit(c.pt, jl)) {
+            --ps;
+            const float* l = scr + (12 * ps + 9) * 64;
+            nl0 = l[0]; nl1 = l[64]; nl2 = l[128];
+        }
+        for (int j = jl; j >= jb; --j) {
+            const f4v k = nk, o = no;
+            const float s = ns, co = nc, l0 = nl0, l1 = nl1, l2 = nl2;
+            const int meta = __float_as_int(o.w);
+            if (j > jb) {
+                nk = *(lds_f4)&p->steps[j - 1].a;
+                no = *(lds_f4)&p->steps[j - 1].ox;
+                ns = sFcol[(2 * (j - 1)) * 64];
+                nc = sFcol[(2 * (j - 1) + 1) * 64];
+                if (dh_bit(c.pt, j - 1)) {
+                    --ps;
+                    const float* l = scr + (12 * ps + 9) * 64;
+                    nl0 = l[0]; nl1 = l[64]; nl2 = l[128];
+                }
+            }
+            if (dh_bit(c.pt, j)) {
+                f0 += l0; f1 += l1; f2 += l2;
+                if (!dh_bit(c.bare, j)) {
+                    n0 = fmaf(o.y, l2, fmaf(-o.z, l1, n0));
+                    n1 = fmaf(o.z, l0, fmaf(-o.x, l2, n1));
+                    n2 = fmaf(o.x, l1, fmaf(-o.y, l0, n2));
+                }
+            }
+            const float a = k.x, d = k.y, sa = k.z, ca = k.w;
+            // Rx(alpha) on (f, n) as packed pairs (f1, n1), (f2, n2); then the moment arm (a, 0, d)
+            const f2v y1 = {f1, n1}, y2 = {f2, n2}, sa2 = {sa, sa}, ca2 = {ca, ca};
+            const f2v yy = __builtin_elementwise_fma(ca2, y1, -(sa2 * y2));   // (fy, ca n1 - sa n2)
+            const f2v zz = __builtin_elementwise_fma(sa2, y1, ca2 * y2);      // (fz, sa n1 + ca n2)
+            const float fy = yy.x, fz = zz.x;
+            const float mx = fmaf(-d, fy, n0);
+            const float my = fmaf(d, f0, fmaf(-a, fz, yy.y));
+            const float mz = fmaf(a, fy, zz.y);
+            if (dh_bit(c.real, j)) gqRow[(meta >> 8) & 0xff] += mz;
+            if (j > jb) {
+                // Rz(theta) on (f0, fy) and (mx, my) as packed pairs
+                const f2v x0 = {f0, mx}, x1 = {fy, my}, s2 = {s, s}, c2 = {co, co};
+                const f2v w1 = __builtin_elementwise_fma(s2, x0, c2 * x1);     // (f1', n1')
+                const f2v w0 = __builtin_elementwise_fma(c2, x0, -(s2 * x1));  // (f0', n0')
+                f0 = w0.x; n0 = w0.y; f1 = w1.x; n1 = w1.y;
+                f2 = fz; n2 = mz;
+            }
+        }
+        jb = je;
+    }
+}
+
+// ---- which walk a launch uses ------------------------------------------------------------------------------------------
+// fkk = 0: FkProg interpreted from its LDS copy (every transform kind);  1: DH arms, FkProg through scalar loads;
+// 2: DH arms, the step table (default where the model has one).  One staged program per launch.
+struct FkWalk {
+    int fkk;
+    const FkProg* g;
+    fk_cptr fk;   // fkk != 2
+    dh_cptr dh;   // fkk == 2
+};
+__device__ __forceinline__ FkWalk fk_stage_sel(int fkk, const FkProg* g, int fk_dwords, const DhArgs& c, float* lds, int tid,
+                                               int nthreads) {
+    FkWalk w;
+    w.fkk = fkk;
+    w.g = g;
+    w.fk = nullptr;
+    w.dh = nullptr;
+    if (fkk == 2) w.dh = stage_dh_prog(c, lds, tid, nthreads);
+    else w.fk = stage_fk_prog(g, lds, tid, nthreads, fk_dwords);
+    return w;
+}
+__device__ __forceinline__ bool fk_is_tree(const FkWalk& w) { return w.fkk == 2 ? false : rfl(w.fk->kind) == DCX_FK_TREE; }
+__device__ __forceinline__ void fk_trig_sel(const FkWalk& w, const DhArgs& c, const float* sQrow, float* sFcol, int wave, int nw) {
+    if (w.fkk == 2) dh2_trig(w.dh, c, sQrow, sFcol, wave, nw);
+    else fk_forward_trig(w.fk, sQrow, sFcol, wave, nw);
+}
+__device__ __forceinline__ void fk_chain_sel(const FkWalk& w, const DhArgs& c, const float* sQrow, float* sXcol, float* sFcol) {
+    if (w.fkk == 2) dh2_chain(w.dh, c, sXcol, sFcol);
+    else if (w.fkk == 1) fk_forward_chain_dh_k((fk_kptr)(uintptr_t)w.g, sXcol, sFcol);
+    else fk_forward_chain(w.fk, sQrow, sXcol, sFcol);
+}
+__device__ __forceinline__ void fk_vjp_sel(const FkWalk& w, const DhArgs& c, const float* sQrow, const float* sFcol,
+                                           const float* sGcol, float* gqRow, int dof) {
+    if (w.fkk == 2) dh2_vjp(w.dh, c, sFcol, sGcol, gqRow, dof);
+    else if (w.fkk == 1) fk_vjp_dh_k((fk_kptr)(uintptr_t)w.g, sFcol, sGcol, gqRow);
+    else fk_vjp(w.fk, sQrow, sFcol, sGcol, gqRow);
 }
 
 }  // namespace dcx

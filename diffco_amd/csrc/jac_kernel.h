@@ -124,16 +124,16 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void score
     float* sRed = smem + lp.red;
 
     // ---- prologue: as score_kernel ----
-    const fk_cptr fk = stage_fk_prog(a.fk, smem + lp.fk, threadIdx.x, blockDim.x);
+    const FkWalk fw = fk_stage_sel(a.fkk, a.fk, a.fk_dwords, a.dh, smem + lp.fk, threadIdx.x, blockDim.x);
     {
         const float* qsrc = a.q + b0 * dof;
         const int n = nb * dof;
         for (int i = threadIdx.x; i < 64 * dof; i += blockDim.x) sQ[i] = qsrc[i < n ? i : (i % dof) + (nb - 1) * dof];
     }
     __syncthreads();
-    fk_forward_trig(fk, sQ + lane * dof, sF + lane, wave, nw);
+    fk_trig_sel(fw, a.dh, sQ + lane * dof, sF + lane, wave, nw);
     __syncthreads();
-    if (wave == 0) fk_chain_sel(a.fkk, a.fk, fk, sQ + lane * dof, sX + lane, sF + lane);
+    if (wave == 0) fk_chain_sel(fw, a.dh, sQ + lane * dof, sX + lane, sF + lane);
     __syncthreads();
     float x[D];
 #pragma unroll
@@ -191,11 +191,11 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void score
     }
     __syncthreads();
     // ---- J^T per class: side by side on waves 0 .. C-1, or one after the other on wave 0 (URDF trees, few waves) ----
-    const bool parallel = (nw >= CC) && (rfl(fk->kind) != DCX_FK_TREE);
+    const bool parallel = (nw >= CC) && !fk_is_tree(fw);
     auto finish_class = [&](int c) __attribute__((always_inline)) {
         float* gq = smem + lp.gq + c * lp.gq_stride;
         for (int i = 0; i < dof; ++i) gq[lane * dof + i] = sQ[lane * dof + i];   // the row is built in place of a copy of q
-        fk_vjp_sel(a.fkk, a.fk, fk, gq + lane * dof, sF + lane, sG + (size_t)c * a.d_fk * 64 + lane, gq + lane * dof);
+        fk_vjp_sel(fw, a.dh, gq + lane * dof, sF + lane, sG + (size_t)c * a.d_fk * 64 + lane, gq + lane * dof, dof);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
         float* gdst = a.grad + b0 * a.grad_stride + (size_t)c * dof;

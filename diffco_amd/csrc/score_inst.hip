@@ -9,6 +9,15 @@
 #error "compile with -DDCX_INST_D=<feature width>"
 #endif
 
+#ifdef DCX_STUB  // developer builds (Makefile ONLY_WIDTHS): this width is not compiled
+namespace dcx {
+#define DCX_CAT_(a, b) a##b
+#define DCX_CAT(a, b) DCX_CAT_(a, b)
+hipError_t DCX_CAT(launch_score_D, DCX_INST_D)(int, int, int, int, size_t, int64_t, const ScoreArgs&, hipStream_t) { return hipErrorNotSupported; }
+hipError_t DCX_CAT(launch_jac_D, DCX_INST_D)(int, int, int, size_t, int64_t, const ScoreArgs&, hipStream_t) { return hipErrorNotSupported; }
+hipError_t DCX_CAT(launch_traj_fused_D, DCX_INST_D)(int, int, size_t, int, const TrajFusedArgs&, hipStream_t) { return hipErrorNotSupported; }
+}  // namespace dcx
+#else
 namespace dcx {
 namespace {
 
@@ -31,23 +40,6 @@ constexpr bool kBothForms = true;
 template <int KF, int CC, int MODE>
 hipError_t go(int nw, size_t lds, int64_t nblk, const ScoreArgs& a, hipStream_t st) {
     const dim3 grid((unsigned)nblk, (unsigned)(a.ys > 1 ? a.ys : 1), (unsigned)(a.nz > 1 ? a.nz : 1));
-#ifdef DCX_WITH_MT
-    if constexpr (kD <= kMtMaxD) if (a.mt >= 2) {  // several tiles per block (score_kernel_mt); `lds` is lds_plan_mt's size, chosen by the caller
-        const dim3 grid_mt((unsigned)((nblk + a.mt - 1) / a.mt));
-        auto launch = [&](auto kern) {
-            if (lds > 64 * 1024) {
-                hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (e != hipSuccess) return e;
-            }
-            kern<<<grid_mt, dim3(64 * nw), lds, st>>>(a, a.mt);
-            return hipGetLastError();
-        };
-        if constexpr (xf_applies(kD, CC, KF)) {
-            if (a.xf || !kBothForms) return launch(score_kernel_mt<kD, KF, CC, MODE, kMaxT, true>);
-        }
-        return launch(score_kernel_mt<kD, KF, CC, MODE, kMaxT, false>);
-    }
-#endif
     if constexpr (xf_applies(kD, CC, KF)) {
         if (!a.mfma && (a.xf || !kBothForms)) {
             score_kernel<kD, KF, CC, MODE, kMaxT, false, true><<<grid, dim3(64 * nw), lds, st>>>(a);
@@ -79,13 +71,15 @@ template <int KF>
 hipError_t by_cc(int cc, int mode, int nw, size_t lds, int64_t nblk, const ScoreArgs& a, hipStream_t st) {
     switch (cc) {
     case 1: return by_mode<KF, 1>(mode, nw, lds, nblk, a, st);
+    case 5: return by_mode<KF, 5>(mode, nw, lds, nblk, a, st);
+#ifndef DCX_DEV_FAST  // developer builds (EXTRA=-DDCX_DEV_FAST): one and five classes only
     case 2: return by_mode<KF, 2>(mode, nw, lds, nblk, a, st);
     case 3: return by_mode<KF, 3>(mode, nw, lds, nblk, a, st);
     case 4: return by_mode<KF, 4>(mode, nw, lds, nblk, a, st);
-    case 5: return by_mode<KF, 5>(mode, nw, lds, nblk, a, st);
     case 6: return by_mode<KF, 6>(mode, nw, lds, nblk, a, st);
     case 7: return by_mode<KF, 7>(mode, nw, lds, nblk, a, st);
     case 8: return by_mode<KF, 8>(mode, nw, lds, nblk, a, st);
+#endif
     default: return hipErrorInvalidValue;
     }
 }
@@ -123,13 +117,15 @@ hipError_t jac_go(int nw, size_t lds, int64_t nblk, const ScoreArgs& a, hipStrea
 template <int KF>
 hipError_t jac_by_cc(int cc, int nw, size_t lds, int64_t nblk, const ScoreArgs& a, hipStream_t st) {
     switch (cc) {
+    case 5: return jac_go<KF, 5>(nw, lds, nblk, a, st);
+#ifndef DCX_DEV_FAST
     case 2: return jac_go<KF, 2>(nw, lds, nblk, a, st);
     case 3: return jac_go<KF, 3>(nw, lds, nblk, a, st);
     case 4: return jac_go<KF, 4>(nw, lds, nblk, a, st);
-    case 5: return jac_go<KF, 5>(nw, lds, nblk, a, st);
     case 6: return jac_go<KF, 6>(nw, lds, nblk, a, st);
     case 7: return jac_go<KF, 7>(nw, lds, nblk, a, st);
     case 8: return jac_go<KF, 8>(nw, lds, nblk, a, st);
+#endif
     default: return hipErrorNotSupported;
     }
 }
@@ -167,3 +163,4 @@ hipError_t DCX_CAT(launch_traj_fused_D, DCX_INST_D)(int kf, int nw, size_t lds, 
 }
 
 }  // namespace dcx
+#endif  // DCX_STUB

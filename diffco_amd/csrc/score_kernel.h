@@ -68,15 +68,18 @@ struct ScoreArgs {
     int32_t red_slots;        // LDS rows for the cross-wave fold: nw (all waves write, fold in parallel) or 1 (waves
                               // take turns through one row: wide shapes, where nw rows would cost occupancy)
 #ifdef DCX_TIMING
-    unsigned long long* ts;   // developer builds: [16 slots][8 waves] cycle stamps of block (ts_block,0)
+    unsigned long long* ts;   // developer builds: [32 slots][16 waves] cycle stamps of block (ts_block,0)
     unsigned int ts_block;
 #endif
     float kp0, kp1;           // kernel parameters
     int32_t mfma;             // 1: the launch uses the MFMA form of the gradient fold (score_kernel<..., MF = true>)
     int32_t xf;               // 1: the launch uses the expanded form of the sweep (score_kernel<..., XF = true>)
-    int32_t prio;             // 1: raise the wave priority outside the sweep (the lone-wave FK / fold / J^T phases)
-    int32_t mt;               // >= 2: score_kernel_mt with this many tiles per block (unsplit launches only)
-    int32_t fkk;              // 1 (DCX_FK_DH only): the FK walks read the program with scalar loads (fk_*_dh_k)
+    int32_t fkk;              // DCX_FK_DH only: 1 = the FK walks read the program with scalar loads (fk_*_dh_k), 2 = the step
+                              // table (fk_device.h dh2_*; `dh` below); 0 = every kind: FkProg interpreted from its LDS copy
+    int32_t fk_dwords;        // dwords of FkProg the transform uses (staged into LDS; the host knows it: no dependent load)
+    DhArgs dh;                // fkk == 2: the step table's control part (counts and masks live in SGPRs)
+    int32_t jt_waves;         // fkk == 2 and the block folds in parallel with room in its scratch rows for 12 columns per
+                              // point step: J^T runs on several waves (fk_device.h dh2_vjp_waves)
     int32_t hinge;            // C == 1: gradient of weight * clamp(score - margin, 0) instead of the score's
     float hinge_margin, hinge_weight;
 };
@@ -97,8 +100,8 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #ifdef DCX_TIMING
 #define DCX_TS(slot)                                                                              \
     do {                                                                                          \
-        if (a.ts && blockIdx.x == a.ts_block && blockIdx.y == 0 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 8) \
-            a.ts[(slot) * 8 + (threadIdx.x >> 6)] = __builtin_readcyclecounter();                \
+        if (a.ts && blockIdx.x == a.ts_block && blockIdx.y == 0 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 16) \
+            a.ts[(slot) * 16 + (threadIdx.x >> 6)] = __builtin_readcyclecounter();               \
     } while (0)
 #else
 #define DCX_TS(slot) do { } while (0)
@@ -192,7 +195,7 @@ __host__ __device__ inline LdsPlan lds_plan(int dof, int d_fk, int frame_floats,
     // (the kernel barriers after that copy), G is written only after wave 0 has read every partial.
     p.red = p.x;
     const int end_xg = p.g + 64 * d_fk;
-    const int end_red = p.red + red_slots * acc_floats * 64;
+    const int end_red = p.red + (red_slots < 1 ? 1 : red_slots) * acc_floats * 64;  // always one row: the one-wave hand-over's totals
     p.fk = end_xg > end_red ? end_xg : end_red;  // the FK program comes last: its size varies with the robot
     p.total = p.fk;                              // and only the host needs it (+ fk_prog_floats)
     return p;
@@ -871,6 +874,49 @@ __device__ __forceinline__ int fresh_lane() {
     return l;
 }
 
+// The parallel cross-wave fold: the nw waves of a block have left their ACC partial sums per lane in sRed[w][e][64]; every
+// wave folds a few of the accumulators over the nw rows - row 0 first, then 1, 2, ..., the order a single wave would use,
+// so the sums do not depend on nw's parallelism - into row 0.  The block sizes the launch rules pick are compiled in: all nw
+// reads of an accumulator are in flight before the first add (a run-time trip count left one dependent LDS round trip per
+// row).  Caller synchronises before and after.
+template <int ACC>
+__device__ __forceinline__ void fold_partial_rows(float* sRed, int wave, int lane, int nw) {
+    auto fold_rows = [&](auto nwc) __attribute__((always_inline)) {
+        constexpr int NWC = decltype(nwc)::value;
+        for (int e = wave; e < ACC; e += NWC) {
+            float r[NWC];
+#pragma unroll
+            for (int w = 0; w < NWC; ++w) r[w] = sRed[((size_t)w * ACC + e) * 64 + lane];
+            float v = r[0];
+#pragma unroll
+            for (int w = 1; w < NWC; ++w) v += r[w];
+            sRed[e * 64 + lane] = v;
+        }
+    };
+    if (nw == 16) fold_rows(std::integral_constant<int, 16>{});
+    else if (nw == 8) fold_rows(std::integral_constant<int, 8>{});
+    else if (nw == 4) fold_rows(std::integral_constant<int, 4>{});
+    else if (nw == 2) fold_rows(std::integral_constant<int, 2>{});
+    else {
+        for (int e = wave; e < ACC; e += nw) {
+            float v = sRed[e * 64 + lane];
+            for (int w = 1; w < nw; ++w) v += sRed[((size_t)w * ACC + e) * 64 + lane];
+            sRed[e * 64 + lane] = v;
+        }
+    }
+}
+
+// The kernel's arguments, read AFRESH from the kernarg segment behind a compiler barrier.  The epilogue uses this copy:
+// anything of `a` that both the prologue and the epilogue touch would otherwise stay live in SGPRs across the sweep, whose
+// scalar row pipeline needs every SGPR the wave has - the allocator then parks row registers in VGPR lanes INSIDE the
+// hot loop (v_writelane / v_readlane: +20 instructions per 4 rows when round 3 first added arguments for the epilogue;
+// tools/check_sgpr_parking.py).  ScoreArgs is the kernel's only parameter, so it sits at offset 0 of the segment.
+__device__ __forceinline__ const __attribute__((address_space(4))) ScoreArgs& reload_args() {
+    auto p = (const __attribute__((address_space(4))) ScoreArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *p;
+}
+
 template <int D, int KF, int CC, int MODE, int MAXT, bool MF = false, bool XF = false>
 __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel(const ScoreArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -892,11 +938,8 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
     float* sRed = smem + lp.red;
 
     DCX_TS(0);
-    // Issue arbitration is oldest-wave-first: a block that starts beside an older, sweeping block would crawl through its
-    // lone-wave phases.  They need few issue slots, so they run at raised priority; the sweep runs at the default.
-    if (a.prio) __builtin_amdgcn_s_setprio(3);
     // ---- prologue: stage the FK description and the q rows (coalesced), FK per lane on wave 0 ----
-    const fk_cptr fk = stage_fk_prog(a.fk, smem + lp.fk, threadIdx.x, blockDim.x);
+    const FkWalk fw = fk_stage_sel(a.fkk, a.fk, a.fk_dwords, a.dh, smem + lp.fk, threadIdx.x, blockDim.x);
 #ifdef DCX_TIMING
     if (threadIdx.x == 0) dcx_fk_ts = (a.ts && blockIdx.x == a.ts_block && blockIdx.y == 0) ? a.ts : nullptr;
 #endif
@@ -910,20 +953,32 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
 #if defined(DCX_ABLATE) && (DCX_ABLATE & 2)  // timing ablation only (wrong results): no FK
     if (wave == 0) for (int k = 0; k < a.d_fk; ++k) sX[k * 64 + lane] = sQ[lane * dof + (k % dof)];
 #else
-    fk_forward_trig(fk, sQ + lane * dof, sF + lane, wave, nw);   // all waves: sin/cos of the joint angles
+    fk_trig_sel(fw, a.dh, sQ + lane * dof, sF + lane, wave, nw);   // all waves: sin/cos of the joint angles
     __syncthreads();
     DCX_TS(6);
-    if (wave == 0) {
-        if (a.fkk) fk_forward_chain_dh_k((fk_kptr)(uintptr_t)a.fk, sX + lane, sF + lane);
-        else fk_forward_chain(fk, sQ + lane * dof, sX + lane, sF + lane);
+    if (a.fkk == 2 && nw > 1) {  // the step table: the chain split by rows over two waves (fk_device.h dh2_chain_rows)
+        if (dh2_unrollable(a.dh)) {
+            if (wave == 0) dh2_chain_rows_u<0>(fw.dh, a.dh, sX + lane, sF + lane);
+            else if (wave == 1) dh2_chain_rows_u<1>(fw.dh, a.dh, sX + lane, sF + lane);
+        } else {
+            if (wave == 0) dh2_chain_rows<0>(fw.dh, a.dh, sX + lane, sF + lane);
+            else if (wave == 1) dh2_chain_rows<1>(fw.dh, a.dh, sX + lane, sF + lane);
+        }
+    } else if (wave == 0) {
+        fk_chain_sel(fw, a.dh, sQ + lane * dof, sX + lane, sF + lane);
     }
 #endif
     __syncthreads();
 
     DCX_TS(2);
     float x[D];
+    if (a.d_fk == D) {  // the usual case (no padding to a compiled width): no per-feature branch on every wave
 #pragma unroll
-    for (int k = 0; k < D; ++k) x[k] = (k < a.d_fk) ? sX[k * 64 + lane] : 0.0f;
+        for (int k = 0; k < D; ++k) x[k] = sX[k * 64 + lane];
+    } else {
+#pragma unroll
+        for (int k = 0; k < D; ++k) x[k] = (k < a.d_fk) ? sX[k * 64 + lane] : 0.0f;
+    }
     if (nw > 1) __syncthreads();  // X is dead from here on: the partial sums reuse its LDS (lds_plan)
 
     float up[CC];
@@ -946,7 +1001,6 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
     const int j0 = (ybase + wave * a.s_chunk < yend) ? (ybase + wave * a.s_chunk) : yend;
     const int j1 = (j0 + a.s_chunk < yend) ? (j0 + a.s_chunk) : yend;
 
-    if (a.prio) __builtin_amdgcn_s_setprio(0);
     if constexpr (MF) {
         // this wave's slice of the reduction scratch doubles as its transpose buffer (X is dead, the fold comes later)
         sweep_rows_mfma<D, KF, CC, MODE>(a, x, up, j0, j1, sc, gx, sRed + (size_t)wave * ACC * 64, lane);
@@ -954,10 +1008,167 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
         sweep_rows<D, KF, CC, MODE, XF>(a, x, up, j0, j1, sc, gx);
     }
     DCX_TS(3);
-    lane = fresh_lane();
-    if (a.prio) __builtin_amdgcn_s_setprio(3);
-    // ---- meet the NW partial sums in LDS; wave 0 finishes --------------------------------
-    if (nw > 1 && a.red_slots == 1) {
+    {   // ---- epilogue: everything below reads the kernel arguments afresh (reload_args) and re-derives what it needs ----
+    const auto& b = reload_args();
+    int lane = fresh_lane();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = blockDim.x >> 6;
+    const int64_t b0 = (int64_t)blockIdx.x * 64;
+    const size_t tile = (size_t)blockIdx.x * gridDim.z + blockIdx.z;
+    const int nb = (int)((b.B - b0) < 64 ? (b.B - b0) : 64);
+    const int dof = b.dof;
+    const LdsPlan lp = lds_plan(dof, b.d_fk, b.frame_floats, nw > 1 ? b.red_slots : 0, ACC, true);
+    float* sQ = smem + lp.q;
+    float* sG = smem + lp.g;
+    float* sF = smem + lp.f;
+    float* sRed = smem + lp.red;
+    DhArgs dhb;  // member by member: the reloaded arguments live in the constant address space
+    dhb.prog = b.dh.prog;
+    dhb.n_dwords = b.dh.n_dwords;
+    dhb.n_steps = b.dh.n_steps;
+    dhb.end0 = b.dh.end0;
+    dhb.n_chains = b.dh.n_chains;
+    dhb.pt = b.dh.pt;
+    dhb.bare = b.dh.bare;
+    dhb.real = b.dh.real;
+    dhb.n_pt = b.dh.n_pt;
+    FkWalk fw;
+    fw.fkk = b.fkk;
+    fw.g = b.fk;
+    fw.fk = (fk_cptr)(uintptr_t)(uint32_t)(uintptr_t)(smem + lp.fk);
+    fw.dh = (dh_cptr)(uintptr_t)(uint32_t)(uintptr_t)(smem + lp.fk);
+    // ---- the block's partial sums meet; the tile is finished ------------------------------------------------------------
+    // Round-3 epilogue ("every wave works", taken whenever the block folds in parallel): the waves fold the partial rows,
+    // and in a split launch the wave that folded an accumulator also PUBLISHES it (one write-through store per wave instead
+    // of ACC on wave 0), and after the arrival count the owning block's waves each RE-READ their accumulator over the ys
+    // rows (ys loads in flight per wave, one round trip) - a lone wave pays ~600 cycles to drain a store, ~700 for the
+    // counter and ~200 per dependent load whatever the volume (tools/lone_wave_ubench.hip), so the hand-over is priced in
+    // serial round trips: publish -> drain -> count -> re-read, each ONCE per block (round 2: 7.4 k cycles, now ~2.5 k).
+    // The sums are formed in the same order as before (row 0, 1, ... in the block; y = 0, 1, ... across blocks).
+    const bool split = b.partial != nullptr;
+    const bool par_tail = nw > 1 && b.red_slots != 1 && (!split || b.tile_done != nullptr);
+    if (par_tail) {
+        float* mine = sRed + (size_t)wave * ACC * 64 + lane;
+#pragma unroll
+        for (int c = 0; c < CC; ++c) mine[c * 64] = sc[c];
+        if constexpr (GRAD) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) mine[(CC + k) * 64] = gx[k];
+        }
+        __syncthreads();
+        DCX_TS(16);
+        float* out = split ? b.partial + (tile * b.ys + blockIdx.y) * ACC * 64 + lane : nullptr;
+        auto fold_mine = [&](auto nwc) __attribute__((always_inline)) {
+            constexpr int NWC = decltype(nwc)::value;
+            const int nwr = NWC > 0 ? NWC : nw;
+            for (int e = wave; e < ACC; e += nwr) {
+                float v;
+                if constexpr (NWC > 0) {
+                    float r[NWC];
+#pragma unroll
+                    for (int w = 0; w < NWC; ++w) r[w] = sRed[((size_t)w * ACC + e) * 64 + lane];
+                    v = r[0];
+#pragma unroll
+                    for (int w = 1; w < NWC; ++w) v += r[w];
+                } else {
+                    v = sRed[e * 64 + lane];
+                    for (int w = 1; w < nw; ++w) v += sRed[((size_t)w * ACC + e) * 64 + lane];
+                }
+                if (split) __hip_atomic_store(out + e * 64, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else sRed[e * 64 + lane] = v;  // row 0's slot of accumulator e: only this wave reads or writes it
+            }
+        };
+        if (nw == 16) fold_mine(std::integral_constant<int, 16>{});
+        else if (nw == 8) fold_mine(std::integral_constant<int, 8>{});
+        else if (nw == 4) fold_mine(std::integral_constant<int, 4>{});
+        else if (nw == 2) fold_mine(std::integral_constant<int, 2>{});
+        else fold_mine(std::integral_constant<int, 0>{});
+        DCX_TS(17);
+        if (split) {
+            // Every value of the row left as an agent-scope atomic store (global_store sc1: written through to where the
+            // other XCDs see it), and this wave stored nothing else.  Waiting for those stores to be acknowledged orders
+            // them before the counter increment; a release fence's buffer_wbl2 would write back OTHER dirty lines and has
+            // nothing of ours to do (LLVM AMDGPU memory model, gfx942 / gfx950; MI355X guide "R1": every storing wave
+            // drains, then a barrier, then ONE lane signals).  -DDCX_HANDOVER_FENCE restores the fence.
+#ifdef DCX_HANDOVER_FENCE
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#else
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "the drained write-through hand-over relies on gfx942 / gfx950 lowering (agent-scope atomic store = global_store sc1, counted by vmcnt): build other targets with -DDCX_HANDOVER_FENCE"
+#endif
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            __syncthreads();
+            DCX_FK_TS(8, 2);
+            // "last block done": whoever sees ys - 1 earlier arrivals owns the tile and adds ALL ys rows in the fixed order
+            // y = 0, 1, ... (so the result does not depend on which block came last).  No block ever waits for another.
+            unsigned int* flag = reinterpret_cast<unsigned int*>(sRed + (size_t)ACC * 64);  // row 1 is dead after the fold
+            if (wave == 0 && lane == 0) *flag = __hip_atomic_fetch_add(b.tile_done + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const unsigned int arrived = __builtin_amdgcn_readfirstlane(*flag);
+            DCX_FK_TS(9, 2);
+            if (arrived != (unsigned int)b.ys - 1u) return;
+            if (wave == 0 && lane == 0) b.tile_done[tile] = 0u;  // ready for the next launch on this stream
+            // The rows were published with agent-scope (sc1, write-through) stores, so agent-scope (sc1) loads read them
+            // where they were written: no acquire fence.  The control dependency on `arrived` keeps the loads behind it.
+            asm volatile("" ::: "memory");
+            const float* part = b.partial + tile * b.ys * ACC * 64 + lane;
+            for (int e = wave; e < ACC; e += nw) {
+                float tot = 0.0f;
+                for (int y = 0; y < b.ys; y += 8) {
+                    float r[8];
+#pragma unroll
+                    for (int v = 0; v < 8; ++v)
+                        if (y + v < b.ys) r[v] = __hip_atomic_load(part + ((size_t)(y + v) * ACC + e) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int v = 0; v < 8; ++v)
+                        if (y + v < b.ys) tot += r[v];
+                }
+                sRed[e * 64 + lane] = tot;
+            }
+            DCX_FK_TS(11, 2);
+        }
+        __syncthreads();  // the tile's totals sit in row 0 of the scratch: [c][64] scores, then [k][64] feature gradient
+        DCX_TS(4);
+        if (wave == 0 && b.score != nullptr && lane < nb && blockIdx.z == 0) {
+#pragma unroll
+            for (int c = 0; c < CC; ++c) b.score[(b0 + lane) * CC + c] = sRed[c * 64 + lane];
+        }
+        if constexpr (!GRAD) {
+            return;
+        } else {
+            if (b.jt_waves) {
+                // J^T on several waves (fk_device.h dh2_vjp_waves), reading the totals row in place: nothing is staged
+                float scale = 1.0f;
+                if constexpr (CC == 1 && MODE == MODE_GRAD_ROW) {
+                    if (b.upstream != nullptr) scale = b.upstream[b0 + (lane < nb ? lane : nb - 1)];
+                    if (b.hinge) scale = (sRed[lane] - b.hinge_margin > 0.0f) ? b.hinge_weight : 0.0f;
+                }
+                float* gq = smem + lp.q;
+                dh2_vjp_waves(fw.dh, dhb, sF + lane, sRed + CC * 64 + lane, scale, sRed + (size_t)ACC * 64 + lane,
+                              gq + lane * dof, dof, wave, nw);
+                if (wave != 0) return;
+                DCX_TS(5);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                float* gdst = b.grad + b0 * b.grad_stride + (b.nz > 1 ? (size_t)blockIdx.z * dof : 0);
+                const int n = nb * dof;
+                if (b.grad_stride == dof) {
+                    for (int i = lane; i < n; i += 64) gdst[i] = gq[i];
+                } else {
+                    for (int i = lane; i < n; i += 64) gdst[(int64_t)(i / dof) * b.grad_stride + (i % dof)] = gq[i];
+                }
+                return;
+            }
+            if (wave != 0) return;
+#pragma unroll
+            for (int c = 0; c < CC; ++c) sc[c] = sRed[c * 64 + lane];
+#pragma unroll
+            for (int k = 0; k < D; ++k) gx[k] = sRed[(CC + k) * 64 + lane];
+        }
+    } else {
+    // ---- the one-wave forms (one wave per block, wide shapes folding through one LDS row, the finish-kernel mode) ----
+    if (nw > 1 && b.red_slots == 1) {
         // one LDS row: waves 1 .. nw-1 hand their partial sums to wave 0 in turn (same summation order as below)
         for (int w = 1; w < nw; ++w) {
             if (wave == w) {
@@ -989,13 +1200,7 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
             for (int k = 0; k < D; ++k) mine[(CC + k) * 64] = gx[k];
         }
         __syncthreads();
-        // every wave folds a few of the ACC accumulators over the nw partial rows (wave 0's row first, then 1, 2, ...:
-        // the same order a single wave would use, so the sums do not depend on nw's parallelism) into row 0
-        for (int e = wave; e < ACC; e += nw) {
-            float v = sRed[e * 64 + lane];
-            for (int w = 1; w < nw; ++w) v += sRed[((size_t)w * ACC + e) * 64 + lane];
-            sRed[e * 64 + lane] = v;
-        }
+        fold_partial_rows<ACC>(sRed, wave, lane, nw);
         __syncthreads();
         if (wave != 0) return;
 #pragma unroll
@@ -1007,11 +1212,11 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
     }
 
     DCX_TS(4);
-    if (__builtin_expect(a.partial != nullptr, 0)) {
-        // split launch (small batches): this block saw only its super-chunk; score_finish_kernel adds the
-        // ys partial rows in a fixed order (deterministic) and applies J^T
-        float* out = a.partial + (tile * a.ys + blockIdx.y) * ACC * 64 + lane;
-        if (a.tile_done == nullptr) {
+    if (__builtin_expect(b.partial != nullptr, 0)) {
+        // split launch (small batches): this block saw only its super-chunk
+        float* out = b.partial + (tile * b.ys + blockIdx.y) * ACC * 64 + lane;
+        if (b.tile_done == nullptr) {
+            // score_finish_kernel adds the ys partial rows in a fixed order (deterministic) and applies J^T
 #pragma unroll
             for (int c = 0; c < CC; ++c) out[c * 64] = sc[c];
             if constexpr (GRAD) {
@@ -1020,12 +1225,8 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
             }
             return;
         }
-        // "last block done": publish this block's row, count arrivals; whoever sees ys-1 earlier arrivals owns the
-        // tile, re-reads ALL ys rows in the fixed order y = 0, 1, ... (so the result does not depend on which block
-        // came last) and carries on into the ordinary epilogue with its own q rows and FK frames (every block of a
-        // tile computed the same ones).  No block ever waits for another.
-        // The row goes out as agent-scope (write-through) stores, so the release fence in front of the counter has
-        // no dirty L2 lines of this block to write back; the owner's acquire fence then makes every row visible.
+        // the in-launch hand-over on ONE wave (blocks whose fold goes through one LDS row, or one wave per block): publish
+        // the row write-through, drain, count; the last block to arrive re-reads every row in the order y = 0, 1, ...
 #pragma unroll
         for (int c = 0; c < CC; ++c) __hip_atomic_store(out + c * 64, sc[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if constexpr (GRAD) {
@@ -1033,269 +1234,85 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
             for (int k = 0; k < D; ++k)
                 __hip_atomic_store(out + (CC + k) * 64, gx[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        DCX_FK_TS(7, 2);
-        // Every value of the row went out as an agent-scope atomic store (global_store sc1: written through to where the
-        // other XCDs see it), and this wave stored nothing else to global memory.  Waiting for those stores to be
-        // acknowledged therefore orders them before the counter increment below; the `buffer_wbl2 sc1` that a release
-        // fence adds writes back OTHER dirty L2 lines and has nothing of ours to do (LLVM AMDGPU memory model, gfx942:
-        // "fence release agent" = buffer_wbl2 sc1 + s_waitcnt vmcnt(0); "store atomic monotonic agent" = store sc1).
-        // Measured: config #2 17.8 -> 16.5 us, headline B = 4096 20.9 -> 19.6 us.  -DDCX_HANDOVER_FENCE restores the fence.
 #ifdef DCX_HANDOVER_FENCE
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 #else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
-        DCX_FK_TS(8, 2);
         unsigned int arrived = 0;
-        if (lane == 0) arrived = __hip_atomic_fetch_add(a.tile_done + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) arrived = __hip_atomic_fetch_add(b.tile_done + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         arrived = __builtin_amdgcn_readfirstlane(arrived);
-        DCX_FK_TS(9, 2);
-        if (arrived != (unsigned int)a.ys - 1u) return;
-        if (lane == 0) a.tile_done[tile] = 0u;  // ready for the next launch on this stream
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        DCX_FK_TS(10, 2);
-        // rows y = 0, 1, ... added in that order (0 + r0 + r1 + ..., as score_finish_kernel does); the loads of up to
-        // 16 accumulators x YU rows are in flight together — one load per round trip cost 4-9 k cycles here
-        const float* part = a.partial + tile * a.ys * ACC * 64 + lane;
-        constexpr int EC = ACC < 16 ? ACC : 16;
-        constexpr int YU = 2;
+        if (arrived != (unsigned int)b.ys - 1u) return;
+        if (lane == 0) b.tile_done[tile] = 0u;  // ready for the next launch on this stream
+        asm volatile("" ::: "memory");
+        const float* part = b.partial + tile * b.ys * ACC * 64 + lane;
+        // a cold path: one accumulator at a time (four rows in flight) through row 0 of the LDS scratch, so that nothing
+        // here claims registers of the hot paths above
+#pragma unroll 1
+        for (int e = 0; e < ACC; ++e) {
+            float tot = 0.0f;
+            for (int y = 0; y < b.ys; y += 4) {
+                float r[4];
 #pragma unroll
-        for (int e0 = 0; e0 < ACC; e0 += EC) {
-            float tot[EC];
+                for (int v = 0; v < 4; ++v)
+                    if (y + v < b.ys) r[v] = __hip_atomic_load(part + ((size_t)(y + v) * ACC + e) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-            for (int u = 0; u < EC; ++u) tot[u] = 0.0f;
-            for (int y = 0; y < a.ys; y += YU) {
-                float r[YU][EC];
-#pragma unroll
-                for (int v = 0; v < YU; ++v) {
-                    const int yy = (y + v < a.ys) ? y + v : y;  // past the end: re-read row y, not added
-#pragma unroll
-                    for (int u = 0; u < EC; ++u)
-                        if (e0 + u < ACC) r[v][u] = __builtin_nontemporal_load(part + ((size_t)yy * ACC + e0 + u) * 64);
-                }
-#pragma unroll
-                for (int v = 0; v < YU; ++v) {
-                    if (y + v < a.ys) {
-#pragma unroll
-                        for (int u = 0; u < EC; ++u)
-                            if (e0 + u < ACC) tot[u] += r[v][u];
-                    }
-                }
+                for (int v = 0; v < 4; ++v)
+                    if (y + v < b.ys) tot += r[v];
             }
-#pragma unroll
-            for (int u = 0; u < EC; ++u) {
-                const int e = e0 + u;
-                if (e < ACC) {
-                    if (e < CC) sc[e < CC ? e : 0] = tot[u];
-                    else if constexpr (GRAD) gx[(e - CC) < D && e >= CC ? e - CC : 0] = tot[u];
-                }
-            }
+            sRed[e * 64 + lane] = tot;
         }
-        DCX_FK_TS(11, 2);
-    }
-
-    if (a.score != nullptr && lane < nb && blockIdx.z == 0) {
 #pragma unroll
-        for (int c = 0; c < CC; ++c) a.score[(b0 + lane) * CC + c] = sc[c];
+        for (int c = 0; c < CC; ++c) sc[c] = sRed[c * 64 + lane];
+        if constexpr (GRAD) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) gx[k] = sRed[(CC + k) * 64 + lane];
+        }
     }
 
+    if (b.score != nullptr && lane < nb && blockIdx.z == 0) {
+#pragma unroll
+        for (int c = 0; c < CC; ++c) b.score[(b0 + lane) * CC + c] = sc[c];
+    }
+    }  // one-wave forms
+
+    // ---- wave 0 alone: G to LDS, J^T, gradient rows out ----
     if constexpr (GRAD) {
         float scale = 1.0f;
         if constexpr (CC == 1 && MODE == MODE_GRAD_ROW) {
-            if (a.upstream != nullptr) scale = a.upstream[b0 + (lane < nb ? lane : nb - 1)];
-            if (a.hinge) scale = (sc[0] - a.hinge_margin > 0.0f) ? a.hinge_weight : 0.0f;
+            if (b.upstream != nullptr) scale = b.upstream[b0 + (lane < nb ? lane : nb - 1)];
+            if (b.hinge) scale = (sc[0] - b.hinge_margin > 0.0f) ? b.hinge_weight : 0.0f;
         }
+        if (b.d_fk == D) {
 #pragma unroll
-        for (int k = 0; k < D; ++k)
-            if (k < a.d_fk) sG[k * 64 + lane] = gx[k] * scale;
+            for (int k = 0; k < D; ++k) sG[k * 64 + lane] = gx[k] * scale;
+        } else {
+#pragma unroll
+            for (int k = 0; k < D; ++k)
+                if (k < b.d_fk) sG[k * 64 + lane] = gx[k] * scale;
+        }
         DCX_FK_TS(12, 2);
         // J^T gX per lane.  The gradient row is built in place of the lane's own q row: every
         // fk_vjp branch reads what it needs from the q row before its first write to gq.
         float* gq = smem + lp.q;
 #if defined(DCX_ABLATE) && (DCX_ABLATE & 1)  // timing ablation only (wrong results): no J^T
-        for (int i = 0; i < dof; ++i) gq[lane * dof + i] = sG[(i % a.d_fk) * 64 + lane];
+        for (int i = 0; i < dof; ++i) gq[lane * dof + i] = sG[(i % b.d_fk) * 64 + lane];
 #else
-        if (a.fkk) fk_vjp_dh_k((fk_kptr)(uintptr_t)a.fk, sF + lane, sG + lane, gq + lane * dof);
-        else fk_vjp(fk, sQ + lane * dof, sF + lane, sG + lane, gq + lane * dof);
+        fk_vjp_sel(fw, dhb, sQ + lane * dof, sF + lane, sG + lane, gq + lane * dof, dof);
 #endif
         DCX_TS(5);
         // rows -> HBM, coalesced (LDS ops of one wave complete in order; no other wave is alive)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
-        float* gdst = a.grad + b0 * a.grad_stride + (a.nz > 1 ? (size_t)blockIdx.z * dof : 0);
+        float* gdst = b.grad + b0 * b.grad_stride + (b.nz > 1 ? (size_t)blockIdx.z * dof : 0);
         const int n = nb * dof;
-        if (a.grad_stride == dof) {
+        if (b.grad_stride == dof) {
             for (int i = lane; i < n; i += 64) gdst[i] = gq[i];
         } else {
-            for (int i = lane; i < n; i += 64) gdst[(int64_t)(i / dof) * a.grad_stride + (i % dof)] = gq[i];
+            for (int i = lane; i < n; i += 64) gdst[(int64_t)(i / dof) * b.grad_stride + (i % dof)] = gq[i];
         }
     }
-}
-
-// ---- several tiles per block (MT) -------------------------------------------------------------------------------------
-// In score_kernel every 16-wave block spends ~25 % of its life with ONE wave working: the FK chain before the sweep,
-// the fold hand-over and J^T after it (profiles/r01_phase_timing.txt).  The two blocks that share a CU run in lock
-// step, so those phases coincide and the CU idles through them once per round of tiles.  Here a block owns NT <= 2
-// consecutive tiles: the chains of its tiles run side by side on waves 0 .. NT-1 (one lone wave each, on different
-// SIMDs), then all waves sweep tile 0, then tile 1 (each sweep ends in the same fixed-order cross-wave fold, into a
-// per-tile accumulator slab), then the J^T products run side by side again — half as many exposed single-wave phases
-// per CU for the same sweeps.  The arithmetic per configuration is exactly score_kernel's (same slices, same fold
-// order), so results are bit-identical to it.  Used for unsplit launches (ys == 1, one class per launch) with the
-// parallel fold; everything else stays on score_kernel.
-constexpr int kMtMaxTiles = 2;
-constexpr int kMtMaxD = 36;      // compiled for the narrow widths only (wider shapes fold through one LDS row anyway)
-constexpr int kMtFoldRows = 8;   // partial rows in LDS at a time: waves fold in rounds of 8 (keeps two blocks per CU)
-
-struct LdsPlanMT {
-    int q, f, x, acc, tile_stride, red, fk, total;
-};
-__host__ __device__ inline LdsPlanMT lds_plan_mt(int dof, int d_fk, int frame_floats, int nw, int acc_floats, int nt) {
-    LdsPlanMT p;
-    p.q = 0;
-    p.f = p.q + ((64 * dof + 3) & ~3);
-    p.x = p.f + 64 * frame_floats;
-    p.acc = p.x + 64 * d_fk;
-    p.tile_stride = p.acc + 64 * acc_floats;
-    p.red = nt * p.tile_stride;
-    const int rows = nw < kMtFoldRows ? nw : kMtFoldRows;
-    p.fk = p.red + rows * acc_floats * 64;
-    p.total = p.fk;
-    return p;
-}
-
-template <int D, int KF, int CC, int MODE, int MAXT, bool XF = false>
-__global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel_mt(const ScoreArgs a, const int nt_max) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr bool GRAD = (MODE != MODE_SCORE);
-    constexpr int ACC = (GRAD ? D : 0) + CC;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nw = blockDim.x >> 6;
-    const int dof = a.dof;
-    const int64_t n_tiles = (a.B + 63) / 64;
-    const int64_t t0 = (int64_t)blockIdx.x * nt_max;
-    const int nt = (int)((n_tiles - t0) < nt_max ? (n_tiles - t0) : nt_max);
-    const LdsPlanMT lp = lds_plan_mt(dof, a.d_fk, a.frame_floats, nw, ACC, nt_max);
-    float* sRed = smem + lp.red;
-    auto tile_q = [&](int i) { return smem + i * lp.tile_stride + lp.q; };
-    auto tile_f = [&](int i) { return smem + i * lp.tile_stride + lp.f; };
-    auto tile_x = [&](int i) { return smem + i * lp.tile_stride + lp.x; };
-    auto tile_a = [&](int i) { return smem + i * lp.tile_stride + lp.acc; };
-    auto tile_nb = [&](int i) {
-        const int64_t left = a.B - (t0 + i) * 64;
-        return (int)(left < 64 ? left : 64);
-    };
-
-    // ---- prologue: FK program and the q rows of every tile (coalesced) ----
-    const fk_cptr fk = stage_fk_prog(a.fk, smem + lp.fk, threadIdx.x, blockDim.x);
-    for (int i = 0; i < nt; ++i) {
-        const float* qsrc = a.q + (t0 + i) * 64 * dof;
-        const int nb = tile_nb(i), n = nb * dof;
-        float* sQ = tile_q(i);
-        for (int k = threadIdx.x; k < 64 * dof; k += blockDim.x) sQ[k] = qsrc[k < n ? k : (k % dof) + (nb - 1) * dof];
-    }
-    __syncthreads();
-    // sin / cos: the waves are dealt to the tiles (wave w -> tile w % nt, as worker w / nt of nw / nt)
-    {
-        const int i = wave % nt, sub = wave / nt, nsub = (nw - i + nt - 1) / nt;
-        fk_forward_trig(fk, tile_q(i) + lane * dof, tile_f(i) + lane, sub, nsub);
-    }
-    __syncthreads();
-    if (wave < nt) fk_forward_chain(fk, tile_q(wave) + lane * dof, tile_x(wave) + lane, tile_f(wave) + lane);
-    __syncthreads();
-
-    // ---- the sweeps, one tile after the other, all waves on each ----
-    const int j0 = (wave * a.s_chunk < a.S) ? wave * a.s_chunk : a.S;
-    const int j1 = (j0 + a.s_chunk < a.S) ? j0 + a.s_chunk : a.S;
-    for (int i = 0; i < nt; ++i) {
-        const float* sX = tile_x(i);
-        float x[D];
-#pragma unroll
-        for (int k = 0; k < D; ++k) x[k] = (k < a.d_fk) ? sX[k * 64 + lane] : 0.0f;
-        float up[CC];
-        if constexpr (MODE == MODE_GRAD_UP) {
-            const int nb = tile_nb(i);
-            const int64_t bl = (t0 + i) * 64 + (lane < nb ? lane : nb - 1);
-#pragma unroll
-            for (int c = 0; c < CC; ++c) up[c] = (a.one_hot >= 0) ? (c == a.one_hot ? 1.0f : 0.0f) : a.upstream[bl * CC + c];
-        }
-        float sc[CC];
-        float gx[D];
-#pragma unroll
-        for (int c = 0; c < CC; ++c) sc[c] = 0.0f;
-#pragma unroll
-        for (int k = 0; k < D; ++k) gx[k] = 0.0f;
-        sweep_rows<D, KF, CC, MODE, XF>(a, x, up, j0, j1, sc, gx);
-        // fixed-order fold (row 0, 1, 2, ... as score_kernel adds them), kMtFoldRows partial rows in LDS at a time
-        float* sA = tile_a(i);
-        if (nw == 1) {
-#pragma unroll
-            for (int c = 0; c < CC; ++c) sA[c * 64 + lane] = sc[c];
-            if constexpr (GRAD) {
-#pragma unroll
-                for (int k = 0; k < D; ++k) sA[(CC + k) * 64 + lane] = gx[k];
-            }
-        } else {
-            for (int w0 = 0; w0 < nw; w0 += kMtFoldRows) {
-                __syncthreads();  // the previous round's (or tile's) fold has finished with sRed
-                if (wave >= w0 && wave < w0 + kMtFoldRows) {
-                    float* mine = sRed + (size_t)(wave - w0) * ACC * 64 + lane;
-#pragma unroll
-                    for (int c = 0; c < CC; ++c) mine[c * 64] = sc[c];
-                    if constexpr (GRAD) {
-#pragma unroll
-                        for (int k = 0; k < D; ++k) mine[(CC + k) * 64] = gx[k];
-                    }
-                }
-                __syncthreads();
-                const int rows = (nw - w0 < kMtFoldRows) ? (nw - w0) : kMtFoldRows;
-                for (int e = wave; e < ACC; e += nw) {
-                    float v = (w0 == 0) ? sRed[e * 64 + lane] : sA[e * 64 + lane];
-                    for (int r = (w0 == 0) ? 1 : 0; r < rows; ++r) v += sRed[((size_t)r * ACC + e) * 64 + lane];
-                    sA[e * 64 + lane] = v;
-                }
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- epilogue: wave i finishes tile i (scores out, J^T, gradient rows out) ----
-    if (wave >= nt) return;
-    {
-        const int i = wave;
-        const int nb = tile_nb(i);
-        const int64_t b0 = (t0 + i) * 64;
-        float* sA = tile_a(i);
-        float sc[CC];
-#pragma unroll
-        for (int c = 0; c < CC; ++c) sc[c] = sA[c * 64 + lane];
-        if (a.score != nullptr && lane < nb) {
-#pragma unroll
-            for (int c = 0; c < CC; ++c) a.score[(b0 + lane) * CC + c] = sc[c];
-        }
-        if constexpr (GRAD) {
-            float scale = 1.0f;
-            if constexpr (CC == 1 && MODE == MODE_GRAD_ROW) {
-                if (a.upstream != nullptr) scale = a.upstream[b0 + (lane < nb ? lane : nb - 1)];
-                if (a.hinge) scale = (sc[0] - a.hinge_margin > 0.0f) ? a.hinge_weight : 0.0f;
-            }
-            float* sG = sA + CC * 64;  // the folded feature gradient, scaled in place: [k][64]
-#pragma unroll
-            for (int k = 0; k < D; ++k)
-                if (k < a.d_fk) sG[k * 64 + lane] = sG[k * 64 + lane] * scale;
-            float* gq = tile_q(i);      // the gradient row is built in place of the lane's own q row (as score_kernel does)
-            fk_vjp(fk, gq + lane * dof, tile_f(i) + lane, sG + lane, gq + lane * dof);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            float* gdst = a.grad + b0 * a.grad_stride;
-            const int n = nb * dof;
-            if (a.grad_stride == dof) {
-                for (int k = lane; k < n; k += 64) gdst[k] = gq[k];
-            } else {
-                for (int k = lane; k < n; k += 64) gdst[(int64_t)(k / dof) * a.grad_stride + (k % dof)] = gq[k];
-            }
-        }
-    }
+    }  // epilogue
 }
 
 // Second half of a split launch: one wave per 64-configuration tile adds the ys partial rows, redoes the

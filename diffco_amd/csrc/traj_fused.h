@@ -96,7 +96,7 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
     float* sRed = smem + lp.red;
     float* sR = smem + lp.r;
 
-    const fk_cptr fk = stage_fk_prog(a.sc.fk, smem + lp.fk, tid, blockDim.x);
+    const FkWalk fw = fk_stage_sel(a.sc.fkk, a.sc.fk, a.sc.fk_dwords, a.sc.dh, smem + lp.fk, tid, blockDim.x);
     {
         // waypoint rows (lanes past the path replicate its last row, like a ragged tile of the sweep) and Adam moments
         const size_t base = (size_t)r * W * dof;
@@ -117,14 +117,14 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
     // this wave's slice of the supports (the sweep's slicing: wave w takes [w * s_chunk, (w + 1) * s_chunk))
     const int j0 = (wave * a.sc.s_chunk < a.sc.S) ? wave * a.sc.s_chunk : a.sc.S;
     const int j1 = (j0 + a.sc.s_chunk < a.sc.S) ? j0 + a.sc.s_chunk : a.sc.S;
-    const bool tree = rfl(fk->kind) == DCX_FK_TREE;  // its reverse sweep keeps adjoint sums in the frames: one at a time
+    const bool tree = fk_is_tree(fw);  // its reverse sweep keeps adjoint sums in the frames: one at a time
 
     int it = 0;
     for (; it < a.n_iters; ++it) {
         // ---- forward kinematics of the current waypoints (once per iteration) -----------------------------------
-        fk_forward_trig(fk, sQ + lane * dof, sF + lane, wave, nw);
+        fk_trig_sel(fw, a.sc.dh, sQ + lane * dof, sF + lane, wave, nw);
         __syncthreads();
-        if (wave == 0) fk_chain_sel(a.sc.fkk, a.sc.fk, fk, sQ + lane * dof, sX + lane, sF + lane);
+        if (wave == 0) fk_chain_sel(fw, a.sc.dh, sQ + lane * dof, sX + lane, sF + lane);
         __syncthreads();
         float x[D];
 #pragma unroll
@@ -144,11 +144,7 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
 #pragma unroll
             for (int k = 0; k < D; ++k) mine[(1 + k) * 64] = gx[k];
             __syncthreads();
-            for (int e = wave; e < ACC; e += nw) {
-                float v = sRed[e * 64 + lane];
-                for (int ww = 1; ww < nw; ++ww) v += sRed[((size_t)ww * ACC + e) * 64 + lane];
-                sRed[e * 64 + lane] = v;
-            }
+            fold_partial_rows<ACC>(sRed, wave, lane, nw);
             __syncthreads();
         }
         // ---- wave 0: hinge + J^T of the collision gradient;  wave 1: path terms + their J^T ------------------------
@@ -166,7 +162,7 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
                 if (k < d_fk) sGc[k * 64 + lane] = gx[k] * scale;
             // q row -> gq row in a separate buffer (the two-launch form overwrites the q row; same arithmetic)
             for (int i = 0; i < dof; ++i) sGQc[lane * dof + i] = sQ[lane * dof + i];
-            fk_vjp_sel(a.sc.fkk, a.sc.fk, fk, sGQc + lane * dof, sF + lane, sGc + lane, sGQc + lane * dof);
+            fk_vjp_sel(fw, a.sc.dh, sGQc + lane * dof, sF + lane, sGc + lane, sGQc + lane * dof, dof);
             const float s0 = sc[0] - a.opt.safety_margin;
             if (live && s0 > 0.f) col = s0;
         }
@@ -190,7 +186,7 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
                 const float cp = 2.f * (a.opt.w_diff + (mp > 0.f ? a.opt.w_max_move : 0.f));
                 for (int c = 0; c < pd; ++c) sGp[(a.coord_major ? c * a.n_points + p : p * pd + c) * 64 + lane] = cp * dp[c] - cn * dn[c];
             }
-            fk_vjp_sel(a.sc.fkk, a.sc.fk, fk, sQ + lane * dof, sF + lane, sGp + lane, sGQp + lane * dof);
+            fk_vjp_sel(fw, a.sc.dh, sQ + lane * dof, sF + lane, sGp + lane, sGQp + lane * dof, dof);
             const float so = traj_wave_sum(obj), sm = traj_wave_sum(mmv);
             if (lane == 0) { sR[0] = so; sR[16] = sm; }
         }

@@ -49,22 +49,26 @@ class Model:
 
 
 class RevolutePlanarRobot(Model):
+    """Planar serial arm of revolute joints: q_i are relative angles, the control points are the link ends (D = 2 dof).
+    Signature and attributes as in the reference (model.py:23-38): `link_length` a number (with `dof`) or a list,
+    `limits` one [lo, hi] pair for every joint or one pair per joint (default [-pi, pi])."""
+
     def __init__(self, link_length, link_width, dof=None, limits=None):
+        scalar_length = isinstance(link_length, (int, float))
+        n = int(dof) if dof is not None else len(link_length)
+        lengths = [float(link_length)] * n if scalar_length else [float(v) for v in link_length]
         if limits is None:
-            limits = [-np.pi, np.pi]
-        if dof is None:
-            dof = len(link_length)
-        if isinstance(link_length, (int, float)):
-            link_length = [link_length] * dof
-        if len(limits) == 2 and isinstance(limits[0], (int, float)):
-            limits = [limits] * dof
-        assert len(limits) == dof and len(link_length) == dof
-        self.dof = dof
+            limits = (-np.pi, np.pi)
+        one_pair = len(limits) == 2 and all(isinstance(v, (int, float)) for v in limits)
+        bounds = [list(limits) for _ in range(n)] if one_pair else [list(row) for row in limits]
+        if len(lengths) != n or len(bounds) != n:
+            raise AssertionError(f"planar arm: {len(lengths)} link lengths and {len(bounds)} limit rows for dof {n}")
+        self.dof = n
         self.link_width = link_width
-        self.link_length = torch.FloatTensor(link_length)
-        self.limits = torch.FloatTensor(limits)
+        self.link_length = torch.FloatTensor(lengths)
+        self.limits = torch.FloatTensor(bounds)
         self.collision_objs = None
-        self._desc = fd.planar_desc(self.link_length.tolist())
+        self._desc = fd.planar_desc(lengths)
 
 
 class RigidPlanarBody(Model):
@@ -107,13 +111,13 @@ class RigidBody(Model):
 
 
 class DHParameters:
+    """Denavit-Hartenberg table of one chain as fp32 tensors; sin / cos of alpha are taken in fp32 from the fp32 alpha, as
+    the reference does (model.py:172-180), so the constants the kernels see are the reference's bit for bit"""
+
     def __init__(self, a=0, alpha=0, d=0, theta=0):
-        self.a = torch.FloatTensor(a)
-        self.alpha = torch.FloatTensor(alpha)
-        self.d = torch.FloatTensor(d)
-        self.theta = torch.FloatTensor(theta)
-        self.s_alpha = self.alpha.sin()
-        self.c_alpha = self.alpha.cos()
+        for name, values in (("a", a), ("alpha", alpha), ("d", d), ("theta", theta)):
+            setattr(self, name, torch.tensor(values, dtype=torch.float32).reshape(-1))
+        self.s_alpha, self.c_alpha = torch.sin(self.alpha), torch.cos(self.alpha)
 
     def chain(self, joint_q, base=None):
         ch = dict(a=self.a.tolist(), d=self.d.tolist(), alpha=self.alpha.tolist(), theta0=self.theta.tolist(),

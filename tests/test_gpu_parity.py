@@ -186,40 +186,6 @@ def test_split_launch_finish_modes_agree_bitwise(ops, name, knob):
     assert relerr(_n(s3), _n(s2)) < 3e-6 and relerr(_n(g3), _n(g2)) < 3e-6
 
 
-@pytest.mark.parametrize("name", ["cfg2_baxter_poly1", "cfg2_baxter_rq", "cfg2_panda_poly1", "cfg3_baxter_rq_c5", "cfg3_baxter_poly1_c5",
-                                  "misc_planar7_rq_p3", "cfg4_se3_keypts_rq"])
-@pytest.mark.parametrize("nw", [16, 8, 4, 1])
-def test_two_tiles_per_block_equals_one_tile_per_block_bitwise(ops, name, nw, knob):
-    """score_kernel_mt (two tiles per block: chains and J^T products of the block's tiles side by side, the sweeps one
-    after the other) against score_kernel with the same slicing: same arithmetic, same fold order -> identical bits;
-    odd tile counts, a ragged last tile, score-only, explicit upstream and the hinge entry point included.  The variant
-    is slower than one tile per block (profiles/r02_mt_probe.txt) and only compiled with EXTRA=-DDCX_WITH_MT."""
-    from diffco_amd import _lib
-    if _lib.load().dcx_debug_set(b"mt", 2) != 0:
-        pytest.skip("libdcx built without score_kernel_mt")
-    d = load(name)
-    m, _, _ = _model(ops, name, d)
-    reps = -(-461 // len(d["q"]))
-    q = _t(np.tile(d["q"], (reps, 1))[:461] if reps > 1 else d["q"][:461])       # 8 tiles, the last one ragged (13 rows)
-    q = q + 0.01 * torch.arange(len(q), device="cuda", dtype=torch.float32)[:, None] / len(q)
-    up = torch.randn((len(q), m.C), device="cuda") if m.C > 1 else None
-    knob("ys", 1)
-    knob("nw", nw)
-    knob("min_rows", 1)
-    for B in (461, 448, 129, 64):
-        knob("mt", 0)
-        s1, g1 = m.score_grad_raw(q[:B], None if up is None else up[:B])
-        so1 = m.score_raw(q[:B])
-        h1 = m.score_hinge_grad_raw(q[:B], 0.05, 3.0) if m.C == 1 else None
-        knob("mt", 2)
-        s2, g2 = m.score_grad_raw(q[:B], None if up is None else up[:B])
-        so2 = m.score_raw(q[:B])
-        assert torch.equal(s1, s2) and torch.equal(g1, g2) and torch.equal(so1, so2)
-        if h1 is not None:
-            h2 = m.score_hinge_grad_raw(q[:B], 0.05, 3.0)
-            assert torch.equal(h1[0], h2[0]) and torch.equal(h1[1], h2[1])
-
-
 @pytest.mark.parametrize("D,C", [(12, 1), (12, 3), (7, 1), (21, 1), (6, 2)])
 def test_expanded_form_around_the_near_threshold(ops, knob, D, C):
     """the expanded sweep's near-pair machinery under load: every query sits at a chosen relative distance
@@ -513,20 +479,21 @@ def test_concurrent_streams_share_a_model(ops):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["baxter_left", "panda", "panda5", "baxter_dual", "dual_panda"])
 @pytest.mark.parametrize("B", [1, 200, 4096, 20000])
-def test_scalar_load_fk_walks_equal_lds_walks_bitwise(ops, knob, name, B):
-    """DH arms walk their FK program with scalar loads (fk_device.h fk_forward_chain_dh_k / fk_vjp_dh_k, knob fkk, the
-    default) or from its LDS copy (fkk = 0): the same arithmetic, so score, gradient and the one-sweep Jacobian must agree bit
-    for bit — for one and two chains, frames with no / one / three control points (Panda's fingers), unsplit and split
-    launches"""
+def test_dh_fk_walks_agree_bitwise(ops, knob, name, B):
+    """DH arms have three FK walks: the step table (fk_device.h dh2_*, knob fkk = 2, the default), the FkProg read with
+    scalar loads (fk_forward_chain_dh_k / fk_vjp_dh_k, fkk = 1) and the FkProg interpreted from its LDS copy (fkk = 0, what
+    every other transform kind uses): the same arithmetic, so score, gradient and the one-sweep Jacobian must agree bit
+    for bit — for one and two chains, frames with no / one / three control points (Panda's fingers become identity steps
+    of the table), unsplit and split launches"""
     rob = make_robot(name)
     g = torch.Generator().manual_seed(len(name) * 1000 + B)
     lim = rob.limits.float()
-    S, C = 300, 3
+    S, C = 300, 5
     rnd = lambda n: torch.rand((n, rob.dof), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]
     sup = rob.fkine(rnd(S).cuda()).reshape(S, -1)
     q = rnd(B).cuda()
     out = {}
-    for fkk in (1, 0):
+    for fkk in (2, 1, 0):
         knob("fkk", fkk)
         m1 = ops.ScoreModel(rob.fk_desc(), 1, 1.0, 1.0, sup, torch.randn((S, 1), generator=torch.Generator().manual_seed(3)).cuda())
         mc = ops.ScoreModel(rob.fk_desc(), 0, 10.0, 2.0, sup, torch.randn((S, C), generator=torch.Generator().manual_seed(4)).cuda())
@@ -536,5 +503,6 @@ def test_scalar_load_fk_walks_equal_lds_walks_bitwise(ops, knob, name, B):
         sj, jj = mc.score_jac_raw(q)
         out[fkk] = [_n(t).copy() for t in (s1, g1, sc, gc, sj, jj)]
     knob("fkk", -1)
-    for a, b in zip(out[1], out[0]):
-        assert np.isfinite(a).all() and np.array_equal(a, b)
+    for other in (2, 1):
+        for a, b in zip(out[other], out[0]):
+            assert np.isfinite(a).all() and np.array_equal(a, b)

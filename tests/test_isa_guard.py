@@ -83,3 +83,36 @@ def test_expanded_form_instruction_count(isa):
     assert ks[0]["v_pk_add_f32"] == 24 and ks[0]["v_pk_fma_f32"] == 48 and valu[0] <= 100, (ks[0], valu[0])
     # the expanded loop range also holds the flush block (6 v_pk_fma) and may hold one rare correction block
     assert 48 <= ks[1]["v_pk_fma_f32"] <= 70 and ks[1]["v_rsq_f32"] <= 6 and valu[1] <= 135, (ks[1], valu[1])
+
+
+def test_handover_publishes_write_through_and_drains_before_the_counter(isa):
+    """The in-launch hand-over of a split launch (score_kernel.h) orders the partial-row stores before the arrival
+    counter WITHOUT a release fence: it relies on gfx942 / gfx950 lowering agent-scope atomic stores to `global_store sc1`
+    (write-through) and on those stores being counted by vmcnt.  Hold the generated code to exactly that: every store of
+    the publish is `sc1`, an `s_waitcnt vmcnt(0)` stands between the last of them and every `global_atomic_add` on the
+    counter, the owner's re-read uses `sc1` loads, and no L2 write-back / L1 invalidate (`buffer_wbl2` / `buffer_inv`)
+    hides in the kernel as a sign that the source went back to fences without this test being revisited."""
+    seen = 0
+    for k in _kernels(isa):
+        body = [l.strip() for l in k["body"]]
+        atomics = [n for n, l in enumerate(body) if l.startswith("global_atomic_add")]
+        assert atomics, "arrival counter not found"
+        for at in atomics:
+            back = body[:at]
+            st = max(n for n, l in enumerate(back) if l.startswith("global_store_dword") and " sc1" in l)
+            between = back[st + 1:]
+            assert any(l.startswith("s_waitcnt") and "vmcnt(0)" in l for l in between), "no vmcnt(0) between the publish and the counter"
+            # the publish run in front of the counter is write-through only
+            run = []
+            for l in reversed(back[:st + 1]):
+                if l.startswith("global_store_dword"):
+                    run.append(l)
+                elif l.startswith(("s_waitcnt", "v_", "s_", ";", "ds_")) or not l:
+                    continue
+                else:
+                    break
+            assert run and all(" sc1" in l for l in run), run
+        assert any(l.startswith("global_load_dword") and " sc1" in l for l in body), "the re-read must use agent-scope (sc1) loads"
+        assert not any(l.startswith(("buffer_wbl2", "buffer_inv")) for l in body)
+        seen += 1
+    assert seen == 4

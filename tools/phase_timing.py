@@ -24,19 +24,21 @@ m, q = w["model"], w["q"]
 for _ in range(3):
     s, g = m.score_grad_raw(q)
 torch.cuda.synchronize()
-buf = (Ct.c_ulonglong * 128)()
+buf = (Ct.c_ulonglong * 512)()
 lib.dcx_debug_read_ts.argtypes = [Ct.POINTER(Ct.c_ulonglong)]
 assert lib.dcx_debug_read_ts(buf) == 0
-names = ["start", "staged+barrier", "after FK+barrier", "after sweep", "after reduce", "after J^T", "after trig+barrier"]
+NWV = 16
+names = {0: "start", 1: "staged+barrier", 6: "after trig+barrier", 2: "after FK+barrier", 3: "after sweep",
+         16: "partials in LDS+barrier", 17: "after fold loop", 4: "after reduce", 5: "after J^T"}
 t0 = buf[0]
-print(f"workload {args.workload} B={args.batch} env NW={os.environ.get('DCX_NW')} YS={os.environ.get('DCX_YS')}")
-for slot, name in enumerate(names):
-    row = [buf[slot * 8 + wv] for wv in range(8)]
-    print(f"{name:<18}" + " ".join(f"{(v - t0) if v else -1:>9d}" for v in row))
+print(f"workload {args.workload} B={args.batch} env NW={os.environ.get('DCX_NW')} YS={os.environ.get('DCX_YS')} FKK={os.environ.get('DCX_FKK')}")
+for slot in (0, 1, 6, 2, 3, 16, 17, 4, 5):
+    row = [buf[slot * NWV + wv] for wv in range(NWV)]
+    print(f"{names[slot]:<24}" + " ".join(f"{(v - t0) if v else -1:>6d}" for v in row))
 for j in range(9):
-    print(f"joint {j}: chain done {buf[(7 + j) * 8] - t0 if buf[(7 + j) * 8] else -1:>9d}   J^T done "
-          f"{buf[(7 + j) * 8 + 1] - t0 if buf[(7 + j) * 8 + 1] else -1:>9d}")
-for j, nm in enumerate(["partial row stored", "release fence", "arrival counted", "second fence", "rows re-read", "G staged"]):
-    v = buf[(7 + j) * 8 + 2]
-    print(f"finish: {nm:<20} {v - t0 if v else -1:>9d}")
-print("(cycles of the constant 100 MHz s_memtime/readcyclecounter clock unless the part reports shader clocks)")
+    a, b = buf[(7 + j) * NWV], buf[(7 + j) * NWV + 1]
+    print(f"step/joint {j}: chain done {a - t0 if a else -1:>9d}   J^T done {b - t0 if b else -1:>9d}")
+for j, nm in enumerate(["partial row stored", "stores drained", "arrival counted", "owner: past the counter", "rows re-read", "G staged"]):
+    v = buf[(7 + j) * NWV + 2]
+    print(f"finish: {nm:<24} {v - t0 if v else -1:>9d}")
+print("(shader cycles, s_memtime; block ts_block of the grid, all 16 waves)")
