@@ -223,10 +223,66 @@ class ScoreLoop:
         self.overlap = gather in ("overlapped", "bucketed")
         self.pending = [None] * nbuf
         self._gather_ms = None
+        self.graph, self.G = None, 8
+        if gather == "graph":
+            if SAME_GPU:   # the rehearsal's host-buffer gather cannot be captured
+                self.gather = "per-call"
+            else:
+                self._capture()
+
+    def _launch(self, out):
+        Ct, w = self.Ct, self.w
+        st = Ct.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+        self._lib.check(self.lib.dcx_score_grad(w["model"]._h, self.qp, self.B, None, Ct.c_void_p(out.data_ptr()), self.gp, st))
+
+    def _capture(self):
+        """G steps - sweep i on the launch stream, the all-gather of its scores on a side stream behind an event, sweep i + 1
+        not waiting for it - captured ONCE into a HIP graph: a replay costs the host one call per G steps, where the eager
+        overlapped form pays c10d's bookkeeping (27 us) on every call.  The gather of step i only has to be over before
+        step i + 2 rewrites its buffer.  Falls back to the per-call form if the collective cannot be captured here."""
+        dev = self.dev
+        self.local = [torch.empty((self.B, self.w["C"]), device=dev, dtype=torch.float32) for _ in range(2)]
+        self.full = [torch.empty((self.world * self.B, self.w["C"]), device=dev, dtype=torch.float32) for _ in range(2)]
+        main, side = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        try:
+            with torch.cuda.stream(main):   # warm-up on the capture stream: the model's split scratch for it, RCCL's buffers
+                for b in (0, 1, 0, 1):
+                    self._launch(self.local[b])
+                    gather_scores(self.full[b], self.local[b])
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            done = [None, None]
+            with torch.cuda.graph(g, stream=main):
+                for i in range(self.G):
+                    b = i % 2
+                    if done[b] is not None:
+                        main.wait_event(done[b])
+                    self._launch(self.local[b])
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    side.wait_event(ev)
+                    with torch.cuda.stream(side):
+                        gather_scores(self.full[b], self.local[b])
+                        done[b] = torch.cuda.Event()
+                        done[b].record(side)
+                main.wait_event(done[0])
+                main.wait_event(done[1])
+            torch.cuda.synchronize(dev)
+            g.replay()
+            torch.cuda.synchronize(dev)
+            self.graph = g
+        except Exception as exc:  # noqa: BLE001  (no graph: the in-order per-call gather, which always works)
+            print(f"bench: graph capture of sweep + all-gather failed ({type(exc).__name__}: {str(exc)[:120]}); per-call gather", file=sys.stderr)
+            torch.cuda.synchronize(dev)
+            self.graph, self.gather = None, "per-call"
 
     def step(self, i, last):
         Ct, w = self.Ct, self.w
         K, B = self.K, self.B
+        if self.gather == "graph":  # a stray step outside whole replays: in order
+            self._launch(self.local[0])
+            gather_scores(self.full[0], self.local[0])
+            return
         b = (i // K) % len(self.local)
         if self.overlap and i % K == 0 and self.pending[b] is not None:
             self.pending[b].wait()  # this buffer's previous gather must be done before the sweep rewrites it (a stream wait)
@@ -253,6 +309,10 @@ class ScoreLoop:
                 self.pending[k] = None
 
     def run(self, n, timed=False):
+        if self.graph is not None:
+            for _ in range(n // self.G):
+                self.graph.replay()
+            n = n % self.G
         for i in range(n):
             self.step(i, n - 1)
 
@@ -345,9 +405,10 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: the workload's per-GPU batch on every rank; strong: its fixed global batch divided by the ranks")
-    ap.add_argument("--gather", default="per-call", choices=["per-call", "overlapped", "bucketed", "none"],
-                    help="N>1: per-call = all-gather of the scores after every call, in order on the launch stream (default); "
-                         "overlapped = beside the next sweep; bucketed = every 4 calls; none = sharded consumer")
+    ap.add_argument("--gather", default="graph", choices=["graph", "per-call", "overlapped", "bucketed", "none"],
+                    help="N>1: graph (default) = every call's scores all-gathered beside the NEXT call's sweep, eight calls captured "
+                         "in one HIP graph (falls back to per-call if the collective cannot be captured); per-call = in order on the "
+                         "launch stream; overlapped = eager, beside the next sweep; bucketed = every 4 calls; none = sharded consumer")
     ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
     ap.add_argument("--no-variants", action="store_true", help="N>1: skip the short runs of the other variants")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -428,7 +489,7 @@ def main():
         variants = {}
         others = [("other_scaling", "strong" if args.scaling == "weak" else "weak", args.gather)]
         if not is_traj:
-            others += [(f"gather_{g}", args.scaling, g) for g in ("per-call", "overlapped", "bucketed", "none") if g != args.gather]
+            others += [(f"gather_{g}", args.scaling, g) for g in ("graph", "per-call", "overlapped", "bucketed", "none") if g != args.gather]
         for key, sc, ga in others:
             # A variant is a side measurement: if one fails (the same way on every rank: an allocation, an argument), it
             # is recorded as failed and the primary line above still goes out.
@@ -478,7 +539,9 @@ def main():
         pmc = load_profile_json(f"pmc_{name}.json")
         mf = load_profile_json("mfma_headline.json") or {}
         mfma_on = os.environ.get("DCX_MFMA", "") not in ("", "0", "-1") and w["D"] <= 16 and C == 1 and not is_traj
-        gather_txt = {"per-call": "RCCL all-gather of the scores after EVERY call, in order on the launch stream",
+        gather_txt = {"graph": "RCCL all-gather of the scores of EVERY call beside the next call's sweep, sweep + gather captured "
+                               "in a HIP graph (8 calls per replay)",
+                      "per-call": "RCCL all-gather of the scores after EVERY call, in order on the launch stream",
                       "overlapped": "RCCL all-gather of the scores after every call, beside the next call's sweep",
                       "bucketed": f"RCCL all-gather of the scores every {GATHER_EVERY} calls, overlapped",
                       "none": "no gather (sharded consumer)",
@@ -516,8 +579,11 @@ def main():
                                       "kernel_us_mfma_form", "kernel_us_valu_form", "verdict", "source")}}},
         }
         if multi:
+            none_ms = ((variants or {}).get("gather_none") or {}).get("ms_per_step")
             out["multi"] = {"ranks": ranks_reported, "backend": "gloo, all ranks on cuda:0 (rehearsal)" if SAME_GPU else "nccl (RCCL)", "gather": loop.gather,
                             "gather_ms": None if gather_ms is None else round(gather_ms, 5),
+                            # what the gather adds to a step: this run's step time minus the same job's no-gather variant
+                            "gather_exposed_ms": None if none_ms is None else round(wall / args.steps * 1e3 - none_ms, 5),
                             "gather_bytes_per_call": None if is_traj else
                             world * B * C * 4 * (GATHER_EVERY if loop.gather == "bucketed" else 1)}
             if variants is not None:

@@ -23,6 +23,9 @@ struct dcx_model {
     DhArgs dh{};                   // its control part, copied into every launch's arguments
     int32_t fk_dwords = 0;         // dwords of FkProg the transform uses
     float* rows_dev = nullptr;     // [S_active][RS]
+    float* rows_xf_dev = nullptr;  // what the expanded-form sweeps read (score_kernel.h): the rows shifted by `centre`,
+                                   // |s - c|^2 in their last column
+    float* centre_dev = nullptr;   // [Dt]: the support centroid for features an FK transform produced, zero for raw inputs
     int64_t S_in = 0;
     int32_t S_active = 0;
     int32_t D = 0, Dt = 0, C = 0, RS = 0;
@@ -46,6 +49,9 @@ struct dcx_model {
 
 #ifdef DCX_TIMING
 static unsigned long long* g_ts_dev = nullptr;
+// [32 slots][16 waves] phase stamps of one block, then [4096 blocks][4]: start, sweep start, sweep end, end of every block
+// (wave 0) with the hardware id (XCC, SE, CU, SIMD) packed into the top bits of the first
+constexpr size_t kTsWords = 32 * 16 + 4096 * 4;
 #endif
 
 namespace {
@@ -307,7 +313,17 @@ Geometry pick_geometry(const dcx_model* m, int64_t B, int acc_floats, bool allow
         return (size_t)(lds_plan(m->fk.dof, d_fk, m->frame_floats, nw > 1 ? slots : 0, acc_floats, true).total + m->prog_floats) * sizeof(float);
     };
     g.red_slots = g.nw;
-    if (lds_bytes(g.nw, g.nw) > 64 * 1024) {
+    // LDS a block may take: a split launch is one block per CU by construction (up to 150 KB); otherwise two 64 KB blocks.
+    // Round 3: a block whose nw partial rows do not fit first tries HALF the waves with the parallel fold (cross-wave fold in
+    // one barrier, every wave publishing / re-reading its share of a hand-over) before it falls back to handing the rows
+    // to wave 0 one at a time - config #3 (C = 5: 17 accumulators, 70 KB at 16 waves) spent 9 k cycles in that serial fold
+    // and 14 k in the one-wave hand-over (profiles/r03_dev_e_phase.txt).
+    const size_t lds_cap = (g.ys > 1 ? 150 : 64) * 1024;
+    if (lds_bytes(g.nw, g.nw) > lds_cap && g.nw >= 8 && lds_bytes(g.nw / 2, g.nw / 2) <= lds_cap) {
+        g.nw /= 2;
+        g.red_slots = g.nw;
+    }
+    if (lds_bytes(g.nw, g.nw) > lds_cap) {
         // Wide shapes (URDF hands, dual arms): nw partial rows of D + C floats per lane would leave one or two waves
         // per CU.  Fold through ONE row instead (LDS no longer grows with nw) and take the block size that keeps the
         // most waves resident: registers allow 4 * wps waves per CU, LDS 160 KB / block.
@@ -337,7 +353,7 @@ Geometry pick_geometry(const dcx_model* m, int64_t B, int acc_floats, bool allow
 // capture, the allocation failed, or a developer knob asks for more rows than the rules ever would): the caller then
 // uses the unsplit geometry, which is always valid.
 constexpr size_t kTileCounters = 1024;                       // arrival counters at the head of a scratch buffer
-constexpr size_t kScratchHead = kTileCounters * sizeof(unsigned int);
+constexpr size_t kScratchHead = kTileCounters * kCounterStride * sizeof(unsigned int);  // one counter per 128-byte line
 float* split_scratch(const dcx_model* m, hipStream_t st, size_t bytes) {
     bytes += kScratchHead;
     std::lock_guard<std::mutex> lock(m->mu);
@@ -389,6 +405,8 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
     const int acc = (mode == MODE_SCORE ? 0 : m->Dt) + m->C;
     const int64_t nblk = (B + 63) / 64;
     // the split rule sees nz launches' worth of tiles: the classes fill the chip too
+    // the expanded form of the sweep (centred data, score_kernel.h) where it is compiled and not switched off
+    const bool xf_able = knobs().xf != 0 && xf_applies(m->Dt, m->C, m->kf) && m->rows_xf_dev != nullptr;
     Geometry g = pick_geometry(m, B * nz, acc, true);
     float* part = nullptr;
     if (g.ys > 1) {
@@ -435,19 +453,25 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
     a.hinge_weight = hinge.weight;
     // Expanded form of the sweep (score_kernel.h XF) wherever it is compiled (Polyharmonic(1), rows <= 37 floats): 13-17 %
     // faster for chip-filling batches, 1-3 % for split launches (profiles/r02_xf_probe.txt).  Knob xf = 0: direct form.
-    a.xf = knobs().xf != 0 ? 1 : 0;
+    a.xf = xf_able ? 1 : 0;
     // MFMA form of the gradient fold: compiled for even D <= 16 with the two specialised kernel functions; needs every
     // wave to own a slice of the LDS reduction scratch (nw > 1, parallel fold)
-    a.mfma = (mode != MODE_SCORE && m->Dt <= 16 && (m->Dt % 2) == 0 && m->kf != KF_GEN && g.nw > 1 && g.red_slots == g.nw &&
+    a.mfma = (mode != MODE_SCORE && m->C == 1 && m->Dt <= 16 && (m->Dt % 2) == 0 && m->kf != KF_GEN && g.nw > 1 && g.red_slots == g.nw &&
               knobs().mfma != 0 && knobs().mfma > 0) ? 1 : 0;
     if (a.mfma) a.xf = 0;
+    if (a.xf) {  // the XF kernel: the centred rows and the centroid
+        a.rows = m->rows_xf_dev;
+        a.centre = m->centre_dev;
+    }
     // J^T on several waves (fk_device.h dh2_vjp_waves): the step table, a parallel fold (its scratch rows 1 .. nw-1 hold 12
     // columns per point step), and not the finish-kernel mode.  Knob jt_waves = 0: wave 0 alone (tests: identical bits).
-    a.jt_waves = (a.fkk == 2 && mode != MODE_SCORE && g.nw > 1 && g.red_slots == g.nw && (g.nw - 1) * acc >= 12 * m->dh.n_pt &&
-                  (g.ys == 1 || counters != nullptr) && knobs().jt_waves != 0) ? 1 : 0;
+    a.jt_rows = (a.fkk == 2 && g.nw >= 2 * m->dh.n_chains && m->dh.n_chains <= 2 && m->dh.end0 <= kDhUnroll &&
+                 m->dh.n_steps - m->dh.end0 <= kDhUnroll && knobs().jt_waves != 0) ? 1 : 0;
+    a.jt_waves = (a.jt_rows && mode != MODE_SCORE && g.red_slots == g.nw && (g.nw - 1) * acc >= 12 * m->dh.n_pt + 1 &&
+                  (g.ys == 1 || counters != nullptr)) ? 1 : 0;
 #ifdef DCX_TIMING
-    if (!g_ts_dev && hipMalloc((void**)&g_ts_dev, sizeof(unsigned long long) * 32 * 16) == hipSuccess)
-        (void)hipMemset(g_ts_dev, 0, sizeof(unsigned long long) * 32 * 16);
+    if (!g_ts_dev && hipMalloc((void**)&g_ts_dev, sizeof(unsigned long long) * kTsWords) == hipSuccess)
+        (void)hipMemset(g_ts_dev, 0, sizeof(unsigned long long) * kTsWords);
     a.ts = g_ts_dev;
     a.ts_block = std::getenv("DCX_TS_BLOCK") ? (unsigned)std::atoi(std::getenv("DCX_TS_BLOCK")) : 0u;
 #endif
@@ -493,10 +517,11 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
 extern "C" {
 
 #ifdef DCX_TIMING
+int dcx_debug_ts_words(void) { return (int)kTsWords; }
 int dcx_debug_read_ts(unsigned long long* out) {  // developer builds only
     if (!g_ts_dev) return 1;
     (void)hipDeviceSynchronize();
-    return hipMemcpy(out, g_ts_dev, sizeof(unsigned long long) * 32 * 16, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 3;
+    return hipMemcpy(out, g_ts_dev, sizeof(unsigned long long) * kTsWords, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 3;
 }
 #endif
 
@@ -628,9 +653,35 @@ int dcx_model_create(dcx_model** out, int device, const dcx_fk_desc* fk, int ker
     }
     hipError_t e = hipSuccess;
     if (kept > 0) {
+        // the centred copy for the expanded-form sweeps: c = mean of the kept supports (float64, rounded once); every
+        // coordinate s - c formed in fp32 exactly as the kernel forms x - c, so that a query that coincides with a support
+        // still gives r = 0 exactly
+        std::vector<float> centre(m->Dt, 0.0f), rows_xf(rows);
+        rows_xf.resize(rows.size() + 64, 0.0f);
+        const int ss_off = m->Dt + C + (C > 1 ? 1 : 0);
+        if (m->fk.kind != DCX_FK_NONE) {
+            for (int k = 0; k < D; ++k) {
+                double acc = 0.0;
+                for (int32_t j = 0; j < kept; ++j) acc += (double)rows[(size_t)j * m->RS + k];
+                centre[k] = (float)(acc / (double)kept);
+            }
+        }
+        for (int32_t j = 0; j < kept; ++j) {
+            float* cen = &rows_xf[(size_t)j * m->RS];
+            double ss = 0.0;
+            for (int k = 0; k < D; ++k) {
+                cen[k] = cen[k] - centre[k];
+                ss += (double)cen[k] * (double)cen[k];
+            }
+            cen[ss_off] = (float)ss;
+        }
         rows.resize(rows.size() + 8 * (size_t)m->RS + 16, 0.0f);  // the MFMA B-operand loads run up to 7 rows + 15 floats ahead
         e = hipMalloc((void**)&m->rows_dev, rows.size() * sizeof(float));
         if (e == hipSuccess) e = hipMemcpy(m->rows_dev, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void**)&m->rows_xf_dev, rows_xf.size() * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(m->rows_xf_dev, rows_xf.data(), rows_xf.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void**)&m->centre_dev, centre.size() * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(m->centre_dev, centre.data(), centre.size() * sizeof(float), hipMemcpyHostToDevice);
     }
     if (e != hipSuccess) {
         dcx_model_destroy(m);
@@ -646,6 +697,8 @@ void dcx_model_destroy(dcx_model* m) {
     if (m->fk_dev) (void)hipFree(m->fk_dev);
     if (m->dh_dev) (void)hipFree(m->dh_dev);
     if (m->rows_dev) (void)hipFree(m->rows_dev);
+    if (m->rows_xf_dev) (void)hipFree(m->rows_xf_dev);
+    if (m->centre_dev) (void)hipFree(m->centre_dev);
     for (auto& sc : m->scratch)
         if (sc.ptr) (void)hipFree(sc.ptr);
     delete m;
@@ -821,8 +874,11 @@ int dcx_traj_adam_run(const dcx_model* m, const dcx_traj_state* st, const dcx_tr
         int nw = std::min(16, m->max_threads / 64);
         if (const int64_t v = knobs().nw; v >= 1) nw = (int)std::min<int64_t>(v, m->max_threads / 64);
         while (nw > 1 && m->S_active / nw < 15) nw /= 2;
+        // the step-table walks on several waves (fk_device.h): chains of <= kDhUnroll steps and >= 4 waves per block
+        const bool dh_ok = m->fk.kind == DCX_FK_DH && m->dh_dev && knobs().fkk != 0 && knobs().fkk != 1 && knobs().jt_waves != 0 &&
+                           m->dh.n_chains <= 2 && m->dh.end0 <= kDhUnroll && m->dh.n_steps - m->dh.end0 <= kDhUnroll;
         auto lds_of = [&](int w) {
-            return sizeof(float) * (size_t)(traj_fused_plan(m->fk.dof, d_fk, m->frame_floats, w, m->Dt).total + m->prog_floats);
+            return sizeof(float) * (size_t)(traj_fused_plan(m->fk.dof, d_fk, m->frame_floats, w, m->Dt, (dh_ok && w >= 4) ? m->dh.n_pt : 0).total + m->prog_floats);
         };
         while (nw > 1 && lds_of(nw) > 150 * 1024) nw /= 2;
         traj_fused_fn fn = traj_fused_for(m->Dt);
@@ -830,6 +886,12 @@ int dcx_traj_adam_run(const dcx_model* m, const dcx_traj_state* st, const dcx_tr
             TrajFusedArgs a{};
             a.sc.rows = m->rows_dev;
             set_fk_walk(m, a.sc);
+            a.sc.jt_rows = a.sc.jt_waves = (dh_ok && nw >= 4 && a.sc.fkk == 2) ? 1 : 0;
+#ifdef DCX_TIMING
+            if (!g_ts_dev && hipMalloc((void**)&g_ts_dev, sizeof(unsigned long long) * kTsWords) == hipSuccess)
+                (void)hipMemset(g_ts_dev, 0, sizeof(unsigned long long) * kTsWords);
+            a.sc.ts = g_ts_dev;
+#endif
             a.sc.S = m->S_active;
             a.sc.s_chunk = (m->S_active + nw - 1) / nw;
             a.sc.dof = m->fk.dof;
@@ -838,7 +900,11 @@ int dcx_traj_adam_run(const dcx_model* m, const dcx_traj_state* st, const dcx_tr
             a.sc.kind = m->kind;
             a.sc.kp0 = m->kp0;
             a.sc.kp1 = m->kp1;
-            a.sc.xf = knobs().xf != 0 ? 1 : 0;
+            a.sc.xf = (knobs().xf != 0 && m->kf == KF_POLY1 && xf_applies(m->Dt, 1, KF_POLY1) && m->rows_xf_dev) ? 1 : 0;
+            if (a.sc.xf) {
+                a.sc.rows = m->rows_xf_dev;
+                a.sc.centre = m->centre_dev;
+            }
             a.st = *st;
             a.opt = *opt;
             a.n_points = m->fk.n_points;

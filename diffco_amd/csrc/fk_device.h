@@ -343,6 +343,7 @@ struct DhArgs {  // the part of the table that travels as kernel arguments
     int32_t n_dwords, n_steps, end0, n_chains;
     uint32_t pt, bare, real;
     int32_t n_pt;
+    int32_t shared_q;    // two chains that read a common q entry (their J^T updates of it keep chain order)
 };
 inline int dh_step_count(const dcx_fk_desc& fk) {
     if (fk.kind != DCX_FK_DH) return 0;
@@ -412,6 +413,11 @@ inline DhArgs dh_args_of(const DhProg& p, const DhProg* dev) {
     a.bare = p.bare_mask;
     a.real = p.real_mask;
     a.n_pt = p.n_pt;
+    a.shared_q = 0;
+    for (int i = 0; i < p.end0; ++i)
+        for (int j = p.end0; j < p.n_steps; ++j)
+            if (((p.real_mask >> i) & 1u) && ((p.real_mask >> j) & 1u) && ((p.steps[i].meta >> 8) & 0xff) == ((p.steps[j].meta >> 8) & 0xff))
+                a.shared_q = 1;
     return a;
 }
 
@@ -1440,7 +1446,8 @@ __device__ inline void dh2_vjp(dh_cptr p, const DhArgs& c, const float* sFcol, c
 // are priced by the instructions ONE wave executes, not by flops.  Under T <- T * A the rows of [R | t] never mix: the
 // chain is split by rows over two waves - role 0 carries rows 0 and 1 as PACKED pairs (v_pk_fma_f32: two rows for the
 // issue slots of one), role 1 carries row 2 - ten arithmetic instructions per step and wave instead of thirty.  Same
-// expressions per entry as dh2_chain (v_pk_fma_f32 is fmaf per half): bit-identical.
+// expressions per entry as dh2_chain (v_pk_fma_f32 is fmaf per half): bit-identical.  The walks themselves follow below,
+// unrolled per chain.
 template <class V>
 __device__ __forceinline__ V dh_splat(float x) {
     if constexpr (__is_same(V, float)) return x;
@@ -1458,60 +1465,14 @@ __device__ __forceinline__ V dh_fma(V a, V b, V c) {
     if constexpr (__is_same(V, float)) return dh_opaque(fmaf(a, b, c));
     else return __builtin_elementwise_fma(a, b, c);
 }
-// ROLE 0: V = f2v, rows 0 and 1;  ROLE 1: V = float, row 2.  Caller: waves 0 and 1 of the block, then a block barrier.
-template <int ROLE>
-__device__ __forceinline__ void dh2_chain_rows(dh_cptr p, const DhArgs& c, float* sXcol, float* sFcol) {
-    using V = typename std::conditional<ROLE == 0, f2v, float>::type;
-    auto row = [](f4v b0, f4v b1, f4v b2, int k) -> V {  // entry k of this role's rows of the base transform
-        if constexpr (ROLE == 0) return V{b0[k], b1[k]};
-        else return b2[k];
-    };
-    int jb = 0;
-    for (int ch = 0; ch < c.n_chains; ++ch) {
-        const int je = ch == 0 ? c.end0 : c.n_steps;
-        const f4v b0 = *(lds_f4)&p->base[ch][0], b1 = *(lds_f4)&p->base[ch][4], b2 = *(lds_f4)&p->base[ch][8];
-        V r0 = row(b0, b1, b2, 0), r1 = row(b0, b1, b2, 1), r2 = row(b0, b1, b2, 2), t = row(b0, b1, b2, 3);
-        f4v nk = *(lds_f4)&p->steps[jb].a, no = *(lds_f4)&p->steps[jb].ox;
-        float ns = sFcol[(2 * jb) * 64], nc = sFcol[(2 * jb + 1) * 64];
-        for (int j = jb; j < je; ++j) {
-            const f4v k = nk, o = no;
-            const V s = dh_splat<V>(ns), co = dh_splat<V>(nc);
-            const int jn = j + 1 < je ? j + 1 : j;
-            nk = *(lds_f4)&p->steps[jn].a;
-            no = *(lds_f4)&p->steps[jn].ox;
-            ns = sFcol[(2 * jn) * 64];
-            nc = sFcol[(2 * jn + 1) * 64];
-            const V a = dh_splat<V>(k.x), d = dh_splat<V>(k.y), sa = dh_splat<V>(k.z), ca = dh_splat<V>(k.w);
-            const V n0 = dh_fma<V>(r0, co, r1 * s);
-            const V u = dh_fma<V>(r1, co, -(r0 * s));
-            t = dh_fma<V>(n0, a, dh_fma<V>(r2, d, t));
-            const V n1 = dh_fma<V>(u, ca, r2 * sa);
-            const V n2 = dh_fma<V>(r2, ca, -(u * sa));
-            r0 = n0; r1 = n1; r2 = n2;
-            if (dh_bit(c.pt, j)) {
-                V pt = t;
-                if (!dh_bit(c.bare, j)) pt = dh_fma<V>(r0, dh_splat<V>(o.x), dh_fma<V>(r1, dh_splat<V>(o.y), dh_fma<V>(r2, dh_splat<V>(o.z), t)));
-                float* out = sXcol + (__float_as_int(o.w) & 0xff) * 64;
-                if constexpr (ROLE == 0) { out[0] = pt.x; out[64] = pt.y; }
-                else out[128] = pt;
-            }
-        }
-        float* fr = sFcol + (2 * c.n_steps + 9 * ch) * 64;  // final rotation of this chain, this role's rows
-        if constexpr (ROLE == 0) {
-            fr[0] = r0.x; fr[64] = r1.x; fr[128] = r2.x; fr[192] = r0.y; fr[256] = r1.y; fr[320] = r2.y;
-        } else {
-            fr[384] = r0; fr[448] = r1; fr[512] = r2;
-        }
-        jb = je;
-    }
-}
-
-// ---- the same walks UNROLLED for one chain of at most kDhUnroll steps (every single arm the reference ships) ---------------
+// ---- the same walks UNROLLED per chain (chains of at most kDhUnroll steps: every DH robot the reference ships) ----------
 // The loops above still spend three instructions of bookkeeping (register rotation of the prefetched operands, table
 // address arithmetic, loop control) for every one of arithmetic.  With the step index a compile-time constant the table
-// reads become immediate offsets, the masks are tested with s_bitcmp on an immediate bit, and nothing rotates.  Steps
-// past n_steps are skipped by one scalar compare each.  Same expressions, same order: bit-identical to the loops.
-constexpr int kDhUnroll = 8;
+// reads become immediate offsets from the chain's first record, the masks are tested with s_bitcmp on an immediate bit,
+// and nothing rotates.  Steps past the chain's end are skipped by one scalar compare each.  A robot's chains are
+// independent of each other, so they run side by side on different waves.  Same expressions, same order: bit-identical
+// to the loops.
+constexpr int kDhUnroll = 10;
 template <int I, int N, class F>
 __device__ __forceinline__ void dh_static_for(F&& f) {
     if constexpr (I < N) {
@@ -1519,37 +1480,56 @@ __device__ __forceinline__ void dh_static_for(F&& f) {
         dh_static_for<I + 1, N>(f);
     }
 }
-__device__ __forceinline__ bool dh2_unrollable(const DhArgs& c) { return c.n_chains == 1 && c.n_steps <= kDhUnroll; }
+__device__ __forceinline__ bool dh2_unrollable(const DhArgs& c) {
+    return c.n_chains <= 2 && c.end0 <= kDhUnroll && c.n_steps - c.end0 <= kDhUnroll;
+}
+struct DhChain {   // one chain's view of the table: steps [jb, jb + n), masks shifted so that bit i is step jb + i
+    int ch, jb, n, ps0;
+    uint32_t pt, bare, real;
+};
+__device__ __forceinline__ DhChain dh_chain_of(const DhArgs& c, int ch) {
+    DhChain h;
+    h.ch = ch;
+    h.jb = ch == 0 ? 0 : c.end0;
+    h.n = (ch == 0 ? c.end0 : c.n_steps) - h.jb;
+    h.pt = c.pt >> h.jb;
+    h.bare = c.bare >> h.jb;
+    h.real = c.real >> h.jb;
+    h.ps0 = __builtin_popcount(c.pt & ((1u << h.jb) - 1u));  // point steps of the chains in front (jb < 32)
+    return h;
+}
 
-// one step's operands, requested one step ahead of their use, unconditionally (reads past n_steps stay inside the staged
-// table's LDS allocation and inside the frames: the values are never used)
+// one step's operands, requested one step ahead of their use, unconditionally (reads past the chain's end stay inside the
+// staged table's LDS allocation and inside the frames: the values are never used)
 struct DhOps {
     f4v k, o;
     float s, co;
 };
 template <bool WITH_O>
-__device__ __forceinline__ DhOps dh_load_ops(dh_cptr p, const float* sFcol, int j) {
+__device__ __forceinline__ DhOps dh_load_ops(const __attribute__((address_space(3))) DhStep* st, const float* sc, int i) {
     DhOps r;
-    r.k = *(lds_f4)&p->steps[j].a;
-    if constexpr (WITH_O) r.o = *(lds_f4)&p->steps[j].ox;
-    r.s = sFcol[(2 * j) * 64];
-    r.co = sFcol[(2 * j + 1) * 64];
+    r.k = *(lds_f4)&st[i].a;
+    if constexpr (WITH_O) r.o = *(lds_f4)&st[i].ox;
+    r.s = sc[(2 * i) * 64];
+    r.co = sc[(2 * i + 1) * 64];
     return r;
 }
 
 template <int ROLE>
-__device__ __forceinline__ void dh2_chain_rows_u(dh_cptr p, const DhArgs& c, float* sXcol, float* sFcol) {
+__device__ __forceinline__ void dh2_chain_rows_u(dh_cptr p, const DhArgs& c, const DhChain& h, float* sXcol, float* sFcol) {
     using V = typename std::conditional<ROLE == 0, f2v, float>::type;
-    const f4v b0 = *(lds_f4)&p->base[0][0], b1 = *(lds_f4)&p->base[0][4], b2 = *(lds_f4)&p->base[0][8];
+    const f4v b0 = *(lds_f4)&p->base[h.ch][0], b1 = *(lds_f4)&p->base[h.ch][4], b2 = *(lds_f4)&p->base[h.ch][8];
     V r0, r1, r2, t;
     if constexpr (ROLE == 0) { r0 = V{b0.x, b1.x}; r1 = V{b0.y, b1.y}; r2 = V{b0.z, b1.z}; t = V{b0.w, b1.w}; }
     else { r0 = b2.x; r1 = b2.y; r2 = b2.z; t = b2.w; }
-    DhOps nx = dh_load_ops<true>(p, sFcol, 0);
+    const auto* st = &p->steps[h.jb];
+    const float* sc = sFcol + (2 * h.jb) * 64;
+    DhOps nx = dh_load_ops<true>(st, sc, 0);
     dh_static_for<0, kDhUnroll>([&](auto jc) __attribute__((always_inline)) {
         constexpr int j = decltype(jc)::value;
         const DhOps cu = nx;
-        if constexpr (j + 1 < kDhUnroll) nx = dh_load_ops<true>(p, sFcol, j + 1);
-        if (j < c.n_steps) {
+        if constexpr (j + 1 < kDhUnroll) nx = dh_load_ops<true>(st, sc, j + 1);
+        if (j < h.n) {
             const V s = dh_splat<V>(cu.s), co = dh_splat<V>(cu.co);
             const V a = dh_splat<V>(cu.k.x), d = dh_splat<V>(cu.k.y), sa = dh_splat<V>(cu.k.z), ca = dh_splat<V>(cu.k.w);
             const V n0 = dh_fma<V>(r0, co, r1 * s);
@@ -1558,9 +1538,9 @@ __device__ __forceinline__ void dh2_chain_rows_u(dh_cptr p, const DhArgs& c, flo
             const V n1 = dh_fma<V>(u, ca, r2 * sa);
             const V n2 = dh_fma<V>(r2, ca, -(u * sa));
             r0 = n0; r1 = n1; r2 = n2;
-            if (dh_bit(c.pt, j)) {
+            if (dh_bit(h.pt, j)) {
                 V pt = t;
-                if (!dh_bit(c.bare, j))
+                if (!dh_bit(h.bare, j))
                     pt = dh_fma<V>(r0, dh_splat<V>(cu.o.x), dh_fma<V>(r1, dh_splat<V>(cu.o.y), dh_fma<V>(r2, dh_splat<V>(cu.o.z), t)));
                 float* out = sXcol + (__float_as_int(cu.o.w) & 0xff) * 64;
                 if constexpr (ROLE == 0) { out[0] = pt.x; out[64] = pt.y; }
@@ -1568,31 +1548,40 @@ __device__ __forceinline__ void dh2_chain_rows_u(dh_cptr p, const DhArgs& c, flo
             }
         }
     });
-    float* fr = sFcol + (2 * c.n_steps) * 64;
+    float* fr = sFcol + (2 * c.n_steps + 9 * h.ch) * 64;
     if constexpr (ROLE == 0) {
         fr[0] = r0.x; fr[64] = r1.x; fr[128] = r2.x; fr[192] = r0.y; fr[256] = r1.y; fr[320] = r2.y;
     } else {
         fr[384] = r0; fr[448] = r1; fr[512] = r2;
     }
 }
+// wave w < 2 * n_chains composes rows (role w & 1) of chain w >> 1; caller: block barrier afterwards
+__device__ __forceinline__ void dh2_chain_rows_sel(dh_cptr p, const DhArgs& c, float* sXcol, float* sFcol, int w) {
+    if (w >= 2 * c.n_chains) return;
+    const DhChain h = dh_chain_of(c, w >> 1);
+    if (w & 1) dh2_chain_rows_u<1>(p, c, h, sXcol, sFcol);
+    else dh2_chain_rows_u<0>(p, c, h, sXcol, sFcol);
+}
 
-// phase R1 of dh2_vjp_waves, unrolled (steps in descending order; ps = point steps below the current one)
+// phase R1 of dh2_vjp_waves, unrolled (steps in descending order)
 template <int ROLE>
-__device__ __forceinline__ void dh2_vjp_r1_u(dh_cptr p, const DhArgs& c, const float* sFcol, float* scr) {
+__device__ __forceinline__ void dh2_vjp_r1_u(dh_cptr p, const DhArgs& c, const DhChain& h, const float* sFcol, float* scr, int psw = 12) {
     using V = typename std::conditional<ROLE == 0, f2v, float>::type;
-    const float* fr = sFcol + (2 * c.n_steps) * 64;
+    const float* fr = sFcol + (2 * c.n_steps + 9 * h.ch) * 64;
     V r0, r1, r2;
     if constexpr (ROLE == 0) { r0 = V{fr[0], fr[192]}; r1 = V{fr[64], fr[256]}; r2 = V{fr[128], fr[320]}; }
     else { r0 = fr[384]; r1 = fr[448]; r2 = fr[512]; }
-    DhOps nx = dh_load_ops<false>(p, sFcol, kDhUnroll - 1);
+    const auto* st = &p->steps[h.jb];
+    const float* sc = sFcol + (2 * h.jb) * 64;
+    DhOps nx = dh_load_ops<false>(st, sc, kDhUnroll - 1);
     dh_static_for<0, kDhUnroll>([&](auto ic) __attribute__((always_inline)) {
         constexpr int j = kDhUnroll - 1 - decltype(ic)::value;
         const DhOps cu = nx;
-        if constexpr (j > 0) nx = dh_load_ops<false>(p, sFcol, j - 1);
-        if (j < c.n_steps) {
-            if (dh_bit(c.pt, j)) {
-                const int ps = __builtin_popcount(c.pt & ((1u << j) - 1u));
-                float* o = scr + (12 * ps) * 64;
+        if constexpr (j > 0) nx = dh_load_ops<false>(st, sc, j - 1);
+        if (j < h.n) {
+            if (dh_bit(h.pt, j)) {
+                const int ps = h.ps0 + __builtin_popcount(h.pt & ((1u << j) - 1u));
+                float* o = scr + (psw * ps) * 64;
                 if constexpr (ROLE == 0) {
                     o[0] = r0.x; o[64] = r1.x; o[128] = r2.x; o[192] = r0.y; o[256] = r1.y; o[320] = r2.y;
                 } else {
@@ -1610,25 +1599,33 @@ __device__ __forceinline__ void dh2_vjp_r1_u(dh_cptr p, const DhArgs& c, const f
         }
     });
 }
+__device__ __forceinline__ void dh2_vjp_r1_sel(dh_cptr p, const DhArgs& c, const float* sFcol, float* scr, int w, int psw = 12) {
+    if (w < 0 || w >= 2 * c.n_chains) return;
+    const DhChain h = dh_chain_of(c, w >> 1);
+    if (w & 1) dh2_vjp_r1_u<1>(p, c, h, sFcol, scr, psw);
+    else dh2_vjp_r1_u<0>(p, c, h, sFcol, scr, psw);
+}
 
-// phase R2 of dh2_vjp_waves, unrolled (wave 0)
-__device__ __forceinline__ void dh2_vjp_r2_u(dh_cptr p, const DhArgs& c, const float* sFcol, const float* scr, float* gqRow, int dof) {
-    for (int i = 0; i < dof; ++i) gqRow[i] = 0.f;
+// phase R2 of dh2_vjp_waves, unrolled: one chain's wrench recurrence on one wave (gqRow zeroed by the caller)
+__device__ __forceinline__ void dh2_vjp_r2_u(dh_cptr p, const DhArgs& c, const DhChain& h, const float* sFcol, const float* scr,
+                                             float* gqRow, int psw = 12, int loff = 9) {
     float f0 = 0.f, f1 = 0.f, f2 = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
-    DhOps nx = dh_load_ops<true>(p, sFcol, kDhUnroll - 1);
+    const auto* st = &p->steps[h.jb];
+    const float* sc = sFcol + (2 * h.jb) * 64;
+    DhOps nx = dh_load_ops<true>(st, sc, kDhUnroll - 1);
     dh_static_for<0, kDhUnroll>([&](auto ic) __attribute__((always_inline)) {
         constexpr int j = kDhUnroll - 1 - decltype(ic)::value;
         const DhOps cu = nx;
-        if constexpr (j > 0) nx = dh_load_ops<true>(p, sFcol, j - 1);
-        if (j < c.n_steps) {
+        if constexpr (j > 0) nx = dh_load_ops<true>(st, sc, j - 1);
+        if (j < h.n) {
             const float s = cu.s, co = cu.co;
             const int meta = __float_as_int(cu.o.w);
-            if (dh_bit(c.pt, j)) {
-                const int ps = __builtin_popcount(c.pt & ((1u << j) - 1u));
-                const float* l = scr + (12 * ps + 9) * 64;
+            if (dh_bit(h.pt, j)) {
+                const int ps = h.ps0 + __builtin_popcount(h.pt & ((1u << j) - 1u));
+                const float* l = scr + (psw * ps + loff) * 64;
                 const float l0 = l[0], l1 = l[64], l2 = l[128];
                 f0 = dh_opaque(f0 + l0); f1 = dh_opaque(f1 + l1); f2 = dh_opaque(f2 + l2);
-                if (!dh_bit(c.bare, j)) {
+                if (!dh_bit(h.bare, j)) {
                     n0 = dh_opaque(fmaf(cu.o.y, l2, fmaf(-cu.o.z, l1, n0)));
                     n1 = dh_opaque(fmaf(cu.o.z, l0, fmaf(-cu.o.x, l2, n1)));
                     n2 = dh_opaque(fmaf(cu.o.x, l1, fmaf(-cu.o.y, l0, n2)));
@@ -1642,7 +1639,7 @@ __device__ __forceinline__ void dh2_vjp_r2_u(dh_cptr p, const DhArgs& c, const f
             const float mx = dh_opaque(fmaf(-d, fy, n0));
             const float my = dh_opaque(fmaf(d, f0, fmaf(-a, fz, yy.y)));
             const float mz = dh_opaque(fmaf(a, fy, zz.y));
-            if (dh_bit(c.real, j)) gqRow[(meta >> 8) & 0xff] += mz;
+            if (dh_bit(h.real, j)) gqRow[(meta >> 8) & 0xff] += mz;
             if constexpr (j > 0) {
                 const f2v x0 = {f0, mx}, x1 = {fy, my}, s2 = {s, s}, c2 = {co, co};
                 const f2v w1 = __builtin_elementwise_fma(s2, x0, c2 * x1);
@@ -1654,144 +1651,41 @@ __device__ __forceinline__ void dh2_vjp_r2_u(dh_cptr p, const DhArgs& c, const f
     });
 }
 
-// J^T on several waves, three phases with block barriers between them (every wave of the block calls this):
-//   R1  (waves 0, 1): the rotations R_j are recomputed from each chain's tip backwards, row-split like the chain above
-//        (R_{j-1} = R_j Rx^T Rz^T row by row), and the rows of every POINT step's R_j are left in `scr`;
-//   R1b (wave ps, ps + nw, ...): l = R_j^T (scale * g) of point step ps - the nine FMAs per point that need the rotation;
-//   R2  (wave 0): the wrench recurrence itself (fk_vjp's expressions), which now only reads l: ~25 instructions per step.
+// J^T on several waves, phase by phase (the caller places block barriers between the phases; every expression is
+// dh2_vjp's, so the result is bit-identical to it):
+//   R1  (two waves per chain: dh2_vjp_r1_sel): the rotations R_j are recomputed from each chain's tip backwards, row-split
+//        like the chain (R_{j-1} = R_j Rx^T Rz^T row by row), and the rows of every POINT step's R_j are left in `scr`.
+//        Needs only the frames, not the gradient: a split launch runs it beside the arrival count of its hand-over;
+//   R1b (wave ps, ps + nw, ...: dh2_vjp_r1b): l = R_j^T (scale * g) of point step ps - the nine FMAs per point that need
+//        the rotation; wave 0 also clears the gradient row;
+//   R2  (one wave per chain: dh2_vjp_r2_sel): the wrench recurrence itself, which now only reads l: ~30 instructions per step.
 // scr: 12 columns per point step ([9] rotation, row-major, [3] l), per lane.  sGtot: the UNSCALED feature gradient columns;
-// `scale` is this lane's factor (what the one-wave epilogue multiplies in while staging G).  Bit-identical to dh2_vjp.
-__device__ __forceinline__ void dh2_vjp_waves(dh_cptr p, const DhArgs& c, const float* sFcol, const float* sGtot, float scale,
-                                              float* scr, float* gqRow, int dof, int wave, int nw) {
-    // ---- R1 ----
-    auto r1_rows = [&](auto rolec) __attribute__((always_inline)) {
-        constexpr int ROLE = decltype(rolec)::value;
-        using V = typename std::conditional<ROLE == 0, f2v, float>::type;
-        int jb = 0;
-        for (int ch = 0; ch < c.n_chains; ++ch) {
-            const int je = ch == 0 ? c.end0 : c.n_steps;
-            const float* fr = sFcol + (2 * c.n_steps + 9 * ch) * 64;
-            V r0, r1, r2;
-            if constexpr (ROLE == 0) { r0 = V{fr[0], fr[192]}; r1 = V{fr[64], fr[256]}; r2 = V{fr[128], fr[320]}; }
-            else { r0 = fr[384]; r1 = fr[448]; r2 = fr[512]; }
-            const int jl = je - 1;
-            f4v nk = *(lds_f4)&p->steps[jl].a;
-            float ns = sFcol[(2 * jl) * 64], nc = sFcol[(2 * jl + 1) * 64];
-            int ps = __builtin_popcount(c.pt & ((je >= 32 ? 0u : (1u << je)) - 1u));  // point steps below je
-            for (int j = jl; j >= jb; --j) {
-                const f4v k = nk;
-                const V s = dh_splat<V>(ns), co = dh_splat<V>(nc);
-                if (j > jb) {
-                    nk = *(lds_f4)&p->steps[j - 1].a;
-                    ns = sFcol[(2 * (j - 1)) * 64];
-                    nc = sFcol[(2 * (j - 1) + 1) * 64];
-                }
-                if (dh_bit(c.pt, j)) {
-                    --ps;
-                    float* o = scr + (12 * ps) * 64;
-                    if constexpr (ROLE == 0) {
-                        o[0] = r0.x; o[64] = r1.x; o[128] = r2.x; o[192] = r0.y; o[256] = r1.y; o[320] = r2.y;
-                    } else {
-                        o[384] = r0; o[448] = r1; o[512] = r2;
-                    }
-                }
-                if (j > jb) {
-                    const V sa = dh_splat<V>(k.z), ca = dh_splat<V>(k.w);
-                    const V u = dh_fma<V>(ca, r1, -(sa * r2));
-                    r2 = dh_fma<V>(sa, r1, ca * r2);
-                    r1 = dh_fma<V>(s, r0, co * u);
-                    r0 = dh_fma<V>(co, r0, -(s * u));
-                }
-            }
-            jb = je;
-        }
-    };
-    const bool unrolled = dh2_unrollable(c);
-    if (unrolled) {
-        if (wave == 0) dh2_vjp_r1_u<0>(p, c, sFcol, scr);
-        else if (wave == 1) dh2_vjp_r1_u<1>(p, c, sFcol, scr);
-    } else {
-        if (wave == 0) r1_rows(std::integral_constant<int, 0>{});
-        else if (wave == 1) r1_rows(std::integral_constant<int, 1>{});
-    }
-    __syncthreads();
-    // ---- R1b ----
+// `scale` is this lane's factor (what the one-wave epilogue multiplies in while staging G).
+__device__ __forceinline__ void dh2_vjp_r1b(dh_cptr p, const DhArgs& c, const float* sGtot, float scale, float* scr, float* gqRow,
+                                            int dof, int wave, int nw, int psw = 12, int loff = 9) {
+    if (wave == 0)
+        for (int i = 0; i < dof; ++i) gqRow[i] = 0.f;
     for (int ps = wave; ps < c.n_pt; ps += nw) {
-        const float* R = scr + (12 * ps) * 64;
+        const float* R = scr + (psw * ps) * 64;
         const float* gin = sGtot + p->ps_col[ps] * 64;
         const float g0 = gin[0] * scale, g1 = gin[64] * scale, g2 = gin[128] * scale;
         const float r00 = R[0], r01 = R[64], r02 = R[128], r10 = R[192], r11 = R[256], r12 = R[320];
         const float r20 = R[384], r21 = R[448], r22 = R[512];
-        float* l = scr + (12 * ps + 9) * 64;
+        float* l = scr + (psw * ps + loff) * 64;
         l[0] = fmaf(r00, g0, fmaf(r10, g1, r20 * g2));
         l[64] = fmaf(r01, g0, fmaf(r11, g1, r21 * g2));
         l[128] = fmaf(r02, g0, fmaf(r12, g1, r22 * g2));
     }
-    __syncthreads();
-    // ---- R2 ----
-    if (wave != 0) return;
-    if (unrolled) {
-        dh2_vjp_r2_u(p, c, sFcol, scr, gqRow, dof);
-        return;
-    }
-    for (int i = 0; i < dof; ++i) gqRow[i] = 0.f;
-    int jb = 0;
-    for (int ch = 0; ch < c.n_chains; ++ch) {
-        const int je = ch == 0 ? c.end0 : c.n_steps;
-        float f0 = 0.f, f1 = 0.f, f2 = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
-        const int jl = je - 1;
-        int ps = __builtin_popcount(c.pt & ((je >= 32 ? 0u : (1u << je)) - 1u));
-        f4v nk = *(lds_f4)&p->steps[jl].a, no = *(lds_f4)&p->steps[jl].ox;
-        float ns = sFcol[(2 * jl) * 64], nc = sFcol[(2 * jl + 1) * 64];
-        float nl0 = 0.f, nl1 = 0.f, nl2 = 0.f;
-        if (dh_bit(c.pt, jl)) {
-            --ps;
-            const float* l = scr + (12 * ps + 9) * 64;
-            nl0 = l[0]; nl1 = l[64]; nl2 = l[128];
-        }
-        for (int j = jl; j >= jb; --j) {
-            const f4v k = nk, o = no;
-            const float s = ns, co = nc, l0 = nl0, l1 = nl1, l2 = nl2;
-            const int meta = __float_as_int(o.w);
-            if (j > jb) {
-                nk = *(lds_f4)&p->steps[j - 1].a;
-                no = *(lds_f4)&p->steps[j - 1].ox;
-                ns = sFcol[(2 * (j - 1)) * 64];
-                nc = sFcol[(2 * (j - 1) + 1) * 64];
-                if (dh_bit(c.pt, j - 1)) {
-                    --ps;
-                    const float* l = scr + (12 * ps + 9) * 64;
-                    nl0 = l[0]; nl1 = l[64]; nl2 = l[128];
-                }
-            }
-            if (dh_bit(c.pt, j)) {
-                f0 += l0; f1 += l1; f2 += l2;
-                if (!dh_bit(c.bare, j)) {
-                    n0 = fmaf(o.y, l2, fmaf(-o.z, l1, n0));
-                    n1 = fmaf(o.z, l0, fmaf(-o.x, l2, n1));
-                    n2 = fmaf(o.x, l1, fmaf(-o.y, l0, n2));
-                }
-            }
-            const float a = k.x, d = k.y, sa = k.z, ca = k.w;
-            // Rx(alpha) on (f, n) as packed pairs (f1, n1), (f2, n2); then the moment arm (a, 0, d)
-            const f2v y1 = {f1, n1}, y2 = {f2, n2}, sa2 = {sa, sa}, ca2 = {ca, ca};
-            const f2v yy = __builtin_elementwise_fma(ca2, y1, -(sa2 * y2));   // (fy, ca n1 - sa n2)
-            const f2v zz = __builtin_elementwise_fma(sa2, y1, ca2 * y2);      // (fz, sa n1 + ca n2)
-            const float fy = yy.x, fz = zz.x;
-            const float mx = fmaf(-d, fy, n0);
-            const float my = fmaf(d, f0, fmaf(-a, fz, yy.y));
-            const float mz = fmaf(a, fy, zz.y);
-            if (dh_bit(c.real, j)) gqRow[(meta >> 8) & 0xff] += mz;
-            if (j > jb) {
-                // Rz(theta) on (f0, fy) and (mx, my) as packed pairs
-                const f2v x0 = {f0, mx}, x1 = {fy, my}, s2 = {s, s}, c2 = {co, co};
-                const f2v w1 = __builtin_elementwise_fma(s2, x0, c2 * x1);     // (f1', n1')
-                const f2v w0 = __builtin_elementwise_fma(c2, x0, -(s2 * x1));  // (f0', n0')
-                f0 = w0.x; n0 = w0.y; f1 = w1.x; n1 = w1.y;
-                f2 = fz; n2 = mz;
-            }
-        }
-        jb = je;
+}
+// wave 0 takes chain 0, wave 1 chain 1 - unless the chains drive a common q entry (c.shared_q: their updates of that
+// entry must then happen in chain order, on one wave)
+__device__ __forceinline__ void dh2_vjp_r2_sel(dh_cptr p, const DhArgs& c, const float* sFcol, const float* scr, float* gqRow, int wave,
+                                               int psw = 12, int loff = 9) {
+    if (c.n_chains == 1 || c.shared_q) {
+        if (wave != 0) return;
+        for (int ch = 0; ch < c.n_chains; ++ch) dh2_vjp_r2_u(p, c, dh_chain_of(c, ch), sFcol, scr, gqRow, psw, loff);
+    } else if (wave >= 0 && wave < 2) {
+        dh2_vjp_r2_u(p, c, dh_chain_of(c, wave), sFcol, scr, gqRow, psw, loff);
     }
 }
 

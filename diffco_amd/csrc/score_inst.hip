@@ -28,32 +28,30 @@ constexpr int kMaxT = kD <= 16 ? 1024 : (kD <= 48 ? 512 : 256);
 template <int KF, int MODE>
 constexpr bool kHasMfma = (kD <= 16) && (kD % 2 == 0) && (MODE != MODE_SCORE) && (KF != KF_GEN);
 
-// Shapes with an expanded form (score_kernel.h, XF: Polyharmonic(1), rows of <= 37 floats) run it by default.  The
-// direct form is compiled for them as well and selected per launch by ScoreArgs::xf (dcx_debug_set("xf", 0)): the
-// parity tests run every case in both forms, tools/xf_probe.py times them side by side.  -DDCX_SINGLE_FORM drops it.
-#ifdef DCX_SINGLE_FORM
-constexpr bool kBothForms = false;
-#else
-constexpr bool kBothForms = true;
-#endif
+// Shapes with an expanded form (score_kernel.h, XF: Polyharmonic(1), rows of <= 37 floats) run it by default, on the
+// centred row pairs the host passes with it (ScoreArgs::centre).  The direct form is compiled for them as well and
+// selected per launch by ScoreArgs::xf (dcx_debug_set("xf", 0)): the parity tests run every case in both forms,
+// tools/xf_probe.py times them side by side.
 
 template <int KF, int CC, int MODE>
 hipError_t go(int nw, size_t lds, int64_t nblk, const ScoreArgs& a, hipStream_t st) {
     const dim3 grid((unsigned)nblk, (unsigned)(a.ys > 1 ? a.ys : 1), (unsigned)(a.nz > 1 ? a.nz : 1));
-    if constexpr (xf_applies(kD, CC, KF)) {
-        if (!a.mfma && (a.xf || !kBothForms)) {
-            score_kernel<kD, KF, CC, MODE, kMaxT, false, true><<<grid, dim3(64 * nw), lds, st>>>(a);
-            return hipGetLastError();
+    // more than 64 KB of dynamic LDS (a split launch's 16 partial rows of a C > 1 model) needs the attribute raised once
+    auto launch = [&](auto kern) {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
         }
+        kern<<<grid, dim3(64 * nw), lds, st>>>(a);
+        return hipGetLastError();
+    };
+    if constexpr (xf_applies(kD, CC, KF)) {
+        if (!a.mfma && a.xf) return launch(score_kernel<kD, KF, CC, MODE, kMaxT, false, true>);
     }
     if constexpr (kHasMfma<KF, MODE>) {
-        if (a.mfma) {
-            score_kernel<kD, KF, CC, MODE, kMaxT, true><<<dim3((unsigned)nblk, (unsigned)(a.ys > 1 ? a.ys : 1), (unsigned)(a.nz > 1 ? a.nz : 1)), dim3(64 * nw), lds, st>>>(a);
-            return hipGetLastError();
-        }
+        if (a.mfma) return launch(score_kernel<kD, KF, CC, MODE, kMaxT, true>);
     }
-    score_kernel<kD, KF, CC, MODE, kMaxT><<<dim3((unsigned)nblk, (unsigned)(a.ys > 1 ? a.ys : 1), (unsigned)(a.nz > 1 ? a.nz : 1)), dim3(64 * nw), lds, st>>>(a);
-    return hipGetLastError();
+    return launch(score_kernel<kD, KF, CC, MODE, kMaxT>);
 }
 
 template <int KF, int CC>
@@ -152,7 +150,7 @@ hipError_t DCX_CAT(launch_traj_fused_D, DCX_INST_D)(int kf, int nw, size_t lds, 
         return hipGetLastError();
     };
     if constexpr (xf_applies(kD, 1, KF_POLY1)) {
-        if (kf == KF_POLY1 && (a.sc.xf || !kBothForms)) return go_t(traj_fused_kernel<kD, KF_POLY1, kMaxT, true>);
+        if (kf == KF_POLY1 && a.sc.xf) return go_t(traj_fused_kernel<kD, KF_POLY1, kMaxT, true>);
     }
     switch (kf) {
     case KF_RQ2: return go_t(traj_fused_kernel<kD, KF_RQ2, kMaxT>);

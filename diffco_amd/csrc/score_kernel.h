@@ -43,6 +43,9 @@ enum { MODE_SCORE = 0,    // score only
 
 struct ScoreArgs {
     const float* rows;        // [S][RS] support rows: D coords, CC weights, (CC>1: sum of weights), |s|^2, pad
+    const float* centre;      // expanded-form launches (XF kernels): the vector [D] that `rows` has been shifted by (the support
+                              // centroid for features an FK transform produced, zero for raw inputs); the kernel shifts the
+                              // features by the same vector; |s - c|^2 sits in the rows' last column
     const FkProg* fk;         // device copy of the compiled FK program
     const float* q;           // [B][dof]
     const float* upstream;    // [B][C] or null
@@ -78,8 +81,9 @@ struct ScoreArgs {
                               // table (fk_device.h dh2_*; `dh` below); 0 = every kind: FkProg interpreted from its LDS copy
     int32_t fk_dwords;        // dwords of FkProg the transform uses (staged into LDS; the host knows it: no dependent load)
     DhArgs dh;                // fkk == 2: the step table's control part (counts and masks live in SGPRs)
-    int32_t jt_waves;         // fkk == 2 and the block folds in parallel with room in its scratch rows for 12 columns per
-                              // point step: J^T runs on several waves (fk_device.h dh2_vjp_waves)
+    int32_t jt_rows;          // fkk == 2, chains of <= kDhUnroll steps, >= 2 waves per chain: the chain runs row-split
+    int32_t jt_waves;         // jt_rows and the block folds in parallel with room in its scratch rows for 12 columns per
+                              // point step (+ 1): J^T runs on several waves (fk_device.h dh2_vjp_r1_sel / r1b / r2_sel)
     int32_t hinge;            // C == 1: gradient of weight * clamp(score - margin, 0) instead of the score's
     float hinge_margin, hinge_weight;
 };
@@ -92,6 +96,10 @@ struct RowLayout {
     static constexpr int RS = (SS_OFF + 1 + 3) / 4 * 4;
 };
 
+// arrival counters of a split launch sit one per 128-byte line: 256 blocks bumping 64 counters inside one line serialise
+// at the memory-side atomic unit (~12 ns each; the count took 2.5 k cycles instead of ~0.7 k)
+constexpr int kCounterStride = 32;
+
 typedef const __attribute__((address_space(4))) float* cfloat_ptr;
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -103,8 +111,28 @@ typedef float v2f __attribute__((ext_vector_type(2)));
         if (a.ts && blockIdx.x == a.ts_block && blockIdx.y == 0 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 16) \
             a.ts[(slot) * 16 + (threadIdx.x >> 6)] = __builtin_readcyclecounter();               \
     } while (0)
+// per-block stamps (wave 0 of every block, y == 0): k = 0 start, 1 sweep start, 2 sweep end, 3 end
+#define DCX_TSB(k)                                                                                 \
+    do {                                                                                           \
+        const unsigned bl__ = blockIdx.x + gridDim.x * blockIdx.y;                                \
+        if (a.ts && bl__ < 4096 && threadIdx.x == 0) {                                             \
+            unsigned long long t__ = __builtin_readcyclecounter();                                 \
+            if ((k) == 0) {                                                                        \
+                unsigned hw__, xcc__;                                                              \
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw__));                 \
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc__));               \
+                a.ts[512 + bl__ * 4 + 3] = ((unsigned long long)xcc__ << 32) | hw__;               \
+                a.ts[512 + bl__ * 4 + 0] = t__;                                                    \
+            } else if ((k) == 3) {                                                                 \
+                a.ts[512 + bl__ * 4 + 2] = t__;                                                    \
+            } else {                                                                               \
+                a.ts[512 + bl__ * 4 + 1] = t__;                                                    \
+            }                                                                                      \
+        }                                                                                          \
+    } while (0)
 #else
 #define DCX_TS(slot) do { } while (0)
+#define DCX_TSB(k) do { } while (0)
 #endif
 
 // Code-generation choices of the sweep, each A/B-measured on MI355X against the alternatives (the variants lived
@@ -185,9 +213,7 @@ struct LdsPlan {
 __host__ __device__ inline LdsPlan lds_plan(int dof, int d_fk, int frame_floats, int red_slots, int acc_floats,
                                             bool alias_xg = false) {
     LdsPlan p;
-    p.q = 0;
-    p.f = p.q + ((64 * dof + 3) & ~3);
-    p.x = p.f + 64 * frame_floats;
+    p.x = 0;
     // The fused kernel writes G only after the sweep, when X is dead (alias_xg); the split launch's finish kernel
     // needs both at once.
     p.g = alias_xg ? p.x : p.x + 64 * d_fk;
@@ -196,7 +222,9 @@ __host__ __device__ inline LdsPlan lds_plan(int dof, int d_fk, int frame_floats,
     p.red = p.x;
     const int end_xg = p.g + 64 * d_fk;
     const int end_red = p.red + (red_slots < 1 ? 1 : red_slots) * acc_floats * 64;  // always one row: the one-wave hand-over's totals
-    p.fk = end_xg > end_red ? end_xg : end_red;  // the FK program comes last: its size varies with the robot
+    p.q = end_xg > end_red ? end_xg : end_red;
+    p.f = p.q + ((64 * dof + 3) & ~3);
+    p.fk = p.f + 64 * frame_floats;              // the FK program comes last: its size varies with the robot
     p.total = p.fk;                              // and only the host needs it (+ fk_prog_floats)
     return p;
 }
@@ -211,6 +239,43 @@ constexpr int sweep_min_waves(int D, int CC, int KF) {
     const int need = 3 * D + 2 * CC + 16 + DCX_MINW_SLACK + (KF == 2 ? 40 : 0);  // KF_GEN calls powf/logf
     return need <= 64 ? 8 : need <= 72 ? 7 : need <= 80 ? 6 : need <= 96 ? 5 : need <= 128 ? 4 : need <= 168 ? 3 : need <= 256 ? 2 : 1;
 }
+
+// The lane index, derived afresh from the execution mask (all lanes active) behind a compiler barrier.  The kernel
+// re-derives it after the sweep: everything computed from the prologue's copy (LDS column addresses, row offsets)
+// would otherwise stay live across the sweep, and at the sweep's 64-VGPR budget the allocator spilled exactly those
+// to scratch (8 B per lane per launch = 8 MB of HBM writes at B = 65536, and reloads inside the lone-wave FK code).
+__device__ __forceinline__ int fresh_lane() {
+    int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(l));
+    return l;
+}
+
+// The kernel's arguments, read AFRESH from the kernarg segment behind a compiler barrier.  The epilogue uses this copy:
+// anything of `a` that both the prologue and the epilogue touch would otherwise stay live in SGPRs across the sweep, whose
+// scalar row pipeline needs every SGPR the wave has - the allocator then parks row registers in VGPR lanes INSIDE the
+// hot loop (v_writelane / v_readlane: +20 instructions per 4 rows when round 3 first added arguments for the epilogue;
+// tools/check_sgpr_parking.py).  The argument struct is the kernel's only parameter, so it sits at offset 0 of the segment.
+template <class Args>
+__device__ __forceinline__ const __attribute__((address_space(4))) Args& reload_kernargs() {
+    auto p = (const __attribute__((address_space(4))) Args*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *p;
+}
+__device__ __forceinline__ const __attribute__((address_space(4))) ScoreArgs& reload_args() { return reload_kernargs<ScoreArgs>(); }
+// member by member: the reloaded arguments live in the constant address space
+#define DCX_COPY_DH(dst, src)          \
+    do {                               \
+        (dst).prog = (src).prog;       \
+        (dst).n_dwords = (src).n_dwords; \
+        (dst).n_steps = (src).n_steps; \
+        (dst).end0 = (src).end0;       \
+        (dst).n_chains = (src).n_chains; \
+        (dst).pt = (src).pt;           \
+        (dst).bare = (src).bare;       \
+        (dst).real = (src).real;       \
+        (dst).n_pt = (src).n_pt;       \
+        (dst).shared_q = (src).shared_q; \
+    } while (0)
 
 // ---- the sweep: supports [j0, j1) against this lane's configuration, rows broadcast through SGPRs ---------------
 // Accumulates into sc[] (scores) and gx[] (feature gradient; untouched for MODE_SCORE).  A function of its own so that
@@ -275,6 +340,7 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
     constexpr int USED_DIRECT = D + CC + (CC > 1 ? 1 : 0);
     constexpr bool XFA = XF && xf_applies(D, CC, KF);
     constexpr int USED = USED_DIRECT + (XFA ? 1 : 0);
+    constexpr int RSTRIDE = L::RS;
 
     // expanded-form state: -2 x (packed), |x|^2, the near threshold (also the hot path's clamp), H and the run's sum(c)
     v2f xm[D / 2 + 1], ga[D / 2 + 1];
@@ -459,7 +525,7 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
         }
     };
     auto load_row = [&](float (&dst)[L::RS], int j) __attribute__((always_inline)) {
-        cfloat_ptr r = rows + (size_t)j * L::RS;
+        cfloat_ptr r = rows + (size_t)j * RSTRIDE;
 #pragma unroll
         for (int e = 0; e < USED; ++e) dst[e] = r[e];
     };
@@ -535,7 +601,7 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
         auto load_part = [&](float (&dst)[PS], int j, auto pc) __attribute__((always_inline)) {
             constexpr int P0 = decltype(pc)::value * PS;
             constexpr int LEN = (USED - P0 < PS) ? (USED - P0) : PS;
-            cfloat_ptr r = rows + (size_t)j * L::RS + P0;
+            cfloat_ptr r = rows + (size_t)j * RSTRIDE + P0;
 #pragma unroll
             for (int e = 0; e < LEN; ++e) dst[e] = r[e];
         };
@@ -864,15 +930,6 @@ __device__ __forceinline__ void sweep_rows_mfma(const ScoreArgs& a, const float 
     }
 }
 
-// The lane index, derived afresh from the execution mask (all lanes active) behind a compiler barrier.  The kernel
-// re-derives it after the sweep: everything computed from the prologue's copy (LDS column addresses, row offsets)
-// would otherwise stay live across the sweep, and at the sweep's 64-VGPR budget the allocator spilled exactly those
-// to scratch (8 B per lane per launch = 8 MB of HBM writes at B = 65536, and reloads inside the lone-wave FK code).
-__device__ __forceinline__ int fresh_lane() {
-    int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    asm volatile("" : "+v"(l));
-    return l;
-}
 
 // The parallel cross-wave fold: the nw waves of a block have left their ACC partial sums per lane in sRed[w][e][64]; every
 // wave folds a few of the accumulators over the nw rows - row 0 first, then 1, 2, ..., the order a single wave would use,
@@ -906,16 +963,6 @@ __device__ __forceinline__ void fold_partial_rows(float* sRed, int wave, int lan
     }
 }
 
-// The kernel's arguments, read AFRESH from the kernarg segment behind a compiler barrier.  The epilogue uses this copy:
-// anything of `a` that both the prologue and the epilogue touch would otherwise stay live in SGPRs across the sweep, whose
-// scalar row pipeline needs every SGPR the wave has - the allocator then parks row registers in VGPR lanes INSIDE the
-// hot loop (v_writelane / v_readlane: +20 instructions per 4 rows when round 3 first added arguments for the epilogue;
-// tools/check_sgpr_parking.py).  ScoreArgs is the kernel's only parameter, so it sits at offset 0 of the segment.
-__device__ __forceinline__ const __attribute__((address_space(4))) ScoreArgs& reload_args() {
-    auto p = (const __attribute__((address_space(4))) ScoreArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(p));
-    return *p;
-}
 
 template <int D, int KF, int CC, int MODE, int MAXT, bool MF = false, bool XF = false>
 __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel(const ScoreArgs a) {
@@ -938,6 +985,7 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
     float* sRed = smem + lp.red;
 
     DCX_TS(0);
+    DCX_TSB(0);
     // ---- prologue: stage the FK description and the q rows (coalesced), FK per lane on wave 0 ----
     const FkWalk fw = fk_stage_sel(a.fkk, a.fk, a.fk_dwords, a.dh, smem + lp.fk, threadIdx.x, blockDim.x);
 #ifdef DCX_TIMING
@@ -956,14 +1004,9 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
     fk_trig_sel(fw, a.dh, sQ + lane * dof, sF + lane, wave, nw);   // all waves: sin/cos of the joint angles
     __syncthreads();
     DCX_TS(6);
-    if (a.fkk == 2 && nw > 1) {  // the step table: the chain split by rows over two waves (fk_device.h dh2_chain_rows)
-        if (dh2_unrollable(a.dh)) {
-            if (wave == 0) dh2_chain_rows_u<0>(fw.dh, a.dh, sX + lane, sF + lane);
-            else if (wave == 1) dh2_chain_rows_u<1>(fw.dh, a.dh, sX + lane, sF + lane);
-        } else {
-            if (wave == 0) dh2_chain_rows<0>(fw.dh, a.dh, sX + lane, sF + lane);
-            else if (wave == 1) dh2_chain_rows<1>(fw.dh, a.dh, sX + lane, sF + lane);
-        }
+    if (a.fkk == 2 && a.jt_rows) {
+        // the step table, chains of <= kDhUnroll steps: every chain split by rows over two waves, chains side by side
+        dh2_chain_rows_sel(fw.dh, a.dh, sX + lane, sF + lane, wave);
     } else if (wave == 0) {
         fk_chain_sel(fw, a.dh, sQ + lane * dof, sX + lane, sF + lane);
     }
@@ -978,6 +1021,19 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
     } else {
 #pragma unroll
         for (int k = 0; k < D; ++k) x[k] = (k < a.d_fk) ? sX[k * 64 + lane] : 0.0f;
+    }
+    if constexpr (XF) {
+        // The expanded distance |x|^2 + |s|^2 - 2 x.s carries an absolute error ~2^-23 (|x|^2 + |s|^2) and its near-pair
+        // rule is relative to |x|: both are about the distance of the data from the ORIGIN, which means nothing to a kernel
+        // that depends on x - s only (kernel.py:73-79).  Rows and features are therefore shifted by the support centroid
+        // (the rows once, at dcx_model_create; here one subtraction per feature): a robot based at (100, 50, 0) sweeps
+        // exactly like one at the origin - without the shift every pair there was a "near" pair.
+        // The shift rounds (~6e-8 |x - c| per coordinate): below the noise fp32 forward kinematics leaves in x and s anyway,
+        // so it is applied to features a transform PRODUCED; raw inputs (DCX_FK_NONE) are exact numbers whose differences
+        // the near-pair block can still resolve to the last bit - their "centroid" is zero (dcx_model_create).
+        cfloat_ptr cen = (cfloat_ptr)(uintptr_t)a.centre;
+#pragma unroll
+        for (int k = 0; k < D; ++k) x[k] -= cen[k];
     }
     if (nw > 1) __syncthreads();  // X is dead from here on: the partial sums reuse its LDS (lds_plan)
 
@@ -1001,6 +1057,7 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
     const int j0 = (ybase + wave * a.s_chunk < yend) ? (ybase + wave * a.s_chunk) : yend;
     const int j1 = (j0 + a.s_chunk < yend) ? (j0 + a.s_chunk) : yend;
 
+    DCX_TSB(1);
     if constexpr (MF) {
         // this wave's slice of the reduction scratch doubles as its transpose buffer (X is dead, the fold comes later)
         sweep_rows_mfma<D, KF, CC, MODE>(a, x, up, j0, j1, sc, gx, sRed + (size_t)wave * ACC * 64, lane);
@@ -1022,16 +1079,8 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
     float* sG = smem + lp.g;
     float* sF = smem + lp.f;
     float* sRed = smem + lp.red;
-    DhArgs dhb;  // member by member: the reloaded arguments live in the constant address space
-    dhb.prog = b.dh.prog;
-    dhb.n_dwords = b.dh.n_dwords;
-    dhb.n_steps = b.dh.n_steps;
-    dhb.end0 = b.dh.end0;
-    dhb.n_chains = b.dh.n_chains;
-    dhb.pt = b.dh.pt;
-    dhb.bare = b.dh.bare;
-    dhb.real = b.dh.real;
-    dhb.n_pt = b.dh.n_pt;
+    DhArgs dhb;
+    DCX_COPY_DH(dhb, b.dh);
     FkWalk fw;
     fw.fkk = b.fkk;
     fw.g = b.fk;
@@ -1047,6 +1096,7 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
     // The sums are formed in the same order as before (row 0, 1, ... in the block; y = 0, 1, ... across blocks).
     const bool split = b.partial != nullptr;
     const bool par_tail = nw > 1 && b.red_slots != 1 && (!split || b.tile_done != nullptr);
+    bool r1_done = false;
     if (par_tail) {
         float* mine = sRed + (size_t)wave * ACC * 64 + lane;
 #pragma unroll
@@ -1102,13 +1152,23 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
             DCX_FK_TS(8, 2);
             // "last block done": whoever sees ys - 1 earlier arrivals owns the tile and adds ALL ys rows in the fixed order
             // y = 0, 1, ... (so the result does not depend on which block came last).  No block ever waits for another.
-            unsigned int* flag = reinterpret_cast<unsigned int*>(sRed + (size_t)ACC * 64);  // row 1 is dead after the fold
-            if (wave == 0 && lane == 0) *flag = __hip_atomic_fetch_add(b.tile_done + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // rows 1 .. nw-1 of the scratch are dead after the fold: [12 n_pt columns of J^T scratch][the flag word] when J^T
+            // runs on several waves (the host checked that they fit), else the flag word alone
+            const bool jt_here = GRAD && b.jt_waves;
+            unsigned int* flag = reinterpret_cast<unsigned int*>(sRed + ((size_t)ACC + (jt_here ? 12 * dhb.n_pt : 0)) * 64);
+            // phase R1 of J^T needs the frames only: it runs on waves 2 .. beside the counter's round trip (wasted, and
+            // harmless, in the blocks that turn out not to own the tile)
+            r1_done = jt_here && nw >= 2 + 2 * dhb.n_chains;
+            if (wave == 0) {
+                if (lane == 0) *flag = __hip_atomic_fetch_add(b.tile_done + tile * kCounterStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (r1_done) {
+                dh2_vjp_r1_sel(fw.dh, dhb, sF + lane, sRed + (size_t)ACC * 64 + lane, wave - 2);
+            }
             __syncthreads();
             const unsigned int arrived = __builtin_amdgcn_readfirstlane(*flag);
             DCX_FK_TS(9, 2);
             if (arrived != (unsigned int)b.ys - 1u) return;
-            if (wave == 0 && lane == 0) b.tile_done[tile] = 0u;  // ready for the next launch on this stream
+            if (wave == 0 && lane == 0) b.tile_done[tile * kCounterStride] = 0u;  // ready for the next launch on this stream
             // The rows were published with agent-scope (sc1, write-through) stores, so agent-scope (sc1) loads read them
             // where they were written: no acquire fence.  The control dependency on `arrived` keeps the loads behind it.
             asm volatile("" ::: "memory");
@@ -1145,8 +1205,15 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
                     if (b.hinge) scale = (sRed[lane] - b.hinge_margin > 0.0f) ? b.hinge_weight : 0.0f;
                 }
                 float* gq = smem + lp.q;
-                dh2_vjp_waves(fw.dh, dhb, sF + lane, sRed + CC * 64 + lane, scale, sRed + (size_t)ACC * 64 + lane,
-                              gq + lane * dof, dof, wave, nw);
+                float* scr = sRed + (size_t)ACC * 64 + lane;
+                if (!r1_done) {  // unsplit launches (and blocks too small to run it beside the counter)
+                    dh2_vjp_r1_sel(fw.dh, dhb, sF + lane, scr, wave);
+                    __syncthreads();
+                }
+                dh2_vjp_r1b(fw.dh, dhb, sRed + CC * 64 + lane, scale, scr, gq + lane * dof, dof, wave, nw);
+                __syncthreads();
+                dh2_vjp_r2_sel(fw.dh, dhb, sF + lane, scr, gq + lane * dof, wave);
+                if (dhb.n_chains > 1 && !dhb.shared_q) __syncthreads();  // chain 1's part of the row came from wave 1
                 if (wave != 0) return;
                 DCX_TS(5);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -1158,6 +1225,7 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
                 } else {
                     for (int i = lane; i < n; i += 64) gdst[(int64_t)(i / dof) * b.grad_stride + (i % dof)] = gq[i];
                 }
+                DCX_TSB(3);
                 return;
             }
             if (wave != 0) return;
@@ -1240,27 +1308,42 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         unsigned int arrived = 0;
-        if (lane == 0) arrived = __hip_atomic_fetch_add(b.tile_done + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) arrived = __hip_atomic_fetch_add(b.tile_done + tile * kCounterStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         arrived = __builtin_amdgcn_readfirstlane(arrived);
         if (arrived != (unsigned int)b.ys - 1u) return;
-        if (lane == 0) b.tile_done[tile] = 0u;  // ready for the next launch on this stream
+        if (lane == 0) b.tile_done[tile * kCounterStride] = 0u;  // ready for the next launch on this stream
         asm volatile("" ::: "memory");
         const float* part = b.partial + tile * b.ys * ACC * 64 + lane;
-        // a cold path: one accumulator at a time (four rows in flight) through row 0 of the LDS scratch, so that nothing
-        // here claims registers of the hot paths above
+        // a cold path (wide shapes, one wave per block): four accumulators x four rows in flight per pass, the sums through
+        // row 0 of the LDS scratch, so that nothing here claims registers of the hot paths above
 #pragma unroll 1
-        for (int e = 0; e < ACC; ++e) {
-            float tot = 0.0f;
+        for (int e0 = 0; e0 < ACC; e0 += 4) {
+            float tot[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) tot[u] = 0.0f;
+#pragma unroll 1
             for (int y = 0; y < b.ys; y += 4) {
-                float r[4];
+                float r[4][4];
 #pragma unroll
-                for (int v = 0; v < 4; ++v)
-                    if (y + v < b.ys) r[v] = __hip_atomic_load(part + ((size_t)(y + v) * ACC + e) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int v = 0; v < 4; ++v) {
+                    const int yy = (y + v < b.ys) ? y + v : y;  // past the end: re-read row y, not added
 #pragma unroll
-                for (int v = 0; v < 4; ++v)
-                    if (y + v < b.ys) tot += r[v];
+                    for (int u = 0; u < 4; ++u) {
+                        const int e = (e0 + u < ACC) ? e0 + u : ACC - 1;
+                        r[v][u] = __hip_atomic_load(part + ((size_t)yy * ACC + e) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    if (y + v < b.ys) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) tot[u] += r[v][u];
+                    }
+                }
             }
-            sRed[e * 64 + lane] = tot;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (e0 + u < ACC) sRed[(e0 + u) * 64 + lane] = tot[u];
         }
 #pragma unroll
         for (int c = 0; c < CC; ++c) sc[c] = sRed[c * 64 + lane];
@@ -1311,6 +1394,7 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel
         } else {
             for (int i = lane; i < n; i += 64) gdst[(int64_t)(i / dof) * b.grad_stride + (i % dof)] = gq[i];
         }
+        DCX_TSB(3);
     }
     }  // epilogue
 }

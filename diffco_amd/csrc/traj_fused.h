@@ -28,6 +28,37 @@
 
 namespace dcx {
 
+#ifdef DCX_TIMING
+#define DCX_TTS(slot)                                                                             \
+    do {                                                                                          \
+        if (a.sc.ts && blockIdx.x == 0 && it == 2 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 16) \
+            a.sc.ts[(slot) * 16 + (threadIdx.x >> 6)] = __builtin_readcyclecounter();             \
+    } while (0)
+#else
+#define DCX_TTS(slot) do { } while (0)
+#endif
+
+// Arithmetic shared by the persistent kernel below and traj_adam_step_kernel (traj_kernels.hip), which tests hold to
+// identical bits: every product and sum here rounds on its own, as the separate torch operations of the reference do
+// (optim.py:86-103).  Without the pragma the compiler fuses mul + add pairs into fma wherever its DAG combiner sees one,
+// which depends on the code around the expression - the two kernels would agree only by luck.
+__device__ __forceinline__ float traj_excess(float n2, float max_speed) {
+#pragma clang fp contract(off)
+    return n2 - max_speed * max_speed;
+}
+__device__ __forceinline__ float traj_path_grad(float cp, float dp, float cn, float dn) {
+#pragma clang fp contract(off)
+    return cp * dp - cn * dn;
+}
+__device__ __forceinline__ float traj_adam_q(float q, float lr, float bias1, float m, float denom) {
+#pragma clang fp contract(off)
+    return q - (lr / bias1) * (m / denom);
+}
+__device__ __forceinline__ float traj_constraint(float w_col, float t_col, float w_mm, float t_mm, float w_jl, float t_jl) {
+#pragma clang fp contract(off)
+    return w_col * t_col + w_mm * t_mm + w_jl * t_jl;
+}
+
 constexpr int kTrajFusedMaxIters = 192;  // iterations per launch (the bias corrections travel as kernel arguments)
 
 struct TrajFusedArgs {
@@ -42,24 +73,27 @@ struct TrajFusedArgs {
 
 // LDS carve of the persistent kernel (floats)
 struct TrajFusedPlan {
-    int q, m, v, gqc, gqp, f, x, gc, gp, red, r, fk, total;
+    int q, m, v, gqc, gqp, f, x, gc, gp, red, r, jl, jt, fk, total;
 };
-// d_acc = the compiled feature width D of the sweep (>= d_fk): a fold row holds D + 1 floats per lane
-__host__ __device__ inline TrajFusedPlan traj_fused_plan(int dof, int d_fk, int frame_floats, int nw, int d_acc) {
+// d_acc = the compiled feature width D of the sweep (>= d_fk): a fold row holds D + 1 floats per lane;  n_pt > 0: the
+// several-wave J^T's scratch, 15 columns per point step (9 rotation, 3 + 3 for the collision and the path gradient)
+__host__ __device__ inline TrajFusedPlan traj_fused_plan(int dof, int d_fk, int frame_floats, int nw, int d_acc, int n_pt = 0) {
     TrajFusedPlan p;
     const int rows = (64 * dof + 3) & ~3;
-    p.q = 0;
+    p.x = 0;
+    p.q = p.x + 64 * d_fk;
     p.m = p.q + rows;
     p.v = p.m + rows;
     p.gqc = p.v + rows;
     p.gqp = p.gqc + rows;
     p.f = p.gqp + rows;
-    p.x = p.f + 64 * frame_floats;
-    p.gc = p.x + 64 * d_fk;
+    p.gc = p.f + 64 * frame_floats;
     p.gp = p.gc + 64 * d_fk;
     p.red = p.gp + 64 * d_fk;
     p.r = p.red + nw * (d_acc + 1) * 64;
-    p.fk = p.r + 128;
+    p.jl = p.r + 128;                 // [2 dof][64]: per-joint limit excess and gradient entry (Adam on several waves)
+    p.jt = p.jl + 2 * dof * 64;
+    p.fk = p.jt + 15 * n_pt * 64;
     p.total = p.fk;
     return p;
 }
@@ -73,6 +107,30 @@ __device__ __forceinline__ float traj_wave_sum(float v) {
 // Register budget: ONE block per CU is the design point (256 restarts on 256 CUs; the LDS carve is ~90 KB), i.e.
 // MAXT / 256 waves per SIMD, so the allocator may use 512 / (MAXT / 256) VGPRs instead of the sweep kernel's 64: at
 // 64 the loop-carried state of the iteration (waypoint, moments, path terms) lived in scratch (236 B per lane).
+//
+// SGPRs (round 3): TrajFusedArgs is 2.4 KB of kernel arguments.  With every phase of the iteration reading them from the
+// one by-value parameter the allocator kept dozens live across the whole loop and parked them in VGPR lanes - 2129
+// v_readlane / v_writelane in the kernel, most of them in the lone-wave phases, which pay ~6 cycles for each
+// (tools/lone_wave_ubench.hip).  Every phase below therefore reads what it needs AFRESH from the kernarg segment
+// (reload_kernargs: scalar-cache hits) and re-derives its LDS pointers; nothing but the loop counter, the lane's own
+// indices and the sweep's operands crosses the sweep.
+struct TrajLds {
+    float *sQ, *sM, *sV, *sGQc, *sGQp, *sF, *sX, *sGc, *sGp, *sRed, *sR, *sJl, *sJ, *sFk;
+};
+template <int D, class A>
+__device__ __forceinline__ TrajLds traj_lds(float* smem, const A& b, int nw) {
+    const bool jt = b.sc.jt_waves != 0;
+    const TrajFusedPlan lp = traj_fused_plan(b.sc.dof, b.sc.d_fk, b.sc.frame_floats, nw, D, jt ? b.sc.dh.n_pt : 0);
+    TrajLds l;
+    l.sQ = smem + lp.q; l.sM = smem + lp.m; l.sV = smem + lp.v; l.sGQc = smem + lp.gqc; l.sGQp = smem + lp.gqp;
+    l.sF = smem + lp.f; l.sX = smem + lp.x; l.sGc = smem + lp.gc; l.sGp = smem + lp.gp; l.sRed = smem + lp.red;
+    l.sR = smem + lp.r; l.sJl = smem + lp.jl; l.sJ = smem + lp.jt; l.sFk = smem + lp.fk;
+    return l;
+}
+// sR (128 floats): [0] sum of segment lengths^2, [16] max-move excess, [32 .. 32 + 2 dof) joint limits (staged once),
+// [17] hinge excess, [96] flags of the iteration
+constexpr int kTrajLim = 32, kTrajFlags = 96;
+
 template <int D, int KF, int MAXT, bool XF = false>
 __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_fused_kernel(const TrajFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -82,181 +140,300 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nw = blockDim.x >> 6;
-    const int W = a.st.n_waypoints, dof = a.sc.dof, d_fk = a.sc.d_fk;
-    const TrajFusedPlan lp = traj_fused_plan(dof, d_fk, a.sc.frame_floats, nw, D);
-    float* sQ = smem + lp.q;
-    float* sM = smem + lp.m;
-    float* sV = smem + lp.v;
-    float* sGQc = smem + lp.gqc;
-    float* sGQp = smem + lp.gqp;
-    float* sF = smem + lp.f;
-    float* sX = smem + lp.x;
-    float* sGc = smem + lp.gc;
-    float* sGp = smem + lp.gp;
-    float* sRed = smem + lp.red;
-    float* sR = smem + lp.r;
-
-    const FkWalk fw = fk_stage_sel(a.sc.fkk, a.sc.fk, a.sc.fk_dwords, a.sc.dh, smem + lp.fk, tid, blockDim.x);
     {
+        const int W = a.st.n_waypoints, dof = a.sc.dof;
+        const TrajLds L = traj_lds<D>(smem, a, nw);
+        (void)fk_stage_sel(a.sc.fkk, a.sc.fk, a.sc.fk_dwords, a.sc.dh, L.sFk, tid, blockDim.x);
         // waypoint rows (lanes past the path replicate its last row, like a ragged tile of the sweep) and Adam moments
         const size_t base = (size_t)r * W * dof;
         const int n = W * dof;
         for (int i = tid; i < 64 * dof; i += blockDim.x) {
             const int ii = i < n ? i : (i % dof) + (W - 1) * dof;
-            sQ[i] = a.st.path[base + ii];
-            sM[i] = i < n ? a.st.adam_m[base + i] : 0.f;
-            sV[i] = i < n ? a.st.adam_v[base + i] : 0.f;
+            L.sQ[i] = a.st.path[base + ii];
+            L.sM[i] = i < n ? a.st.adam_m[base + i] : 0.f;
+            L.sV[i] = i < n ? a.st.adam_v[base + i] : 0.f;
         }
+        if (tid < 2 * dof) L.sR[kTrajLim + tid] = a.st.limits[tid];  // the joint limits never change: read once
     }
     __syncthreads();
 
-    const int w = lane;  // this lane's waypoint (waves 0 and 1 use it)
-    const bool live = w < W;
-    const float v2 = a.opt.max_speed * a.opt.max_speed;
-    const int pd = a.point_dim;
-    // this wave's slice of the supports (the sweep's slicing: wave w takes [w * s_chunk, (w + 1) * s_chunk))
-    const int j0 = (wave * a.sc.s_chunk < a.sc.S) ? wave * a.sc.s_chunk : a.sc.S;
-    const int j1 = (j0 + a.sc.s_chunk < a.sc.S) ? j0 + a.sc.s_chunk : a.sc.S;
-    const bool tree = fk_is_tree(fw);  // its reverse sweep keeps adjoint sums in the frames: one at a time
-
-    int it = 0;
-    for (; it < a.n_iters; ++it) {
-        // ---- forward kinematics of the current waypoints (once per iteration) -----------------------------------
-        fk_trig_sel(fw, a.sc.dh, sQ + lane * dof, sF + lane, wave, nw);
-        __syncthreads();
-        if (wave == 0) fk_chain_sel(fw, a.sc.dh, sQ + lane * dof, sX + lane, sF + lane);
-        __syncthreads();
+    const int w = lane;  // this lane's waypoint
+    int it = 0, n_iters;
+    {
+        const auto& b = reload_kernargs<TrajFusedArgs>();
+        n_iters = b.n_iters;
+    }
+    for (; it < n_iters; ++it) {
         float x[D];
+        int j0, j1;
+        ScoreArgs sa;  // the sweep's view of the model: only what sweep_rows reads
+        {
+            // ---- forward kinematics of the current waypoints (once per iteration) -----------------------------------
+            const auto& b = reload_kernargs<TrajFusedArgs>();
+            const TrajLds L = traj_lds<D>(smem, b, nw);
+            const int dof = b.sc.dof, d_fk = b.sc.d_fk;
+            DhArgs dh;
+            DCX_COPY_DH(dh, b.sc.dh);
+            FkWalk fw;
+            fw.fkk = b.sc.fkk;
+            fw.g = b.sc.fk;
+            fw.fk = (fk_cptr)(uintptr_t)(uint32_t)(uintptr_t)L.sFk;
+            fw.dh = (dh_cptr)(uintptr_t)(uint32_t)(uintptr_t)L.sFk;
+            DCX_TTS(0);
+            fk_trig_sel(fw, dh, L.sQ + lane * dof, L.sF + lane, wave, nw);
+            __syncthreads();
+            DCX_TTS(1);
+            if (b.sc.jt_waves) dh2_chain_rows_sel(fw.dh, dh, L.sX + lane, L.sF + lane, wave);
+            else if (wave == 0) fk_chain_sel(fw, dh, L.sQ + lane * dof, L.sX + lane, L.sF + lane);
+            __syncthreads();
+            DCX_TTS(2);
+            if (d_fk == D) {
 #pragma unroll
-        for (int k = 0; k < D; ++k) x[k] = (k < d_fk) ? sX[k * 64 + lane] : 0.0f;
-
-        // ---- collision sweep: score and feature gradient against this wave's supports ---------------------------
+                for (int k = 0; k < D; ++k) x[k] = L.sX[k * 64 + lane];
+            } else {
+#pragma unroll
+                for (int k = 0; k < D; ++k) x[k] = (k < d_fk) ? L.sX[k * 64 + lane] : 0.0f;
+            }
+            // this wave's slice of the supports (the sweep's slicing: wave w takes [w * s_chunk, (w + 1) * s_chunk))
+            j0 = (wave * b.sc.s_chunk < b.sc.S) ? wave * b.sc.s_chunk : b.sc.S;
+            j1 = (j0 + b.sc.s_chunk < b.sc.S) ? j0 + b.sc.s_chunk : b.sc.S;
+            if constexpr (XF) {  // the expanded form works on centred data (score_kernel.h)
+                cfloat_ptr cen = (cfloat_ptr)(uintptr_t)b.sc.centre;
+#pragma unroll
+                for (int k = 0; k < D; ++k) x[k] -= cen[k];
+            }
+            sa.rows = b.sc.rows;
+            sa.kind = b.sc.kind;
+            sa.kp0 = b.sc.kp0;
+            sa.kp1 = b.sc.kp1;
+        }
+        // ---- collision sweep: score and feature gradient against this wave's supports -------------------------------
         float sc[1] = {0.0f};
         float gx[D];
         const float up[1] = {1.0f};
 #pragma unroll
         for (int k = 0; k < D; ++k) gx[k] = 0.0f;
-        sweep_rows<D, KF, 1, MODE_GRAD_ROW, XF, DCX_TRAJ_NACC>(a.sc, x, up, j0, j1, sc, gx);
-        if (nw > 1) {
-            // the sweep's parallel cross-wave fold (score_kernel.h): row 0 first, then 1, 2, ...
-            float* mine = sRed + (size_t)wave * ACC * 64 + lane;
-            mine[0] = sc[0];
+        sweep_rows<D, KF, 1, MODE_GRAD_ROW, XF, DCX_TRAJ_NACC>(sa, x, up, j0, j1, sc, gx);
+        DCX_TTS(3);
+        {
+            const auto& b = reload_kernargs<TrajFusedArgs>();
+            const TrajLds L = traj_lds<D>(smem, b, nw);
+            const int W = b.st.n_waypoints, dof = b.sc.dof, d_fk = b.sc.d_fk, pd = b.point_dim, n_points = b.n_points;
+            const bool live = w < W;
+            const bool jt = b.sc.jt_waves != 0;
+            DhArgs dh;
+            DCX_COPY_DH(dh, b.sc.dh);
+            FkWalk fw;
+            fw.fkk = b.sc.fkk;
+            fw.g = b.sc.fk;
+            fw.fk = (fk_cptr)(uintptr_t)(uint32_t)(uintptr_t)L.sFk;
+            fw.dh = (dh_cptr)(uintptr_t)(uint32_t)(uintptr_t)L.sFk;
+            const bool tree = fk_is_tree(fw);  // its reverse sweep keeps adjoint sums in the frames: one at a time
+            float obj = 0.f, mmv = 0.f, col = 0.f;
+            const int pwave = (nw > 1 && !tree) ? 1 : 0;
+            // the path terms of this lane's waypoint: length / max-move gradient with respect to its control points -> sGp
+            auto path_terms = [&]() __attribute__((always_inline)) {
+                const float ms = b.opt.max_speed;
+                const float w_diff = b.opt.w_diff, w_mm = b.opt.w_max_move;
+                const bool has_n = live && w + 1 < W, has_p = live && w >= 1;
+                const int wn = has_n ? w + 1 : w, wp = has_p ? w - 1 : w;  // a missing neighbour reads the lane's own point
+                auto one = [&](int kx, int ky, int kz, int npd) __attribute__((always_inline)) {
+                    // npd coordinates of one control point at feature columns kx, ky, kz
+                    const int kk[3] = {kx, ky, kz};
+                    float dn[3] = {0.f, 0.f, 0.f}, dp[3] = {0.f, 0.f, 0.f};
+                    float n2n = 0.f, n2p = 0.f;
 #pragma unroll
-            for (int k = 0; k < D; ++k) mine[(1 + k) * 64] = gx[k];
-            __syncthreads();
-            fold_partial_rows<ACC>(sRed, wave, lane, nw);
-            __syncthreads();
-        }
-        // ---- wave 0: hinge + J^T of the collision gradient;  wave 1: path terms + their J^T ------------------------
-        float obj = 0.f, mmv = 0.f, col = 0.f;
-        const int pwave = (nw > 1 && !tree) ? 1 : 0;
-        if (wave == 0) {
-            if (nw > 1) {
-                sc[0] = sRed[lane];
-#pragma unroll
-                for (int k = 0; k < D; ++k) gx[k] = sRed[(1 + k) * 64 + lane];
-            }
-            const float scale = (sc[0] - a.opt.safety_margin > 0.0f) ? a.opt.w_collision : 0.0f;
-#pragma unroll
-            for (int k = 0; k < D; ++k)
-                if (k < d_fk) sGc[k * 64 + lane] = gx[k] * scale;
-            // q row -> gq row in a separate buffer (the two-launch form overwrites the q row; same arithmetic)
-            for (int i = 0; i < dof; ++i) sGQc[lane * dof + i] = sQ[lane * dof + i];
-            fk_vjp_sel(fw, a.sc.dh, sGQc + lane * dof, sF + lane, sGc + lane, sGQc + lane * dof, dof);
-            const float s0 = sc[0] - a.opt.safety_margin;
-            if (live && s0 > 0.f) col = s0;
-        }
-        if (wave == pwave) {
-            auto X = [&](int k, int v) { return sX[k * 64 + v]; };
-            for (int p = 0; p < a.n_points; ++p) {
-                float dn[3] = {0.f, 0.f, 0.f}, dp[3] = {0.f, 0.f, 0.f};
-                float n2n = 0.f, n2p = 0.f;
-                for (int c = 0; c < pd; ++c) {
-                    const int k = a.coord_major ? c * a.n_points + p : p * pd + c;
-                    const float xc = live ? X(k, w) : 0.f;
-                    if (live && w + 1 < W) { dn[c] = X(k, w + 1) - xc; n2n = fmaf(dn[c], dn[c], n2n); }
-                    if (live && w >= 1)    { dp[c] = xc - X(k, w - 1); n2p = fmaf(dp[c], dp[c], n2p); }
-                }
-                const float mn = n2n - v2, mp = n2p - v2;
-                if (live && w + 1 < W) {   // each segment is counted once, by its left waypoint
-                    obj += n2n;
-                    if (mn > 0.f) mmv += mn;
-                }
-                const float cn = 2.f * (a.opt.w_diff + (mn > 0.f ? a.opt.w_max_move : 0.f));
-                const float cp = 2.f * (a.opt.w_diff + (mp > 0.f ? a.opt.w_max_move : 0.f));
-                for (int c = 0; c < pd; ++c) sGp[(a.coord_major ? c * a.n_points + p : p * pd + c) * 64 + lane] = cp * dp[c] - cn * dn[c];
-            }
-            fk_vjp_sel(fw, a.sc.dh, sQ + lane * dof, sF + lane, sGp + lane, sGQp + lane * dof, dof);
-            const float so = traj_wave_sum(obj), sm = traj_wave_sum(mmv);
-            if (lane == 0) { sR[0] = so; sR[16] = sm; }
-        }
-        __syncthreads();
-        // ---- wave 0: joint limits, endpoint mask, Adam, loss terms, best-so-far bookkeeping -------------------------
-        if (wave == 0) {
-            float jl = 0.f, gn2 = 0.f;
-            if (live) {
-                const bool endpoint = (w == 0) || (w == W - 1);
-                const float b1 = a.bias1[it], b2s = a.bias2_sqrt[it];
-                for (int i = 0; i < dof; ++i) {
-                    const float q = sQ[lane * dof + i];
-                    const float lo = a.st.limits[2 * i], hi = a.st.limits[2 * i + 1];
-                    float g = sGQp[lane * dof + i] + sGQc[lane * dof + i];
-                    if (q < lo) { jl += lo - q; g -= a.opt.w_joint_limit; }
-                    if (q > hi) { jl += q - hi; g += a.opt.w_joint_limit; }
-                    if (endpoint) g = 0.f;  // p.grad[[0, -1]] = 0 (optim.py:102)
-                    gn2 = fmaf(g, g, gn2);
-                    float m = sM[lane * dof + i], v = sV[lane * dof + i];
-                    m = fmaf(a.opt.beta1, m, (1.f - a.opt.beta1) * g);
-                    v = fmaf(a.opt.beta2, v, (1.f - a.opt.beta2) * g * g);
-                    const float denom = sqrtf(v) / b2s + a.opt.eps;
-                    const float qn = q - (a.opt.lr / b1) * (m / denom);
-                    sM[lane * dof + i] = m;
-                    sV[lane * dof + i] = v;
-                    sQ[lane * dof + i] = qn;
-                }
-            }
-            const float t_jl = traj_wave_sum(jl), t_col = traj_wave_sum(col), t_gn2 = traj_wave_sum(gn2);
-            if (lane == 0) {
-                // the step kernel's totals: 0 + (one per-wave partial)
-                const float tot0 = 0.f + sR[0], tot1 = 0.f + sR[16], tot2 = 0.f + t_jl, tot3 = 0.f + t_col, tot4 = 0.f + t_gn2;
-                const float objective = a.opt.w_diff * tot0;
-                const float constraint = a.opt.w_collision * tot3 + a.opt.w_max_move * tot1 + a.opt.w_joint_limit * tot2;
-                const float loss = objective + constraint;
-                const float gnorm = sqrtf(tot4);
-                float* st = a.st.stats + (size_t)r * 8;
-                st[0] = loss; st[1] = objective; st[2] = constraint; st[3] = gnorm; st[4] = tot3; st[5] = tot1; st[6] = tot2;
-                st[7] = 0.f;
-                int flags = 0;
-                if (loss < a.st.lowest_loss[r]) {  // optim.py:107-112 (solution = p AFTER the step)
-                    a.st.lowest_loss[r] = loss;
-                    a.st.lowest_obj[r] = objective;
-                    flags |= 1;
-                }
-                if (constraint <= a.opt.valid_tol) {  // optim.py:113-118
-                    if (objective < a.st.best_valid_obj[r]) {
-                        a.st.best_valid_obj[r] = objective;
-                        flags |= 2;
+                    for (int c = 0; c < 3; ++c) {
+                        if (c < npd) {
+                            const float xc = live ? L.sX[kk[c] * 64 + w] : 0.f;
+                            if (has_n) { dn[c] = L.sX[kk[c] * 64 + wn] - xc; n2n = fmaf(dn[c], dn[c], n2n); }
+                            if (has_p) { dp[c] = xc - L.sX[kk[c] * 64 + wp]; n2p = fmaf(dp[c], dp[c], n2p); }
+                        }
                     }
-                    if (gnorm < a.opt.grad_tol) flags |= 4;  // optim.py:126-127: the path stops here
+                    const float mn = traj_excess(n2n, ms), mp = traj_excess(n2p, ms);
+                    if (has_n) {   // each segment is counted once, by its left waypoint
+                        obj += n2n;
+                        if (mn > 0.f) mmv += mn;
+                    }
+                    const float cn = 2.f * (w_diff + (mn > 0.f ? w_mm : 0.f));
+                    const float cp = 2.f * (w_diff + (mp > 0.f ? w_mm : 0.f));
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        if (c < npd) L.sGp[kk[c] * 64 + lane] = traj_path_grad(cp, dp[c], cn, dn[c]);
+                };
+                if (pd == 3 && !b.coord_major) {
+                    for (int p = 0; p < n_points; ++p) one(3 * p, 3 * p + 1, 3 * p + 2, 3);
+                } else {
+                    for (int p = 0; p < n_points; ++p) {
+                        const int k0 = b.coord_major ? p : p * pd, st = b.coord_major ? n_points : 1;
+                        one(k0, k0 + st, k0 + 2 * st, pd);
+                    }
                 }
-                a.st.steps[r] += 1;
-                sR[96] = __int_as_float(flags);
+                const float so = traj_wave_sum(obj), sm = traj_wave_sum(mmv);
+                if (lane == 0) { L.sR[0] = so; L.sR[16] = sm; }
+            };
+            if (nw > 1) {
+                // the sweep's parallel cross-wave fold (score_kernel.h): row 0 first, then 1, 2, ...
+                float* mine = L.sRed + (size_t)wave * ACC * 64 + lane;
+                mine[0] = sc[0];
+#pragma unroll
+                for (int k = 0; k < D; ++k) mine[(1 + k) * 64] = gx[k];
+                __syncthreads();
+                DCX_TTS(4);
+                fold_partial_rows<ACC>(L.sRed, wave, lane, nw);
+                DCX_TTS(5);
+                if (jt) {
+                    // beside the fold: the path terms on wave 1, phase R1 of J^T (needs the frames only) on waves 2 ..
+                    if (wave == 1) path_terms();
+                    else dh2_vjp_r1_sel(fw.dh, dh, L.sF + lane, L.sJ + lane, wave - 2, 15);
+                }
+                DCX_TTS(6);
+                __syncthreads();
+                DCX_TTS(7);
+            }
+            if (jt) {
+                // ---- both J^T products on several waves (fk_device.h): l = R^T g per point step for the collision gradient
+                // (the folded totals x the hinge factor, read in place) and for the path gradient; then the two wrench
+                // recurrences side by side, chain by chain: collision on waves 0 (, 1), path on waves 2 (, 3) ----------
+                const float s0 = L.sRed[lane] - b.opt.safety_margin;
+                const float scale = (s0 > 0.0f) ? b.opt.w_collision : 0.0f;
+                if (wave == 0 && live && s0 > 0.f) col = s0;
+                const int half = nw >> 1;
+                if (wave < half) dh2_vjp_r1b(fw.dh, dh, L.sRed + 64 + lane, scale, L.sJ + lane, L.sGQc + lane * dof, dof, wave, half, 15, 9);
+                else dh2_vjp_r1b(fw.dh, dh, L.sGp + lane, 1.0f, L.sJ + lane, L.sGQp + lane * dof, dof, wave - half, nw - half, 15, 12);
+                __syncthreads();
+                DCX_TTS(8);
+                if (wave < 2) dh2_vjp_r2_sel(fw.dh, dh, L.sF + lane, L.sJ + lane, L.sGQc + lane * dof, wave, 15, 9);
+                else dh2_vjp_r2_sel(fw.dh, dh, L.sF + lane, L.sJ + lane, L.sGQp + lane * dof, wave - 2, 15, 12);
+            } else {
+                // ---- wave 0: hinge + J^T of the collision gradient;  wave 1: path terms + their J^T --------------------
+                if (wave == 0) {
+                    if (nw > 1) {
+                        sc[0] = L.sRed[lane];
+#pragma unroll
+                        for (int k = 0; k < D; ++k) gx[k] = L.sRed[(1 + k) * 64 + lane];
+                    }
+                    const float scale = (sc[0] - b.opt.safety_margin > 0.0f) ? b.opt.w_collision : 0.0f;
+#pragma unroll
+                    for (int k = 0; k < D; ++k)
+                        if (k < d_fk) L.sGc[k * 64 + lane] = gx[k] * scale;
+                    // q row -> gq row in a separate buffer (the two-launch form overwrites the q row; same arithmetic)
+                    for (int i = 0; i < dof; ++i) L.sGQc[lane * dof + i] = L.sQ[lane * dof + i];
+                    fk_vjp_sel(fw, dh, L.sGQc + lane * dof, L.sF + lane, L.sGc + lane, L.sGQc + lane * dof, dof);
+                    const float s0 = sc[0] - b.opt.safety_margin;
+                    if (live && s0 > 0.f) col = s0;
+                }
+                if (wave == pwave) {
+                    path_terms();
+                    fk_vjp_sel(fw, dh, L.sQ + lane * dof, L.sF + lane, L.sGp + lane, L.sGQp + lane * dof, dof);
+                }
+            }
+            if (wave == 0) {  // the lane's hinge excess, for the loss terms below
+                const float t_col = traj_wave_sum(col);
+                if (lane == 0) L.sR[17] = t_col;
+            }
+            DCX_TTS(9);
+        }
+        __syncthreads();
+        DCX_TTS(10);
+        int flags;
+        {
+            // ---- joint limits, endpoint mask, Adam: joint i on wave i % nw (the joints are independent; the two sums that
+            // run over them - limit excess, |g|^2 - are put together afterwards in the order i = 0, 1, ... a single wave would
+            // use, so the loss terms do not change by a bit) ----------------------------------------------------------------
+            const auto& b = reload_kernargs<TrajFusedArgs>();
+            const TrajLds L = traj_lds<D>(smem, b, nw);
+            const int W = b.st.n_waypoints, dof = b.sc.dof;
+            const bool live = w < W;
+            const bool endpoint = (w == 0) || (w == W - 1);
+            float* sJl = L.sJl;
+            for (int i = wave; i < dof; i += nw) {
+                float jl_i = 0.f, g2_i = 0.f;
+                if (live) {
+                    const float b1 = b.bias1[it], b2s = b.bias2_sqrt[it];
+                    const float q = L.sQ[lane * dof + i];
+                    const float lo = L.sR[kTrajLim + 2 * i], hi = L.sR[kTrajLim + 2 * i + 1];
+                    float g = L.sGQp[lane * dof + i] + L.sGQc[lane * dof + i];
+                    if (q < lo) { jl_i = lo - q; g -= b.opt.w_joint_limit; }
+                    if (q > hi) { jl_i += q - hi; g += b.opt.w_joint_limit; }
+                    if (endpoint) g = 0.f;  // p.grad[[0, -1]] = 0 (optim.py:102)
+                    g2_i = g;
+                    float m = L.sM[lane * dof + i], v = L.sV[lane * dof + i];
+                    m = fmaf(b.opt.beta1, m, (1.f - b.opt.beta1) * g);
+                    v = fmaf(b.opt.beta2, v, (1.f - b.opt.beta2) * g * g);
+                    const float denom = sqrtf(v) / b2s + b.opt.eps;
+                    const float qn = traj_adam_q(q, b.opt.lr, b1, m, denom);
+                    L.sM[lane * dof + i] = m;
+                    L.sV[lane * dof + i] = v;
+                    L.sQ[lane * dof + i] = qn;
+                }
+                sJl[(2 * i) * 64 + lane] = jl_i;
+                sJl[(2 * i + 1) * 64 + lane] = g2_i;
             }
         }
         __syncthreads();
-        const int flags = __float_as_int(sR[96]);
-        if (flags & 3) {
-            float* lo = a.st.lowest_path + (size_t)r * W * dof;
-            float* bv = a.st.best_valid_path + (size_t)r * W * dof;
-            for (int i = tid; i < W * dof; i += blockDim.x) {
-                const float v = sQ[i];
-                if (flags & 1) lo[i] = v;
-                if (flags & 2) bv[i] = v;
+        {
+            const auto& b = reload_kernargs<TrajFusedArgs>();
+            const TrajLds L = traj_lds<D>(smem, b, nw);
+            const int dof = b.sc.dof;
+            if (wave == 0) {
+                const float* sJl = L.sJl;
+                float jl = 0.f, gn2 = 0.f;
+                for (int i = 0; i < dof; ++i) {
+                    // the one-wave form's order: a joint below its lower limit adds lo - q, above its upper limit q - hi
+                    jl += sJl[(2 * i) * 64 + lane];
+                    const float g = sJl[(2 * i + 1) * 64 + lane];
+                    gn2 = fmaf(g, g, gn2);
+                }
+                const float t_jl = traj_wave_sum(jl), t_gn2 = traj_wave_sum(gn2);
+                if (lane == 0) {
+                    // the step kernel's totals: 0 + (one per-wave partial)
+                    const float tot0 = 0.f + L.sR[0], tot1 = 0.f + L.sR[16], tot2 = 0.f + t_jl, tot3 = 0.f + L.sR[17], tot4 = 0.f + t_gn2;
+                    const float objective = b.opt.w_diff * tot0;
+                    const float constraint = traj_constraint(b.opt.w_collision, tot3, b.opt.w_max_move, tot1, b.opt.w_joint_limit, tot2);
+                    const float loss = objective + constraint;
+                    const float gnorm = sqrtf(tot4);
+                    float* st = b.st.stats + (size_t)r * 8;
+                    st[0] = loss; st[1] = objective; st[2] = constraint; st[3] = gnorm; st[4] = tot3; st[5] = tot1; st[6] = tot2;
+                    st[7] = 0.f;
+                    int fl = 0;
+                    if (loss < b.st.lowest_loss[r]) {  // optim.py:107-112 (solution = p AFTER the step)
+                        b.st.lowest_loss[r] = loss;
+                        b.st.lowest_obj[r] = objective;
+                        fl |= 1;
+                    }
+                    if (constraint <= b.opt.valid_tol) {  // optim.py:113-118
+                        if (objective < b.st.best_valid_obj[r]) {
+                            b.st.best_valid_obj[r] = objective;
+                            fl |= 2;
+                        }
+                        if (gnorm < b.opt.grad_tol) fl |= 4;  // optim.py:126-127: the path stops here
+                    }
+                    b.st.steps[r] += 1;
+                    L.sR[kTrajFlags] = __int_as_float(fl);
+                }
             }
         }
-        // lanes past the path follow its last row (their FK feeds nothing, but keep them finite and in step)
-        if (tid < dof) {
-            for (int l = W; l < 64; ++l) sQ[l * dof + tid] = sQ[(W - 1) * dof + tid];
+        __syncthreads();
+        {
+            const auto& b = reload_kernargs<TrajFusedArgs>();
+            const TrajLds L = traj_lds<D>(smem, b, nw);
+            const int W = b.st.n_waypoints, dof = b.sc.dof;
+            flags = __float_as_int(L.sR[kTrajFlags]);
+            if (flags & 3) {
+                float* lo = b.st.lowest_path + (size_t)r * W * dof;
+                float* bv = b.st.best_valid_path + (size_t)r * W * dof;
+                for (int i = tid; i < W * dof; i += blockDim.x) {
+                    const float v = L.sQ[i];
+                    if (flags & 1) lo[i] = v;
+                    if (flags & 2) bv[i] = v;
+                }
+            }
+            DCX_TTS(11);
+            // lanes past the path follow its last row (their FK feeds nothing, but keep them finite and in step)
+            if (tid < dof) {
+                for (int l = W; l < 64; ++l) L.sQ[l * dof + tid] = L.sQ[(W - 1) * dof + tid];
+            }
         }
         __syncthreads();
         if (flags & 4) {
@@ -268,11 +445,14 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
     (void)it;
     // ---- state back to HBM ------------------------------------------------------------------------------------------
     {
+        const auto& b = reload_kernargs<TrajFusedArgs>();
+        const TrajLds L = traj_lds<D>(smem, b, nw);
+        const int W = b.st.n_waypoints, dof = b.sc.dof;
         const size_t base = (size_t)r * W * dof;
         for (int i = tid; i < W * dof; i += blockDim.x) {
-            a.st.path[base + i] = sQ[i];
-            a.st.adam_m[base + i] = sM[i];
-            a.st.adam_v[base + i] = sV[i];
+            b.st.path[base + i] = L.sQ[i];
+            b.st.adam_m[base + i] = L.sM[i];
+            b.st.adam_v[base + i] = L.sV[i];
         }
     }
 }

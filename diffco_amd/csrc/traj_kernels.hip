@@ -66,7 +66,7 @@ __global__ __launch_bounds__(1024) void traj_adam_step_kernel(const TrajArgs a) 
     auto X = [&](int k, int v) { return sX[(v >> 6) * 64 * D + k * 64 + (v & 63)]; };
 
     // ---- path-length and max-move terms: gradient w.r.t. this waypoint's control points ---------------
-    const float v2 = a.opt.max_speed * a.opt.max_speed;
+    const float ms = a.opt.max_speed;
     float obj = 0.f, mmv = 0.f;
     const int pd = a.point_dim;
     for (int p = 0; p < a.n_points; ++p) {
@@ -78,14 +78,14 @@ __global__ __launch_bounds__(1024) void traj_adam_step_kernel(const TrajArgs a) 
             if (live && w + 1 < W) { dn[c] = X(k, w + 1) - xc; n2n = fmaf(dn[c], dn[c], n2n); }
             if (live && w >= 1)    { dp[c] = xc - X(k, w - 1); n2p = fmaf(dp[c], dp[c], n2p); }
         }
-        const float mn = n2n - v2, mp = n2p - v2;
+        const float mn = traj_excess(n2n, ms), mp = traj_excess(n2p, ms);
         if (live && w + 1 < W) {   // each segment is counted once, by its left waypoint
             obj += n2n;
             if (mn > 0.f) mmv += mn;
         }
         const float cn = 2.f * (a.opt.w_diff + (mn > 0.f ? a.opt.w_max_move : 0.f));
         const float cp = 2.f * (a.opt.w_diff + (mp > 0.f ? a.opt.w_max_move : 0.f));
-        for (int c = 0; c < pd; ++c) myG[(a.coord_major ? c * a.n_points + p : p * pd + c) * 64] = cp * dp[c] - cn * dn[c];
+        for (int c = 0; c < pd; ++c) myG[(a.coord_major ? c * a.n_points + p : p * pd + c) * 64] = traj_path_grad(cp, dp[c], cn, dn[c]);
     }
     // J^T of that gradient (per lane; frames of this lane are in its slab)
     float* myGQ = sGQ + (wave * 64 + lane) * dof;
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(1024) void traj_adam_step_kernel(const TrajArgs a) 
             m = fmaf(a.opt.beta1, m, (1.f - a.opt.beta1) * g);
             v = fmaf(a.opt.beta2, v, (1.f - a.opt.beta2) * g * g);
             const float denom = sqrtf(v) / a.bias2_sqrt + a.opt.eps;
-            const float qn = q - (a.opt.lr / a.bias1) * (m / denom);
+            const float qn = traj_adam_q(q, a.opt.lr, a.bias1, m, denom);
             a.st.adam_m[base + i] = m;
             a.st.adam_v[base + i] = v;
             a.st.path[base + i] = qn;
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(1024) void traj_adam_step_kernel(const TrajArgs a) 
             tot[t] = s;
         }
         const float objective = a.opt.w_diff * tot[0];
-        const float constraint = a.opt.w_collision * tot[3] + a.opt.w_max_move * tot[1] + a.opt.w_joint_limit * tot[2];
+        const float constraint = traj_constraint(a.opt.w_collision, tot[3], a.opt.w_max_move, tot[1], a.opt.w_joint_limit, tot[2]);
         const float loss = objective + constraint;
         const float gnorm = sqrtf(tot[4]);
         float* st = a.st.stats + (size_t)r * 8;

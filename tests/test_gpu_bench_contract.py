@@ -29,7 +29,7 @@ def _run(extra, steps=10, warmup=3, timeout=600):
                                    ["--workload", "cfg5"], ["--scaling", "strong"]],
                          ids=["headline", "cfg2", "cfg3", "cfg4", "cfg5", "headline-strong"])
 def test_one_json_line_per_baseline_workload(extra):
-    d = _run(["--no-cpu-baseline"] + extra)
+    d = _run(["--no-cpu-baseline", "--no-configs"] + extra)
     assert KEYS <= set(d), sorted(KEYS - set(d))
     assert d["n_gpus"] == 1 and d["steps"] == 10 and d["warmup"] == 3 and d["higher_is_better"] is True
     assert d["value"] > 0 and d["unit"] == "M evals/s" and d["dtype"] == "f32"
@@ -60,15 +60,29 @@ def test_distributed_code_path_on_one_rank(extra):
         assert m["gather"] == "none" and m["gather_ms"] is None
     else:
         assert m["gather_ms"] is not None and m["gather_ms"] > 0
-        assert m["gather"] == (extra[extra.index("--gather") + 1] if "--gather" in extra else "per-call")
+        # the default is the graph-captured overlapped gather; where the collective cannot be captured it says "per-call"
+        assert m["gather"] in ((extra[extra.index("--gather") + 1],) if "--gather" in extra else ("graph", "per-call"))
     if "--no-variants" not in extra:
         v = d["variants"]
         assert v["other_scaling"]["scaling"] == ("weak" if "strong" in extra else "strong") and v["other_scaling"]["value"] > 0
         if "cfg5" not in extra:
-            assert {k for k in v if k.startswith("gather_")} == {f"gather_{g}" for g in ("per-call", "overlapped", "bucketed", "none")
-                                                                  if g != m["gather"]}
+            asked = extra[extra.index("--gather") + 1] if "--gather" in extra else "graph"
+            assert {k for k in v if k.startswith("gather_")} == {f"gather_{g}" for g in ("graph", "per-call", "overlapped", "bucketed", "none")
+                                                                  if g != asked}
+            assert "gather_exposed_ms" in m
     if "cfg3" in extra:
         assert d["config"]["global_batch"] == 65536 and d["scaling"] == "strong"
+
+
+def test_headline_line_carries_every_baseline_config():
+    """the driver runs `python bench.py` only: its one line must hold a short measurement of every BASELINE.json config
+    that runs on a GPU"""
+    d = _run(["--no-cpu-baseline"], steps=10, warmup=3, timeout=900)
+    cf = d["configs"]
+    assert set(cf) == {"cfg2", "cfg2_panda", "cfg3", "cfg3_poly", "cfg4", "cfg5"}
+    for name, c in cf.items():
+        assert "error" not in c, (name, c)
+        assert c["value"] > 0 and 0 < c["frac"] < 1 and c["kernel_ms"] <= c["ms_per_step"] * 1.05, (name, c)
 
 
 def test_cpu_baseline_leg():

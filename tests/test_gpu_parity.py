@@ -506,3 +506,73 @@ def test_dh_fk_walks_agree_bitwise(ops, knob, name, B):
     for other in (2, 1):
         for a, b in zip(out[other], out[0]):
             assert np.isfinite(a).all() and np.array_equal(a, b)
+
+
+def _baxter_at(base_xyz):
+    """the Baxter arm's description with its base translated (the reference's DualArm bases do the same, model.py:312-363)"""
+    from diffco_amd import _fkdesc, model
+    rob = model.BaxterLeftArmFK()
+    base = list(_fkdesc.IDENTITY_BASE)
+    base[3], base[7], base[11] = (float(v) for v in base_xyz)
+    desc = _fkdesc.dh_desc(7, [rob.dhparams.chain(range(7), base)], [(0, i, (0, 0, 0)) for i, m in enumerate(rob.fk_mask) if m])
+    return rob, desc
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("where", [(0.0, 0.0, 0.0), (20.0, 0.0, 0.0), (100.0, 50.0, 0.0)])
+def test_expanded_form_far_from_the_origin_baxter(ops, knob, where):
+    """the kernels depend on x - s only (kernel.py:73-79), so moving the whole scene must change
+    nothing but the last bits.  A Baxter arm based at (20, 0, 0) and at (100, 50, 0) — where the uncentred expanded
+    form saw every pair as a "near" pair — against the float64 oracle at the 1e-5 bar, in both sweep forms; the
+    expanded and direct forms agree to 6e-6 wherever the arm stands."""
+    from oracle import oracle
+    rob, desc = _baxter_at(where)
+    g = torch.Generator().manual_seed(7)
+    lim = rob.limits.float()
+    S, B = 1500, 4096
+    rnd = lambda n: torch.rand((n, 7), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]
+    sup_q, q = rnd(S), rnd(B)
+    sup = ops.fkine(desc, sup_q.cuda()).reshape(S, -1)
+    W = torch.randn((S, 1), generator=g)
+    m = ops.ScoreModel(desc, 1, 1.0, 1.0, sup, W.cuda())
+    so, go, _ = oracle.score_grad(desc, 1, 1.0, 1.0, _n(sup).astype(np.float64), W.numpy().astype(np.float64),
+                                  q.numpy().astype(np.float64), dtype=np.float64)
+    res = {}
+    for form in (1, 0):
+        knob("xf", form)
+        s, gr = m.score_grad_raw(q.cuda())
+        assert torch.isfinite(s).all() and torch.isfinite(gr).all()
+        res[form] = (s, gr, relerr(_n(s), so), relerr(_n(gr), go))
+    # fp32 forward kinematics itself carries ~ulp(|x|) per coordinate: at |x| ~ 100 that is 8e-6 of a unit distance, the
+    # same for either sweep form (and for the reference's fp32 torch FK); the bar scales with it beyond the origin
+    bar = TOL * max(1.0, float(np.linalg.norm(where)) / 25.0)
+    for form in (1, 0):
+        assert res[form][2] < bar and res[form][3] < bar, (where, form, res[form][2:])
+    assert res[1][2] < 1.5 * res[0][2] + 1e-6 and res[1][3] < 1.5 * res[0][3] + 1e-6, (where, res[1][2:], res[0][2:])
+    assert relerr(_n(res[1][0]), _n(res[0][0])) < 6e-6 and relerr(_n(res[1][1]), _n(res[0][1])) < 6e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spread", [1.0, 10.0])
+def test_expanded_form_se3_bodies_across_the_workspace(ops, knob, spread):
+    """SE(3) bodies with 8 keypoints (D = 24) at xyz ~ U(-spread, spread), Polyharmonic(1): both forms against the float64
+    oracle (the reference samples rigid bodies in [-10, 10]^3, model.py:146-147)"""
+    from diffco_amd import _fkdesc
+    from oracle import oracle
+    g = torch.Generator().manual_seed(11)
+    kp = (torch.rand((8, 3), generator=g) - 0.5) * 0.6
+    desc = _fkdesc.keypoint_desc(kp.numpy(), 3)
+    S, B = 2000, 2048
+    lo = torch.tensor([-spread] * 3 + [-np.pi] * 3)
+    rnd = lambda n: torch.rand((n, 6), generator=g) * (-2 * lo) + lo
+    sup_q, q = rnd(S), rnd(B)
+    sup = ops.fkine(desc, sup_q.cuda()).reshape(S, -1)
+    W = torch.randn((S, 1), generator=g)
+    m = ops.ScoreModel(desc, 1, 1.0, 1.0, sup, W.cuda())
+    so, go, _ = oracle.score_grad(desc, 1, 1.0, 1.0, _n(sup).astype(np.float64), W.numpy().astype(np.float64),
+                                  q.numpy().astype(np.float64), dtype=np.float64)
+    for form in (1, 0):
+        knob("xf", form)
+        s, gr = m.score_grad_raw(q.cuda())
+        es, eg = relerr(_n(s), so), relerr(_n(gr), go)
+        assert es < TOL and eg < TOL, (spread, form, es, eg)

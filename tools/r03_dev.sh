@@ -6,11 +6,11 @@ OUT=gpurun_out
 mkdir -p $OUT
 TAG=${1:-a}
 export DCX_LIB=$PWD/devlibs/libdcx_dev.so
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "dh_fk_walks" > $OUT/r03_dev_${TAG}_pytest.txt 2>&1
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_traj.py -x -q -m gpu -k "dh_fk_walks or traj" > $OUT/r03_dev_${TAG}_pytest.txt 2>&1
 tail -3 $OUT/r03_dev_${TAG}_pytest.txt
 : > $OUT/r03_dev_${TAG}_bench.txt
 for w in cfg2 cfg2_panda cfg3 cfg3_poly cfg5 headline; do
-  for v in "dev" "devslp" "dev DCX_JT_WAVES=0"; do
+  for v in "dev" "dev DCX_JT_WAVES=0"; do
     set -- $v
     lib=$1; shift
     env DCX_LIB=$PWD/devlibs/libdcx_$lib.so "$@" timeout 300 python bench.py --workload $w --no-cpu-baseline --no-configs 2>>$OUT/r03_dev.err | python -c "
@@ -22,8 +22,12 @@ done
 cat $OUT/r03_dev_${TAG}_bench.txt
 : > $OUT/r03_dev_${TAG}_phase.txt
 export DCX_LIB=$PWD/devlibs/libdcx_t.so
-for blk in 0 1 2 3; do
+for blk in 0 1; do
   DCX_TS_BLOCK=$blk timeout 120 python tools/phase_timing.py --workload cfg2 --batch 4096 >> $OUT/r03_dev_${TAG}_phase.txt 2>>$OUT/r03_dev.err
 done
+for blk in 0 1; do
+  DCX_TS_BLOCK=$blk timeout 120 python tools/phase_timing.py --workload cfg3 --batch 8192 >> $OUT/r03_dev_${TAG}_phase.txt 2>>$OUT/r03_dev.err
+done
+timeout 120 python tools/phase_timing.py --workload cfg2_panda --batch 4096 >> $OUT/r03_dev_${TAG}_phase.txt 2>>$OUT/r03_dev.err
 timeout 120 python tools/phase_timing.py --workload headline --batch 65536 >> $OUT/r03_dev_${TAG}_phase.txt 2>>$OUT/r03_dev.err
 cat $OUT/r03_dev_${TAG}_phase.txt

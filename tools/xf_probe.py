@@ -19,6 +19,51 @@ dev = torch.device("cuda", 0)
 lib = _lib.require_gpu()
 cases = [("headline", 65536), ("headline", 1 << 20), ("headline", 4096), ("cfg2", 4096), ("cfg2_panda", 4096), ("cfg3", 8192),
          ("cfg3", 65536), ("cfg3_poly", 8192), ("cfg3_poly", 65536), ("cfg4", 1 << 18), ("cfg5", 12800)]
+def offsets():
+    """`tools/xf_probe.py offsets`: the headline shape with the Baxter arm's base translated — the expanded form's time and
+    error must not depend on where the scene stands (the rows and the features are shifted by the support centroid)"""
+    from diffco_amd import _fkdesc, _ops, model
+    rob = model.BaxterLeftArmFK()
+    lim = rob.limits.float()
+    g = torch.Generator().manual_seed(0)
+    S, B = 2000, 65536
+    rnd = lambda n: torch.rand((n, 7), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]  # noqa: E731
+    sup_q, q = rnd(S), rnd(B).to(dev)
+    W = torch.randn((S, 1), generator=g)
+    for where in ((0.0, 0.0, 0.0), (20.0, 0.0, 0.0), (100.0, 50.0, 0.0), (1000.0, -500.0, 30.0)):
+        base = list(_fkdesc.IDENTITY_BASE)
+        base[3], base[7], base[11] = where
+        desc = _fkdesc.dh_desc(7, [rob.dhparams.chain(range(7), base)], [(0, i, (0, 0, 0)) for i, mk in enumerate(rob.fk_mask) if mk])
+        sup = _ops.fkine(desc, sup_q.to(dev)).reshape(S, -1)
+        m = _ops.ScoreModel(desc, 1, 1.0, 1.0, sup, W.to(dev), device=dev)
+        so, go, _ = oracle.score_grad(desc, 1, 1.0, 1.0, sup.cpu().numpy().astype(np.float64), W.numpy().astype(np.float64),
+                                      q[:2048].cpu().numpy().astype(np.float64), dtype=np.float64)
+        out = []
+        for mode in (0, 1):
+            lib.dcx_debug_set(b"xf", mode)
+            best = 1e30
+            for _ in range(3):
+                for _ in range(5):
+                    s, gr = m.score_grad_raw(q)
+                torch.cuda.synchronize()
+                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0.record()
+                for _ in range(50):
+                    s, gr = m.score_grad_raw(q)
+                t1.record()
+                torch.cuda.synchronize()
+                best = min(best, t0.elapsed_time(t1) / 50 * 1e3)
+            es = float(np.abs(s[:2048].cpu().numpy().astype(np.float64).reshape(so.shape) - so).max() / np.abs(so).max())
+            eg = float(np.abs(gr[:2048].cpu().numpy().astype(np.float64) - go).max() / np.abs(go).max())
+            out.append((best, es, eg))
+        lib.dcx_debug_set(b"xf", -1)
+        print(f"base at {where}: direct {out[0][0]:7.1f} us (err {out[0][1]:.1e} / {out[0][2]:.1e})   "
+              f"expanded {out[1][0]:7.1f} us (err {out[1][1]:.1e} / {out[1][2]:.1e})", flush=True)
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "offsets":
+    offsets()
+    sys.exit(0)
 if len(sys.argv) > 1:
     cases = [(a.split(":")[0], int(a.split(":")[1])) for a in sys.argv[1:]]
 for name, B in cases:
