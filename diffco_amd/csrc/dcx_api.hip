@@ -319,7 +319,7 @@ Geometry pick_geometry(const dcx_model* m, int64_t B, int acc_floats, bool allow
     // to wave 0 one at a time - config #3 (C = 5: 17 accumulators, 70 KB at 16 waves) spent 9 k cycles in that serial fold
     // and 14 k in the one-wave hand-over (profiles/r03_dev_e_phase.txt).
     const size_t lds_cap = (g.ys > 1 ? 150 : 64) * 1024;
-    if (lds_bytes(g.nw, g.nw) > lds_cap && g.nw >= 8 && lds_bytes(g.nw / 2, g.nw / 2) <= lds_cap) {
+    if (lds_bytes(g.nw, g.nw) > lds_cap && g.nw >= 8 && lds_bytes(g.nw / 2, g.nw / 2) <= lds_cap && kn.nw < 1) {  // (not against an explicit knob)
         g.nw /= 2;
         g.red_slots = g.nw;
     }

@@ -9,7 +9,7 @@ R=$PWD
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline"
+B="python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-configs"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $B > $OUT/trace.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -o bench -- $B > $OUT/pmc_$C.log 2>&1
