@@ -946,17 +946,10 @@ int dcx_train_perceptron(int device, int kernel_kind, const float* kparams, floa
     if (int rc = check_kernel(kernel_kind, kparams)) return rc;
     if (int rc = set_device(device)) return rc;
     // The register-resident kernels (one label column; one workgroup up to N = 10240, several up to 131072) keep a label as
-    // one sign bit; labels other than -1 / +1 (0 / 1 labels, y = 0) must take the generic kernel, which evaluates the
-    // reference's expressions on y itself.  The check reads the labels back (<= 512 KB, on the caller's stream): the
-    // trainer is the one entry point that waits.
-    bool sign_labels = false;
-    if (C == 1 && N <= kTrainGridMaxN) {
-        std::vector<float> yh((size_t)N);
-        hipError_t ce = hipMemcpyAsync(yh.data(), y, yh.size() * sizeof(float), hipMemcpyDefault, (hipStream_t)stream);
-        if (ce == hipSuccess) ce = hipStreamSynchronize((hipStream_t)stream);
-        if (ce != hipSuccess) return fail_hip(ce, "perceptron trainer: reading the labels");
-        sign_labels = std::all_of(yh.begin(), yh.end(), [](float v) { return v == 1.0f || v == -1.0f; });
-    }
+    // one sign bit; labels other than -1 / +1 (0 / 1 labels, y = 0) must take the generic loop, which evaluates the
+    // reference's expressions on y itself.  The kernels decide that themselves, on the device (train_kernels.hip): no
+    // entry point of this library synchronises the caller's stream, and the trainer can sit in a captured HIP graph.
+    bool sign_labels = (C == 1 && N <= kTrainGridMaxN);
     // Several workgroups (one grid barrier per iteration) pay once a single workgroup would hold more than four samples
     // per thread.  Knob train_grid: 0 = never, 1 = whenever N >= 2048,
     // 2 = the generic kernel whatever the labels.

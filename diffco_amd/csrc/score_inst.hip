@@ -25,8 +25,9 @@ constexpr int kD = DCX_INST_D;
 constexpr int kMaxT = kD <= 16 ? 1024 : (kD <= 48 ? 512 : 256);
 
 // widths / modes that carry the MFMA form of the gradient fold (sweep_rows_mfma)
-template <int KF, int MODE>
-constexpr bool kHasMfma = (kD <= 16) && (kD % 2 == 0) && (MODE != MODE_SCORE) && (KF != KF_GEN);
+// (one class only: the developer knob takes it for C == 1 models, dcx_api.hip)
+template <int KF, int CC, int MODE>
+constexpr bool kHasMfma = (kD <= 16) && (kD % 2 == 0) && (CC == 1) && (MODE != MODE_SCORE) && (KF != KF_GEN);
 
 // Shapes with an expanded form (score_kernel.h, XF: Polyharmonic(1), rows of <= 37 floats) run it by default, on the
 // centred row pairs the host passes with it (ScoreArgs::centre).  The direct form is compiled for them as well and
@@ -48,7 +49,7 @@ hipError_t go(int nw, size_t lds, int64_t nblk, const ScoreArgs& a, hipStream_t 
     if constexpr (xf_applies(kD, CC, KF)) {
         if (!a.mfma && a.xf) return launch(score_kernel<kD, KF, CC, MODE, kMaxT, false, true>);
     }
-    if constexpr (kHasMfma<KF, MODE>) {
+    if constexpr (kHasMfma<KF, CC, MODE>) {
         if (a.mfma) return launch(score_kernel<kD, KF, CC, MODE, kMaxT, true>);
     }
     return launch(score_kernel<kD, KF, CC, MODE, kMaxT>);

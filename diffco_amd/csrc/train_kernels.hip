@@ -373,7 +373,8 @@ struct GridRec {
 struct GridSync {
     unsigned int counter;   // arrivals, monotonically increasing
     unsigned int abort;
-    unsigned int pad[2];
+    unsigned int bad_labels;  // some label is neither -1 nor +1: workgroup 0 runs the generic loop, the others leave
+    unsigned int pad[1];
     GridRec rec[2][128];    // double-buffered by barrier parity
 };
 constexpr int kGridMaxWg = 128;
@@ -448,6 +449,31 @@ __global__ __launch_bounds__(NT) void perceptron_grid_kernel(const TrainArgs a, 
     const int base = blockIdx.x * NT + tid, stride = G * NT;
     float m[EPT], yg[EPT], dg[EPT];
     unsigned ypos = 0;
+    unsigned n_bar = 0;
+    {
+        // The margin form below needs y in {-1, +1}; the check happens HERE, on the device (round 3: the host used to read
+        // the labels back and synchronise the caller's stream for it - the one entry point of the library that waited).  Any
+        // other label (0 / 1 labels, y = 0): one grid-wide agreement, then workgroup 0 runs the generic loop, which
+        // evaluates the reference's expressions on y itself, and the other workgroups leave.
+        int bad = 0;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int j = base + e * stride;
+            if (j < N) bad |= (a.y[j] != 1.0f && a.y[j] != -1.0f);
+        }
+        if (__syncthreads_or(bad) && tid == 0) __hip_atomic_store(&gs->bad_labels, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool alive = grid_barrier(gs, n_bar, tid);
+        if (!alive || __hip_atomic_load(&gs->bad_labels, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            if (blockIdx.x != 0) return;
+            int it = 0;
+            bool converged = false;
+            if (alive)
+                for (; it < a.max_iter; ++it)
+                    if (class_step(a, 0, sX, sB, sCnt)) { converged = true; break; }
+            if (tid == 0) { a.info[0] = it; a.info[1] = alive ? (converged ? 1 : 0) : -1; }
+            return;
+        }
+    }
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
         const int j = base + e * stride;
@@ -459,7 +485,6 @@ __global__ __launch_bounds__(NT) void perceptron_grid_kernel(const TrainArgs a, 
         dg[e] = in ? a.K[(size_t)j * N + j] : 0.0f;
     }
     auto ysign = [&](int e) { return (ypos >> e) & 1u ? 1.0f : -1.0f; };
-    unsigned n_bar = 0;
     int it = 0;
     int converged = 0;
     for (; it < a.max_iter; ++it) {
@@ -599,14 +624,19 @@ hipError_t launch_perceptron(int kind, float kp0, float kp1, float beta, const f
     const size_t lds = sizeof(float) * ((D + 3) & ~3) + 16 * sizeof(Best) + 16 * sizeof(int) + 4 * sizeof(float) + sizeof(GridRec);
     if (grid && sign_labels && C == 1 && perceptron_grid_workgroups(N) <= kGridMaxWg) {
         // several workgroups: a stream-ordered scratch for the records and the arrival counter, a cooperative launch
+        // (if the cooperative launch is refused - partition mode, resources - the one-workgroup kernels below take over)
         GridSync* gs = nullptr;
-        if (hipError_t e = hipMallocAsync((void**)&gs, sizeof(GridSync), st)) return e;
-        if (hipError_t e = hipMemsetAsync(gs, 0, sizeof(GridSync), st)) return e;
-        void* params[] = {(void*)&a, (void*)&gs};
-        hipError_t e = hipLaunchCooperativeKernel((const void*)perceptron_grid_kernel<kGridEPT, kGridNT>,
-                                                  dim3(perceptron_grid_workgroups(N)), dim3(kGridNT), params, (unsigned)lds, st);
-        const hipError_t f = hipFreeAsync(gs, st);
-        return e != hipSuccess ? e : f;
+        hipError_t e = hipMallocAsync((void**)&gs, sizeof(GridSync), st);
+        if (e == hipSuccess) {
+            e = hipMemsetAsync(gs, 0, sizeof(GridSync), st);
+            void* params[] = {(void*)&a, (void*)&gs};
+            if (e == hipSuccess)
+                e = hipLaunchCooperativeKernel((const void*)perceptron_grid_kernel<kGridEPT, kGridNT>,
+                                               dim3(perceptron_grid_workgroups(N)), dim3(kGridNT), params, (unsigned)lds, st);
+            const hipError_t f = hipFreeAsync(gs, st);
+            if (e == hipSuccess) return f;
+        }
+        (void)hipGetLastError();
     }
     if (sign_labels && C == 1 && N <= 1024 * 4) {
         perceptron_reg_kernel<4, 1024><<<dim3(1), dim3(1024), lds, st>>>(a);

@@ -446,6 +446,55 @@ def test_trainer_on_several_workgroups_equals_one_workgroup_bitwise(n, kind, kno
             assert torch.equal(a[k], b[k]), k
 
 
+def test_trainer_decides_about_the_labels_on_the_device_and_never_waits(knob):
+    """`dcx_train_perceptron` used to read the labels back (a stream synchronisation) to decide whether
+    the sign-bit kernels apply.  The decision is the kernels' own now: 0 / 1 labels on the several-workgroup path (one
+    grid-wide agreement, then workgroup 0 runs the generic loop) and on the one-workgroup register kernels give exactly
+    what the generic kernel gives, and the call can be captured in a HIP graph and replayed."""
+    from diffco_amd import _ops
+    rob = make_robot("baxter_left")
+    g = torch.Generator().manual_seed(5)
+    lim = rob.limits
+    for n in (6000, 3000):
+        q = torch.rand((n, 7), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]
+        feats = rob.fkine(q.cuda()).reshape(n, -1)
+        y01 = torch.where(feats[:, -1] + 0.3 * feats[:, -2] > 0.2, 1.0, 0.0)   # not sign labels
+        zeros = torch.zeros(n, device="cuda")
+        runs = {}
+        for mode in (2, 1, 0):   # the generic kernel (referee), several workgroups, one workgroup
+            knob("train_grid", mode)
+            runs[mode] = _ops.train_perceptron_device(0, 10.0, 2.0, 0.8, feats, y01, zeros, zeros, None, 120)
+        for mode in (1, 0):
+            assert runs[mode][3] == runs[2][3] and runs[mode][4] == runs[2][4]
+            for k in (0, 1, 2):
+                assert torch.equal(runs[mode][k], runs[2][k]), (n, mode, k)
+    # capture + replay of the C ABI call (one-workgroup path: no allocation inside the call)
+    knob("train_grid", 0)
+    import ctypes as C
+    from diffco_amd import _lib
+    lib = _lib.load()
+    n = 2000
+    q = torch.rand((n, 7), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]
+    feats = rob.fkine(q.cuda()).reshape(n, -1).contiguous()
+    y = torch.where(feats[:, -1] > 0.2, 1.0, -1.0).contiguous()
+    want = _ops.train_perceptron_device(0, 10.0, 2.0, 0.8, feats, y, torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda"), None, 80)
+    gains, hypo = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    K = torch.zeros((n, n), device="cuda")
+    info = torch.zeros(2, device="cuda", dtype=torch.int32)
+    kp = (C.c_float * 2)(10.0, 2.0)
+    s = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph, stream=s):
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(lib.dcx_train_perceptron(0, 0, kp, C.c_float(0.8), C.c_void_p(feats.data_ptr()), n, feats.shape[1],
+                                            C.c_void_p(y.data_ptr()), 1, C.c_void_p(gains.data_ptr()), C.c_void_p(hypo.data_ptr()),
+                                            C.c_void_p(K.data_ptr()), 80, C.c_void_p(info.data_ptr()), st))
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(gains, want[0]) and torch.equal(hypo, want[1]) and int(info[0]) == want[3]
+
+
 def test_trainer_survives_a_diverging_run(knob):
     """MultiQuadratic is not positive definite: the perceptron's margins overflow to inf / NaN.  The reference keeps
     walking (torch.min returns a NaN's index); so must every device kernel — a NaN wins the argmin instead of leaving
