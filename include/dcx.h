@@ -264,11 +264,13 @@ int dcx_traj_adam_run(const dcx_model* model, const dcx_traj_state* st, const dc
  *                 over the kept supports is complete even for a sample that was never selected itself
  *   info [2] dev out: iterations used; 1 if converged, 0 if not, -1 if the multi-workgroup form gave up on a
  *                 grid barrier (another kernel kept its workgroups from running for seconds)
- * For one label column and N <= 131072 the entry point reads the labels back once (a stream synchronisation) to decide
- * whether a register-resident kernel, which keeps a label as its sign, may be used: one workgroup up to N = 4096,
- * beyond that N / 1024 workgroups on as many CUs (a cooperative launch, one grid-wide barrier per iteration; the same
- * argmin sequence, bit for bit).  Debug knob "train_grid": 0 = one workgroup only, 1 = several from N = 2048,
- * 2 = the generic one-workgroup kernel whatever the labels.                                                 */
+ * For one label column and N <= 131072 a register-resident kernel, which keeps a label as its sign, is used: one
+ * workgroup up to N = 4096, beyond that N / 1024 workgroups on as many CUs (a cooperative launch, one grid-wide barrier
+ * per iteration; the same argmin sequence, bit for bit).  Whether the labels really are -1 / +1 is checked by those
+ * kernels themselves, on the device (any other label: the generic loop, which uses y as given) - like every entry
+ * point of this library the call does not synchronise the caller's stream, and its one-workgroup form can be captured
+ * in a HIP graph.  Debug knob "train_grid": 0 = one workgroup only, 1 = several from N = 2048, 2 = the generic
+ * one-workgroup kernel whatever the labels.                                                                  */
 int dcx_train_perceptron(int device, int kernel_kind, const float* kparams, float beta, const float* feats, int64_t N,
                          int32_t D, const float* y, int32_t C, float* gains, float* hypothesis, float* kernel_matrix,
                          int32_t max_iteration, int32_t* info, void* stream);
