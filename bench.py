@@ -48,6 +48,8 @@ WORKLOADS = {
     "cfg3_poly": ("baxter", (1, 1.0, 1.0), 2000, 5, 8192, 65536,
                   "config #3 with the Polyharmonic(1,1) spline nodes MultiDiffCo.rbf_score evaluates "
                   "(deprecated/MultiDiffCo.py:156-169): C=5, S=2000, 8192 per GPU"),
+    "cfg3_c8": ("baxter", (0, 10.0, 2.0), 2000, 8, 8192, 65536,
+                "config #3 with eight classes (the widest compiled class count; matrix-core A/B, profiles/r03_mfma_ab.txt)"),
     "cfg4": (None, (0, 10.0, 2.0), 10000, 1, 1 << 20, 1 << 20, "BASELINE config #4: SE(3) no-FK (D=6), RQ(10), S=10k, 1M configs"),
     # config #5: a "step" is ONE fused Adam iteration over R restarts x 50 waypoints (= 50 R score+grad evals)
     "cfg5": ("baxter", (1, 1.0, 1.0), 2000, 1, 256 * 50, 256 * 50,
@@ -107,7 +109,7 @@ def make_workload(name, batch, dev, seed=0):
         desc = rob.fk_desc()
     sup_q = torch.rand((S, len(lo)), generator=g) * (hi - lo) + lo
     W = torch.randn((S, C), generator=g)
-    if name in ("cfg3", "cfg3_poly"):  # 40 % of the entries zeroed per class (mimics deprecated/MultiDiffCo.py:152-153)
+    if name in ("cfg3", "cfg3_poly", "cfg3_c8"):  # 40 % of the entries zeroed per class (mimics deprecated/MultiDiffCo.py:152-153)
         W = W * (torch.rand((S, C), generator=g) >= 0.4)
     q = torch.rand((B, len(lo)), generator=gq) * (hi - lo) + lo
     sup = _ops.fkine(desc, sup_q.to(dev)).reshape(S, -1)
@@ -250,9 +252,14 @@ class ScoreLoop:
                     self._launch(self.local[b])
                     gather_scores(self.full[b], self.local[b])
             torch.cuda.synchronize(dev)
+            # c10d's watchdog thread polls the events of earlier collectives (the warm-up's, an eager variant's): under the
+            # default global capture mode such a query from ANOTHER thread invalidates the capture and takes the process
+            # down from the watchdog (hipErrorStreamCaptureUnsupported).  Thread-local mode confines the capture's rules to
+            # this thread; the short sleep lets the watchdog retire what is already complete.
+            time.sleep(0.3)
             g = torch.cuda.CUDAGraph()
             done = [None, None]
-            with torch.cuda.graph(g, stream=main):
+            with torch.cuda.graph(g, stream=main, capture_error_mode="thread_local"):
                 for i in range(self.G):
                     b = i % 2
                     if done[b] is not None:
@@ -537,8 +544,11 @@ def main():
         ach_tf = F * B / (kern_ms * 1e-3) / 1e12
         ach_gbs = bytes_per_eval(dof, C) * B / (kern_ms * 1e-3) / 1e9
         pmc = load_profile_json(f"pmc_{name}.json")
-        mf = load_profile_json("mfma_headline.json") or {}
-        mfma_on = os.environ.get("DCX_MFMA", "") not in ("", "0", "-1") and w["D"] <= 16 and C == 1 and not is_traj
+        mfc = load_profile_json("mfma_contractions.json") or {}
+        forms = mfc.get("forms") or {}
+        head_form = next((v for k, v in forms.items() if k.startswith("headline")), {})
+        this_form = next((v for k, v in forms.items() if k.split(" ")[0] == name), head_form)
+        mfma_on = os.environ.get("DCX_MFMA", "") not in ("", "0", "-1") and w["D"] <= 16 and w["D"] % 2 == 0 and C in (1, 5, 8) and not is_traj
         gather_txt = {"graph": "RCCL all-gather of the scores of EVERY call beside the next call's sweep, sweep + gather captured "
                                "in a HIP graph (8 calls per replay)",
                       "per-call": "RCCL all-gather of the scores after EVERY call, in order on the launch stream",
@@ -571,12 +581,20 @@ def main():
                          "hbm": {"achieved": round(ach_gbs, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                  "frac": round(ach_gbs / PEAK_HBM_GBS, 5),
                                  "bytes_per_eval": bytes_per_eval(dof, C)},
+                         # the matrix cores: what the default path issues (nothing) and what the measured MFMA forms of
+                         # this path cost - the north star's K[B,S].W[S,C] contraction at C >= 4 included
+                         # (profiles/mfma_contractions.json <- profiles/r03_mfma_ab.txt)
                          "mfma": {"used": bool(mfma_on),
-                                  "instructions_per_launch": mf.get("instructions_per_launch") if mfma_on else 0,
-                                  "busy_frac": mf.get("busy_frac") if mfma_on else 0.0,
-                                  "measured_variant": {k: mf.get(k) for k in (
-                                      "instructions_per_launch", "busy_frac", "achieved_tflops_on_matrix_cores",
-                                      "kernel_us_mfma_form", "kernel_us_valu_form", "verdict", "source")}}},
+                                  "instructions_per_launch": this_form.get("instructions_per_launch") if mfma_on else 0,
+                                  "busy_frac": this_form.get("busy_frac") if mfma_on else 0.0,
+                                  "contraction": ("K[B,S].W[S,C] (C >= 4) and the (configurations x supports).(supports x features) "
+                                                  "gradient fold on v_mfma_f32_16x16x4_f32; upstream.W^T measured in isolation"),
+                                  "measured_variant": {**{k: head_form.get(k) for k in (
+                                      "instructions_per_launch", "busy_frac", "mfma_flops_per_launch", "kernel_us_mfma_form",
+                                      "kernel_us_valu_form")}, "verdict": mfc.get("verdict"), "source": mfc.get("source")},
+                                  "forms": mfc.get("forms"),
+                                  "contractions_in_isolation": mfc.get("contractions_in_isolation_8_waves_per_simd"),
+                                  "coissue": mfc.get("coissue")}},
         }
         if multi:
             none_ms = ((variants or {}).get("gather_none") or {}).get("ms_per_step")

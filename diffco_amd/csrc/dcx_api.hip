@@ -239,7 +239,7 @@ int fk_device_copy(int device, const dcx_fk_desc& fk, FkProg** out) {
 // path calls getenv.  -1 = "use the rule".
 struct Knobs {
     std::atomic<int64_t> ys{-1}, nw{-1}, min_rows{-1}, split_finish_kernel{-1}, inlaunch_tiles{-1}, jac_per_class{-1},
-        mfma{-1}, traj_fused{-1}, xf{-1}, jac_one_sweep{-1}, train_grid{-1}, fkk{-1}, jt_waves{-1};
+        mfma{-1}, traj_fused{-1}, xf{-1}, jac_one_sweep{-1}, train_grid{-1}, fkk{-1}, jt_waves{-1}, hess_ys{-1};
     Knobs() {
         auto rd = [](const char* name, std::atomic<int64_t>& dst, bool flag) {
             if (const char* e = std::getenv(name)) dst = flag ? 1 : std::atoll(e);
@@ -257,6 +257,7 @@ struct Knobs {
         rd("DCX_TRAIN_GRID", train_grid, false);
         rd("DCX_FKK", fkk, false);
         rd("DCX_JT_WAVES", jt_waves, false);
+        rd("DCX_HESS_YS", hess_ys, false);
     }
 };
 Knobs& knobs() {
@@ -456,7 +457,7 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
     a.xf = xf_able ? 1 : 0;
     // MFMA form of the gradient fold: compiled for even D <= 16 with the two specialised kernel functions; needs every
     // wave to own a slice of the LDS reduction scratch (nw > 1, parallel fold)
-    a.mfma = (mode != MODE_SCORE && m->C == 1 && m->Dt <= 16 && (m->Dt % 2) == 0 && m->kf != KF_GEN && g.nw > 1 && g.red_slots == g.nw &&
+    a.mfma = (mode != MODE_SCORE && (m->C == 1 || m->C == 5 || m->C == 8) && m->Dt <= 16 && (m->Dt % 2) == 0 && m->kf != KF_GEN && g.nw > 1 && g.red_slots == g.nw &&
               knobs().mfma != 0 && knobs().mfma > 0) ? 1 : 0;
     if (a.mfma) a.xf = 0;
     if (a.xf) {  // the XF kernel: the centred rows and the centroid
@@ -533,7 +534,7 @@ int dcx_debug_set(const char* name, int64_t value) {
     const std::string n(name);
     std::atomic<int64_t>* dst = n == "ys" ? &k.ys : n == "nw" ? &k.nw : n == "min_rows" ? &k.min_rows
         : n == "split_finish_kernel" ? &k.split_finish_kernel : n == "inlaunch_tiles" ? &k.inlaunch_tiles
-        : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : n == "traj_fused" ? &k.traj_fused : n == "xf" ? &k.xf : n == "jac_one_sweep" ? &k.jac_one_sweep : n == "train_grid" ? &k.train_grid : n == "fkk" ? &k.fkk : n == "jt_waves" ? &k.jt_waves : nullptr;
+        : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : n == "traj_fused" ? &k.traj_fused : n == "xf" ? &k.xf : n == "jac_one_sweep" ? &k.jac_one_sweep : n == "train_grid" ? &k.train_grid : n == "fkk" ? &k.fkk : n == "jt_waves" ? &k.jt_waves : n == "hess_ys" ? &k.hess_ys : nullptr;
     if (!dst) return fail(DCX_ERR_INVALID, "unknown knob: " + n);
     *dst = value;
     return DCX_OK;
@@ -764,8 +765,17 @@ int dcx_score_hess(const dcx_model* m, const float* q, int64_t B, const float* u
     v.kf = m->kf;
     v.kp0 = m->kp0;
     v.kp1 = m->kp1;
+    v.n_cu = m->n_cu;
+    v.ys_knob = (int32_t)knobs().hess_ys;
+    if (float* sc = split_scratch(m, (hipStream_t)stream, 0)) {  // small batches split the supports across blocks
+        v.counters = reinterpret_cast<unsigned int*>(sc);
+        v.n_counters = (int32_t)kTileCounters;
+        v.counter_stride = kCounterStride;
+        v.scratch = sc + kScratchHead / sizeof(float);
+        v.scratch_bytes = (size_t)2 * m->n_cu * (m->Dt + m->C) * 64 * sizeof(float);
+    }
     const hipError_t e = launch_hess(v, q, B, upstream, grad, hess, (hipStream_t)stream);
-    if (e == hipErrorInvalidValue) return fail(DCX_ERR_UNSUPPORTED, "dcx_score_hess: the transform's frames do not fit the LDS in duals");
+    if (e == hipErrorInvalidValue) return fail(DCX_ERR_UNSUPPORTED, "dcx_score_hess: the transform's feature row does not fit the LDS in duals");
     if (e != hipSuccess) return fail_hip(e, "dcx_score_hess");
     return DCX_OK;
 }

@@ -72,6 +72,12 @@ struct ModelView {
     const FkProg* fk;
     int32_t S, Dt, C, RS, dof, d_fk, frame_floats, prog_floats, kind, kf;
     float kp0, kp1;
+    // this stream's split-launch scratch (dcx_api.hip split_scratch) or null: partial rows + zeroed arrival counters
+    float* scratch = nullptr;
+    size_t scratch_bytes = 0;
+    unsigned int* counters = nullptr;
+    int32_t n_counters = 0, counter_stride = 0, n_cu = 0;
+    int32_t ys_knob = -1;   // developer knob hess_ys: blocks per tile (1 = never split)
 };
 hipError_t launch_hess(const ModelView& m, const float* q, int64_t B, const float* upstream, float* grad, float* hess,
                        hipStream_t stream);

@@ -21,6 +21,8 @@
 // and lane).
 #include "dcx_internal.h"
 
+#include <algorithm>
+
 namespace dcx {
 
 struct HessArgs {
@@ -36,8 +38,18 @@ struct HessArgs {
     int32_t kind, kf;
     float kp0, kp1;
     int32_t s_chunk;
+    // supports split across gridDim.y blocks per 64-lane tile (small batches): block y sweeps [y * s_super, (y + 1) * s_super),
+    // leaves its partial sums in `part`, and the block that arrives last at the tile's counter adds them in y order and
+    // runs the reverse sweep
+    int32_t ys, s_super, counter_stride;
+    Dual* part;               // [tile][ys][D][64]
+    unsigned int* counters;   // [tile * counter_stride], zero between launches
+    // transforms whose frames do not fit the LDS in duals (the 23-joint iiwa7 + Allegro tree): the frames of block b live
+    // in global memory at frames_g + b * frame_floats * 64 (same column layout, coalesced 512-byte columns)
+    Dual* frames_g;
+    int64_t lane0;            // first (configuration, direction) pair of this launch (chunked launches)
     // LDS plan, in Dual elements (8 bytes)
-    int32_t o_q, o_f, o_x, o_acc, o_fk_floats;
+    int32_t o_q, o_f, o_x, o_acc, o_fk_floats, prog_floats;
 };
 
 // value, gradient coefficient g (dK/dx = g * delta) and h = 2 dg/dd2 (d2K/dx2 = g I + h delta delta^T)
@@ -150,7 +162,15 @@ __device__ __forceinline__ void sweep_hess_regs(const HessArgs& a, const Dual* s
         return w;
     };
     constexpr int NV = NP + (ODD ? 1 : 0);
-    auto pair = [&](cfloat_ptr r) __attribute__((always_inline)) {
+    // one support row: its D coordinates and its weight, read one row ahead of their use (two scalar-register buffers;
+    // with one to four waves per SIMD nothing else hides the scalar-load latency)
+    auto load_row = [&](float (&dst)[D + 1], int j) __attribute__((always_inline)) {
+        cfloat_ptr r = rows + (size_t)j * a.RS;
+#pragma unroll
+        for (int k = 0; k < D; ++k) dst[k] = r[k];
+        dst[D] = up ? 0.0f : r[C > 1 ? a.wsum_off : w_off];
+    };
+    auto pair = [&](const float (&r)[D + 1], int j) __attribute__((always_inline)) {
         v2f dl[NV], s2a = {0.0f, 0.0f}, s2b = {0.0f, 0.0f}, sda = {0.0f, 0.0f}, sdb = {0.0f, 0.0f};
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
@@ -161,7 +181,7 @@ __device__ __forceinline__ void sweep_hess_regs(const HessArgs& a, const Dual* s
         }
         s2a += s2b;
         sda += sdb;
-        const float w = weight(r);
+        const float w = up ? weight(rows + (size_t)j * a.RS) : r[D];
         float g, h;
         kernel_eval_h(a, s2a.x + s2a.y, g, h);
         const float cf = w * g, ef = w * h * (sda.x + sda.y);
@@ -172,7 +192,25 @@ __device__ __forceinline__ void sweep_hess_regs(const HessArgs& a, const Dual* s
             ad[k] = __builtin_elementwise_fma(c2, xd[k], __builtin_elementwise_fma(e2, dl[k], ad[k]));
         }
     };
-    for (int j = j0; j < j1; ++j) pair(rows + (size_t)j * a.RS);
+    if (j0 < j1) {
+        float ra[D + 1], rb[D + 1];
+        const int jl = j1 - 1;
+        load_row(ra, j0);
+        for (int j = j0; j < j1; j += 2) {
+            load_row(rb, j + 1 < j1 ? j + 1 : jl);
+            __builtin_amdgcn_sched_barrier(0);
+            pair(ra, j);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_sched_barrier(0);
+            load_row(ra, j + 2 < j1 ? j + 2 : jl);
+            __builtin_amdgcn_sched_barrier(0);
+            if (j + 1 < j1) pair(rb, j + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         sAcc[(2 * k) * 64] = Dual(av[k].x, ad[k].x);
@@ -189,13 +227,14 @@ __global__ __launch_bounds__(SMALL ? 1024 : 512) void score_hess_kernel(const He
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nw = blockDim.x >> 6;
     const int dof = a.dof;
-    int64_t gl = (int64_t)blockIdx.x * 64 + lane;
+    int64_t gl = a.lane0 + (int64_t)blockIdx.x * 64 + lane;
     const bool live = gl < a.n_lanes;
     if (!live) gl = a.n_lanes - 1;  // surplus lanes repeat the last pair and store nothing
     const int64_t b = gl / dof;
     const int dir = (int)(gl - b * dof);
     Dual* sQ = sd + a.o_q + lane * dof;  // this lane's row
-    Dual* sF = sd + a.o_f + lane;        // columns, stride 64
+    Dual* sF = a.frames_g ? a.frames_g + (size_t)blockIdx.x * a.frame_floats * 64 + lane  // columns, stride 64
+                          : sd + a.o_f + lane;
     Dual* sX = sd + a.o_x + lane;
     Dual* sAcc = sd + a.o_acc + (size_t)wave * a.D * 64 + lane;
 
@@ -212,9 +251,11 @@ __global__ __launch_bounds__(SMALL ? 1024 : 512) void score_hess_kernel(const He
     for (int k = 0; k < a.D; ++k) sAcc[k * 64] = Dual(0.0f, 0.0f);
     __syncthreads();
 
-    // ---- the sweep: this wave's slice of the supports ----
-    const int j0 = (wave * a.s_chunk < a.S) ? wave * a.s_chunk : a.S;
-    const int j1 = (j0 + a.s_chunk < a.S) ? j0 + a.s_chunk : a.S;
+    // ---- the sweep: this wave's slice of this block's supports ----
+    const int ybase = (int)blockIdx.y * a.s_super;
+    const int yend = (ybase + a.s_super < a.S) ? ybase + a.s_super : a.S;
+    const int j0 = (ybase + wave * a.s_chunk < yend) ? ybase + wave * a.s_chunk : yend;
+    const int j1 = (j0 + a.s_chunk < yend) ? j0 + a.s_chunk : yend;
     const float* up = a.upstream ? a.upstream + b * a.C : nullptr;
 #define DCX_HESS_CASE(W) case W: sweep_hess_regs<W>(a, sX, sAcc, up, j0, j1); break;
     if constexpr (SMALL) {
@@ -230,20 +271,78 @@ __global__ __launch_bounds__(SMALL ? 1024 : 512) void score_hess_kernel(const He
     }
 #undef DCX_HESS_CASE
     __syncthreads();
-    // ---- wave 0: add the other waves' sums in wave order, then the reverse sweep in duals ----
-    if (wave == 0) {
-        for (int k = 0; k < a.D; ++k) {
-            Dual t = sAcc[k * 64];
-            for (int w = 1; w < nw; ++w) t += sAcc[((size_t)w * a.D + k) * 64];
-            sAcc[k * 64] = t;
+    // ---- every wave adds its share of the sums (accumulator k belongs to wave k % nw) over the waves' rows, in wave order;
+    //      totals land in row 0.  In a split launch (ys > 1) they go straight out instead: the fused gradient kernel's
+    //      hand-over (score_kernel.h) - agent-scope (write-through) stores, every storing wave waits for their
+    //      acknowledgement, a barrier, ONE arrival atomic per block; the block that arrives last re-reads all ys rows
+    //      with agent-scope loads, again one share per wave, and adds them in y order (whatever the arrival order was: the
+    //      result does not depend on the schedule), then leaves the counter at zero for the next launch.  No fence on
+    //      either side: a release fence's L2 write-back + the acquire's invalidate let 252 blocks evict each other's
+    //      support rows.
+    typedef unsigned long long u64;
+    Dual* row0 = sd + a.o_acc + lane;
+    u64* prow = reinterpret_cast<u64*>(a.part + ((size_t)blockIdx.x * a.ys) * a.D * 64 + lane);
+    u64* mine = prow + (size_t)blockIdx.y * a.D * 64;
+    for (int k = wave; k < a.D; k += nw) {
+        Dual t = row0[k * 64];
+        for (int w = 1; w < nw; ++w) t += row0[((size_t)w * a.D + k) * 64];
+        if (a.ys > 1) {
+            const u64 bits = (u64)__float_as_uint(t.v) | ((u64)__float_as_uint(t.d) << 32);
+            __hip_atomic_store(mine + k * 64, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            row0[k * 64] = t;
         }
-        fk_vjp<Dual>(fk, sQ, sF, sAcc, sQ);  // the gradient row is built in place of the q row
-        if (live) {
-            float* hrow = a.hess + gl * dof;
-            for (int k = 0; k < dof; ++k) hrow[k] = sQ[k].d;
-            if (a.grad && dir == 0)
-                for (int k = 0; k < dof; ++k) a.grad[b * dof + k] = sQ[k].v;
+    }
+    if (a.ys > 1) {
+#ifdef DCX_HANDOVER_FENCE
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#else
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "the drained write-through hand-over relies on gfx942 / gfx950 lowering: build other targets with -DDCX_HANDOVER_FENCE"
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        __syncthreads();
+        unsigned int* cnt = a.counters + (size_t)blockIdx.x * a.counter_stride;
+        int* flag = reinterpret_cast<int*>(smem + a.o_fk_floats + a.prog_floats);  // one word behind the staged program
+        if (threadIdx.x == 0) *flag = (int)__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*flag != a.ys - 1) return;
+#ifdef DCX_HANDOVER_FENCE
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+        // the re-read: up to 16 rows of one accumulator in flight per wave (one dependent agent-scope load per value cost
+        // 300 cycles each, 30 us at ys = 9, when wave 0 read them one by one)
+        for (int k = wave; k < a.D; k += nw) {
+            Dual t(0.0f, 0.0f);
+            for (int y0 = 0; y0 < a.ys; y0 += 16) {
+                u64 r[16];
+#pragma unroll
+                for (int yy = 0; yy < 16; ++yy) {
+                    const int y = (y0 + yy < a.ys) ? y0 + yy : a.ys - 1;
+                    r[yy] = __hip_atomic_load(prow + ((size_t)y * a.D + k) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int yy = 0; yy < 16; ++yy) {
+                    if (y0 + yy < a.ys) {
+                        const Dual v(__uint_as_float((unsigned int)r[yy]), __uint_as_float((unsigned int)(r[yy] >> 32)));
+                        t = (y0 + yy == 0) ? v : t + v;
+                    }
+                }
+            }
+            row0[k * 64] = t;
         }
+        if (threadIdx.x == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    // ---- wave 0: the reverse sweep in duals ----
+    if (wave != 0) return;
+    fk_vjp<Dual>(fk, sQ, sF, sAcc, sQ);  // the gradient row is built in place of the q row
+    if (live) {
+        float* hrow = a.hess + gl * dof;
+        for (int k = 0; k < dof; ++k) hrow[k] = sQ[k].d;
+        if (a.grad && dir == 0)
+            for (int k = 0; k < dof; ++k) a.grad[b * dof + k] = sQ[k].v;
     }
 }
 
@@ -270,33 +369,70 @@ hipError_t launch_hess(const ModelView& m, const float* q, int64_t B, const floa
     a.kf = m.kf;
     a.kp0 = m.kp0;
     a.kp1 = m.kp1;
-    // waves per block: as many support slices as the LDS allows (Dual = 8 bytes; 64 lanes per column)
-    const int fixed = m.dof + m.frame_floats + m.Dt;               // q row, frames, x
+    // Frames that do not fit the LDS as (value, tangent) pairs go to global memory (one 512-byte column per frame float and
+    // block, L2-resident): the q row, x and one wave's sums must fit beside the program.
     const int budget = (int)((150 * 1024 - 4 * (size_t)m.prog_floats) / 512);  // Dual columns that fit
+    bool paged = m.dof + m.frame_floats + 2 * m.Dt > budget;
+    const int fixed = m.dof + (paged ? 0 : m.frame_floats) + m.Dt;  // q row, frames, x
+    if (fixed + m.Dt > budget) return hipErrorInvalidValue;
+    const int64_t nblk = (a.n_lanes + 63) / 64;
+    if (nblk > 0x7fffffffLL) return hipErrorInvalidValue;
+    // Small batches (trust-constr's few hundred dense-path points): split the supports across blocks until the chip is
+    // full - each (configuration, direction) tile is swept by ys blocks, the last to arrive folds (kernel above).
+    const size_t part_row = (size_t)m.Dt * 64 * sizeof(Dual);
+    int ys = 1;
+    if (m.scratch && !paged && nblk * 2 <= m.n_cu && nblk <= m.n_counters) {
+        ys = (int)(m.n_cu / nblk);
+        if (ys > 12) ys = 12;                                                 // (measured: 9-12 blocks per tile, profiles/r03_hess_probe.txt)
+        while (ys > 1 && (m.S + ys - 1) / ys < 64) --ys;                      // at least four short slices per block
+        if (m.ys_knob >= 1) ys = m.ys_knob;
+        while (ys > 1 && (size_t)nblk * ys * part_row > m.scratch_bytes) --ys;
+    }
+    a.s_super = (m.S + ys - 1) / ys;
+    ys = (m.S + a.s_super - 1) / a.s_super;  // no empty blocks
+    a.ys = ys;
+    a.part = reinterpret_cast<Dual*>(m.scratch);
+    a.counters = m.counters;
+    a.counter_stride = m.counter_stride;
+    // waves per block: as many support slices as the LDS allows (Dual = 8 bytes; 64 lanes per column)
     int nw = (budget - fixed) / m.Dt;
-    if (nw < 1) return hipErrorInvalidValue;
     const bool small = m.Dt <= 16;
     const int nw_max = small ? 16 : 8;
     if (nw > nw_max) nw = nw_max;
-    while (nw > 1 && (m.S + nw - 1) / nw < 32) nw >>= 1;  // a slice shorter than 32 supports is all FK and fold
-    a.s_chunk = (m.S + nw - 1) / nw;
+    while (nw & (nw - 1)) nw &= nw - 1;                                      // a power of two
+    while (nw > 1 && (a.s_super + nw - 1) / nw < (ys > 1 ? 14 : 24)) nw >>= 1;  // a slice shorter than that is all FK and fold
+    a.s_chunk = (a.s_super + nw - 1) / nw;
     a.o_q = 0;
     a.o_f = a.o_q + 64 * m.dof;
-    a.o_x = a.o_f + 64 * m.frame_floats;
+    a.o_x = a.o_f + (paged ? 0 : 64 * m.frame_floats);
     a.o_acc = a.o_x + 64 * m.Dt;
     a.o_fk_floats = 2 * (a.o_acc + nw * 64 * m.Dt);
-    const size_t lds = sizeof(float) * ((size_t)a.o_fk_floats + m.prog_floats);
+    a.prog_floats = m.prog_floats;
+    const size_t lds = sizeof(float) * ((size_t)a.o_fk_floats + m.prog_floats + 4);  // + the arrival flag of a split launch
     if (lds > 64 * 1024) {
         const void* fn = small ? (const void*)score_hess_kernel<true> : (const void*)score_hess_kernel<false>;
         if (hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return e;
     }
-    const int64_t nblk = (a.n_lanes + 63) / 64;
-    if (nblk > 0x7fffffffLL) return hipErrorInvalidValue;
-    if (small)
-        hipLaunchKernelGGL(score_hess_kernel<true>, dim3((unsigned)nblk), dim3(64 * nw), lds, stream, a);
-    else
-        hipLaunchKernelGGL(score_hess_kernel<false>, dim3((unsigned)nblk), dim3(64 * nw), lds, stream, a);
-    return hipGetLastError();
+    auto go = [&](int64_t blocks) {
+        const dim3 grid((unsigned)blocks, (unsigned)ys);
+        if (small)
+            hipLaunchKernelGGL(score_hess_kernel<true>, grid, dim3(64 * nw), lds, stream, a);
+        else
+            hipLaunchKernelGGL(score_hess_kernel<false>, grid, dim3(64 * nw), lds, stream, a);
+        return hipGetLastError();
+    };
+    if (!paged) return go(nblk);
+    // paged frames: stream-ordered scratch for at most 2 blocks per CU at a time, the batch in as many launches as that takes
+    const int64_t per_launch = std::min<int64_t>(nblk, 2 * (int64_t)m.n_cu);
+    const size_t fbytes = (size_t)per_launch * m.frame_floats * 64 * sizeof(Dual);
+    if (hipError_t e = hipMallocAsync((void**)&a.frames_g, fbytes, stream)) return e;
+    hipError_t rc = hipSuccess;
+    for (int64_t b0 = 0; b0 < nblk && rc == hipSuccess; b0 += per_launch) {
+        a.lane0 = b0 * 64;
+        rc = go(std::min(per_launch, nblk - b0));
+    }
+    const hipError_t fe = hipFreeAsync(a.frames_g, stream);
+    return rc != hipSuccess ? rc : fe;
 }
 
 }  // namespace dcx

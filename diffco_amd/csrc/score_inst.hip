@@ -25,9 +25,10 @@ constexpr int kD = DCX_INST_D;
 constexpr int kMaxT = kD <= 16 ? 1024 : (kD <= 48 ? 512 : 256);
 
 // widths / modes that carry the MFMA form of the gradient fold (sweep_rows_mfma)
-// (one class only: the developer knob takes it for C == 1 models, dcx_api.hip)
+// (one, five and eight classes: the developer knob takes it for those models, dcx_api.hip; with C > 1 the weight
+// contraction K . W runs on the matrix cores beside the gradient fold)
 template <int KF, int CC, int MODE>
-constexpr bool kHasMfma = (kD <= 16) && (kD % 2 == 0) && (CC == 1) && (MODE != MODE_SCORE) && (KF != KF_GEN);
+constexpr bool kHasMfma = (kD <= 16) && (kD % 2 == 0) && (CC == 1 || CC == 5 || CC == 8) && (MODE != MODE_SCORE) && (KF != KF_GEN);
 
 // Shapes with an expanded form (score_kernel.h, XF: Polyharmonic(1), rows of <= 37 floats) run it by default, on the
 // centred row pairs the host passes with it (ScoreArgs::centre).  The direct form is compiled for them as well and

@@ -235,8 +235,9 @@ __host__ __device__ inline LdsPlan lds_plan(int dof, int d_fk, int frame_floats,
 #ifndef DCX_MINW_SLACK
 #define DCX_MINW_SLACK 0
 #endif
-constexpr int sweep_min_waves(int D, int CC, int KF) {
-    const int need = 3 * D + 2 * CC + 16 + DCX_MINW_SLACK + (KF == 2 ? 40 : 0);  // KF_GEN calls powf/logf
+constexpr int sweep_min_waves(int D, int CC, int KF, bool MF = false) {
+    // KF_GEN calls powf/logf; the MFMA form adds 16 accumulator registers per contraction + the operand fragments
+    const int need = 3 * D + 2 * CC + 16 + DCX_MINW_SLACK + (KF == 2 ? 40 : 0) + (MF ? (CC > 1 ? 48 : 24) : 0);
     return need <= 64 ? 8 : need <= 72 ? 7 : need <= 80 ? 6 : need <= 96 ? 5 : need <= 128 ? 4 : need <= 168 ? 3 : need <= 256 ? 2 : 1;
 }
 
@@ -794,8 +795,13 @@ __device__ __forceinline__ void sweep_rows_mfma(const ScoreArgs& a, const float 
     const float* rows_g = a.rows;
     const int grp = lane >> 4, col = lane & 15;
     v4f acc[4];
+    // C > 1: the weight contraction K[configurations x supports] . W[supports x classes] runs on the matrix cores too
+    // (KW): the kernel values of a step are transposed like the coefficients, the B operand is the W block of the same
+    // four rows (classes past C read as zero), one accumulator per 16-configuration tile
+    constexpr bool KW = CC > 1;
+    v4f accS[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < 4; ++t) acc[t] = accS[t] = v4f{0.f, 0.f, 0.f, 0.f};
     float asum = 0.0f;
     float near2 = 1e-30f;  // pairs closer than 0.1 |x| take the direct form (see pair): the expanded sweep's threshold.  At the
                            // first version's 1e-3 |x| the fold lost 2e-5 on queries planted 0.001-0.1 |x| from a support
@@ -804,7 +810,7 @@ __device__ __forceinline__ void sweep_rows_mfma(const ScoreArgs& a, const float 
     for (int k = 0; k < D; ++k) near2 = fmaf(DCX_XF_TAU * x[k], x[k], near2);
 
     // one support row: score accumulation on the VALU, returns the gradient coefficient
-    auto pair = [&](const float (&r)[L::RS]) __attribute__((always_inline)) -> float {
+    auto pair = [&](const float (&r)[L::RS], float& val) __attribute__((always_inline)) -> float {
         v2f d2a = {0.0f, 0.0f};
 #pragma unroll
         for (int k = 0; k + 1 < D; k += 2) {
@@ -814,10 +820,9 @@ __device__ __forceinline__ void sweep_rows_mfma(const ScoreArgs& a, const float 
             d2a = __builtin_elementwise_fma(dv, dv, d2a);
         }
         const float d2 = d2a.x + d2a.y;
-        float val, g;
+        float g;
         kernel_eval<KF>(d2, a, val, g);
-#pragma unroll
-        for (int c = 0; c < CC; ++c) sc[c] = fmaf(r[L::W_OFF + c], val, sc[c]);
+        if constexpr (!KW) sc[0] = fmaf(r[L::W_OFF], val, sc[0]);
         float coef;
         if constexpr (MODE == MODE_GRAD_ROW) {
             coef = g * r[CC > 1 ? L::WSUM_OFF : L::W_OFF];
@@ -861,9 +866,39 @@ __device__ __forceinline__ void sweep_rows_mfma(const ScoreArgs& a, const float 
         for (int k = 0; k < D; ++k) gx[k] = fmaf(x[k], asum, gx[k] - wscr[lane * PITCH + k]);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
+        if constexpr (KW) {   // the score tiles: lane (n, g) holds class n of configurations 16 t + 4 g + i
+            if (col < CC) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
+                for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) wscr[(16 * t + 4 * grp + i) * PITCH + col] = accS[t][i];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int c = 0; c < CC; ++c) sc[c] += wscr[lane * PITCH + c];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = accS[t] = v4f{0.f, 0.f, 0.f, 0.f};
         asum = 0.0f;
+    };
+    // four per-lane values of a step (one per support row) -> the A fragments of the four 16-configuration tiles
+    auto frags = [&](float c0, float c1, float c2, float c3, float (&f)[4]) __attribute__((always_inline)) {
+        auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(c0), __float_as_uint(c2), false, false);
+        auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(c1), __float_as_uint(c3), false, false);
+        auto t01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
+        auto t23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
+        f[0] = __uint_as_float(t01[0]); f[1] = __uint_as_float(t01[1]);
+        f[2] = __uint_as_float(t23[0]); f[3] = __uint_as_float(t23[1]);
+    };
+    auto contract_kw = [&](float v0, float v1, float v2, float v3, float bw) __attribute__((always_inline)) {
+        float f[4];
+        frags(v0, v1, v2, v3, f);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) accS[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[t], bw, accS[t], 0, 0, 0);
     };
     // the four coefficients of a step -> A fragments of the four 16-configuration tiles, then the MFMAs
     auto contract = [&](float c0, float c1, float c2, float c3, float bv) __attribute__((always_inline)) {
@@ -886,31 +921,39 @@ __device__ __forceinline__ void sweep_rows_mfma(const ScoreArgs& a, const float 
         // (dcx_model_create pads it): they only ever meet a zero coefficient.
         const float* bp = rows_g + (size_t)j0 * L::RS;
         const int boff = grp * L::RS + col;
+        const int woff = grp * L::RS + L::W_OFF + (col < CC ? col : 0);  // B operand of the weight contraction
+        const float wmask = (col < CC) ? 1.0f : 0.0f;
         load_row(rowA, j0);
         load_row(rowB, (j0 + 1 < j1) ? j0 + 1 : jl);
         float bcur = bp[boff];
+        float wcur = KW ? bp[woff] * wmask : 0.0f;
+        float v0, v1, v2, v3;
         int j = j0, since = 0;
         for (; j + 3 < j1; j += 4) {
             bp += 4 * L::RS;
             const float bnext = bp[boff];
+            float wnext = 0.0f;
+            if constexpr (KW) wnext = bp[woff] * wmask;
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_sched_barrier(0);
             load_row(rowC, j + 2);
             load_row(rowD, j + 3);
             __builtin_amdgcn_sched_barrier(0);
-            const float c0 = pair(rowA);
-            const float c1 = pair(rowB);
+            const float c0 = pair(rowA, v0);
+            const float c1 = pair(rowB, v1);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_sched_barrier(0);
             load_row(rowA, (j + 4 < j1) ? j + 4 : jl);
             load_row(rowB, (j + 5 < j1) ? j + 5 : jl);
             __builtin_amdgcn_sched_barrier(0);
-            const float c2 = pair(rowC);
-            const float c3 = pair(rowD);
+            const float c2 = pair(rowC, v2);
+            const float c3 = pair(rowD, v3);
             contract(c0, c1, c2, c3, bcur);
+            if constexpr (KW) contract_kw(v0, v1, v2, v3, wcur);
             __builtin_amdgcn_sched_barrier(0);
             bcur = bnext;
+            wcur = wnext;
             if (++since == DCX_MF_FLUSH) {
                 flush();
                 since = 0;
@@ -918,13 +961,15 @@ __device__ __forceinline__ void sweep_rows_mfma(const ScoreArgs& a, const float 
         }
         // up to three rows left (rowA / rowB hold rows j and j+1): absent rows contribute a zero coefficient
         if (j < j1) {
-            float c0 = pair(rowA), c1 = 0.0f, c2 = 0.0f;
-            if (j + 1 < j1) c1 = pair(rowB);
+            v1 = v2 = 0.0f;
+            float c0 = pair(rowA, v0), c1 = 0.0f, c2 = 0.0f;
+            if (j + 1 < j1) c1 = pair(rowB, v1);
             if (j + 2 < j1) {
                 load_row(rowC, j + 2);
-                c2 = pair(rowC);
+                c2 = pair(rowC, v2);
             }
             contract(c0, c1, c2, 0.0f, bcur);
+            if constexpr (KW) contract_kw(v0, v1, v2, 0.0f, wcur);
         }
         flush();
     }
@@ -965,7 +1010,7 @@ __device__ __forceinline__ void fold_partial_rows(float* sRed, int wave, int lan
 
 
 template <int D, int KF, int CC, int MODE, int MAXT, bool MF = false, bool XF = false>
-__global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF)) void score_kernel(const ScoreArgs a) {
+__global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF, MF)) void score_kernel(const ScoreArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr bool GRAD = (MODE != MODE_SCORE);
     constexpr int ACC = (GRAD ? D : 0) + CC;

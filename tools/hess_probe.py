@@ -54,3 +54,9 @@ for name, B in (("cfg2", 256), ("cfg2", 2048), ("headline", 2048), ("cfg3", 512)
     rel = lambda a: float(np.abs(a[:n64] - Ho).max() / np.abs(Ho).max())  # noqa: E731
     print(f"{name:<9} points={B:<5} S={w['S']:<5} C={w['C']}  analytic {t_an:8.1f} us (err {rel(H_an):.1e})   "
           f"gradient differences {t_fd:8.1f} us (err {rel(H_fd):.1e})", flush=True)
+    if (name, B) == ("cfg2", 256):  # the same launch with 16 supports: what is left is launch + the dual FK walks + hand-over
+        from diffco_amd import _ops
+        m16 = _ops.ScoreModel(w["desc"], *w["kspec"], w["sup"][:16].contiguous(), w["W"][:16].to(dev).contiguous(), device=dev)
+        t16, _ = timed(lambda: m16.score_hess_raw(q, up))
+        tg16, _ = timed(lambda: m16.score_grad_raw(q, up))
+        print(f"          the same with S = 16: analytic {t16:8.1f} us   one gradient launch {tg16:8.1f} us", flush=True)

@@ -5,7 +5,7 @@
 //   M   : MFMA only (4 independent accumulators per wave)
 //   V   : VALU only (v_fma_f32 or v_pk_fma_f32, 8 independent chains)
 //   M+V : the same number of each, interleaved in ONE wave's instruction stream (1 MFMA : R VALU)
-//   M|V : waves 0-3 of every 512-thread block MFMA only, waves 4-7 VALU only (each SIMD hosts one of each)
+//   M|V : half the waves of every SIMD MFMA only, the other half VALU only (roles by hardware SIMD id)
 // If the pipes overlap, M+V and M|V cost max(M, V); if they share one datapath they cost M + V.
 // Build: hipcc --offload-arch=gfx950 -O3 [-DBF16 [-DM32]] tools/mfma_coissue_ubench.hip -o tools/mfma_coissue_ubench
 //   default: v_mfma_f32_16x16x4_f32;  -DBF16: v_mfma_f32_16x16x32_bf16;  -DBF16 -DM32: v_mfma_f32_32x32x16_bf16
@@ -39,25 +39,54 @@ __global__ __launch_bounds__(512) void k(float* out, int iters, float seed) {
     const float av = seed * 1e-3f, bv = seed * 2e-3f;
     v8bf a8, b8;
     for (int e = 0; e < 8; ++e) { a8[e] = (__bf16)(seed * 0.01f * e); b8[e] = (__bf16)(seed * 0.02f * e); }
-    const int wave = threadIdx.x >> 8;  // M|V: a 512-thread block puts two waves on every SIMD, w and w + 4: one of each kind
-    const bool do_m = MODE == 0 || MODE == 2 || (MODE == 3 && (wave & 1) == 0);
-    const bool do_v = MODE == 1 || MODE == 2 || (MODE == 3 && (wave & 1) == 1);
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
+    // M|V: every SIMD hosts as many MFMA-only waves as VALU-only waves.  The role is decided ONCE, outside the loops (each
+    // loop body is fixed at compile time), from the SIMD the wave actually landed on (HW_ID bits 5:4) and its order of
+    // arrival there within the block - the hardware does not place wave w on SIMD w % 4.  (Round 2's version tested a
+    // run-time flag inside the loop and computed the wave index with the wrong shift: its M|V column is void.)
+    __shared__ int arrivals[4];
+    if (threadIdx.x < 4) arrivals[threadIdx.x] = 0;
+    __syncthreads();
+    int role = 0;
+    if (MODE == 3) {
+        const int simd = (__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4)) & 3;
+        int slot = 0;
+        if ((threadIdx.x & 63) == 0) slot = atomicAdd(&arrivals[simd], 1);
+        role = __builtin_amdgcn_readfirstlane(slot) & 1;
+    }
+    auto m_step = [&](int u) __attribute__((always_inline)) {
 #ifdef M32
-            if (do_m) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[u]) : "v"(a8), "v"(b8));
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[u]) : "v"(a8), "v"(b8));
 #elif defined(BF16)
-            if (do_m) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[u]) : "v"(a8), "v"(b8));
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[u]) : "v"(a8), "v"(b8));
 #else
-            if (do_m) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[u]) : "v"(av), "v"(bv));
+        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[u]) : "v"(av), "v"(bv));
 #endif
-            if (do_v) {
+    };
+    auto v_step = [&]() __attribute__((always_inline)) {
 #pragma unroll
-                for (int i = 0; i < R; ++i) {
-                    if (PK) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i % 8]) : "v"(m2), "v"(c2));
-                    else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i % 8]) : "v"(m), "v"(c));
-                }
+        for (int i = 0; i < R; ++i) {
+            if (PK) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i % 8]) : "v"(m2), "v"(c2));
+            else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i % 8]) : "v"(m), "v"(c));
+        }
+    };
+    const bool m_only = MODE == 0 || (MODE == 3 && role == 0);
+    const bool v_only = MODE == 1 || (MODE == 3 && role == 1);
+    if (m_only) {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) m_step(u);
+        }
+    } else if (v_only) {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v_step();
+        }
+    } else {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                m_step(u);
+                v_step();
             }
         }
     }
@@ -93,7 +122,8 @@ template <int PK, int R>
 void suite(int w) {
     const int iters = 4000;
     const float tm = run<0, PK, R>(w, iters), tv = run<1, PK, R>(w, iters), tb = run<2, PK, R>(w, iters), ts = run<3, PK, R>(w, iters);
-    // MODE 3 runs half the waves on each stream: its M and V parts are half of tm / tv each
+    // MODE 3 runs half the waves on each stream (one MFMA wave + one VALU wave per SIMD at 2 waves/SIMD): its M and V parts
+    // are half of tm / tv each
     printf("waves/SIMD=%d  %-13s x%-2d per MFMA:  M %.3f ms   V %.3f ms   M+V interleaved %.3f ms  (max %.3f, sum %.3f)   "
            "M|V by wave %.3f ms  (max %.3f, sum %.3f)\n",
            w, PK ? "v_pk_fma_f32" : "v_fma_f32", R, tm, tv, tb, tm > tv ? tm : tv, tm + tv, ts, (tm > tv ? tm : tv) / 2, (tm + tv) / 2);
