@@ -231,6 +231,14 @@ class ScoreLoop:
                 self.gather = "per-call"
             else:
                 self._capture()
+                # every rank takes the same form: one rank replaying graphs against peers issuing per-call gathers would
+                # still match collective for collective, but the timings would describe neither
+                if dist.is_available() and dist.is_initialized():
+                    ok = torch.tensor([1 if self.graph is not None else 0], device=dev, dtype=torch.int32)
+                    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                    if int(ok.item()) == 0 and self.graph is not None:
+                        print("bench: a peer could not capture the gather; per-call gather on every rank", file=sys.stderr)
+                        self.graph, self.gather = None, "per-call"
 
     def _launch(self, out):
         Ct, w = self.Ct, self.w

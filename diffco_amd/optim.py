@@ -289,9 +289,10 @@ class _ScipyTerms:
             _, S = model.score_hess_raw(q32)
             S = S.double().cpu()
         except _lib.DcxUnsupported:
-            # a transform whose frames do not fit the LDS as (value, tangent) pairs (of the reference's robots: the
-            # 23-joint iiwa7 + Allegro tree): central differences of the analytic fused gradient, all 2 * dof probes
-            # of every dense point in one launch (step: fp32 gradient noise ~1e-6 / step against step^2 truncation)
+            # a feature row too wide for the Hessian kernel's LDS in (value, tangent) pairs (none of the reference's robots
+            # since round 3: the 23-joint iiwa7 + Allegro tree pages its frames to global memory): central differences of
+            # the analytic fused gradient, all 2 * dof probes of every dense point in one launch (step: fp32 gradient
+            # noise ~1e-6 / step against step^2 truncation)
             eps = self.HESS_FD_STEP
             probes = pts[:, None, None, :] + eps * torch.stack([torch.eye(dof), -torch.eye(dof)]).to(pts.dtype)[None]
             _, gp = model.score_grad_raw(probes.reshape(-1, dof).to(device=model.dev, dtype=torch.float32).contiguous())

@@ -197,7 +197,10 @@ int dcx_score_jac(const dcx_model* m, const float* q, int64_t B, float* score, f
  * reference obtains by a double backward through dist_est for trust-constr's constraint Hessian (optim.py:380-391,
  * torch.autograd.functional.hessian).  upstream [B, C] dev or NULL (= all ones); grad [B, dof] dev or NULL receives
  * the gradient of the same function.  A configuration that sits exactly on a support (|x - s| = 0) takes no
- * contribution from that support for Polyharmonic kernels (the kernel is not twice differentiable there).    */
+ * contribution from that support for Polyharmonic kernels (the kernel is not twice differentiable there).
+ * Every transform kind is accepted (a tree whose frames do not fit the LDS as (value, tangent) pairs keeps them in
+ * stream-ordered global scratch); a batch of a few hundred points splits the supports across blocks like
+ * dcx_score_grad does.  DCX_ERR_UNSUPPORTED only if one feature row in duals exceeds a block's LDS.                */
 int dcx_score_hess(const dcx_model* m, const float* q, int64_t B, const float* upstream, float* grad, float* hess,
                    void* stream);
 
