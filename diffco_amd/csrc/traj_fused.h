@@ -131,6 +131,56 @@ __device__ __forceinline__ TrajLds traj_lds(float* smem, const A& b, int nw) {
 // [17] hinge excess, [96] flags of the iteration
 constexpr int kTrajLim = 32, kTrajFlags = 96;
 
+// The path terms of one lane's waypoint: length / max-move gradient with respect to its control points -> sGp, and the
+// wave's objective / max-move sums -> sR[0], sR[16].  They read the features in LDS only, so the persistent kernel runs
+// them BEFORE the sweep, on a wave whose latency the other waves' sweeps hide (round 3; after the fold they cost 5 k
+// exposed cycles per iteration: profiles/r03_traj_phase.txt).
+template <typename A>
+__device__ __forceinline__ void traj_path_terms(const A& b, const TrajLds& L, int lane) {
+    const int w = lane;
+    const int W = b.st.n_waypoints, pd = b.point_dim, n_points = b.n_points;
+    const bool live = w < W;
+    float obj = 0.f, mmv = 0.f;
+        const float ms = b.opt.max_speed;
+        const float w_diff = b.opt.w_diff, w_mm = b.opt.w_max_move;
+        const bool has_n = live && w + 1 < W, has_p = live && w >= 1;
+        const int wn = has_n ? w + 1 : w, wp = has_p ? w - 1 : w;  // a missing neighbour reads the lane's own point
+        auto one = [&](int kx, int ky, int kz, int npd) __attribute__((always_inline)) {
+            // npd coordinates of one control point at feature columns kx, ky, kz
+            const int kk[3] = {kx, ky, kz};
+            float dn[3] = {0.f, 0.f, 0.f}, dp[3] = {0.f, 0.f, 0.f};
+            float n2n = 0.f, n2p = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (c < npd) {
+                    const float xc = live ? L.sX[kk[c] * 64 + w] : 0.f;
+                    if (has_n) { dn[c] = L.sX[kk[c] * 64 + wn] - xc; n2n = fmaf(dn[c], dn[c], n2n); }
+                    if (has_p) { dp[c] = xc - L.sX[kk[c] * 64 + wp]; n2p = fmaf(dp[c], dp[c], n2p); }
+                }
+            }
+            const float mn = traj_excess(n2n, ms), mp = traj_excess(n2p, ms);
+            if (has_n) {   // each segment is counted once, by its left waypoint
+                obj += n2n;
+                if (mn > 0.f) mmv += mn;
+            }
+            const float cn = 2.f * (w_diff + (mn > 0.f ? w_mm : 0.f));
+            const float cp = 2.f * (w_diff + (mp > 0.f ? w_mm : 0.f));
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                if (c < npd) L.sGp[kk[c] * 64 + lane] = traj_path_grad(cp, dp[c], cn, dn[c]);
+        };
+        if (pd == 3 && !b.coord_major) {
+            for (int p = 0; p < n_points; ++p) one(3 * p, 3 * p + 1, 3 * p + 2, 3);
+        } else {
+            for (int p = 0; p < n_points; ++p) {
+                const int k0 = b.coord_major ? p : p * pd, st = b.coord_major ? n_points : 1;
+                one(k0, k0 + st, k0 + 2 * st, pd);
+            }
+        }
+        const float so = traj_wave_sum(obj), sm = traj_wave_sum(mmv);
+        if (lane == 0) { L.sR[0] = so; L.sR[16] = sm; }
+}
+
 template <int D, int KF, int MAXT, bool XF = false>
 __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_fused_kernel(const TrajFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -187,6 +237,12 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
             else if (wave == 0) fk_chain_sel(fw, dh, L.sQ + lane * dof, L.sX + lane, L.sF + lane);
             __syncthreads();
             DCX_TTS(2);
+            // What needs the features / frames but not the collision gradient goes in front of the sweep, where the other
+            // waves' sweeps hide its latency: the path terms on wave 1, phase R1 of J^T on waves 2 ..
+            if (b.sc.jt_waves && nw > 1) {
+                if (wave == 1) traj_path_terms(b, L, lane);
+                else if (wave >= 2) dh2_vjp_r1_sel(fw.dh, dh, L.sF + lane, L.sJ + lane, wave - 2, 15);
+            }
             if (d_fk == D) {
 #pragma unroll
                 for (int k = 0; k < D; ++k) x[k] = L.sX[k * 64 + lane];
@@ -229,49 +285,9 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
             fw.fk = (fk_cptr)(uintptr_t)(uint32_t)(uintptr_t)L.sFk;
             fw.dh = (dh_cptr)(uintptr_t)(uint32_t)(uintptr_t)L.sFk;
             const bool tree = fk_is_tree(fw);  // its reverse sweep keeps adjoint sums in the frames: one at a time
-            float obj = 0.f, mmv = 0.f, col = 0.f;
+            float col = 0.f;
             const int pwave = (nw > 1 && !tree) ? 1 : 0;
-            // the path terms of this lane's waypoint: length / max-move gradient with respect to its control points -> sGp
-            auto path_terms = [&]() __attribute__((always_inline)) {
-                const float ms = b.opt.max_speed;
-                const float w_diff = b.opt.w_diff, w_mm = b.opt.w_max_move;
-                const bool has_n = live && w + 1 < W, has_p = live && w >= 1;
-                const int wn = has_n ? w + 1 : w, wp = has_p ? w - 1 : w;  // a missing neighbour reads the lane's own point
-                auto one = [&](int kx, int ky, int kz, int npd) __attribute__((always_inline)) {
-                    // npd coordinates of one control point at feature columns kx, ky, kz
-                    const int kk[3] = {kx, ky, kz};
-                    float dn[3] = {0.f, 0.f, 0.f}, dp[3] = {0.f, 0.f, 0.f};
-                    float n2n = 0.f, n2p = 0.f;
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        if (c < npd) {
-                            const float xc = live ? L.sX[kk[c] * 64 + w] : 0.f;
-                            if (has_n) { dn[c] = L.sX[kk[c] * 64 + wn] - xc; n2n = fmaf(dn[c], dn[c], n2n); }
-                            if (has_p) { dp[c] = xc - L.sX[kk[c] * 64 + wp]; n2p = fmaf(dp[c], dp[c], n2p); }
-                        }
-                    }
-                    const float mn = traj_excess(n2n, ms), mp = traj_excess(n2p, ms);
-                    if (has_n) {   // each segment is counted once, by its left waypoint
-                        obj += n2n;
-                        if (mn > 0.f) mmv += mn;
-                    }
-                    const float cn = 2.f * (w_diff + (mn > 0.f ? w_mm : 0.f));
-                    const float cp = 2.f * (w_diff + (mp > 0.f ? w_mm : 0.f));
-#pragma unroll
-                    for (int c = 0; c < 3; ++c)
-                        if (c < npd) L.sGp[kk[c] * 64 + lane] = traj_path_grad(cp, dp[c], cn, dn[c]);
-                };
-                if (pd == 3 && !b.coord_major) {
-                    for (int p = 0; p < n_points; ++p) one(3 * p, 3 * p + 1, 3 * p + 2, 3);
-                } else {
-                    for (int p = 0; p < n_points; ++p) {
-                        const int k0 = b.coord_major ? p : p * pd, st = b.coord_major ? n_points : 1;
-                        one(k0, k0 + st, k0 + 2 * st, pd);
-                    }
-                }
-                const float so = traj_wave_sum(obj), sm = traj_wave_sum(mmv);
-                if (lane == 0) { L.sR[0] = so; L.sR[16] = sm; }
-            };
+            auto path_terms = [&]() __attribute__((always_inline)) { traj_path_terms(b, L, lane); };
             if (nw > 1) {
                 // the sweep's parallel cross-wave fold (score_kernel.h): row 0 first, then 1, 2, ...
                 float* mine = L.sRed + (size_t)wave * ACC * 64 + lane;
@@ -282,12 +298,7 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
                 DCX_TTS(4);
                 fold_partial_rows<ACC>(L.sRed, wave, lane, nw);
                 DCX_TTS(5);
-                if (jt) {
-                    // beside the fold: the path terms on wave 1, phase R1 of J^T (needs the frames only) on waves 2 ..
-                    if (wave == 1) path_terms();
-                    else dh2_vjp_r1_sel(fw.dh, dh, L.sF + lane, L.sJ + lane, wave - 2, 15);
-                }
-                DCX_TTS(6);
+                DCX_TTS(6);  // (the path terms and phase R1 of J^T ran in front of the sweep)
                 __syncthreads();
                 DCX_TTS(7);
             }

@@ -225,6 +225,40 @@ def test_expanded_form_around_the_near_threshold(ops, knob, D, C):
     assert relerr(_n(res[1][0]), _n(res[0][0])) < 6e-6 and relerr(_n(res[1][1]), _n(res[0][1])) < 6e-6
 
 
+@pytest.mark.parametrize("C,kspec", [(5, (0, 10.0, 2.0)), (8, (0, 10.0, 2.0)), (8, (1, 1.0, 1.0)), (1, (1, 1.0, 1.0))])
+@pytest.mark.parametrize("B", [200, 4096, 20000])
+def test_matrix_core_form_of_the_weight_contraction(ops, knob, C, kspec, B):
+    """K[B,S] . W[S,C] and the gradient fold on v_mfma_f32_16x16x4_f32 (knob mfma = 1; C = 1, 5 and 8 are instantiated)
+    against the VALU form of the same launch and against the float64 oracle, Baxter features, an explicit upstream and
+    the all-ones one, ragged batches, split and unsplit launches"""
+    from diffco_amd import model
+    from oracle import oracle
+    rob = model.BaxterLeftArmFK()
+    desc = rob.fk_desc()
+    g = torch.Generator().manual_seed(17 * C + B)
+    lo, hi = rob.limits[:, 0], rob.limits[:, 1]
+    S = 700
+    sq = torch.rand((S, 7), generator=g) * (hi - lo) + lo
+    q = (torch.rand((B, 7), generator=g) * (hi - lo) + lo).cuda()
+    W = torch.randn((S, C), generator=g)
+    sup = ops.fkine(desc, sq.cuda()).reshape(S, -1)
+    m = ops.ScoreModel(desc, *kspec, sup, W.cuda())
+    ups = [None] + ([torch.randn((B, C), generator=g).cuda()] if C > 1 else [])
+    n64 = min(B, 1024)
+    for up in ups:
+        so, go, _ = oracle.score_grad(desc, *kspec, _n(sup).astype(np.float64), W.numpy().astype(np.float64),
+                                      _n(q[:n64]).astype(np.float64), upstream=None if up is None else _n(up[:n64]).astype(np.float64),
+                                      dtype=np.float64)
+        knob("mfma", 0)
+        s0, g0 = m.score_grad_raw(q, up)
+        knob("mfma", 1)
+        s1, g1 = m.score_grad_raw(q, up)
+        assert relerr(_n(s1[:n64]), so) < TOL and relerr(_n(g1[:n64]), go) < TOL, (relerr(_n(s1[:n64]), so), relerr(_n(g1[:n64]), go))
+        assert relerr(_n(s1), _n(s0)) < 4e-6 and relerr(_n(g1), _n(g0)) < 4e-6
+        s1b, g1b = m.score_grad_raw(q, up)
+        assert torch.equal(s1, s1b) and torch.equal(g1, g1b)
+
+
 @pytest.mark.parametrize("name", ["cfg3_baxter_rq_c5", "cfg3_baxter_poly1_c5", "misc_baxterR_mq_c2"])
 @pytest.mark.parametrize("nw", [16, 4, 1])
 def test_one_sweep_jacobian_equals_one_sweep_per_class(ops, name, nw, knob):

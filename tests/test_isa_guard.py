@@ -116,3 +116,19 @@ def test_handover_publishes_write_through_and_drains_before_the_counter(isa):
         assert not any(l.startswith(("buffer_wbl2", "buffer_inv")) for l in body)
         seen += 1
     assert seen == 4
+
+
+@pytest.mark.parametrize("src,flags", [("tools/contraction_ubench.hip", []), ("tools/mfma_coissue_ubench.hip", []),
+                                       ("tools/mfma_coissue_ubench.hip", ["-DBF16"]), ("tools/lone_wave_ubench.hip", [])])
+def test_measurement_tools_still_compile_for_gfx950(tmp_path, src, flags):
+    """the micro-benchmarks the profiles cite are part of the evidence: they must keep building (device code only, no GPU)"""
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    out = tmp_path / "t.s"
+    subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-S", "--cuda-device-only"] + flags + [os.path.join(ROOT, src), "-o", str(out)],
+                   check=True, stderr=subprocess.DEVNULL)
+    text = out.read_text()
+    if "contraction" in src:   # the three matrix-core variants really issue matrix instructions
+        assert text.count("v_mfma_f32_16x16x4_f32") >= 8 and "v_mfma_f32_16x16x32_bf16" in text
+    elif "mfma_coissue" in src:
+        assert ("v_mfma_f32_16x16x32_bf16" if flags else "v_mfma_f32_16x16x4_f32") in text and "s_getreg_b32" in text
