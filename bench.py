@@ -58,7 +58,8 @@ WORKLOADS = {
 }
 TRAJ_W = 50
 GATHER_EVERY = 4  # --gather bucketed: calls per all-gather
-SETTLE_STEPS = 24  # untimed launches before the W warm-up steps (see measure())
+SETTLE_STEPS = 24  # first untimed launches before the W warm-up steps: one-off costs, and the estimate for the settle phase
+SETTLE_MS = 100.0  # untimed launches keep the GPU busy this long before the warm-up (clock ramp, see measure())
 
 
 SAME_GPU = os.environ.get("DCX_BENCH_SAME_GPU", "") not in ("", "0")
@@ -382,10 +383,29 @@ class TrajLoop:
 def measure(loop, steps, warmup, dev, multi):
     """W untimed warm-up steps, then exactly `steps` steps bracketed by barrier + synchronize; max over ranks.
     Returns (wall seconds, average launch-to-launch kernel milliseconds from HIP events on the launch stream)"""
-    # Settle first: a freshly built model / process group pays one-off costs in its first launches (clock ramp after the
-    # host-side setup, lazy RCCL buffers for a new message size) that a short warm-up does not always cover — seen as a
-    # 50 ms hiccup inside 50-step variant runs.  These launches are untimed and in addition to the W warm-up steps.
+    # Settle first.  (1) A freshly built model / process group pays one-off costs in its first launches (lazy RCCL buffers
+    # for a new message size ...).  (2) The GPU's clocks ramp for ~50 ms of sustained load after an idle period: the headline
+    # launch takes 102 us in its first 100 launches, 93, 88, 86 in the next hundreds and 85.1-85.3 us from 45 ms on
+    # (tools/clock_ramp.py, profiles/r03_clock_ramp.txt); a 20-step run behind 5 warm-up steps measures the ramp, not the
+    # kernel.  So the loop first keeps the GPU busy for SETTLE_MS with untimed launches - the state a planner's loop is
+    # in - and only then runs the W warm-up steps and the K timed ones.  The count is agreed across ranks (they issue
+    # the same collectives).
     loop.run(SETTLE_STEPS)
+    loop.drain()
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    loop.run(SETTLE_STEPS)
+    loop.drain()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    est_ms = max(e0.elapsed_time(e1) / SETTLE_STEPS, 1e-3)
+    n_settle = int(min(max(SETTLE_MS / est_ms, 0), 20000))
+    if multi:
+        t = torch.tensor([n_settle], device="cpu" if SAME_GPU else dev, dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        n_settle = int(t.item())
+    loop.run(n_settle)
     loop.drain()
     torch.cuda.synchronize(dev)
     loop.run(warmup)
@@ -569,6 +589,8 @@ def main():
             "value": round(value, 3), "unit": "M evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(wall / args.steps * 1e3, 5), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            # untimed launches that keep the GPU busy before the W warm-up steps (clock ramp: tools/clock_ramp.py)
+            "settle_ms": SETTLE_MS,
             "config": {"workload": f"{w['name']}: {w['text']}", "batch_per_gpu": B, "global_batch": ge,
                        "supports": w["S"], "features": w["D"], "classes": C,
                        "parallelism": f"batch-sharded x{world}, model replicated" + ("" if not multi else ", " + gather_txt),

@@ -143,18 +143,24 @@ def test_hessian_empty_batch(ops):
     assert H.shape == (0, 2, 2) and g.shape == (0, 2)
 
 
+@pytest.mark.parametrize("name", ["cfg2_baxter_poly1", "cfg3_baxter_rq_c5", "misc_dualpanda_rq", "misc_planar3_poly2"])
 @pytest.mark.parametrize("B", [1, 40, 256, 700])
-def test_hessian_split_across_blocks_equals_the_unsplit_launch(ops, knob, B):
+def test_hessian_split_across_blocks_equals_the_unsplit_launch(ops, knob, name, B):
     """small batches split the supports across blocks (the last block to arrive folds the partial rows in a fixed
-    order): same Hessian as the one-block-per-tile launch up to the order of the fp32 sums, every batch size, and
-    identical from call to call"""
-    d = load("cfg2_baxter_poly1")
-    m, desc, kspec = _model(ops, "cfg2_baxter_poly1", d)
+    order): same Hessian as the one-block-per-tile launch up to the order of the fp32 sums - every batch size, one and
+    several classes with an explicit upstream, narrow and wide feature rows, forced block counts - and identical from
+    call to call"""
+    d = load(name)
+    m, desc, kspec = _model(ops, name, d)
     rng = np.random.default_rng(5)
     q = _t(np.repeat(d["q"], -(-B // len(d["q"])), axis=0)[:B] + 0.05 * rng.standard_normal((B, d["q"].shape[1])).astype(np.float32))
-    g1, H1 = m.score_hess_raw(q)
-    g1b, H1b = m.score_hess_raw(q)
-    assert torch.equal(H1, H1b) and torch.equal(g1, g1b)
+    up = _t(rng.standard_normal((B, m.C)).astype(np.float32)) if m.C > 1 else None
     knob("hess_ys", 1)
-    g0, H0 = m.score_hess_raw(q)
-    assert relerr(_n(H1), _n(H0)) < 2e-6 and relerr(_n(g1), _n(g0)) < 2e-6
+    g0, H0 = m.score_hess_raw(q, up)
+    for ys in (-1, 2, 5, 12):
+        knob("hess_ys", ys)
+        g1, H1 = m.score_hess_raw(q, up)
+        g1b, H1b = m.score_hess_raw(q, up)
+        assert torch.equal(H1, H1b) and torch.equal(g1, g1b), ys
+        scale = max(float(H0.abs().max()), 1e-30)
+        assert float((H1 - H0).abs().max()) / scale < 3e-6 and relerr(_n(g1), _n(g0)) < 3e-6, ys
