@@ -542,6 +542,62 @@ def test_dh_fk_walks_agree_bitwise(ops, knob, name, B):
             assert np.isfinite(a).all() and np.array_equal(a, b)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["long14", "long16_pts", "two_chains_12_5", "short3"])
+@pytest.mark.parametrize("B", [3, 300, 5000])
+def test_dh_step_table_beyond_the_unrolled_walks(ops, knob, shape, B):
+    """synthetic DH arms outside the shapes the unrolled multi-wave walks cover (fk_device.h kDhUnroll = 10 steps per chain):
+    14 and 16 joints in one chain, up to three control points on a frame (identity steps), a 12 + 5 pair of chains sharing
+    no joint, and a 3-joint arm - the step table's single-wave walks take over; all three FK walks must still agree bit for
+    bit, and match the float64 oracle"""
+    from diffco_amd import _fkdesc
+    from oracle import oracle
+    rng = np.random.default_rng({"long14": 1, "long16_pts": 2, "two_chains_12_5": 3, "short3": 4}[shape])
+
+    def chain(n, q0, base=None):
+        c = dict(a=rng.uniform(-0.3, 0.3, n), d=rng.uniform(-0.3, 0.3, n), alpha=rng.choice([0.0, np.pi / 2, -np.pi / 2, 0.3], n),
+                 theta0=rng.uniform(-0.5, 0.5, n), joint_q=list(range(q0, q0 + n)))
+        if base is not None:
+            c["base"] = base
+        return c
+    if shape == "long14":
+        dof, chains = 14, [chain(14, 0)]
+        pts = [(0, f, (0, 0, 0)) for f in (1, 3, 5, 8, 11, 13)]
+    elif shape == "long16_pts":
+        dof, chains = 16, [chain(16, 0)]
+        pts = [(0, 2, (0, 0, 0)), (0, 2, (0.1, 0, 0.05)), (0, 2, (0, -0.1, 0)), (0, 9, (0, 0, 0)), (0, 15, (0.05, 0.05, 0)), (0, 15, (0, 0, 0))]
+    elif shape == "two_chains_12_5":
+        dof, chains = 17, [chain(12, 0), chain(5, 12, _fkdesc.rotz_base(0.7, (0.2, -0.4, 0.1)))]
+        pts = [(0, f, (0, 0, 0)) for f in (2, 6, 11)] + [(1, f, (0, 0, 0)) for f in (1, 4)]
+    else:
+        dof, chains = 3, [chain(3, 0)]
+        pts = [(0, 0, (0, 0, 0)), (0, 2, (0, 0, 0))]
+    desc = _fkdesc.dh_desc(dof, chains, pts)
+    S, C = 200, 2
+    sq = rng.uniform(-2.0, 2.0, (S, dof)).astype(np.float32)
+    q = _t(rng.uniform(-2.0, 2.0, (B, dof)).astype(np.float32))
+    sup = ops.fkine(desc, _t(sq)).reshape(S, -1)
+    W1 = rng.standard_normal((S, 1)).astype(np.float32)
+    WC = rng.standard_normal((S, C)).astype(np.float32)
+    up = _t(rng.standard_normal((B, C)).astype(np.float32))
+    out = {}
+    for fkk in (2, 1, 0):
+        knob("fkk", fkk)
+        m1 = ops.ScoreModel(desc, 1, 1.0, 1.0, sup, _t(W1))
+        mc = ops.ScoreModel(desc, 0, 10.0, 2.0, sup, _t(WC))
+        s1, g1 = m1.score_grad_raw(q)
+        sc, gc = mc.score_grad_raw(q, up)
+        out[fkk] = [_n(t).copy() for t in (s1, g1, sc, gc)]
+    knob("fkk", -1)
+    for other in (2, 1):
+        for a, b in zip(out[other], out[0]):
+            assert np.isfinite(a).all() and np.array_equal(a, b), (shape, other)
+    n64 = min(B, 256)
+    so, go, _ = oracle.score_grad(desc, 1, 1.0, 1.0, _n(sup).astype(np.float64), W1.astype(np.float64), _n(q[:n64]).astype(np.float64),
+                                  dtype=np.float64)
+    assert relerr(out[2][0][:n64], so) < TOL and relerr(out[2][1][:n64], go) < TOL
+
+
 def _baxter_at(base_xyz):
     """the Baxter arm's description with its base translated (the reference's DualArm bases do the same, model.py:312-363)"""
     from diffco_amd import _fkdesc, model
