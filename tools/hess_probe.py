@@ -20,10 +20,14 @@ for name, B in (("cfg2", 256), ("cfg2", 2048), ("headline", 2048), ("cfg3", 512)
     dof = q.shape[1]
     up = torch.randn((B, w["C"]), device=dev) if w["C"] > 1 else None
 
-    def timed(fn, n=20):
-        for _ in range(3):
-            fn()
-        torch.cuda.synchronize()
+    def timed(fn, n=50):
+        # keep the GPU busy for ~100 ms first: its clocks ramp for ~50 ms after idling (tools/clock_ramp.py)
+        import time
+        t_end = time.perf_counter() + 0.1
+        while time.perf_counter() < t_end:
+            for _ in range(20):
+                fn()
+            torch.cuda.synchronize()
         t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0.record()
         for _ in range(n):
