@@ -601,7 +601,11 @@ def main():
                          "traffic_source": None if pmc is None else f"profiles/pmc_{name}.json (rocprofv3 --pmc passes of an earlier run of "
                                                                      "this command, calibrated; a constant, not an observation of this run)",
                          "kernel": "dcx::traj_fused_kernel<D,KF,MAXT,XF>" if is_traj else "dcx::score_kernel<D,KF,C,MODE,MAXT,MF,XF>",
-                         "sweep_form": ("expanded (XF: d2 = |x|^2+|s|^2-2x.s, gX = x*sum(c)-sum(c s); 20 VALU/pair at D=12)"
+                         "sweep_form": ("expanded with x.s^T on the matrix cores (XM: bf16x3 split operands on v_mfma_f32_16x16x32_bf16; DCX_XM=1)"
+                                        if (os.environ.get("DCX_XM", "") not in ("", "0", "-1") and w["kspec"][0] == 1 and w["kspec"][1] == 1.0
+                                            and C == 1 and w["D"] <= 16 and w["D"] % 2 == 0 and not is_traj and not mfma_on
+                                            and os.environ.get("DCX_XF", "") != "0") else
+                                        "expanded (XF: d2 = |x|^2+|s|^2-2x.s, gX = x*sum(c)-sum(c s); 20 VALU/pair at D=12)"
                                         if (w["kspec"][0] == 1 and w["kspec"][1] == 1.0 and w["D"] + C + (C > 1) + 1 <= 38
                                             and os.environ.get("DCX_XF", "") != "0" and not mfma_on)
                                         else "direct (differences; 24 VALU/pair at D=12)"),

@@ -25,6 +25,7 @@ struct dcx_model {
     float* rows_dev = nullptr;     // [S_active][RS]
     float* rows_xf_dev = nullptr;  // what the expanded-form sweeps read (score_kernel.h): the rows shifted by `centre`,
                                    // |s - c|^2 in their last column
+    unsigned short* aplanes_dev = nullptr;  // XM sweep (score_kernel.h): the centred supports as bf16 planes, MFMA A-operand layout
     float* centre_dev = nullptr;   // [Dt]: the support centroid for features an FK transform produced, zero for raw inputs
     int64_t S_in = 0;
     int32_t S_active = 0;
@@ -239,7 +240,7 @@ int fk_device_copy(int device, const dcx_fk_desc& fk, FkProg** out) {
 // path calls getenv.  -1 = "use the rule".
 struct Knobs {
     std::atomic<int64_t> ys{-1}, nw{-1}, min_rows{-1}, split_finish_kernel{-1}, inlaunch_tiles{-1}, jac_per_class{-1},
-        mfma{-1}, traj_fused{-1}, xf{-1}, jac_one_sweep{-1}, train_grid{-1}, fkk{-1}, jt_waves{-1}, hess_ys{-1};
+        mfma{-1}, traj_fused{-1}, xf{-1}, jac_one_sweep{-1}, train_grid{-1}, fkk{-1}, jt_waves{-1}, hess_ys{-1}, xm{-1};
     Knobs() {
         auto rd = [](const char* name, std::atomic<int64_t>& dst, bool flag) {
             if (const char* e = std::getenv(name)) dst = flag ? 1 : std::atoll(e);
@@ -258,6 +259,7 @@ struct Knobs {
         rd("DCX_FKK", fkk, false);
         rd("DCX_JT_WAVES", jt_waves, false);
         rd("DCX_HESS_YS", hess_ys, false);
+        rd("DCX_XM", xm, false);
     }
 };
 Knobs& knobs() {
@@ -464,6 +466,14 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
         a.rows = m->rows_xf_dev;
         a.centre = m->centre_dev;
     }
+    // XM: the expanded form's distance on the matrix cores (score_kernel.h sweep_rows, XM).  Slices then start on the
+    // 16-row blocks of the A planes.
+    a.xm = (a.xf && mode == MODE_GRAD_ROW && m->aplanes_dev != nullptr && xm_applies(m->Dt, m->C, m->kf) && knobs().xm > 0) ? 1 : 0;
+    if (a.xm) {
+        a.aplanes = m->aplanes_dev;
+        a.s_super = (a.s_super + 15) / 16 * 16;
+        a.s_chunk = ((a.s_super + g.nw - 1) / g.nw + 15) / 16 * 16;
+    }
     // J^T on several waves (fk_device.h dh2_vjp_waves): the step table, a parallel fold (its scratch rows 1 .. nw-1 hold 12
     // columns per point step), and not the finish-kernel mode.  Knob jt_waves = 0: wave 0 alone (tests: identical bits).
     a.jt_rows = (a.fkk == 2 && g.nw >= 2 * m->dh.n_chains && m->dh.n_chains <= 2 && m->dh.end0 <= kDhUnroll &&
@@ -534,7 +544,7 @@ int dcx_debug_set(const char* name, int64_t value) {
     const std::string n(name);
     std::atomic<int64_t>* dst = n == "ys" ? &k.ys : n == "nw" ? &k.nw : n == "min_rows" ? &k.min_rows
         : n == "split_finish_kernel" ? &k.split_finish_kernel : n == "inlaunch_tiles" ? &k.inlaunch_tiles
-        : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : n == "traj_fused" ? &k.traj_fused : n == "xf" ? &k.xf : n == "jac_one_sweep" ? &k.jac_one_sweep : n == "train_grid" ? &k.train_grid : n == "fkk" ? &k.fkk : n == "jt_waves" ? &k.jt_waves : n == "hess_ys" ? &k.hess_ys : nullptr;
+        : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : n == "traj_fused" ? &k.traj_fused : n == "xf" ? &k.xf : n == "jac_one_sweep" ? &k.jac_one_sweep : n == "train_grid" ? &k.train_grid : n == "fkk" ? &k.fkk : n == "jt_waves" ? &k.jt_waves : n == "hess_ys" ? &k.hess_ys : n == "xm" ? &k.xm : nullptr;
     if (!dst) return fail(DCX_ERR_INVALID, "unknown knob: " + n);
     *dst = value;
     return DCX_OK;
@@ -676,11 +686,42 @@ int dcx_model_create(dcx_model** out, int device, const dcx_fk_desc* fk, int ker
             }
             cen[ss_off] = (float)ss;
         }
+        // XM sweep: the centred coordinates split into three bf16 planes by truncation and laid out as the A operands of
+        // v_mfma_f32_16x16x32_bf16: [16-row block][chunk c][support m][k'][8], K slot 8 k' + e of chunk c = term 2c + slot / 16,
+        // feature slot % 16; terms hi.hi hi.mid mid.hi hi.lo lo.hi mid.mid take the s planes hi mid hi lo hi mid
+        std::vector<unsigned short> aplanes;
+        if (xm_applies(m->Dt, C, m->kf)) {
+            const int splane_of_term[6] = {0, 1, 0, 2, 0, 1};
+            aplanes.assign(((size_t)(kept + 15) / 16 + 2) * 3 * 16 * 4 * 8, 0);
+            for (int32_t j = 0; j < kept; ++j) {
+                unsigned short pl[3][16] = {};
+                for (int k = 0; k < D; ++k) {
+                    float r = rows_xf[(size_t)j * m->RS + k];
+                    for (int p = 0; p < 3; ++p) {
+                        uint32_t u;
+                        std::memcpy(&u, &r, 4);
+                        u &= 0xFFFF0000u;
+                        float h;
+                        std::memcpy(&h, &u, 4);
+                        pl[p][k] = (unsigned short)(u >> 16);
+                        r -= h;
+                    }
+                }
+                for (int c = 0; c < 3; ++c)
+                    for (int kq = 0; kq < 4; ++kq)
+                        for (int e2 = 0; e2 < 8; ++e2) {
+                            const int slot = 8 * kq + e2, term = 2 * c + slot / 16, kk = slot % 16;
+                            aplanes[((((size_t)(j / 16) * 3 + c) * 16 + (j % 16)) * 4 + kq) * 8 + e2] = pl[splane_of_term[term]][kk];
+                        }
+            }
+        }
         rows.resize(rows.size() + 8 * (size_t)m->RS + 16, 0.0f);  // the MFMA B-operand loads run up to 7 rows + 15 floats ahead
         e = hipMalloc((void**)&m->rows_dev, rows.size() * sizeof(float));
         if (e == hipSuccess) e = hipMemcpy(m->rows_dev, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMalloc((void**)&m->rows_xf_dev, rows_xf.size() * sizeof(float));
         if (e == hipSuccess) e = hipMemcpy(m->rows_xf_dev, rows_xf.data(), rows_xf.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess && !aplanes.empty()) e = hipMalloc((void**)&m->aplanes_dev, aplanes.size() * sizeof(unsigned short));
+        if (e == hipSuccess && !aplanes.empty()) e = hipMemcpy(m->aplanes_dev, aplanes.data(), aplanes.size() * sizeof(unsigned short), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMalloc((void**)&m->centre_dev, centre.size() * sizeof(float));
         if (e == hipSuccess) e = hipMemcpy(m->centre_dev, centre.data(), centre.size() * sizeof(float), hipMemcpyHostToDevice);
     }
@@ -700,6 +741,7 @@ void dcx_model_destroy(dcx_model* m) {
     if (m->rows_dev) (void)hipFree(m->rows_dev);
     if (m->rows_xf_dev) (void)hipFree(m->rows_xf_dev);
     if (m->centre_dev) (void)hipFree(m->centre_dev);
+    if (m->aplanes_dev) (void)hipFree(m->aplanes_dev);
     for (auto& sc : m->scratch)
         if (sc.ptr) (void)hipFree(sc.ptr);
     delete m;

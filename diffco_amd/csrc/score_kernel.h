@@ -63,6 +63,8 @@ struct ScoreArgs {
                               // grad + z * dof (all Jacobian rows at once: the per-class sweeps of a small batch run side by side)
     int64_t grad_stride;      // floats between consecutive configurations' gradient rows (dof, or C*dof for jac)
     float* partial;           // split launch: per (tile, y) partial sums [(tile*ys + y)][ACC][64]; null = finish in-kernel
+    const unsigned short* aplanes;  // XM sweep: the centred supports as bf16 planes laid out as MFMA A operands (xm_applies)
+    int32_t xm;               // 1: the launch takes the distance of the expanded form from the matrix cores (score_kernel<..., XM>)
     unsigned int* tile_done;  // split launch: per-tile arrival counters (zero between launches).  Non-null: the LAST of a
                               // tile's ys blocks to arrive adds the partial rows and finishes in this launch; null: a
                               // second launch (score_finish_kernel) does
@@ -235,7 +237,11 @@ __host__ __device__ inline LdsPlan lds_plan(int dof, int d_fk, int frame_floats,
 #ifndef DCX_MINW_SLACK
 #define DCX_MINW_SLACK 0
 #endif
-constexpr int sweep_min_waves(int D, int CC, int KF, bool MF = false) {
+// The XM sweep (round 3): the expanded form with its distance GEMM x . s^T on v_mfma_f32_16x16x32_bf16 in split operands
+// (sweep_rows, XM).  One class, Polyharmonic(1), even D <= 16 (a term's 16 K slots hold the features).
+constexpr bool xm_applies(int D, int CC, int KF) { return KF == 1 /* KF_POLY1 */ && CC == 1 && D <= 16 && (D % 2) == 0 && D >= 4; }
+constexpr int sweep_min_waves(int D, int CC, int KF, bool MF = false, bool XM = false) {
+    if (XM) return 4;  // 48 VGPRs of loop-invariant B fragments + 16 distances in flight: 128 VGPRs
     // KF_GEN calls powf/logf; the MFMA form adds 16 accumulator registers per contraction + the operand fragments
     const int need = 3 * D + 2 * CC + 16 + DCX_MINW_SLACK + (KF == 2 ? 40 : 0) + (MF ? (CC > 1 ? 48 : 24) : 0);
     return need <= 64 ? 8 : need <= 72 ? 7 : need <= 80 ? 6 : need <= 96 ? 5 : need <= 128 ? 4 : need <= 168 ? 3 : need <= 256 ? 2 : 1;
@@ -328,7 +334,7 @@ constexpr bool xf_applies(int D, int CC, int KF) {
 
 // NACC > 0 overrides the number of independent squared-distance accumulator pairs of the expanded form (callers that run
 // at few waves per SIMD trade one packed add per row for a shorter dependent chain)
-template <int D, int KF, int CC, int MODE, bool XF = false, int NACC = 0>
+template <int D, int KF, int CC, int MODE, bool XF = false, int NACC = 0, bool XM = false>
 __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[D], const float (&up)[CC], int j0, int j1,
                                            float (&sc)[CC], float (&gx)[D]) {
     using L = RowLayout<D, CC>;
@@ -538,7 +544,142 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
     // (v_writelane / v_readlane) inside the sweep.
     constexpr int PARTS = (4 * USED <= (CC > 1 ? DCX_P0_MAX_MULTI : DCX_P0_MAX_SINGLE)) ? 0 : (USED + 37) / 38;  // parts of <= 38 floats
     static_assert(!XFA || PARTS <= 1, "expanded form: whole rows only");
-    if constexpr (PARTS == 0) {
+    if constexpr (XM) {
+    // ---- XM: the expanded form with x . s^T on the matrix cores (round 3) ---------------------------------------------------
+    // d2 = (|x|^2 + |s_j|^2) + sum_k (-2 x_k) s_jk: the one contraction of the sweep whose per-lane operand is loop
+    // invariant.  -2x is split ONCE per lane into three bf16 planes (hi, mid, lo by truncation: 24 bits) and turned into
+    // the B fragments of the four 16-configuration tiles with the 4 x 4 lane transpose; the supports were split on the
+    // host and laid out as A operands (dcx_model_create, `aplanes`).  The six plane products that matter (hi.hi, hi.mid,
+    // mid.hi, hi.lo, lo.hi, mid.mid) sit side by side along K (6 terms x 16 slots = three v_mfma_f32_16x16x32_bf16 per
+    // tile), accumulated in fp32 inside the instruction: the sum carries the 2^-24 (|x| |s|) error of the fp32 expanded
+    // form.  Per 16 supports and wave: 12 MFMAs + 16 lane swaps give every lane its 16 dot products; the rest of the
+    // pair body (clamp, 1 / r, score, fold, near pairs) is the XF one, two rows per scalar-load stage.  Measured in
+    // isolation (tools/contraction_ubench.hip, "pair body"): 82-86 cycles per wave-row against 96-98.
+    static_assert(XFA && CC == 1 && D <= 16 && (D % 2) == 0, "XM: one class, even D <= 16, expanded form");
+    if (j0 < j1) {
+        typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+        typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+        typedef float v4f_ __attribute__((ext_vector_type(4)));
+        const int lane_ = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        auto frags = [&](unsigned int c0, unsigned int c1, unsigned int c2, unsigned int c3, unsigned int (&f)[4]) __attribute__((always_inline)) {
+            auto s02 = __builtin_amdgcn_permlane32_swap(c0, c2, false, false);
+            auto s13 = __builtin_amdgcn_permlane32_swap(c1, c3, false, false);
+            auto t01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
+            auto t23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
+            f[0] = t01[0]; f[1] = t01[1]; f[2] = t23[0]; f[3] = t23[1];
+        };
+        v4u bfrag[4][3];
+        {
+            unsigned int pk[3][8];  // [plane][feature pair], features past D are zero
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                float r0 = (2 * p < D) ? -2.0f * x[2 * p < D ? 2 * p : 0] : 0.0f;
+                float r1 = (2 * p + 1 < D) ? -2.0f * x[2 * p + 1 < D ? 2 * p + 1 : 0] : 0.0f;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    const unsigned int u0 = __float_as_uint(r0) & 0xFFFF0000u, u1 = __float_as_uint(r1) & 0xFFFF0000u;
+                    pk[pl][p] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+                    r0 -= __uint_as_float(u0);
+                    r1 -= __uint_as_float(u1);
+                }
+            }
+            constexpr int xplane_of_term[6] = {0, 0, 1, 0, 2, 1};  // terms: hi.hi hi.mid mid.hi hi.lo lo.hi mid.mid (x plane)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // lane (n, k'): k' = 0, 1 -> term 2c, features 8 k' + 2e, + 1;  k' = 2, 3 -> term 2c + 1
+                    unsigned int f[4];
+                    frags(pk[xplane_of_term[2 * c]][e], pk[xplane_of_term[2 * c]][4 + e], pk[xplane_of_term[2 * c + 1]][e],
+                          pk[xplane_of_term[2 * c + 1]][4 + e], f);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) bfrag[t][c][e] = f[t];
+                }
+        }
+        // one row with its distance term from the matrix cores; returns the clamped distance
+        auto pair_m = [&](const auto& r, float dot) __attribute__((always_inline)) -> float {
+            const float d2 = fmaxf((xx + r[L::SS_OFF]) + dot, thr);
+            apply_x(r, d2, std::integral_constant<int, 1>{}, true);
+            return d2;
+        };
+        auto stage_m = [&](const auto& r0, const auto& r1, float dt0, float dt1) __attribute__((always_inline)) {
+            const float d0 = pair_m(r0, dt0), d1 = pair_m(r1, dt1);
+            const auto m0 = __builtin_amdgcn_ballot_w64(d0 <= thr);
+            const auto m1 = __builtin_amdgcn_ballot_w64(d1 <= thr);
+            if (__builtin_expect((m0 | m1) != 0, 0)) {
+                fix_near(r0, d0);
+                fix_near(r1, d1);
+            }
+        };
+        float rowA[L::RS], rowB[L::RS], rowC[L::RS], rowD[L::RS];
+        const int jl = j1 - 1;
+        int j = j0;
+        // rows in front of the first 16-row block of the A planes (slices start on a block boundary except where a caller's
+        // slicing does not: then at most 15 rows): the XF body
+        for (; j < j1 && (j & 15) != 0; ++j) {
+            load_row(rowA, j);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            single_x(rowA);
+        }
+        if (j + 16 <= j1) {
+            // A operand of a 16-row block: lane (m, k') reads 16 bytes of [block][chunk][support m][k']
+            const v4u* ap = reinterpret_cast<const v4u*>(a.aplanes) + (lane_ & 15) * 4 + (lane_ >> 4);
+            v4u a0 = ap[(size_t)(j >> 4) * 192], a1 = ap[(size_t)(j >> 4) * 192 + 64], a2 = ap[(size_t)(j >> 4) * 192 + 128];
+            load_row(rowA, j);
+            load_row(rowB, j + 1);
+            for (; j + 16 <= j1; j += 16) {
+                const size_t nb = (size_t)((j >> 4) + 1) * 192;   // (the planes are padded by two blocks)
+                const v4u n0 = ap[nb], n1 = ap[nb + 64], n2 = ap[nb + 128];
+                float dot[16];
+                {
+                    v4f_ d[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        v4f_ c = {0.f, 0.f, 0.f, 0.f};  // small terms first
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a2), __builtin_bit_cast(v8bf, bfrag[t][2]), c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a1), __builtin_bit_cast(v8bf, bfrag[t][1]), c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a0), __builtin_bit_cast(v8bf, bfrag[t][0]), c, 0, 0, 0);
+                        d[t] = c;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        unsigned int f[4];
+                        frags(__float_as_uint(d[0][i]), __float_as_uint(d[1][i]), __float_as_uint(d[2][i]), __float_as_uint(d[3][i]), f);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) dot[4 * g + i] = __uint_as_float(f[g]);
+                    }
+                }
+                a0 = n0; a1 = n1; a2 = n2;
+#pragma unroll
+                for (int q = 0; q < 16; q += 4) {
+                    __builtin_amdgcn_s_waitcnt(0xC07F);
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_row(rowC, j + q + 2);
+                    load_row(rowD, j + q + 3);
+                    __builtin_amdgcn_sched_barrier(0);
+                    stage_m(rowA, rowB, dot[q], dot[q + 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_waitcnt(0xC07F);
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_row(rowA, (j + q + 4 < j1) ? j + q + 4 : jl);
+                    load_row(rowB, (j + q + 5 < j1) ? j + q + 5 : jl);
+                    __builtin_amdgcn_sched_barrier(0);
+                    stage_m(rowC, rowD, dot[q + 2], dot[q + 3]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (GRAD) {
+                    if ((j & 48) == 0) flush_x();  // once per 64 rows
+                }
+            }
+        }
+        // what is left of the slice (< 16 rows): the XF body
+        for (; j < j1; ++j) {
+            load_row(rowA, j);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            single_x(rowA);
+        }
+    }
+    } else if constexpr (PARTS == 0) {
     // Explicit software pipeline, two rows per stage (4 row buffers): the wait before a stage covers loads
     // issued TWO row bodies earlier, which is what hides an L2-latency scalar miss when only a few waves
     // share a SIMD (small batches).  wait -> issue {C,D} -> body(A), body(B) -> wait -> issue {A,B} -> body(C), body(D)
@@ -1009,8 +1150,8 @@ __device__ __forceinline__ void fold_partial_rows(float* sRed, int wave, int lan
 }
 
 
-template <int D, int KF, int CC, int MODE, int MAXT, bool MF = false, bool XF = false>
-__global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF, MF)) void score_kernel(const ScoreArgs a) {
+template <int D, int KF, int CC, int MODE, int MAXT, bool MF = false, bool XF = false, bool XM = false>
+__global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF, MF, XM)) void score_kernel(const ScoreArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr bool GRAD = (MODE != MODE_SCORE);
     constexpr int ACC = (GRAD ? D : 0) + CC;
@@ -1107,7 +1248,7 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF, MF)) void score_ke
         // this wave's slice of the reduction scratch doubles as its transpose buffer (X is dead, the fold comes later)
         sweep_rows_mfma<D, KF, CC, MODE>(a, x, up, j0, j1, sc, gx, sRed + (size_t)wave * ACC * 64, lane);
     } else {
-        sweep_rows<D, KF, CC, MODE, XF>(a, x, up, j0, j1, sc, gx);
+        sweep_rows<D, KF, CC, MODE, XF, 0, XM>(a, x, up, j0, j1, sc, gx);
     }
     DCX_TS(3);
     {   // ---- epilogue: everything below reads the kernel arguments afresh (reload_args) and re-derives what it needs ----

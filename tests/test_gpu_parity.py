@@ -225,6 +225,73 @@ def test_expanded_form_around_the_near_threshold(ops, knob, D, C):
     assert relerr(_n(res[1][0]), _n(res[0][0])) < 6e-6 and relerr(_n(res[1][1]), _n(res[0][1])) < 6e-6
 
 
+@pytest.mark.parametrize("D", [4, 6, 8, 12, 16])
+def test_distance_gemm_on_the_matrix_cores_around_the_near_threshold(ops, knob, D):
+    """XM (knob xm = 1): the expanded form's x . s^T as a bf16x3 split-operand GEMM on v_mfma_f32_16x16x32_bf16 - the
+    near-threshold gauntlet of the expanded form (queries at 1e-7 .. 1 relative distance from a support, exact
+    coincidences, many per wave) against the float64 oracle, every compiled width, and bit-exact batch-order invariance"""
+    from diffco_amd import _fkdesc
+    from oracle import oracle
+    g = torch.Generator().manual_seed(7 * D)
+    S, B = 333, 4096          # 333: head / tail rows outside the 16-row blocks in every slice
+    sup = (torch.rand((S, D), generator=g) * 2 - 1) * 1.5
+    W = torch.randn((S, 1), generator=g)
+    j = torch.randint(0, S, (B,), generator=g)
+    u = torch.randn((B, D), generator=g)
+    u = u / u.norm(dim=1, keepdim=True)
+    rel = 10.0 ** (torch.rand((B, 1), generator=g) * 7 - 7)
+    rel[::97] = 0.0
+    q = sup[j] + rel * sup[j].norm(dim=1, keepdim=True) * u
+    desc = _fkdesc.none_desc(D)
+    m = ops.ScoreModel(desc, 1, 1.0, 1.0, sup.cuda(), W.cuda())
+    so, go, _ = oracle.score_grad(desc, 1, 1.0, 1.0, sup.numpy().astype(np.float64), W.numpy().astype(np.float64),
+                                  q.numpy().astype(np.float64), dtype=np.float64)
+    knob("xf", 1)
+    knob("mfma", 0)
+    knob("xm", 1)
+    s, gr = m.score_grad_raw(q.cuda())
+    assert torch.isfinite(s).all() and torch.isfinite(gr).all()
+    assert relerr(_n(s), so) < TOL and relerr(_n(gr), go) < TOL, (relerr(_n(s), so), relerr(_n(gr), go))
+    perm = torch.randperm(B, generator=g).cuda()
+    sp, gp = m.score_grad_raw(q.cuda()[perm].contiguous())
+    assert torch.equal(sp, s[perm]) and torch.equal(gp, gr[perm])
+    knob("xm", 0)
+    s0, g0 = m.score_grad_raw(q.cuda())
+    assert relerr(_n(s), _n(s0)) < 6e-6 and relerr(_n(gr), _n(g0)) < 6e-6
+
+
+@pytest.mark.parametrize("name", ["baxter_left", "panda", "baxter_dual"])
+@pytest.mark.parametrize("B", [1, 200, 4096, 30000])
+def test_distance_gemm_on_the_matrix_cores_with_fk(ops, knob, name, B):
+    """XM on FK-produced (centred) features: the Baxter arm (12 features; Panda's 21 and the dual arm's 24 are outside the
+    XM widths and must silently take the VALU expanded form), split and unsplit launches, against the VALU expanded form and
+    the float64 oracle"""
+    from oracle import oracle
+    rob = make_robot(name)
+    g = torch.Generator().manual_seed(len(name) + B)
+    lim = rob.limits.float()
+    S = 700
+    rnd = lambda n: torch.rand((n, rob.dof), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]  # noqa: E731
+    sq, q = rnd(S), rnd(B).cuda()
+    desc = rob.fk_desc()
+    sup = rob.fkine(sq.cuda()).reshape(S, -1)
+    W = torch.randn((S, 1), generator=g)
+    m = ops.ScoreModel(desc, 1, 1.0, 1.0, sup, W.cuda())
+    knob("xf", 1)
+    knob("mfma", 0)
+    knob("xm", 0)
+    s0, g0 = m.score_grad_raw(q)
+    knob("xm", 1)
+    s1, g1 = m.score_grad_raw(q)
+    s1b, g1b = m.score_grad_raw(q)
+    assert torch.equal(s1, s1b) and torch.equal(g1, g1b)
+    assert relerr(_n(s1), _n(s0)) < 4e-6 and relerr(_n(g1), _n(g0)) < 4e-6
+    n64 = min(B, 512)
+    so, go, _ = oracle.score_grad(desc, 1, 1.0, 1.0, _n(sup).astype(np.float64), W.numpy().astype(np.float64),
+                                  _n(q[:n64]).astype(np.float64), dtype=np.float64)
+    assert relerr(_n(s1[:n64]), so) < TOL and relerr(_n(g1[:n64]), go) < TOL
+
+
 @pytest.mark.parametrize("C,kspec", [(5, (0, 10.0, 2.0)), (8, (0, 10.0, 2.0)), (8, (1, 1.0, 1.0)), (1, (1, 1.0, 1.0))])
 @pytest.mark.parametrize("B", [200, 4096, 20000])
 def test_matrix_core_form_of_the_weight_contraction(ops, knob, C, kspec, B):

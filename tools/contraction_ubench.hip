@@ -224,6 +224,265 @@ __global__ __launch_bounds__(256) void fold_kernel(const float* __restrict__ row
     for (int k = 0; k < D; ++k) o[k] = gx[k];
 }
 
+// ---- d2 ---------------------------------------------------------------------------------------------------------------
+// The squared distance in its expanded form, d2[b][j] = (|x_b|^2 + |s_j|^2) + sum_k (-2 x_bk) s_jk, D = 12: the one
+// contraction of the sweep whose per-lane operand (x) is loop invariant, so a split-operand matrix-core form needs no
+// per-pair splitting at all.
+//   valu   : 6 v_pk_fma_f32 per row + the adds (what the XF sweep ships)
+//   bf16x3 : -2x split once per lane into three bf16 planes (B fragments, loop invariant), s split on the host; the six plane
+//            products (hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid) are laid side by side along K (6 x 16 slots = three
+//            K = 32 instructions), the support block is the A operand, the 16 x 16 outputs come back to one lane per
+//            configuration through the 4 x 4 lane transpose: 12 v_mfma_f32_16x16x32_bf16 + 16 swaps per 16 rows and wave.
+// rows: [S][16] floats, column 12 = t_j, column 13 = |s_j|^2.  aplanes: [S / 16][3 chunks][16 supports][4 k'][8] bf16.
+template <int VAR>
+__global__ __launch_bounds__(256) void d2_kernel(const float* __restrict__ rows_g, const float* __restrict__ ss_g,
+                                                 const uint16_t* __restrict__ aplanes, float* __restrict__ out, int S) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    cfloat_ptr rows = (cfloat_ptr)(uintptr_t)rows_g;
+    cfloat_ptr ss = (cfloat_ptr)(uintptr_t)ss_g;
+    float x[D], xx = 0.0f;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        x[k] = 0.37f * (float)(((gw * 64 + lane) * 7 + 13 * k) % 31) / 31.0f - 0.2f;
+        xx = fmaf(x[k], x[k], xx);
+    }
+    float acc = 0.0f;  // consumes d2 the way the sweep would start to: here simply sum_j d2
+    if constexpr (VAR == 0) {
+        v2f xm[D / 2];
+#pragma unroll
+        for (int k = 0; k < D; k += 2) xm[k / 2] = v2f{-2.0f * x[k], -2.0f * x[k + 1]};
+        auto row = [&](const float (&r)[14]) __attribute__((always_inline)) {
+            v2f a = {xx + r[13], 0.0f};
+#pragma unroll
+            for (int k = 0; k < D; k += 2) a = __builtin_elementwise_fma(xm[k / 2], v2f{r[k], r[k + 1]}, a);
+            acc += a.x + a.y;
+        };
+        float ra[2][14], rb[2][14];
+        load2(ra, rows, 0, S);
+        for (int j = 0; j < S; j += 4) {
+            load2(rb, rows, j + 2, S);
+            __builtin_amdgcn_sched_barrier(0);
+            row(ra[0]);
+            row(ra[1]);
+            PIPE_FENCE();
+            load2(ra, rows, j + 4, S);
+            __builtin_amdgcn_sched_barrier(0);
+            row(rb[0]);
+            row(rb[1]);
+            PIPE_FENCE();
+        }
+    } else {
+        const int grp = lane >> 4, col = lane & 15;
+        // B fragments: K slot (term, kk) of chunk c = term 2c + (slot / 16): the x plane each term multiplies
+        //   terms: 0 hi.hi  1 hi.mid  2 mid.hi  3 hi.lo  4 lo.hi  5 mid.mid   (x plane: hi hi mid hi lo mid)
+        __shared__ uint16_t sxp[4][3][64][16];  // [wave][x plane][configuration][feature, zero padded to 16]
+        uint16_t(*xp)[64][16] = sxp[threadIdx.x >> 6];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float r = (k < D) ? -2.0f * x[k] : 0.0f;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const uint32_t u = fu(r) & 0xFFFF0000u;
+                xp[pl][lane][k] = (uint16_t)(u >> 16);
+                r -= uf(u);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        v4u bfrag[4][3];  // [tile][chunk]: lane (n, k') holds K slots 8 k' .. 8 k' + 7 of configuration 16 t + n
+        constexpr int xplane_of_term[6] = {0, 0, 1, 0, 2, 1};
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int term = 2 * c + (grp >> 1), f0 = 8 * (grp & 1);
+                uint32_t w[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    uint32_t lo = 0, hi = 0;
+#pragma unroll
+                    for (int tt = 0; tt < 6; ++tt)
+                        if (tt == term) {
+                            lo = xp[xplane_of_term[tt]][16 * t + col][f0 + 2 * e];
+                            hi = xp[xplane_of_term[tt]][16 * t + col][f0 + 2 * e + 1];
+                        }
+                    w[e] = lo | (hi << 16);
+                }
+                bfrag[t][c] = v4u{w[0], w[1], w[2], w[3]};
+            }
+        const v4u* ap = (const v4u*)aplanes + col * 4 + grp;  // 16 B per (support, k')
+        float sc_[16], sn[16];
+        loadt(sc_, ss, 0);
+        v4u a0 = ap[0], a1 = ap[64], a2 = ap[128];
+        for (int j = 0; j < S; j += 16) {
+            loadt(sn, ss, j + 16);
+            const size_t nb = (size_t)(j / 16 + 1) * 192;
+            const v4u n0 = ap[nb], n1 = ap[nb + 64], n2 = ap[nb + 128];
+            __builtin_amdgcn_sched_barrier(0);
+            v4f d[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                v4f c = {0.f, 0.f, 0.f, 0.f};
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a2), __builtin_bit_cast(v8bf, bfrag[t][2]), c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a1), __builtin_bit_cast(v8bf, bfrag[t][1]), c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a0), __builtin_bit_cast(v8bf, bfrag[t][0]), c, 0, 0, 0);
+                d[t] = c;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint32_t f[4];
+                frags(fu(d[0][i]), fu(d[1][i]), fu(d[2][i]), fu(d[3][i]), f);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc += (xx + sc_[4 * g + i]) + uf(f[g]);
+            }
+            a0 = n0; a1 = n1; a2 = n2;
+            PIPE_FENCE();
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sc_[e] = sn[e];
+        }
+    }
+    out[(size_t)gw * 64 + lane] = acc;
+}
+
+// ---- the whole pair body of the expanded-form sweep, with the distance on the VALU or on the matrix cores --------------
+// What a sweep that takes d2 from the bf16x3 form above would cost per row INCLUDING everything that stays on the VALU
+// (clamp, v_rsq, coefficient, score, the 6 v_pk_fma of the gradient fold with the row in SGPRs), at the register budget
+// it really needs (48 VGPRs of loop-invariant B fragments): the number to hold against the shipped sweep's.
+template <int VAR>
+__global__ __launch_bounds__(256) void xf_kernel(const float* __restrict__ rows_g, const float* __restrict__ ss_g,
+                                                 const uint16_t* __restrict__ aplanes, float* __restrict__ out, int S) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    cfloat_ptr rows = (cfloat_ptr)(uintptr_t)rows_g;
+    float x[D], xx = 0.0f;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        x[k] = 0.37f * (float)(((gw * 64 + lane) * 7 + 13 * k) % 31) / 31.0f - 0.2f;
+        xx = fmaf(x[k], x[k], xx);
+    }
+    const float thr = fmaxf(0.01f * xx, 1e-30f);
+    v2f ga[D / 2];
+#pragma unroll
+    for (int k = 0; k < D / 2; ++k) ga[k] = v2f{0.0f, 0.0f};
+    float sc = 0.0f, asum = 0.0f;
+    // everything behind the distance: clamp, 1 / r, coefficient (w / r), score (w r = coef d2), fold, sum of coefficients
+    auto tail = [&](const float (&r)[14], float d2raw) __attribute__((always_inline)) {
+        const float d2 = fmaxf(d2raw, thr);
+        const float coef = r[12] * __builtin_amdgcn_rsqf(d2);
+        sc = fmaf(coef, d2, sc);
+        const v2f c2 = {coef, coef};
+#pragma unroll
+        for (int k = 0; k < D; k += 2) ga[k / 2] = __builtin_elementwise_fma(c2, v2f{r[k], r[k + 1]}, ga[k / 2]);
+        asum += coef;
+    };
+    if constexpr (VAR == 0) {
+        v2f xm[D / 2];
+#pragma unroll
+        for (int k = 0; k < D; k += 2) xm[k / 2] = v2f{-2.0f * x[k], -2.0f * x[k + 1]};
+        auto row = [&](const float (&r)[14]) __attribute__((always_inline)) {
+            v2f a = {xx + r[13], 0.0f};
+#pragma unroll
+            for (int k = 0; k < D; k += 2) a = __builtin_elementwise_fma(xm[k / 2], v2f{r[k], r[k + 1]}, a);
+            tail(r, a.x + a.y);
+        };
+        float ra[2][14], rb[2][14];
+        load2(ra, rows, 0, S);
+        for (int j = 0; j < S; j += 4) {
+            load2(rb, rows, j + 2, S);
+            __builtin_amdgcn_sched_barrier(0);
+            row(ra[0]);
+            row(ra[1]);
+            PIPE_FENCE();
+            load2(ra, rows, j + 4, S);
+            __builtin_amdgcn_sched_barrier(0);
+            row(rb[0]);
+            row(rb[1]);
+            PIPE_FENCE();
+        }
+    } else {
+        const int grp = lane >> 4, col = lane & 15;
+        // B fragments straight from registers: the three planes of -2x as packed pairs, then one 4 x 4 lane transpose per
+        // (chunk, dword) hands every tile its fragment (no LDS)
+        uint32_t pk[3][8];  // [plane][feature pair 2p, 2p + 1], features past D are zero
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            float r0 = (2 * p < D) ? -2.0f * x[2 * p] : 0.0f, r1 = (2 * p + 1 < D) ? -2.0f * x[2 * p + 1] : 0.0f;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const uint32_t u0 = fu(r0) & 0xFFFF0000u, u1 = fu(r1) & 0xFFFF0000u;
+                pk[pl][p] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+                r0 -= uf(u0);
+                r1 -= uf(u1);
+            }
+        }
+        v4u bfrag[4][3];
+        constexpr int xplane_of_term[6] = {0, 0, 1, 0, 2, 1};
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // lane (n, k'): k' = 0, 1 -> term 2c, features 8 k' + 2e, +1;  k' = 2, 3 -> term 2c + 1
+                uint32_t f[4];
+                frags(pk[xplane_of_term[2 * c]][e], pk[xplane_of_term[2 * c]][4 + e], pk[xplane_of_term[2 * c + 1]][e],
+                      pk[xplane_of_term[2 * c + 1]][4 + e], f);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) bfrag[t][c][e] = f[t];
+            }
+        (void)grp;
+        const v4u* ap = (const v4u*)aplanes + col * 4 + (lane >> 4);
+        v4u a0 = ap[0], a1 = ap[64], a2 = ap[128];
+        for (int j = 0; j < S; j += 16) {
+            const size_t nb = (size_t)(j / 16 + 1) * 192;
+            const v4u n0 = ap[nb], n1 = ap[nb + 64], n2 = ap[nb + 128];
+            float dot[16];
+            {
+                v4f d[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    v4f c = {0.f, 0.f, 0.f, 0.f};
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a2), __builtin_bit_cast(v8bf, bfrag[t][2]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a1), __builtin_bit_cast(v8bf, bfrag[t][1]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a0), __builtin_bit_cast(v8bf, bfrag[t][0]), c, 0, 0, 0);
+                    d[t] = c;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    uint32_t f[4];
+                    frags(fu(d[0][i]), fu(d[1][i]), fu(d[2][i]), fu(d[3][i]), f);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) dot[4 * g + i] = uf(f[g]);
+                }
+            }
+            a0 = n0; a1 = n1; a2 = n2;
+            // the 16 rows of this step through the two-row scalar pipeline
+            float ra[2][14], rb[2][14];
+            load2(ra, rows, j, S);
+#pragma unroll
+            for (int q = 0; q < 16; q += 4) {
+                load2(rb, rows, j + q + 2, S);
+                __builtin_amdgcn_sched_barrier(0);
+                tail(ra[0], (xx + ra[0][13]) + dot[q]);
+                tail(ra[1], (xx + ra[1][13]) + dot[q + 1]);
+                PIPE_FENCE();
+                load2(ra, rows, j + q + 4, S);
+                __builtin_amdgcn_sched_barrier(0);
+                tail(rb[0], (xx + rb[0][13]) + dot[q + 2]);
+                tail(rb[1], (xx + rb[1][13]) + dot[q + 3]);
+                PIPE_FENCE();
+            }
+        }
+    }
+    float* o = out + ((size_t)gw * 64 + lane) * 16;
+#pragma unroll
+    for (int k = 0; k < D / 2; ++k) {
+        o[2 * k] = ga[k].x;
+        o[2 * k + 1] = ga[k].y;
+    }
+    o[12] = sc;
+    o[13] = asum;
+}
+
 // ---- kw and gwt -----------------------------------------------------------------------------------------------------------
 // wrows: [S][16] floats (W[j][0..C-1], zeros up to column 8, t_j at column 12).  up: [configurations][8].
 template <int C, int VAR>
@@ -486,6 +745,68 @@ int main(int argc, char** argv) {
             bool bw;
             const double rel = max_rel(ref, fetch(d_out, n), &bw);
             report("fold D=12", v == 1 ? "mfma32" : "bf16x3", t, t0, rel, bw);
+        }
+    }
+    {   // d2
+        // A operand of the split form: per 16 supports three K = 32 chunks; chunk c, K slot (half, kk): term 2 c + half, feature kk
+        //   terms: 0 hi.hi  1 hi.mid  2 mid.hi  3 hi.lo  4 lo.hi  5 mid.mid   (s plane: hi mid hi lo hi mid)
+        const int splane_of_term[6] = {0, 1, 0, 2, 0, 1};
+        std::vector<float> ssarr(S + 64, 0.0f);
+        std::vector<uint16_t> ap((size_t)(S / 16 + 2) * 3 * 16 * 4 * 8, 0);
+        for (int j = 0; j < S; ++j) {
+            uint16_t pl[3][16] = {};
+            double s2 = 0;
+            for (int k = 0; k < D; ++k) {
+                float r = rows[(size_t)j * 16 + k];
+                s2 += (double)r * r;
+                for (int p = 0; p < 3; ++p) {
+                    uint32_t u;
+                    std::memcpy(&u, &r, 4);
+                    u &= 0xFFFF0000u;
+                    float h;
+                    std::memcpy(&h, &u, 4);
+                    pl[p][k] = (uint16_t)(u >> 16);
+                    r -= h;
+                }
+            }
+            ssarr[j] = (float)s2;
+            rows[(size_t)j * 16 + 13] = (float)s2;
+            for (int c = 0; c < 3; ++c)
+                for (int kq = 0; kq < 4; ++kq)
+                    for (int e = 0; e < 8; ++e) {
+                        const int slot = 8 * kq + e, term = 2 * c + slot / 16, kk = slot % 16;
+                        ap[((((size_t)(j / 16) * 3 + c) * 16 + (j % 16)) * 4 + kq) * 8 + e] = pl[splane_of_term[term]][kk];
+                    }
+        }
+        float* d_ss;
+        uint16_t* d_ap;
+        hipMalloc(&d_ss, ssarr.size() * 4);
+        hipMalloc(&d_ap, ap.size() * 2);
+        hipMemcpy(d_ss, ssarr.data(), ssarr.size() * 4, hipMemcpyHostToDevice);
+        hipMemcpy(d_ap, ap.data(), ap.size() * 2, hipMemcpyHostToDevice);
+        hipMemcpy(d_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice);
+        hipMemset(d_ref, 0, nconf * 4);
+        hipMemset(d_out, 0, nconf * 4);
+        const float t0 = time_ms([&] { d2_kernel<0><<<g_blocks, 256>>>(d_rows, d_ss, d_ap, d_ref, S); }, reps);
+        const float t1 = time_ms([&] { d2_kernel<1><<<g_blocks, 256>>>(d_rows, d_ss, d_ap, d_out, S); }, reps);
+        bool bw;
+        const double rel = max_rel(fetch(d_ref, nconf), fetch(d_out, nconf), &bw);
+        report("d2 D=12", "valu", t0, t0, -1, false);
+        report("d2 D=12", "bf16x3", t1, t0, rel, bw);
+        {   // the whole pair body
+            const size_t n = nconf * 16;
+            float *d_o0, *d_o1;
+            hipMalloc(&d_o0, n * 4);
+            hipMalloc(&d_o1, n * 4);
+            hipMemset(d_o0, 0, n * 4);
+            hipMemset(d_o1, 0, n * 4);
+            const float x0 = time_ms([&] { xf_kernel<0><<<g_blocks, 256>>>(d_rows, d_ss, d_ap, d_o0, S); }, reps);
+            const float x1 = time_ms([&] { xf_kernel<1><<<g_blocks, 256>>>(d_rows, d_ss, d_ap, d_o1, S); }, reps);
+            const double relx = max_rel(fetch(d_o0, n), fetch(d_o1, n), &bw);
+            report("pair body", "valu", x0, x0, -1, false);
+            report("pair body", "d2:bf16x3", x1, x0, relx, bw);
+            hipFree(d_o0);
+            hipFree(d_o1);
         }
     }
     auto kw = [&](auto cc) {
