@@ -38,7 +38,7 @@ def isa(tmp_path_factory):
 
 
 def _kernels(txt):
-    for m in re.finditer(r"^(_ZN3dcx12score_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi1024ELb0ELb(\d)EEEvNS_9ScoreArgsE):", txt, re.M):
+    for m in re.finditer(r"^(_ZN3dcx12score_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi1024ELb0ELb(\d)ELb0EEEvNS_9ScoreArgsE):", txt, re.M):
         body = txt[m.end():txt.index(".Lfunc_end", m.end())].split("\n")
         meta = txt[txt.index(".name:           " + m.group(1)):]
         yield dict(D=int(m.group(2)), KF=int(m.group(3)), C=int(m.group(4)), MODE=int(m.group(5)), XF=int(m.group(6)), body=body,

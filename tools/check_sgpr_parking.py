@@ -39,7 +39,7 @@ def main():
     with ThreadPoolExecutor(8) as ex:
         for d, path in ex.map(compile_width, widths):
             txt = open(path).read()
-            for m in re.finditer(r"^(_ZN3dcx12score_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELb(\d)EEEvNS_9ScoreArgsE):", txt, re.M):
+            for m in re.finditer(r"^(_ZN3dcx12score_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELb(\d)ELb\dEEEvNS_9ScoreArgsE):", txt, re.M):
                 name, D, KF, CC, MODE = m.group(1), *map(int, m.group(2, 3, 4, 5))
                 MF, XF = int(m.group(7)), int(m.group(8))
                 body = txt[m.end():txt.index(".Lfunc_end", m.end())].split("\n")
