@@ -299,9 +299,11 @@ Geometry pick_geometry(const dcx_model* m, int64_t B, int acc_floats, bool allow
         g.ys = 3;
         g.nw = std::min(16, cap);
     } else {
-        // from four tiles per CU on, four 8-wave blocks per CU beat two 16-wave ones (expanded sweep, B = 65536: 98.8 -> 96.6 us,
-        // B = 262144: 364.6 -> 350.0 us; r01's direct sweep was level at B = 65536)
-        g.nw = std::min((tiles < 4 * (int64_t)m->n_cu) ? 16 : 8, cap);
+        // beyond four tiles per CU, 8-wave blocks beat 16-wave ones (expanded sweep, B = 262144: 364.6 -> 350.0 us in round 2;
+        // round 3 at steady clocks: B = 131072 160.7 vs 162.5 us, B = 1 M 1189 vs 1236).  At exactly four tiles per CU
+        // (B = 65536 on 256 CUs) round 2 measured the same and round 3 - whose epilogue runs on all waves of a block -
+        // measures the opposite: 16 waves 84.4 us, 8 waves 85.5 (three interleaved runs); five and six tiles per CU are level
+        g.nw = std::min((tiles <= 4 * (int64_t)m->n_cu) ? 16 : 8, cap);
     }
     const Knobs& kn = knobs();
     if (const int64_t v = kn.ys; v >= 1 && allow_split) g.ys = (int)std::min<int64_t>(v, 64);
