@@ -53,21 +53,28 @@ struct HessArgs {
 };
 
 // value, gradient coefficient g (dK/dx = g * delta) and h = 2 dg/dd2 (d2K/dx2 = g I + h delta delta^T)
+// KFT: the kernel function fixed at compile time (KF_POLY1 / KF_RQ2: the two the sweeps specialise) or KF_GEN = decided
+// per launch.  With everything behind a run-time switch the compiler if-converted parts of the general branch (powf / logf)
+// into the specialised ones' path: ~170 VALU instructions per pair where ~60 do the work (round 3, cycle stamps).
+template <int KFT>
 __device__ __forceinline__ void kernel_eval_h(const HessArgs& a, float d2, float& g, float& h) {
-    if (a.kf == KF_POLY1) {  // r / eps with 1 / eps in the row weights: g = 1 / r, h = -1 / r^3 (v_rsq, like the sweep's kernel_eval)
+    if (KFT == KF_POLY1 || (KFT == KF_GEN && a.kf == KF_POLY1)) {  // r / eps with 1 / eps in the row weights: g = 1 / r, h = -1 / r^3 (v_rsq, like the sweep's kernel_eval)
         const float ri = __builtin_amdgcn_rsqf(fmaxf(d2, 1e-30f));
         const bool on = d2 >= 1e-20f;  // on a support the kernel is not twice differentiable: the pair contributes nothing
         g = on ? ri : 0.0f;
         h = on ? -(ri * ri) * ri : 0.0f;
         return;
     }
-    if (a.kf == KF_RQ2) {  // (1 + gamma/2 d2)^-2: g = -2 gamma u^3, h = 6 gamma^2 u^4 with u = 1 / t (v_rcp)
+    if (KFT == KF_RQ2 || (KFT == KF_GEN && a.kf == KF_RQ2)) {  // (1 + gamma/2 d2)^-2: g = -2 gamma u^3, h = 6 gamma^2 u^4 with u = 1 / t (v_rcp)
         const float u = __builtin_amdgcn_rcpf(fmaf(0.5f * a.kp0, d2, 1.0f));
         const float u3 = (u * u) * u;
         g = -2.0f * a.kp0 * u3;
         h = 6.0f * a.kp0 * a.kp0 * (u3 * u);
         return;
     }
+    if constexpr (KFT != KF_GEN) {
+        return;  // (not reached: the two specialised functions returned above)
+    } else
     if (a.kf == KF_RQ2 || (a.kf == KF_GEN && a.kind == DCX_K_RQ)) {
         // K = t^-p, t = 1 + gamma/p d2:  g = -2 gamma t^(-p-1),  h = 4 gamma^2 (p+1)/p t^(-p-2)
         const float p = (a.kf == KF_RQ2) ? 2.0f : a.kp1;
@@ -113,6 +120,7 @@ __device__ __forceinline__ float pair_weight(const HessArgs& a, const float* r, 
 }
 
 // supports [j0, j1) of one wave, any width: x, dx and the sums stay in LDS
+template <int KFT>
 __device__ __forceinline__ void sweep_hess_lds(const HessArgs& a, const Dual* sX, Dual* sAcc, const float* up, int j0, int j1) {
     for (int j = j0; j < j1; ++j) {
         const float* r = a.rows + (size_t)j * a.RS;  // uniform address: scalar loads
@@ -125,7 +133,7 @@ __device__ __forceinline__ void sweep_hess_lds(const HessArgs& a, const Dual* sX
         }
         const float w = pair_weight(a, r, up);
         float g, h;
-        kernel_eval_h(a, d2, g, h);
+        kernel_eval_h<KFT>(a, d2, g, h);
         const float cf = w * g, ef = w * h * dd;
         for (int k = 0; k < a.D; ++k) {
             const Dual xk = sX[k * 64];
@@ -141,7 +149,7 @@ __device__ __forceinline__ void sweep_hess_lds(const HessArgs& a, const Dual* sX
 // the same for one of the compiled widths D <= 32 with x, dx and the sums in registers as packed pairs (v_pk_add /
 // v_pk_fma: 3 D instructions per pair for the differences, d2, delta . dx and the two accumulations) and the rows read
 // through the scalar cache (constant address space, like the sweep of score_kernel.h)
-template <int D>
+template <int D, int KFT>
 __device__ __forceinline__ void sweep_hess_regs(const HessArgs& a, const Dual* sX, Dual* sAcc, const float* up, int j0, int j1) {
     constexpr int NP = D / 2;
     constexpr bool ODD = (D & 1) != 0;
@@ -183,7 +191,7 @@ __device__ __forceinline__ void sweep_hess_regs(const HessArgs& a, const Dual* s
         sda += sdb;
         const float w = up ? weight(rows + (size_t)j * a.RS) : r[D];
         float g, h;
-        kernel_eval_h(a, s2a.x + s2a.y, g, h);
+        kernel_eval_h<KFT>(a, s2a.x + s2a.y, g, h);
         const float cf = w * g, ef = w * h * (sda.x + sda.y);
         const v2f c2 = {cf, cf}, e2 = {ef, ef};
 #pragma unroll
@@ -257,18 +265,24 @@ __global__ __launch_bounds__(SMALL ? 1024 : 512) void score_hess_kernel(const He
     const int j0 = (ybase + wave * a.s_chunk < yend) ? ybase + wave * a.s_chunk : yend;
     const int j1 = (j0 + a.s_chunk < yend) ? j0 + a.s_chunk : yend;
     const float* up = a.upstream ? a.upstream + b * a.C : nullptr;
-#define DCX_HESS_CASE(W) case W: sweep_hess_regs<W>(a, sX, sAcc, up, j0, j1); break;
-    if constexpr (SMALL) {
-        switch (a.D) {  // a.D is one of the compiled widths (dcx_internal.h kTemplateD)
-            DCX_HESS_CASE(2) DCX_HESS_CASE(4) DCX_HESS_CASE(6) DCX_HESS_CASE(8) DCX_HESS_CASE(12) DCX_HESS_CASE(16)
-            default: break;
+#define DCX_HESS_CASE(W) case W: sweep_hess_regs<W, KFT>(a, sX, sAcc, up, j0, j1); break;
+    auto sweep = [&](auto kft) __attribute__((always_inline)) {
+        constexpr int KFT = decltype(kft)::value;
+        if constexpr (SMALL) {
+            switch (a.D) {  // a.D is one of the compiled widths (dcx_internal.h kTemplateD)
+                DCX_HESS_CASE(2) DCX_HESS_CASE(4) DCX_HESS_CASE(6) DCX_HESS_CASE(8) DCX_HESS_CASE(12) DCX_HESS_CASE(16)
+                default: break;
+            }
+        } else {
+            switch (a.D) {
+                DCX_HESS_CASE(18) DCX_HESS_CASE(21) DCX_HESS_CASE(24) DCX_HESS_CASE(27) DCX_HESS_CASE(30) DCX_HESS_CASE(32)
+                default: sweep_hess_lds<KFT>(a, sX, sAcc, up, j0, j1);
+            }
         }
-    } else {
-        switch (a.D) {
-            DCX_HESS_CASE(18) DCX_HESS_CASE(21) DCX_HESS_CASE(24) DCX_HESS_CASE(27) DCX_HESS_CASE(30) DCX_HESS_CASE(32)
-            default: sweep_hess_lds(a, sX, sAcc, up, j0, j1);
-        }
-    }
+    };
+    if (a.kf == KF_POLY1) sweep(std::integral_constant<int, KF_POLY1>{});
+    else if (a.kf == KF_RQ2) sweep(std::integral_constant<int, KF_RQ2>{});
+    else sweep(std::integral_constant<int, KF_GEN>{});
 #undef DCX_HESS_CASE
     __syncthreads();
     // ---- every wave adds its share of the sums (accumulator k belongs to wave k % nw) over the waves' rows, in wave order;
