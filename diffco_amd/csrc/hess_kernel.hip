@@ -325,26 +325,31 @@ __global__ __launch_bounds__(SMALL ? 1024 : 512) void score_hess_kernel(const He
 #ifdef DCX_HANDOVER_FENCE
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #endif
-        // the re-read: up to 16 rows of one accumulator in flight per wave (one dependent agent-scope load per value cost
-        // 300 cycles each, 30 us at ys = 9, when wave 0 read them one by one)
-        for (int k = wave; k < a.D; k += nw) {
+        // the re-read: a wave's first two accumulators go out together, one load per row and accumulator (ys <= 12: at most
+        // 24 loads in flight), so most waves pay one agent-scope round trip (one dependent load per value cost 300 cycles
+        // each, 30 us at ys = 9, when wave 0 read them one by one; clamped duplicate loads of the last row and one
+        // accumulator at a time still cost 4.7 k cycles)
+        auto sum_rows = [&](const u64 (&r)[12]) __attribute__((always_inline)) -> Dual {
             Dual t(0.0f, 0.0f);
-            for (int y0 = 0; y0 < a.ys; y0 += 16) {
-                u64 r[16];
 #pragma unroll
-                for (int yy = 0; yy < 16; ++yy) {
-                    const int y = (y0 + yy < a.ys) ? y0 + yy : a.ys - 1;
-                    r[yy] = __hip_atomic_load(prow + ((size_t)y * a.D + k) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int y = 0; y < 12; ++y)
+                if (y < a.ys) {
+                    const Dual v(__uint_as_float((unsigned int)r[y]), __uint_as_float((unsigned int)(r[y] >> 32)));
+                    t = (y == 0) ? v : t + v;
                 }
+            return t;
+        };
+        for (int k0 = wave; k0 < a.D; k0 += 2 * nw) {
+            const int k1 = k0 + nw;
+            u64 r0[12], r1[12];
 #pragma unroll
-                for (int yy = 0; yy < 16; ++yy) {
-                    if (y0 + yy < a.ys) {
-                        const Dual v(__uint_as_float((unsigned int)r[yy]), __uint_as_float((unsigned int)(r[yy] >> 32)));
-                        t = (y0 + yy == 0) ? v : t + v;
-                    }
+            for (int y = 0; y < 12; ++y)
+                if (y < a.ys) {
+                    r0[y] = __hip_atomic_load(prow + ((size_t)y * a.D + k0) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (k1 < a.D) r1[y] = __hip_atomic_load(prow + ((size_t)y * a.D + k1) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-            }
-            row0[k * 64] = t;
+            row0[k0 * 64] = sum_rows(r0);
+            if (k1 < a.D) row0[k1 * 64] = sum_rows(r1);
         }
         if (threadIdx.x == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -399,7 +404,7 @@ hipError_t launch_hess(const ModelView& m, const float* q, int64_t B, const floa
         ys = (int)(m.n_cu / nblk);
         if (ys > 12) ys = 12;                                                 // (measured: 9-12 blocks per tile, profiles/r03_hess_probe.txt)
         while (ys > 1 && (m.S + ys - 1) / ys < 64) --ys;                      // at least four short slices per block
-        if (m.ys_knob >= 1) ys = m.ys_knob;
+        if (m.ys_knob >= 1) ys = m.ys_knob < 12 ? m.ys_knob : 12;  // (the hand-over reads at most 12 rows per pass)
         while (ys > 1 && (size_t)nblk * ys * part_row > m.scratch_bytes) --ys;
     }
     a.s_super = (m.S + ys - 1) / ys;
