@@ -811,6 +811,7 @@ int dcx_score_hess(const dcx_model* m, const float* q, int64_t B, const float* u
     v.kp1 = m->kp1;
     v.n_cu = m->n_cu;
     v.ys_knob = (int32_t)knobs().hess_ys;
+    v.fk_dh = (m->fk.kind == DCX_FK_DH && knobs().fkk != 0) ? 1 : 0;
     if (float* sc = split_scratch(m, (hipStream_t)stream, 0)) {  // small batches split the supports across blocks
         v.counters = reinterpret_cast<unsigned int*>(sc);
         v.n_counters = (int32_t)kTileCounters;

@@ -77,6 +77,7 @@ struct ModelView {
     size_t scratch_bytes = 0;
     unsigned int* counters = nullptr;
     int32_t n_counters = 0, counter_stride = 0, n_cu = 0;
+    int32_t fk_dh = 0;      // the transform is a DH arm
     int32_t ys_knob = -1;   // developer knob hess_ys: blocks per tile (1 = never split)
 };
 hipError_t launch_hess(const ModelView& m, const float* q, int64_t B, const float* upstream, float* grad, float* hess,

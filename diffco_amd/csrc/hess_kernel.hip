@@ -36,6 +36,7 @@ struct HessArgs {
     int32_t S, D, C, RS, w_off, wsum_off;
     int32_t dof, d_fk, frame_floats;
     int32_t kind, kf;
+    int32_t fk_dh;          // 1: a DH arm - the chain and its reverse sweep read the FK program with scalar loads (fk_*_dh_k)
     float kp0, kp1;
     int32_t s_chunk;
     // supports split across gridDim.y blocks per 64-lane tile (small batches): block y sweeps [y * s_super, (y + 1) * s_super),
@@ -253,7 +254,8 @@ __global__ __launch_bounds__(SMALL ? 1024 : 512) void score_hess_kernel(const He
     fk_forward_trig<Dual>(fk, sQ, sF, wave, nw);
     __syncthreads();
     if (wave == 0) {
-        fk_forward_chain<Dual>(fk, sQ, sX, sF);
+        if (a.fk_dh) fk_forward_chain_dh_k<Dual>((fk_kptr)(uintptr_t)a.fk, sX, sF);
+        else fk_forward_chain<Dual>(fk, sQ, sX, sF);
         for (int k = a.d_fk; k < a.D; ++k) sX[k * 64] = Dual(0.0f, 0.0f);  // zero padding up to the compiled width
     }
     for (int k = 0; k < a.D; ++k) sAcc[k * 64] = Dual(0.0f, 0.0f);
@@ -356,7 +358,8 @@ __global__ __launch_bounds__(SMALL ? 1024 : 512) void score_hess_kernel(const He
     __syncthreads();
     // ---- wave 0: the reverse sweep in duals ----
     if (wave != 0) return;
-    fk_vjp<Dual>(fk, sQ, sF, sAcc, sQ);  // the gradient row is built in place of the q row
+    if (a.fk_dh) fk_vjp_dh_k<Dual>((fk_kptr)(uintptr_t)a.fk, sF, sAcc, sQ);
+    else fk_vjp<Dual>(fk, sQ, sF, sAcc, sQ);  // the gradient row is built in place of the q row
     if (live) {
         float* hrow = a.hess + gl * dof;
         for (int k = 0; k < dof; ++k) hrow[k] = sQ[k].d;
@@ -386,6 +389,7 @@ hipError_t launch_hess(const ModelView& m, const float* q, int64_t B, const floa
     a.frame_floats = m.frame_floats;
     a.kind = m.kind;
     a.kf = m.kf;
+    a.fk_dh = m.fk_dh;
     a.kp0 = m.kp0;
     a.kp1 = m.kp1;
     // Frames that do not fit the LDS as (value, tangent) pairs go to global memory (one 512-byte column per frame float and
