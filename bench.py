@@ -13,12 +13,15 @@ of synthetic configurations already resident in HBM.
 N > 1: one process per GPU, the model replicated, the configuration batch sharded, no data-path collective; the scores
 of EVERY call are all-gathered over RCCL/xGMI (`--gather per-call`, the default: in order on the launch stream, what a
 consumer that needs the scores before its next call sees; `overlapped`: the gather of call i runs beside the
-sweep of call i+1 on the process group's stream).  `--scaling weak` (default) keeps the per-GPU batch fixed as N grows,
+sweep of call i+1 on the process group's stream; `graph`: the same inside a captured HIP graph).  `--scaling weak` (default) keeps the per-GPU batch fixed as N grows,
 `--scaling strong` divides the workload's fixed global batch (65536 for headline / config #3, 256 restarts for
 config #5) by N.  With N > 1 the line also carries short measurements of the other variants (`variants`): the
 other scaling mode, the overlapped gather, the gather bucketed every 4 calls, and no gather.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` and `cpu_baseline`.
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` and `cpu_baseline`.  The line cannot
+be lost to a side measurement: rank 0 hands the PRIMARY line (timed region + CPU baseline) to a keeper process as soon as
+it exists, and the complete line (with `variants` / `configs`) at the end; the keeper prints the complete line if it
+arrived and the primary one if this process died first (`LineKeeper`).
 """
 import argparse
 import json
@@ -41,6 +44,8 @@ WORKLOADS = {
     # name: (robot, kernel (kind,p0,p1), S, C, per-GPU batch (weak), global batch (strong), description)
     "headline": ("baxter", (1, 1.0, 1.0), 2000, 1, 65536, 65536,
                  "7-DoF Baxter DH chain (D=12), Polyharmonic(1,1), S=2000, C=1 (SURVEY.md §8d headline)"),
+    "headline_rq": ("baxter", (0, 10.0, 2.0), 2000, 1, 65536, 65536,
+                    "DiffCo.score at the metric's size: RQKernel(10) gains, 7-DoF Baxter (D=12), S=2000, C=1 (kernel_perceptrons.py:359-370)"),
     "cfg2": ("baxter", (1, 1.0, 1.0), 1000, 1, 4096, 4096, "BASELINE config #2: 7-DoF, FK kernel, 1k supports, batch 4096"),
     "cfg2_panda": ("panda", (1, 1.0, 1.0), 1000, 1, 4096, 4096, "config #2 with PandaFK (D=21)"),
     "cfg3": ("baxter", (0, 10.0, 2.0), 2000, 5, 8192, 65536,
@@ -71,6 +76,59 @@ arithmetic, the variants, the reductions and the JSON assembly are the real ones
 class _Done:
     def wait(self):
         return True
+
+
+_KEEPER_SRC = r"""
+import signal, sys
+for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+    signal.signal(sg, signal.SIG_IGN)   # the launcher tears the job down after a rank died: the line still goes out
+best = None
+for ln in sys.stdin:
+    ln = ln.rstrip("\n")
+    if ln.startswith("P ") and best is None:
+        best = ln[2:]
+    elif ln.startswith("F "):
+        best = ln[2:]
+if best is not None:
+    sys.stdout.write(best + "\n")
+    sys.stdout.flush()
+"""
+
+
+class LineKeeper:
+    """Owner of the ONE line on the real stdout.  A tiny child process (plain Python, no torch, no GPU) reads this
+    process's pipe: `primary(line)` parks the line of the timed region, `final(line)` the complete one; when the pipe closes
+    - normally, or because this process was aborted from a library thread in the middle of a side measurement (c10d's
+    watchdog does that when a graph capture of a collective goes wrong; no Python handler runs then) - the keeper prints
+    the complete line if it has one, else the primary line.  Either way exactly one line, and never none once the timed
+    region is over."""
+
+    def __init__(self, fd):
+        import subprocess
+        self.proc = subprocess.Popen([sys.executable, "-c", _KEEPER_SRC], stdin=subprocess.PIPE, stdout=fd, close_fds=True)
+
+    def _send(self, tag, obj):
+        self.proc.stdin.write((tag + " " + json.dumps(obj) + "\n").encode())
+        self.proc.stdin.flush()
+
+    def primary(self, obj):
+        self._send("P", obj)
+
+    def final(self, obj):
+        self._send("F", obj)
+
+    def close(self):
+        self.proc.stdin.close()
+        self.proc.wait(timeout=30)
+
+
+def _fault(where):
+    """developer fault injection (tests/test_gpu_bench_contract.py): DCX_BENCH_FAULT=<where> kills the process the way a
+    library thread would (abort(), no Python clean-up)"""
+    if os.environ.get("DCX_BENCH_FAULT", "") == where:
+        sys.stderr.write(f"bench: injected fault at {where}\n")
+        sys.stderr.flush()
+        os.abort()
 
 
 def gather_scores(full, local, async_op=False):
@@ -164,27 +222,54 @@ def cpu_baseline(w, budget_s=12.0):
                       f"best of {reps}", "seconds": round(best, 3)}
 
 
-def torch_cpu_baseline(w, budget_s=6.0):
-    """A torch-CPU restatement of the reference EXPRESSION (cdist -> kernel -> matmul, autograd backward)
-    on precomputed features — what the reference does per call minus its FK.  Secondary information."""
+def _torch_dh_fkine(desc):
+    """differentiable torch-CPU forward kinematics of a single DH chain from its description: the reference's expression
+    (DH2mat -> cumulative products -> translation columns of the masked frames) as torch ops"""
+    n = desc.chain_len[0]
+    col = lambda arr: torch.tensor([arr[0][i] for i in range(n)], dtype=torch.float32)
+    a_, d_, sa_, ca_, t0_ = col(desc.a), col(desc.d), col(desc.sin_alpha), col(desc.cos_alpha), col(desc.theta0)
+    frames = [desc.pt_frame[k] for k in range(desc.n_points)]
+    offs = [[desc.pt_off[k][j] for j in range(3)] + [1.0] for k in range(desc.n_points)]
+
+    def fkine(q):
+        th = q + t0_
+        c, s_ = th.cos(), th.sin()
+        z, o = torch.zeros_like(c), torch.ones_like(c)
+        A = torch.stack([torch.stack([c, -s_ * ca_, s_ * sa_, a_ * c], -1), torch.stack([s_, c * ca_, -c * sa_, a_ * s_], -1),
+                         torch.stack([z, sa_ * o, ca_ * o, d_ * o], -1), torch.stack([z, z, z, o], -1)], 2)  # [B, n, 4, 4]
+        T, cum = A[:, 0], [A[:, 0]]
+        for i in range(1, n):
+            T = torch.bmm(T, A[:, i])
+            cum.append(T)
+        return torch.stack([(cum[f] @ torch.tensor(off))[:, :3] for f, off in zip(frames, offs)], 1)
+    return fkine
+
+
+def torch_cpu_baseline(w, budget_s=8.0):
+    """A torch-CPU restatement of the reference EXPRESSION on this box's host cores, as SURVEY.md §8d specifies it: FK ->
+    cdist -> kernel -> matmul, `.sum().backward()` down to the joint angles, `torch.set_num_threads(os.cpu_count())`.
+    Secondary information beside `cpu_baseline` (the C/OpenMP oracle)."""
     if w["kspec"][0] not in (0, 1):
         return None
-    nthr = min(os.cpu_count() or 1, 32)  # more threads than that only slows torch down at this size
+    nthr = os.cpu_count() or 1
     torch.set_num_threads(nthr)
     sup = w["sup"].cpu()
     Wt = w["W"]
     n = min(4096, w["B"])
-    from diffco_amd import _ops
-    X = _ops.fkine(w["desc"], w["q"][:n]).reshape(n, -1).cpu()
+    q0 = w["q_cpu"][:n].clone()
+    fk = None
+    if w["rob_name"] is not None:
+        fk = _torch_dh_fkine(w["desc"])
 
     def run():
-        x = X.clone().requires_grad_(True)
+        q = q0.clone().requires_grad_(True)
+        x = q if fk is None else fk(q).reshape(n, -1)
         if w["kspec"][0] == 0:
             kv = 1 / (1 + w["kspec"][1] / w["kspec"][2] * torch.cdist(x, sup).square()) ** w["kspec"][2]
         else:
             kv = torch.cdist(x, sup) / w["kspec"][2]
         (kv @ Wt).sum().backward()
-        return x.grad
+        return q.grad
     run()
     best, t_start, reps = 1e30, time.perf_counter(), 0
     while reps < 5 and time.perf_counter() - t_start < budget_s:
@@ -193,7 +278,8 @@ def torch_cpu_baseline(w, budget_s=6.0):
         best = min(best, time.perf_counter() - t0)
         reps += 1
     return {"value": round(n / best / 1e6, 5), "unit": "M evals/s", "cores": nthr,
-            "sample": f"{n} configs, torch {torch.__version__} CPU cdist+matmul+backward on precomputed features (no FK)"}
+            "sample": f"{n} configs, torch {torch.__version__} CPU: " + ("FK -> " if fk is not None else "") +
+                      "cdist -> kernel -> matmul -> backward to q, best of " + str(reps)}
 
 
 def load_profile_json(fname):
@@ -229,6 +315,7 @@ class ScoreLoop:
         self.graph, self.G = None, 8
         if gather == "graph":
             if SAME_GPU:   # the rehearsal's host-buffer gather cannot be captured
+                _fault("capture")
                 self.gather = "per-call"
             else:
                 self._capture()
@@ -252,6 +339,7 @@ class ScoreLoop:
         overlapped form pays c10d's bookkeeping (27 us) on every call.  The gather of step i only has to be over before
         step i + 2 rewrites its buffer.  Falls back to the per-call form if the collective cannot be captured here."""
         dev = self.dev
+        _fault("capture")
         self.local = [torch.empty((self.B, self.w["C"]), device=dev, dtype=torch.float32) for _ in range(2)]
         self.full = [torch.empty((self.world * self.B, self.w["C"]), device=dev, dtype=torch.float32) for _ in range(2)]
         main, side = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
@@ -382,7 +470,8 @@ class TrajLoop:
 
 def measure(loop, steps, warmup, dev, multi):
     """W untimed warm-up steps, then exactly `steps` steps bracketed by barrier + synchronize; max over ranks.
-    Returns (wall seconds, average launch-to-launch kernel milliseconds from HIP events on the launch stream)"""
+    Returns (wall seconds, average launch-to-launch kernel milliseconds from HIP events on the launch stream, number of
+    untimed settle steps issued before the warm-up)"""
     # Settle first.  (1) A freshly built model / process group pays one-off costs in its first launches (lazy RCCL buffers
     # for a new message size ...).  (2) The GPU's clocks ramp for ~50 ms of sustained load after an idle period: the headline
     # launch takes 102 us in its first 100 launches, 93, 88, 86 in the next hundreds and 85.1-85.3 us from 45 ms on
@@ -428,7 +517,85 @@ def measure(loop, steps, warmup, dev, multi):
         tt = torch.tensor([wall, kern_ms], device="cpu" if SAME_GPU else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall, kern_ms = float(tt[0]), float(tt[1])
-    return wall, kern_ms
+    return wall, kern_ms, 2 * SETTLE_STEPS + n_settle
+
+
+def primary_line(args, w, loop, world, multi, ranks_reported, wall, kern_ms, n_settle, gather_ms, ge, is_traj, cpu_base, cpu_torch):
+    """the JSON line of the timed region (everything but the side measurements `variants` / `configs`)"""
+    name = args.workload
+    B, C, dof = w["B"], w["C"], w["dof"]
+    value = ge * args.steps / wall / 1e6
+    F = flops_per_eval(w["D"], C, w["S"])
+    ach_tf = F * B / (kern_ms * 1e-3) / 1e12
+    ach_gbs = bytes_per_eval(dof, C) * B / (kern_ms * 1e-3) / 1e9
+    pmc = load_profile_json(f"pmc_{name}.json")
+    mfc = load_profile_json("mfma_contractions.json") or {}
+    forms = mfc.get("forms") or {}
+    head_form = next((v for k, v in forms.items() if k.startswith("headline")), {})
+    this_form = next((v for k, v in forms.items() if k.split(" ")[0] == name), head_form)
+    mfma_on = os.environ.get("DCX_MFMA", "") not in ("", "0", "-1") and w["D"] <= 16 and w["D"] % 2 == 0 and C in (1, 5, 8) and not is_traj
+    gather_txt = {"graph": "RCCL all-gather of the scores of EVERY call beside the next call's sweep, sweep + gather captured "
+                           "in a HIP graph (8 calls per replay)",
+                  "per-call": "RCCL all-gather of the scores after EVERY call, in order on the launch stream",
+                  "overlapped": "RCCL all-gather of the scores after every call, beside the next call's sweep",
+                  "bucketed": f"RCCL all-gather of the scores every {GATHER_EVERY} calls, overlapped",
+                  "none": "no gather (sharded consumer)",
+                  "summaries": "restarts sharded; only per-restart summaries + candidate paths gathered, once"}[loop.gather]
+    out = {
+        "metric": "million collision-score+grad evals/sec, 7-DoF FK-kernel, 2k supports",
+        "value": round(value, 3), "unit": "M evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(wall / args.steps * 1e3, 5), "higher_is_better": True, "scaling": args.scaling,
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        # untimed launches that keep the GPU busy before the W warm-up steps (clock ramp: tools/clock_ramp.py)
+        "settle_ms": SETTLE_MS, "settle_steps": n_settle,
+        "config": {"workload": f"{w['name']}: {w['text']}", "batch_per_gpu": B, "global_batch": ge,
+                   "supports": w["S"], "features": w["D"], "classes": C,
+                   "parallelism": f"batch-sharded x{world}, model replicated" + ("" if not multi else ", " + gather_txt),
+                   "launches_per_step": round(-(-args.steps // 192) / max(args.steps, 1), 4) if is_traj else 1},
+        "roofline": {"bound": "valu", "achieved": round(ach_tf, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(ach_tf / PEAK_FP32_TFLOPS, 4),
+                     "traffic": None if pmc is None else pmc.get("hbm_bytes_per_launch"),
+                     "traffic_source": None if pmc is None else f"profiles/pmc_{name}.json (rocprofv3 --pmc passes of an earlier run of "
+                                                                 "this command, calibrated; a constant, not an observation of this run)",
+                     "kernel": "dcx::traj_fused_kernel<D,KF,MAXT,XF>" if is_traj else "dcx::score_kernel<D,KF,C,MODE,MAXT,MF,XF>",
+                     "sweep_form": ("expanded with x.s^T on the matrix cores (XM: bf16x3 split operands on v_mfma_f32_16x16x32_bf16; DCX_XM=1)"
+                                    if (os.environ.get("DCX_XM", "") not in ("", "0", "-1") and w["kspec"][0] == 1 and w["kspec"][1] == 1.0
+                                        and C == 1 and w["D"] <= 16 and w["D"] % 2 == 0 and not is_traj and not mfma_on
+                                        and os.environ.get("DCX_XF", "") != "0") else
+                                    "expanded (XF: d2 = |x|^2+|s|^2-2x.s, gX = x*sum(c)-sum(c s); 20 VALU/pair at D=12)"
+                                    if (w["kspec"][0] == 1 and w["kspec"][1] == 1.0 and w["D"] + C + (C > 1) + 1 <= 38
+                                        and os.environ.get("DCX_XF", "") != "0" and not mfma_on)
+                                    else "direct (differences; 24 VALU/pair at D=12)"),
+                     "kernel_ms": round(kern_ms, 5), "flops_per_eval": F,
+                     "note": "fp32 VALU bound (peak == fp32 MFMA peak 157.3 TFLOP/s); algorithmic flops "
+                             "S*(5D+4C+6)+800 per eval (SURVEY.md §8d)",
+                     "hbm": {"achieved": round(ach_gbs, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                             "frac": round(ach_gbs / PEAK_HBM_GBS, 5),
+                             "bytes_per_eval": bytes_per_eval(dof, C)},
+                     # the matrix cores: what the default path issues (nothing) and what the measured MFMA forms of
+                     # this path cost - the north star's K[B,S].W[S,C] contraction at C >= 4 included
+                     # (profiles/mfma_contractions.json <- profiles/r03_mfma_ab.txt)
+                     "mfma": {"used": bool(mfma_on),
+                              "instructions_per_launch": this_form.get("instructions_per_launch") if mfma_on else 0,
+                              "busy_frac": this_form.get("busy_frac") if mfma_on else 0.0,
+                              "contraction": ("K[B,S].W[S,C] (C >= 4) and the (configurations x supports).(supports x features) "
+                                              "gradient fold on v_mfma_f32_16x16x4_f32; upstream.W^T measured in isolation"),
+                              "measured_variant": {**{k: head_form.get(k) for k in (
+                                  "instructions_per_launch", "busy_frac", "mfma_flops_per_launch", "kernel_us_mfma_form",
+                                  "kernel_us_valu_form")}, "verdict": mfc.get("verdict"), "source": mfc.get("source")},
+                              "forms": mfc.get("forms"),
+                              "contractions_in_isolation": mfc.get("contractions_in_isolation_8_waves_per_simd"),
+                              "coissue": mfc.get("coissue")}},
+    }
+    if multi:
+        out["multi"] = {"ranks": ranks_reported, "backend": "gloo, all ranks on cuda:0 (rehearsal)" if SAME_GPU else "nccl (RCCL)", "gather": loop.gather,
+                        "gather_ms": None if gather_ms is None else round(gather_ms, 5),
+                        "gather_bytes_per_call": None if is_traj else
+                        world * B * C * 4 * (GATHER_EVERY if loop.gather == "bucketed" else 1)}
+    out["cpu_baseline"] = cpu_base
+    if cpu_torch:
+        out["cpu_baseline_torch"] = cpu_torch
+    return out
 
 
 def main():
@@ -440,10 +607,12 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: the workload's per-GPU batch on every rank; strong: its fixed global batch divided by the ranks")
-    ap.add_argument("--gather", default="graph", choices=["graph", "per-call", "overlapped", "bucketed", "none"],
-                    help="N>1: graph (default) = every call's scores all-gathered beside the NEXT call's sweep, eight calls captured "
-                         "in one HIP graph (falls back to per-call if the collective cannot be captured); per-call = in order on the "
-                         "launch stream; overlapped = eager, beside the next sweep; bucketed = every 4 calls; none = sharded consumer")
+    ap.add_argument("--gather", default="per-call", choices=["graph", "per-call", "overlapped", "bucketed", "none"],
+                    help="N>1: per-call (default) = every call's scores all-gathered in order on the launch stream (always works, and "
+                         "the fastest form measured on one rank, profiles/r03_bench_forcedist.jsonl); graph = beside the NEXT call's "
+                         "sweep, eight calls captured in one HIP graph (falls back to per-call if the collective cannot be captured); "
+                         "overlapped = eager, beside the next sweep; bucketed = every 4 calls; none = sharded consumer.  The other "
+                         "forms are measured briefly as `variants` AFTER the primary line is safe, graph last")
     ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
     ap.add_argument("--no-variants", action="store_true", help="N>1: skip the short runs of the other variants")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -475,6 +644,16 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     multi = world > 1 or args.force_dist
+    keeper = LineKeeper(real_stdout) if rank == 0 else None
+
+    # The CPU baseline (rank 0's host cores) runs FIRST, before the process group exists: the other ranks wait in the TCP
+    # rendezvous, not inside a collective kernel, and the primary line below is complete the moment the timed region ends.
+    cpu_base, cpu_torch = None, None
+    if rank == 0 and not args.no_cpu_baseline:
+        w0 = make_workload(args.workload, args.batch or min(WORKLOADS[args.workload][4], 65536), dev, seed=rank)
+        cpu_base = cpu_baseline(w0)
+        cpu_torch = torch_cpu_baseline(w0) if world == 1 else None
+        del w0
     if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -513,18 +692,27 @@ def main():
         return strong_global
 
     w, loop = build(args.scaling, args.gather)
-    wall, kern_ms = measure(loop, args.steps, args.warmup, dev, multi)
+    wall, kern_ms, n_settle = measure(loop, args.steps, args.warmup, dev, multi)
     gather_ms = loop.gather_ms()
     B, C, dof = w["B"], w["C"], w["dof"]
+
+    out = None
+    if rank == 0:
+        out = primary_line(args, w, loop, world, multi, ranks_reported, wall, kern_ms, n_settle, gather_ms, global_evals(args.scaling, w),
+                           is_traj, cpu_base, cpu_torch)
+        keeper.primary(out)   # from here on the driver gets a line whatever happens below
+    _fault("after_primary")
 
     variants = None
     if multi and not args.no_variants:
         # the other ways to run N > 1, measured briefly in the same job (primary numbers above are untouched)
         vs, vw = max(48, args.steps // 4), max(8, args.warmup // 2)
         variants = {}
-        others = [("other_scaling", "strong" if args.scaling == "weak" else "weak", args.gather)]
+        others = [("other_scaling", "strong" if args.scaling == "weak" else "weak", args.gather if args.gather != "graph" else "per-call")]
         if not is_traj:
-            others += [(f"gather_{g}", args.scaling, g) for g in ("graph", "per-call", "overlapped", "bucketed", "none") if g != args.gather]
+            # the captured form LAST: a collective that cannot be captured can take the process down from c10d's watchdog
+            # thread (see ScoreLoop._capture); by then every other variant is measured and the primary line is with the keeper
+            others += [(f"gather_{g}", args.scaling, g) for g in ("per-call", "none", "bucketed", "overlapped", "graph") if g != args.gather]
         for key, sc, ga in others:
             # A variant is a side measurement: if one fails (the same way on every rank: an allocation, an argument), it
             # is recorded as failed and the primary line above still goes out.
@@ -532,7 +720,7 @@ def main():
                 w2, l2 = build(sc, ga)
                 # best of two short runs: with a process group alive, a ~100 ms stall of unknown origin (seen in the no-gather
                 # variant too) occasionally lands inside one 48-step run; the primary measurement above is a single run, as agreed
-                wl, km = min(measure(l2, vs, vw, dev, multi), measure(l2, vs, vw, dev, multi))
+                wl, km = min(measure(l2, vs, vw, dev, multi)[:2], measure(l2, vs, vw, dev, multi)[:2])
                 ge = global_evals(sc, w2)
                 variants[key] = {"scaling": sc, "gather": l2.gather, "value": round(ge * vs / wl / 1e6, 3),
                                  "ms_per_step": round(wl / vs * 1e3, 5), "kernel_ms": round(km, 5), "steps": vs,
@@ -547,14 +735,17 @@ def main():
     configs = None
     if world == 1 and not multi and name == "headline" and not args.batch and not args.no_configs:
         configs = {}
-        for cname, csteps in (("cfg2", 200), ("cfg2_panda", 200), ("cfg3", 200), ("cfg3_poly", 200), ("cfg4", 12), ("cfg5", 200)):
+        for cname, csteps in (("cfg2", 200), ("cfg2_panda", 200), ("cfg3", 200), ("cfg3_b65536", 100), ("cfg3_poly", 200), ("cfg4", 12),
+                              ("cfg5", 200), ("cfg5_shard32", 200), ("headline_rq", 100)):
             try:
-                cw = make_workload(cname, WORKLOADS[cname][4], dev, seed=rank)
-                if cname == "cfg5":
-                    cl = TrajLoop(cw, dev, 1, WORKLOADS[cname][4] // TRAJ_W, None)
+                wname = cname.split("_shard")[0].split("_b")[0]
+                cbatch = {"cfg5_shard32": 32 * TRAJ_W, "cfg3_b65536": 65536}.get(cname, WORKLOADS[wname][4])
+                cw = make_workload(wname, cbatch, dev, seed=rank)
+                if wname == "cfg5":
+                    cl = TrajLoop(cw, dev, 1, cbatch // TRAJ_W, None)
                 else:
                     cl = ScoreLoop(cw, dev, 1, "none")
-                cwall, ckm = measure(cl, csteps, 10, dev, False)
+                cwall, ckm = measure(cl, csteps, 10, dev, False)[:2]
                 cF = flops_per_eval(cw["D"], cw["C"], cw["S"])
                 ctf = cF * cw["B"] / (ckm * 1e-3) / 1e12
                 configs[cname] = {"workload": cw["text"], "batch": cw["B"], "steps": csteps,
@@ -566,95 +757,19 @@ def main():
                 configs[cname] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
 
     if rank == 0:
-        ge = global_evals(args.scaling, w)
-        value = ge * args.steps / wall / 1e6
-        F = flops_per_eval(w["D"], C, w["S"])
-        ach_tf = F * B / (kern_ms * 1e-3) / 1e12
-        ach_gbs = bytes_per_eval(dof, C) * B / (kern_ms * 1e-3) / 1e9
-        pmc = load_profile_json(f"pmc_{name}.json")
-        mfc = load_profile_json("mfma_contractions.json") or {}
-        forms = mfc.get("forms") or {}
-        head_form = next((v for k, v in forms.items() if k.startswith("headline")), {})
-        this_form = next((v for k, v in forms.items() if k.split(" ")[0] == name), head_form)
-        mfma_on = os.environ.get("DCX_MFMA", "") not in ("", "0", "-1") and w["D"] <= 16 and w["D"] % 2 == 0 and C in (1, 5, 8) and not is_traj
-        gather_txt = {"graph": "RCCL all-gather of the scores of EVERY call beside the next call's sweep, sweep + gather captured "
-                               "in a HIP graph (8 calls per replay)",
-                      "per-call": "RCCL all-gather of the scores after EVERY call, in order on the launch stream",
-                      "overlapped": "RCCL all-gather of the scores after every call, beside the next call's sweep",
-                      "bucketed": f"RCCL all-gather of the scores every {GATHER_EVERY} calls, overlapped",
-                      "none": "no gather (sharded consumer)",
-                      "summaries": "restarts sharded; only per-restart summaries + candidate paths gathered, once"}[loop.gather]
-        out = {
-            "metric": "million collision-score+grad evals/sec, 7-DoF FK-kernel, 2k supports",
-            "value": round(value, 3), "unit": "M evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(wall / args.steps * 1e3, 5), "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            # untimed launches that keep the GPU busy before the W warm-up steps (clock ramp: tools/clock_ramp.py)
-            "settle_ms": SETTLE_MS,
-            "config": {"workload": f"{w['name']}: {w['text']}", "batch_per_gpu": B, "global_batch": ge,
-                       "supports": w["S"], "features": w["D"], "classes": C,
-                       "parallelism": f"batch-sharded x{world}, model replicated" + ("" if not multi else ", " + gather_txt),
-                       "launches_per_step": round(-(-args.steps // 192) / max(args.steps, 1), 4) if is_traj else 1},
-            "roofline": {"bound": "valu", "achieved": round(ach_tf, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach_tf / PEAK_FP32_TFLOPS, 4),
-                         "traffic": None if pmc is None else pmc.get("hbm_bytes_per_launch"),
-                         "traffic_source": None if pmc is None else f"profiles/pmc_{name}.json (rocprofv3 --pmc passes of an earlier run of "
-                                                                     "this command, calibrated; a constant, not an observation of this run)",
-                         "kernel": "dcx::traj_fused_kernel<D,KF,MAXT,XF>" if is_traj else "dcx::score_kernel<D,KF,C,MODE,MAXT,MF,XF>",
-                         "sweep_form": ("expanded with x.s^T on the matrix cores (XM: bf16x3 split operands on v_mfma_f32_16x16x32_bf16; DCX_XM=1)"
-                                        if (os.environ.get("DCX_XM", "") not in ("", "0", "-1") and w["kspec"][0] == 1 and w["kspec"][1] == 1.0
-                                            and C == 1 and w["D"] <= 16 and w["D"] % 2 == 0 and not is_traj and not mfma_on
-                                            and os.environ.get("DCX_XF", "") != "0") else
-                                        "expanded (XF: d2 = |x|^2+|s|^2-2x.s, gX = x*sum(c)-sum(c s); 20 VALU/pair at D=12)"
-                                        if (w["kspec"][0] == 1 and w["kspec"][1] == 1.0 and w["D"] + C + (C > 1) + 1 <= 38
-                                            and os.environ.get("DCX_XF", "") != "0" and not mfma_on)
-                                        else "direct (differences; 24 VALU/pair at D=12)"),
-                         "kernel_ms": round(kern_ms, 5), "flops_per_eval": F,
-                         "note": "fp32 VALU bound (peak == fp32 MFMA peak 157.3 TFLOP/s); algorithmic flops "
-                                 "S*(5D+4C+6)+800 per eval (SURVEY.md §8d)",
-                         "hbm": {"achieved": round(ach_gbs, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                 "frac": round(ach_gbs / PEAK_HBM_GBS, 5),
-                                 "bytes_per_eval": bytes_per_eval(dof, C)},
-                         # the matrix cores: what the default path issues (nothing) and what the measured MFMA forms of
-                         # this path cost - the north star's K[B,S].W[S,C] contraction at C >= 4 included
-                         # (profiles/mfma_contractions.json <- profiles/r03_mfma_ab.txt)
-                         "mfma": {"used": bool(mfma_on),
-                                  "instructions_per_launch": this_form.get("instructions_per_launch") if mfma_on else 0,
-                                  "busy_frac": this_form.get("busy_frac") if mfma_on else 0.0,
-                                  "contraction": ("K[B,S].W[S,C] (C >= 4) and the (configurations x supports).(supports x features) "
-                                                  "gradient fold on v_mfma_f32_16x16x4_f32; upstream.W^T measured in isolation"),
-                                  "measured_variant": {**{k: head_form.get(k) for k in (
-                                      "instructions_per_launch", "busy_frac", "mfma_flops_per_launch", "kernel_us_mfma_form",
-                                      "kernel_us_valu_form")}, "verdict": mfc.get("verdict"), "source": mfc.get("source")},
-                                  "forms": mfc.get("forms"),
-                                  "contractions_in_isolation": mfc.get("contractions_in_isolation_8_waves_per_simd"),
-                                  "coissue": mfc.get("coissue")}},
-        }
         if multi:
             none_ms = ((variants or {}).get("gather_none") or {}).get("ms_per_step")
-            out["multi"] = {"ranks": ranks_reported, "backend": "gloo, all ranks on cuda:0 (rehearsal)" if SAME_GPU else "nccl (RCCL)", "gather": loop.gather,
-                            "gather_ms": None if gather_ms is None else round(gather_ms, 5),
-                            # what the gather adds to a step: this run's step time minus the same job's no-gather variant
-                            "gather_exposed_ms": None if none_ms is None else round(wall / args.steps * 1e3 - none_ms, 5),
-                            "gather_bytes_per_call": None if is_traj else
-                            world * B * C * 4 * (GATHER_EVERY if loop.gather == "bucketed" else 1)}
+            # what the gather adds to a step: this run's step time minus the same job's no-gather variant
+            out["multi"]["gather_exposed_ms"] = None if none_ms is None else round(wall / args.steps * 1e3 - none_ms, 5)
             if variants is not None:
                 out["variants"] = variants
         if configs is not None:
             out["configs"] = configs
-        # the CPU port beside the GPU number, on rank 0's host cores, for every N (after the timed region and the closing
-        # barrier: the other ranks only wait in destroy_process_group)
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w)
-            tb = torch_cpu_baseline(w) if world == 1 else None
-            if tb:
-                out["cpu_baseline_torch"] = tb
-        else:
-            out["cpu_baseline"] = None
-        sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        keeper.final(out)
     if multi:
         dist.destroy_process_group()
+    if keeper is not None:
+        keeper.close()
 
 
 if __name__ == "__main__":

@@ -46,6 +46,15 @@ struct dcx_model {
     };
     mutable std::mutex mu;
     mutable std::vector<Scratch> scratch;
+    // exchange rows of the persistent trajectory kernel's cluster form (traj_fused.h traj_exchange): one buffer per stream,
+    // zeroed once; `epoch` numbers the launches that have used it (their tags never repeat)
+    struct TrajExch {
+        hipStream_t stream;
+        unsigned long long* ptr;
+        size_t bytes;
+        uint32_t epoch;
+    };
+    mutable std::vector<TrajExch> traj_exch;
 };
 
 #ifdef DCX_TIMING
@@ -240,7 +249,8 @@ int fk_device_copy(int device, const dcx_fk_desc& fk, FkProg** out) {
 // path calls getenv.  -1 = "use the rule".
 struct Knobs {
     std::atomic<int64_t> ys{-1}, nw{-1}, min_rows{-1}, split_finish_kernel{-1}, inlaunch_tiles{-1}, jac_per_class{-1},
-        mfma{-1}, traj_fused{-1}, xf{-1}, jac_one_sweep{-1}, train_grid{-1}, fkk{-1}, jt_waves{-1}, hess_ys{-1}, xm{-1};
+        mfma{-1}, traj_fused{-1}, xf{-1}, jac_one_sweep{-1}, train_grid{-1}, fkk{-1}, jt_waves{-1}, hess_ys{-1}, xm{-1},
+        traj_ys{-1};
     Knobs() {
         auto rd = [](const char* name, std::atomic<int64_t>& dst, bool flag) {
             if (const char* e = std::getenv(name)) dst = flag ? 1 : std::atoll(e);
@@ -260,6 +270,7 @@ struct Knobs {
         rd("DCX_JT_WAVES", jt_waves, false);
         rd("DCX_HESS_YS", hess_ys, false);
         rd("DCX_XM", xm, false);
+        rd("DCX_TRAJ_YS", traj_ys, false);
     }
 };
 Knobs& knobs() {
@@ -381,6 +392,45 @@ float* split_scratch(const dcx_model* m, hipStream_t st, size_t bytes) {
     }
     m->scratch.push_back({st, p, fixed});
     return p;
+}
+
+// This stream's exchange rows for the cluster form of the persistent trajectory kernel, and the tag base of the launch that
+// is about to use them.  Sized once for the largest grid the rule can pick (n_cu workgroups, two parities); null when
+// the buffer cannot be provided now (the stream is being captured, allocation failed): the caller runs one workgroup per path.
+unsigned long long* traj_exchange_rows(const dcx_model* m, hipStream_t st, size_t bytes, uint32_t* tag_base) {
+    std::lock_guard<std::mutex> lock(m->mu);
+    dcx_model::TrajExch* hit = nullptr;
+    for (auto& ex : m->traj_exch)
+        if (ex.stream == st) hit = &ex;
+    if (hit && hit->bytes < bytes) return nullptr;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
+    if (!hit) {
+        const size_t fixed = (size_t)2 * m->n_cu * (m->Dt + 1) * 64 * sizeof(unsigned long long);
+        if (bytes > fixed) return nullptr;
+        unsigned long long* p = nullptr;
+        if (hipMalloc((void**)&p, fixed) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        if (hipMemsetAsync(p, 0, fixed, st) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(p);
+            return nullptr;
+        }
+        m->traj_exch.push_back({st, p, fixed, 0u});
+        hit = &m->traj_exch.back();
+    }
+    if (hit->epoch >= 0x00fffffeu) {  // 2^24 launches: start the tags over on zeroed rows
+        if (hipMemsetAsync(hit->ptr, 0, hit->bytes, st) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        hit->epoch = 0;
+    }
+    hit->epoch += 1;
+    *tag_base = hit->epoch << 8;   // tags tag_base + 1 .. + kTrajFusedMaxIters (< 256) belong to this launch
+    return hit->ptr;
 }
 
 // Which FK walk a launch of this model uses (fk_device.h FkWalk).  DH arms: the step table where the model has one, else
@@ -546,7 +596,7 @@ int dcx_debug_set(const char* name, int64_t value) {
     const std::string n(name);
     std::atomic<int64_t>* dst = n == "ys" ? &k.ys : n == "nw" ? &k.nw : n == "min_rows" ? &k.min_rows
         : n == "split_finish_kernel" ? &k.split_finish_kernel : n == "inlaunch_tiles" ? &k.inlaunch_tiles
-        : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : n == "traj_fused" ? &k.traj_fused : n == "xf" ? &k.xf : n == "jac_one_sweep" ? &k.jac_one_sweep : n == "train_grid" ? &k.train_grid : n == "fkk" ? &k.fkk : n == "jt_waves" ? &k.jt_waves : n == "hess_ys" ? &k.hess_ys : n == "xm" ? &k.xm : nullptr;
+        : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : n == "traj_fused" ? &k.traj_fused : n == "xf" ? &k.xf : n == "jac_one_sweep" ? &k.jac_one_sweep : n == "train_grid" ? &k.train_grid : n == "fkk" ? &k.fkk : n == "jt_waves" ? &k.jt_waves : n == "hess_ys" ? &k.hess_ys : n == "xm" ? &k.xm : n == "traj_ys" ? &k.traj_ys : nullptr;
     if (!dst) return fail(DCX_ERR_INVALID, "unknown knob: " + n);
     *dst = value;
     return DCX_OK;
@@ -746,6 +796,8 @@ void dcx_model_destroy(dcx_model* m) {
     if (m->aplanes_dev) (void)hipFree(m->aplanes_dev);
     for (auto& sc : m->scratch)
         if (sc.ptr) (void)hipFree(sc.ptr);
+    for (auto& ex : m->traj_exch)
+        if (ex.ptr) (void)hipFree(ex.ptr);
     delete m;
 }
 
@@ -928,7 +980,19 @@ int dcx_traj_adam_run(const dcx_model* m, const dcx_traj_state* st, const dcx_tr
         const int d_fk = m->fk.n_points * m->fk.point_dim;
         int nw = std::min(16, m->max_threads / 64);
         if (const int64_t v = knobs().nw; v >= 1) nw = (int)std::min<int64_t>(v, m->max_threads / 64);
-        while (nw > 1 && m->S_active / nw < 15) nw /= 2;
+        // Cluster form (traj_fused.h, round 4): with fewer paths than CUs a path's supports are split over ys workgroups that
+        // exchange their partial rows once per iteration - ys = the power of two that fills the chip, at most 8, and the
+        // sweep's >= 15 supports per wave slice.  Knob traj_ys: 1 = one workgroup per path always, k = k workgroups.
+        int ys = 1;
+        {
+            int64_t want = std::min<int64_t>(8, (int64_t)m->n_cu / std::max(1, st->n_paths));
+            if (const int64_t v = knobs().traj_ys; v >= 1) want = std::min<int64_t>(v, 32);
+            while (2 * ys <= want) ys *= 2;
+            int min_rows = 15;
+            if (const int64_t v = knobs().min_rows; v >= 1) min_rows = (int)v;
+            while (ys > 1 && (m->S_active / (ys * nw) < min_rows || (int64_t)ys * st->n_paths > m->n_cu)) ys /= 2;
+        }
+        while (nw > 1 && m->S_active / (ys * nw) < 15) nw /= 2;
         // the step-table walks on several waves (fk_device.h): chains of <= kDhUnroll steps and >= 4 waves per block
         const bool dh_ok = m->fk.kind == DCX_FK_DH && m->dh_dev && knobs().fkk != 0 && knobs().fkk != 1 && knobs().jt_waves != 0 &&
                            m->dh.n_chains <= 2 && m->dh.end0 <= kDhUnroll && m->dh.n_steps - m->dh.end0 <= kDhUnroll;
@@ -948,7 +1012,8 @@ int dcx_traj_adam_run(const dcx_model* m, const dcx_traj_state* st, const dcx_tr
             a.sc.ts = g_ts_dev;
 #endif
             a.sc.S = m->S_active;
-            a.sc.s_chunk = (m->S_active + nw - 1) / nw;
+            a.s_super = (m->S_active + ys - 1) / ys;
+            a.sc.s_chunk = (a.s_super + nw - 1) / nw;
             a.sc.dof = m->fk.dof;
             a.sc.d_fk = d_fk;
             a.sc.frame_floats = m->frame_floats;
@@ -972,7 +1037,26 @@ int dcx_traj_adam_run(const dcx_model* m, const dcx_traj_state* st, const dcx_tr
                     a.bias1[i] = (float)(1.0 - std::pow((double)opt->beta1, t));
                     a.bias2_sqrt[i] = (float)std::sqrt(1.0 - std::pow((double)opt->beta2, t));
                 }
+                a.ys = 1;
+                if (ys > 1) {
+                    a.exch = traj_exchange_rows(m, (hipStream_t)stream, (size_t)st->n_paths * 2 * ys * (m->Dt + 1) * 64 * sizeof(unsigned long long),
+                                                &a.tag_base);
+                    if (a.exch) a.ys = ys;
+                }
+                if (a.ys != ys) {  // no exchange rows right now: one workgroup per path, the whole support set each
+                    ys = 1;
+                    a.s_super = m->S_active;
+                    a.sc.s_chunk = (m->S_active + nw - 1) / nw;
+                }
                 hipError_t e = fn(m->kf, nw, lds_of(nw), st->n_paths, a, (hipStream_t)stream);
+                if (e != hipSuccess && a.ys > 1) {
+                    // the cooperative launch was refused (the grid does not fit beside what else is resident): nothing ran
+                    (void)hipGetLastError();
+                    ys = a.ys = 1;
+                    a.s_super = m->S_active;
+                    a.sc.s_chunk = (m->S_active + nw - 1) / nw;
+                    e = fn(m->kf, nw, lds_of(nw), st->n_paths, a, (hipStream_t)stream);
+                }
                 if (e != hipSuccess) return fail_hip(e, "fused trajectory launch");
             }
             return DCX_OK;

@@ -151,9 +151,28 @@ hipError_t DCX_CAT(launch_traj_fused_D, DCX_INST_D)(int kf, int nw, size_t lds, 
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
+        if (a.ys > 1) {
+            // the cluster form: the ys workgroups of a path wait for each other once per iteration, so the whole grid must be
+            // resident at once - a cooperative launch checks that and keeps other cooperative grids off the device meanwhile
+            TrajFusedArgs copy = a;
+            void* params[] = {&copy};
+            return hipLaunchCooperativeKernel((const void*)kern, dim3((unsigned)n_paths, (unsigned)a.ys), dim3(64 * nw), params,
+                                              (unsigned int)lds, st);
+        }
         kern<<<dim3((unsigned)n_paths), dim3(64 * nw), lds, st>>>(a);
         return hipGetLastError();
     };
+    if (a.ys > 1) {
+        if constexpr (xf_applies(kD, 1, KF_POLY1)) {
+            if (kf == KF_POLY1 && a.sc.xf) return go_t(traj_fused_kernel<kD, KF_POLY1, kMaxT, true, true>);
+        }
+        switch (kf) {
+        case KF_RQ2: return go_t(traj_fused_kernel<kD, KF_RQ2, kMaxT, false, true>);
+        case KF_POLY1: return go_t(traj_fused_kernel<kD, KF_POLY1, kMaxT, false, true>);
+        case KF_GEN: return go_t(traj_fused_kernel<kD, KF_GEN, kMaxT, false, true>);
+        default: return hipErrorInvalidValue;
+        }
+    }
     if constexpr (xf_applies(kD, 1, KF_POLY1)) {
         if (kf == KF_POLY1 && a.sc.xf) return go_t(traj_fused_kernel<kD, KF_POLY1, kMaxT, true>);
     }

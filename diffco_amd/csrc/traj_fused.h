@@ -31,7 +31,7 @@ namespace dcx {
 #ifdef DCX_TIMING
 #define DCX_TTS(slot)                                                                             \
     do {                                                                                          \
-        if (a.sc.ts && blockIdx.x == 0 && it == 2 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 16) \
+        if (a.sc.ts && blockIdx.x == 0 && blockIdx.y == 0 && it == 2 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 16) \
             a.sc.ts[(slot) * 16 + (threadIdx.x >> 6)] = __builtin_readcyclecounter();             \
     } while (0)
 #else
@@ -67,6 +67,10 @@ struct TrajFusedArgs {
     dcx_traj_opts opt;
     int32_t n_iters;
     int32_t n_points, point_dim, coord_major;
+    // cluster form (traj_fused_kernel<..., CL = true>, gridDim.y = ys): a path's supports split over ys workgroups
+    int32_t ys, s_super;            // block y sweeps supports [y * s_super, (y + 1) * s_super), its waves s_chunk each
+    unsigned long long* exch;       // [n_paths][2 (iteration parity)][ys][D + 1][64] (value, tag) words, see traj_exchange
+    uint32_t tag_base;              // tags of this launch: tag_base + iteration + 1 (unique per launch on this buffer)
     float bias1[kTrajFusedMaxIters];       // 1 - beta1^t          (host double arithmetic, like launch_traj_adam_step)
     float bias2_sqrt[kTrajFusedMaxIters];  // sqrt(1 - beta2^t)
 };
@@ -128,8 +132,104 @@ __device__ __forceinline__ TrajLds traj_lds(float* smem, const A& b, int nw) {
     return l;
 }
 // sR (128 floats): [0] sum of segment lengths^2, [16] max-move excess, [32 .. 32 + 2 dof) joint limits (staged once),
-// [17] hinge excess, [96] flags of the iteration
-constexpr int kTrajLim = 32, kTrajFlags = 96;
+// [17] hinge excess, [96] flags of the iteration; the path's records, read once at the start of the launch, kept here while
+// it iterates and written back once at its end (round 4: as global read-modify-writes of one lane they put a memory round
+// trip in front of a barrier every iteration; in the cluster form every workgroup needs its own copy anyway - all must
+// take the same decisions): [18] lowest loss so far, [19] best valid objective so far, [21] objective at the lowest loss,
+// [22] steps taken (int bits), [97 .. 104] the loss terms of the last step (`stats`);  [20] != 0: an exchange gave up
+constexpr int kTrajLim = 32, kTrajFlags = 96, kTrajLowest = 18, kTrajBestValid = 19, kTrajAbort = 20, kTrajLowestObj = 21,
+              kTrajSteps = 22, kTrajStats = 97;
+
+// ---- the cluster form's exchange (round 4) ---------------------------------------------------------------------------
+// One workgroup per path leaves a 32-restart shard (BASELINE config #5 on 8 GPUs) on 32 of 256 CUs, each spending 3/4 of
+// an iteration in a sweep that 8 CUs could share.  In the cluster form ys workgroups (gridDim.y) own a path TOGETHER: each
+// keeps the whole state of the path in its LDS and runs the whole iteration - FK, path terms, both J^T, Adam, bookkeeping -
+// redundantly and identically, but sweeps only its 1 / ys of the supports.  Once per iteration the ys partial rows (score +
+// feature gradient per waypoint: D + 1 floats x 64 lanes) are exchanged ALL TO ALL through global memory, so every
+// workgroup ends up with the same totals and the iteration needs no second hand-over and no leader:
+//   * a value travels as ONE 8-byte word (value, tag) written with an agent-scope store (write-through to where the
+//     other XCDs read); 8-byte stores are single-copy atomic, so a reader that sees the tag sees the value: no drain, no
+//     arrival counter, no fence - one store and one round of polling loads per iteration;
+//   * tag = tag_base + iteration + 1 is unique per launch and iteration on this buffer (the host hands out tag_base), so
+//     nothing is ever reset; rows alternate between two slots by iteration parity: a workgroup can be at most one
+//     exchange ahead of its slowest peer, which is then still reading the OTHER slot;
+//   * wave w of every workgroup owns accumulator w (w, w + nw, ...): it folds it over the block's nw partial rows
+//     (row 0 first, like fold_partial_rows), publishes it, polls the ys copies and adds them in the order y = 0, 1, ... -
+//     the sums a split launch of the sweep kernel forms (score_kernel.h), so for equal slicing the cluster form is
+//     bit-identical to the two-launch loop as well.  No barrier inside the exchange;
+//   * what does not need the totals - the path terms, phase R1 of J^T - runs BETWEEN publishing and polling (the one-
+//     workgroup form runs it in front of the sweep, where 125 rows per wave hide it; here a wave sweeps 16): by the time
+//     those waves poll, the rows have arrived.
+// The ys workgroups of a path must be resident together: the host launches the grid cooperatively (n_paths * ys <= CUs).
+// A poll that sees nothing for ~1 s gives up: the launch ends with stats[r][7] = -1, the path and its moments as the
+// launch found them (the loss records may have been touched).
+constexpr int kTrajPollLimit = 1 << 19;
+__device__ __forceinline__ unsigned long long traj_pack(float v, uint32_t tag) {
+    return ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
+}
+// first half: fold this wave's accumulators over the block's rows and publish them
+template <int ACC>
+__device__ __forceinline__ void traj_exchange_publish(const float* sRed, unsigned long long* slot /* this path's rows of this parity, + lane */,
+                                                      uint32_t tag, int y, int wave, int lane, int nw) {
+    auto fold_pub = [&](auto nwc) __attribute__((always_inline)) {
+        constexpr int NWC = decltype(nwc)::value;
+        const int nwr = NWC > 0 ? NWC : nw;
+        for (int e = wave; e < ACC; e += nwr) {
+            float v;
+            if constexpr (NWC > 0) {
+                float r[NWC];
+#pragma unroll
+                for (int w = 0; w < NWC; ++w) r[w] = sRed[((size_t)w * ACC + e) * 64 + lane];
+                v = r[0];
+#pragma unroll
+                for (int w = 1; w < NWC; ++w) v += r[w];
+            } else {
+                v = sRed[e * 64 + lane];
+                for (int w = 1; w < nw; ++w) v += sRed[((size_t)w * ACC + e) * 64 + lane];
+            }
+            __hip_atomic_store(slot + ((size_t)y * ACC + e) * 64, traj_pack(v, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    if (nw == 16) fold_pub(std::integral_constant<int, 16>{});
+    else if (nw == 8) fold_pub(std::integral_constant<int, 8>{});
+    else if (nw == 4) fold_pub(std::integral_constant<int, 4>{});
+    else fold_pub(std::integral_constant<int, 0>{});
+}
+// second half: poll the ys copies of each of this wave's accumulators; totals to row 0 of the scratch (only this wave touches
+// accumulator e's slots).  Whatever a wave does between the two halves hides the rows' way through the memory system.
+template <int ACC>
+__device__ __forceinline__ bool traj_exchange_collect(float* sRed, const unsigned long long* slot, uint32_t tag, int ys, int wave, int lane,
+                                                      int nw) {
+    bool ok = true;
+    for (int e = wave; e < ACC; e += nw) {
+        float tot = 0.0f;
+        int spins = 0;
+        for (;;) {
+            tot = 0.0f;
+            bool all = true;
+            for (int y0 = 0; y0 < ys; y0 += 8) {
+                unsigned long long w[8];
+#pragma unroll
+                for (int v = 0; v < 8; ++v)
+                    if (y0 + v < ys) w[v] = __hip_atomic_load(slot + ((size_t)(y0 + v) * ACC + e) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int v = 0; v < 8; ++v)
+                    if (y0 + v < ys) {
+                        all = all && ((uint32_t)(w[v] >> 32) == tag);
+                        tot += __uint_as_float((uint32_t)w[v]);
+                    }
+            }
+            if (__builtin_amdgcn_ballot_w64(!all) == 0) break;
+            if (++spins > kTrajPollLimit) {
+                ok = false;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        sRed[e * 64 + lane] = tot;
+    }
+    return ok;
+}
 
 // The path terms of one lane's waypoint: length / max-move gradient with respect to its control points -> sGp, and the
 // wave's objective / max-move sums -> sR[0], sR[16].  They read the features in LDS only, so the persistent kernel runs
@@ -181,12 +281,13 @@ __device__ __forceinline__ void traj_path_terms(const A& b, const TrajLds& L, in
         if (lane == 0) { L.sR[0] = so; L.sR[16] = sm; }
 }
 
-template <int D, int KF, int MAXT, bool XF = false>
+template <int D, int KF, int MAXT, bool XF = false, bool CL = false>
 __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_fused_kernel(const TrajFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int ACC = D + 1;
     const int r = blockIdx.x;
-    if (a.st.done[r]) return;  // frozen path
+    if (a.st.done[r]) return;  // frozen path (cluster form: the ys workgroups of a path all see the same flag - it is only
+                               // ever written by a workgroup that leaves, and none leaves before all have passed here)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nw = blockDim.x >> 6;
@@ -204,6 +305,14 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
             L.sV[i] = i < n ? a.st.adam_v[base + i] : 0.f;
         }
         if (tid < 2 * dof) L.sR[kTrajLim + tid] = a.st.limits[tid];  // the joint limits never change: read once
+        if (tid == 0) {
+            L.sR[kTrajLowest] = a.st.lowest_loss[r];
+            L.sR[kTrajBestValid] = a.st.best_valid_obj[r];
+            L.sR[kTrajLowestObj] = a.st.lowest_obj[r];
+            L.sR[kTrajSteps] = __int_as_float(a.st.steps[r]);
+            L.sR[kTrajAbort] = 0.0f;
+        }
+        if (tid < 8) L.sR[kTrajStats + tid] = a.st.stats[(size_t)r * 8 + tid];
     }
     __syncthreads();
 
@@ -239,7 +348,7 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
             DCX_TTS(2);
             // What needs the features / frames but not the collision gradient goes in front of the sweep, where the other
             // waves' sweeps hide its latency: the path terms on wave 1, phase R1 of J^T on waves 2 ..
-            if (b.sc.jt_waves && nw > 1) {
+            if (!CL && b.sc.jt_waves && nw > 1) {   // (cluster form: between the two halves of the exchange, below)
                 if (wave == 1) traj_path_terms(b, L, lane);
                 else if (wave >= 2) dh2_vjp_r1_sel(fw.dh, dh, L.sF + lane, L.sJ + lane, wave - 2, 15);
             }
@@ -251,8 +360,15 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
                 for (int k = 0; k < D; ++k) x[k] = (k < d_fk) ? L.sX[k * 64 + lane] : 0.0f;
             }
             // this wave's slice of the supports (the sweep's slicing: wave w takes [w * s_chunk, (w + 1) * s_chunk))
+            if constexpr (CL) {  // ... of this workgroup's share [y * s_super, (y + 1) * s_super) (score_kernel's split slicing)
+                const int ybase = (int)blockIdx.y * b.s_super;
+                const int yend = (ybase + b.s_super < b.sc.S) ? ybase + b.s_super : b.sc.S;
+                j0 = (ybase + wave * b.sc.s_chunk < yend) ? ybase + wave * b.sc.s_chunk : yend;
+                j1 = (j0 + b.sc.s_chunk < yend) ? j0 + b.sc.s_chunk : yend;
+            } else {
             j0 = (wave * b.sc.s_chunk < b.sc.S) ? wave * b.sc.s_chunk : b.sc.S;
             j1 = (j0 + b.sc.s_chunk < b.sc.S) ? j0 + b.sc.s_chunk : b.sc.S;
+            }
             if constexpr (XF) {  // the expanded form works on centred data (score_kernel.h)
                 cfloat_ptr cen = (cfloat_ptr)(uintptr_t)b.sc.centre;
 #pragma unroll
@@ -288,7 +404,7 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
             float col = 0.f;
             const int pwave = (nw > 1 && !tree) ? 1 : 0;
             auto path_terms = [&]() __attribute__((always_inline)) { traj_path_terms(b, L, lane); };
-            if (nw > 1) {
+            if (CL || nw > 1) {
                 // the sweep's parallel cross-wave fold (score_kernel.h): row 0 first, then 1, 2, ...
                 float* mine = L.sRed + (size_t)wave * ACC * 64 + lane;
                 mine[0] = sc[0];
@@ -296,7 +412,18 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
                 for (int k = 0; k < D; ++k) mine[(1 + k) * 64] = gx[k];
                 __syncthreads();
                 DCX_TTS(4);
+                if constexpr (CL) {
+                    unsigned long long* slot = b.exch + ((size_t)(r * 2 + (it & 1)) * b.ys) * ACC * 64 + lane;
+                    const uint32_t tag = b.tag_base + (uint32_t)it + 1u;
+                    traj_exchange_publish<ACC>(L.sRed, slot, tag, (int)blockIdx.y, wave, lane, nw);
+                    if (jt && nw > 1) {
+                        if (wave == 1) traj_path_terms(b, L, lane);
+                        else if (wave >= 2) dh2_vjp_r1_sel(fw.dh, dh, L.sF + lane, L.sJ + lane, wave - 2, 15);
+                    }
+                    if (!traj_exchange_collect<ACC>(L.sRed, slot, tag, b.ys, wave, lane, nw)) L.sR[kTrajAbort] = 1.0f;
+                } else {
                 fold_partial_rows<ACC>(L.sRed, wave, lane, nw);
+                }
                 DCX_TTS(5);
                 DCX_TTS(6);  // (the path terms and phase R1 of J^T ran in front of the sweep)
                 __syncthreads();
@@ -404,23 +531,23 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
                     const float constraint = traj_constraint(b.opt.w_collision, tot3, b.opt.w_max_move, tot1, b.opt.w_joint_limit, tot2);
                     const float loss = objective + constraint;
                     const float gnorm = sqrtf(tot4);
-                    float* st = b.st.stats + (size_t)r * 8;
+                    float* st = L.sR + kTrajStats;   // (to global memory once, after the last iteration)
                     st[0] = loss; st[1] = objective; st[2] = constraint; st[3] = gnorm; st[4] = tot3; st[5] = tot1; st[6] = tot2;
                     st[7] = 0.f;
                     int fl = 0;
-                    if (loss < b.st.lowest_loss[r]) {  // optim.py:107-112 (solution = p AFTER the step)
-                        b.st.lowest_loss[r] = loss;
-                        b.st.lowest_obj[r] = objective;
+                    if (loss < L.sR[kTrajLowest]) {  // optim.py:107-112 (solution = p AFTER the step)
+                        L.sR[kTrajLowest] = loss;
+                        L.sR[kTrajLowestObj] = objective;
                         fl |= 1;
                     }
                     if (constraint <= b.opt.valid_tol) {  // optim.py:113-118
-                        if (objective < b.st.best_valid_obj[r]) {
-                            b.st.best_valid_obj[r] = objective;
+                        if (objective < L.sR[kTrajBestValid]) {
+                            L.sR[kTrajBestValid] = objective;
                             fl |= 2;
                         }
                         if (gnorm < b.opt.grad_tol) fl |= 4;  // optim.py:126-127: the path stops here
                     }
-                    b.st.steps[r] += 1;
+                    L.sR[kTrajSteps] = __int_as_float(__float_as_int(L.sR[kTrajSteps]) + 1);
                     L.sR[kTrajFlags] = __int_as_float(fl);
                 }
             }
@@ -431,7 +558,10 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
             const TrajLds L = traj_lds<D>(smem, b, nw);
             const int W = b.st.n_waypoints, dof = b.sc.dof;
             flags = __float_as_int(L.sR[kTrajFlags]);
-            if (flags & 3) {
+            if constexpr (CL) {
+                if (L.sR[kTrajAbort] != 0.0f) flags = 8;  // an exchange gave up in this workgroup: leave, state untouched
+            }
+            if ((flags & 3) && (!CL || blockIdx.y == 0)) {
                 float* lo = b.st.lowest_path + (size_t)r * W * dof;
                 float* bv = b.st.best_valid_path + (size_t)r * W * dof;
                 for (int i = tid; i < W * dof; i += blockDim.x) {
@@ -442,18 +572,25 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
             }
             DCX_TTS(11);
             // lanes past the path follow its last row (their FK feeds nothing, but keep them finite and in step)
-            if (tid < dof) {
-                for (int l = W; l < 64; ++l) L.sQ[l * dof + tid] = L.sQ[(W - 1) * dof + tid];
-            }
+            for (int i = W * dof + tid; i < 64 * dof; i += blockDim.x) L.sQ[i] = L.sQ[(W - 1) * dof + (i % dof)];
         }
         __syncthreads();
+        if constexpr (CL) {
+            if (flags & 8) {
+                if (tid == 0) a.st.stats[(size_t)r * 8 + 7] = -1.0f;
+                return;
+            }
+        }
         if (flags & 4) {
-            if (tid == 0) a.st.done[r] = 1;
+            if (tid == 0 && (!CL || blockIdx.y == 0)) a.st.done[r] = 1;
             ++it;
             break;
         }
     }
     (void)it;
+    if constexpr (CL) {
+        if (blockIdx.y != 0) return;  // workgroup 0 of the cluster writes the state back
+    }
     // ---- state back to HBM ------------------------------------------------------------------------------------------
     {
         const auto& b = reload_kernargs<TrajFusedArgs>();
@@ -464,6 +601,13 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
             b.st.path[base + i] = L.sQ[i];
             b.st.adam_m[base + i] = L.sM[i];
             b.st.adam_v[base + i] = L.sV[i];
+        }
+        if (tid < 8) b.st.stats[(size_t)r * 8 + tid] = L.sR[kTrajStats + tid];
+        if (tid == 0) {
+            b.st.lowest_loss[r] = L.sR[kTrajLowest];
+            b.st.lowest_obj[r] = L.sR[kTrajLowestObj];
+            b.st.best_valid_obj[r] = L.sR[kTrajBestValid];
+            b.st.steps[r] = __float_as_int(L.sR[kTrajSteps]);
         }
     }
 }

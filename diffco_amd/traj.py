@@ -118,6 +118,10 @@ class ShardedAdamRun:
         lowest_path [R_total, W, dof] on the device) — identical on every rank"""
         from .sharded import all_gather_rows
         t = self.t
+        if self.R and bool((t['stats'][:, 7] < 0).any()):
+            # the cluster form of the persistent kernel (csrc/traj_fused.h) waited ~1 s for a peer workgroup's rows
+            raise _lib.DcxError("dcx_traj_adam_run: a workgroup exchange gave up (stats[:, 7] == -1); the paths were left "
+                                "as the last launch found them.  DCX_TRAJ_YS=1 runs one workgroup per path")
         summ = torch.stack([t['best_valid_obj'], t['lowest_loss'], t['lowest_obj'], t['steps'].float()], dim=1)
         bvp, lop = t['best_valid_path'], t['lowest_path']
         if self.sharded and self.world > 1:

@@ -286,6 +286,46 @@ def test_adam_and_slsqp_on_the_hip_path():
                                         torch.from_numpy(d["target"]), dict(opts, constraint_hessian="fused"))
 
 
+def test_scipy_constraint_and_drivers_against_the_reference_fixture():
+    """row f4 pinned to the REFERENCE (tools/make_golden.py gen_optim_scipy): the fused route of `_ScipyTerms` - constraint
+    values from the HIP score, the Jacobian assembled from one hinge-gradient launch, the Hessian from dcx_score_hess -
+    against the reference's con_collision_free / jac_con_collision_free / hess_con_collision_free at the initial path
+    (optim.py:190-218, 380-391), and both scipy drivers against the records the reference's drivers produced
+    (optim.py:166-321, 324-516: cost, solution, cnt_check)"""
+    from diffco_amd import kernel, optim
+    from diffco_amd.kernel_perceptrons import DiffCo
+    d = load("optim_scipy_baxter")
+    rob = make_robot("baxter_left")
+    dc = DiffCo(transform=rob.fkine)
+    dc.support_points = torch.from_numpy(d["sup_q"])
+    dc.support_transformed = rob.fkine(dc.support_points)
+    dc.rbf_kernel, dc.rbf_nodes = kernel.Polyharmonic(1, 1.0), torch.from_numpy(d["weights"])
+    start, target, init = (torch.from_numpy(d[k]).double() for k in ("start", "target", "init"))
+    opts = {"N_WAYPOINTS": len(init), "NUM_RE_TRIALS": 1, "MAXITER": int(d["slsqp_maxiter"]), "safety_margin": float(d["margin"]),
+            "max_speed": float(d["max_speed"]), "seed": 4321, "history": False, "extra_optimizer_options": {"disp": False},
+            "init_solution": init.clone()}
+    prob = optim._PathProblem(rob, start, target, dict(opts))
+    prob.make_init(0)
+    terms = optim._ScipyTerms(prob, dc.poly_score)
+    assert terms._fused_model() is not None
+    x = prob.init_path[1:-1].reshape(-1).numpy()
+    n_dense = int(d["n_dense"])
+    c = terms.collision(x)
+    assert relerr(c, d["con0_f64"]) < 1e-5 and relerr(c, d["con0_ref"]) < 2e-5 and prob.cnt_check == n_dense
+    J = terms.jac_collision(x)
+    assert relerr(J, d["jac0_f64"]) < 1e-5 and relerr(J, d["jac0_ref"]) < 2e-5 and prob.cnt_check == 2 * n_dense
+    H = terms.hess_collision(x, d["v"])
+    assert relerr(H, d["hess0_f64"]) < 5e-5 and relerr(H, d["hess0_ref"]) < 5e-5 and prob.cnt_check == 3 * n_dense
+    rec = optim.givengrad_traj_optimize(rob, dc.poly_score, start, target, dict(opts))
+    assert rec["success"] == bool(d["slsqp_success"]) and rec["cnt_check"] == int(d["slsqp_cnt_check"])
+    assert abs(rec["cost"] - float(d["slsqp_cost"])) < 1e-3 * float(d["slsqp_cost"])
+    assert relerr(np.array(rec["solution"]), d["slsqp_solution"]) < 1e-3
+    rec = optim.trustconstr_traj_optimize(rob, dc.poly_score, start, target, dict(opts, MAXITER=int(d["tc_maxiter"])))
+    assert rec["success"] == bool(d["tc_success"]) and rec["cnt_check"] == int(d["tc_cnt_check"])
+    assert abs(rec["cost"] - float(d["tc_cost"])) < 1e-3 * float(d["tc_cost"])
+    assert relerr(np.array(rec["solution"]), d["tc_solution"]) < 1e-3
+
+
 def test_device_trainer_equals_host_trainer_and_reference(monkeypatch):
     """f1: the persistent-workgroup trainer (dcx_train_perceptron) walks the same sequence as the host loop — same
     supports in the same order as the reference's model — for the single- and the multi-class perceptron."""

@@ -60,13 +60,13 @@ def test_distributed_code_path_on_one_rank(extra):
         assert m["gather"] == "none" and m["gather_ms"] is None
     else:
         assert m["gather_ms"] is not None and m["gather_ms"] > 0
-        # the default is the graph-captured overlapped gather; where the collective cannot be captured it says "per-call"
-        assert m["gather"] in ((extra[extra.index("--gather") + 1],) if "--gather" in extra else ("graph", "per-call"))
+        # the default is the in-order per-call gather (always works); the captured form is a variant, measured last
+        assert m["gather"] == (extra[extra.index("--gather") + 1] if "--gather" in extra else "per-call")
     if "--no-variants" not in extra:
         v = d["variants"]
         assert v["other_scaling"]["scaling"] == ("weak" if "strong" in extra else "strong") and v["other_scaling"]["value"] > 0
         if "cfg5" not in extra:
-            asked = extra[extra.index("--gather") + 1] if "--gather" in extra else "graph"
+            asked = extra[extra.index("--gather") + 1] if "--gather" in extra else "per-call"
             assert {k for k in v if k.startswith("gather_")} == {f"gather_{g}" for g in ("graph", "per-call", "overlapped", "bucketed", "none")
                                                                   if g != asked}
             assert "gather_exposed_ms" in m
@@ -79,7 +79,11 @@ def test_headline_line_carries_every_baseline_config():
     that runs on a GPU"""
     d = _run(["--no-cpu-baseline"], steps=10, warmup=3, timeout=900)
     cf = d["configs"]
-    assert set(cf) == {"cfg2", "cfg2_panda", "cfg3", "cfg3_poly", "cfg4", "cfg5"}
+    assert set(cf) == {"cfg2", "cfg2_panda", "cfg3", "cfg3_b65536", "cfg3_poly", "cfg4", "cfg5", "cfg5_shard32", "headline_rq"}
+    assert cf["cfg5_shard32"]["batch"] == 32 * 50 and cf["cfg3_b65536"]["batch"] == 65536
+    # the 8-GPU shard of config #5 runs its paths on several workgroups each (cluster form): well under the 256-restart time
+    assert cf["cfg5_shard32"]["ms_per_step"] < 0.7 * cf["cfg5"]["ms_per_step"]
+    assert d["settle_steps"] > 0
     for name, c in cf.items():
         assert "error" not in c, (name, c)
         assert c["value"] > 0 and 0 < c["frac"] < 1 and c["kernel_ms"] <= c["ms_per_step"] * 1.05, (name, c)
@@ -119,3 +123,34 @@ def test_two_rank_rehearsal_on_one_gpu(extra):
     else:
         assert cfg["global_batch"] == 2 * cfg["batch_per_gpu"] == 2 * 65536
     assert d["variants"]["other_scaling"]["value"] > 0
+
+
+def _one_line(stdout):
+    lines = [ln for ln in stdout.split("\n") if ln.strip().startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+def test_the_line_survives_an_abort_after_the_timed_region():
+    """fault injection: the process is aborted - as a library thread would, no Python clean-up - right
+    after the timed region, before any variant: the keeper process still prints the primary line, exactly once"""
+    env = dict(os.environ, MASTER_PORT="29549", DCX_BENCH_FAULT="after_primary")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "3", "--force-dist", "--batch", "4096"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode != 0
+    d = _one_line(r.stdout)
+    assert KEYS <= set(d) and d["n_gpus"] == 1 and d["multi"]["ranks"] == 1 and d["value"] > 0
+    assert d["cpu_baseline"]["value"] > 0 and "variants" not in d
+
+
+def test_two_rank_line_survives_an_abort_inside_the_graph_capture():
+    """the same with two ranks launched as the driver launches them, the abort INSIDE the construction of the captured
+    gather - the last variant: one valid line with the primary numbers (n_gpus, multi.ranks), no variants"""
+    env = dict(os.environ, DCX_BENCH_SAME_GPU="1", DCX_BENCH_FAULT="capture")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29877", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12",
+                        "--warmup", "2", "--batch", "8192"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode != 0
+    d = _one_line(r.stdout)
+    assert (KEYS - {"cpu_baseline"}) <= set(d) and d["n_gpus"] == 2 and d["multi"]["ranks"] == 2 and d["value"] > 0
+    assert d["multi"]["gather"] == "per-call" and "variants" not in d

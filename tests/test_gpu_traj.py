@@ -273,6 +273,7 @@ def test_persistent_launch_is_bit_identical_to_the_two_launch_loop(robot_name, R
     outs = []
     knob("nw", 16)
     knob("ys", 1)
+    knob("traj_ys", 1)
     for fused in (0, 1):
         knob("traj_fused", fused)
         st, bufs = _traj_state(model, rob, paths)
@@ -289,3 +290,82 @@ def test_persistent_launch_is_bit_identical_to_the_two_launch_loop(robot_name, R
     assert torch.equal(a["path"][:, 0].cpu(), paths[:, 0]) and torch.equal(a["path"][:, -1].cpu(), paths[:, -1])
     if robot_name == "baxter_left" and R == 7:
         assert int(a["done"].sum()) >= 0
+
+
+@pytest.mark.parametrize("robot_name,R,W,iters,S,ys", [("baxter_left", 32, 50, 200, 2000, 8), ("baxter_left", 7, 20, 40, 500, 2),
+                                                       ("baxter_left", 64, 50, 30, 2000, 4), ("panda", 5, 33, 30, 1000, 4),
+                                                       ("planar3", 5, 64, 25, 600, 2), ("se3", 4, 33, 25, 300, 2),
+                                                       ("urdf_panda", 6, 30, 30, 1000, 4)])
+def test_cluster_form_is_bit_identical_to_the_two_launch_loop(robot_name, R, W, iters, S, ys, knob):
+    """the persistent launch with a path's supports split over ys workgroups (traj_fused.h, cluster form: config #5's
+    8-GPU shard of 32 restarts on all 256 CUs) against the two-launch loop whose sweep is split the same way: same
+    slices, same order of the sums -> every output bit-identical, early stops included"""
+    import ctypes as C
+    from diffco_amd import _lib, _ops
+    from helpers import urdf_robot
+    rob = urdf_robot(robot_name) if robot_name.startswith("urdf_") else make_robot(robot_name)
+    lib = _lib.require_gpu()
+    g = torch.Generator().manual_seed(S + ys)
+    lim = rob.limits
+    sup_q = torch.rand((S, rob.dof), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]
+    desc = rob.fk_desc()
+    sup = _ops.fkine(desc, sup_q.cuda()).reshape(S, -1)
+    model = _ops.ScoreModel(desc, 1, 1.0, 1.0, sup, (0.02 * torch.randn(S, generator=g)).cuda())
+    paths = _random_paths(rob, R, W, seed=R * W + ys)
+    s0, _ = model.score_grad_raw(paths.reshape(-1, rob.dof).cuda())
+    opt = _lib.TrajOpts(0.02, 0.9, 0.999, 1e-8, 1, 10, 10, 10, float(s0.median()), 0.3, 1e9, 0.35)
+    outs = []
+    knob("nw", 16)   # (clamped to the width's block-size ceiling by both forms)
+    knob("ys", ys)
+    knob("traj_ys", ys)
+    for fused in (0, 1):
+        knob("traj_fused", fused)
+        st, bufs = _traj_state(model, rob, paths)
+        stream = C.c_void_p(torch.cuda.current_stream(model.dev).cuda_stream)
+        _lib.check(lib.dcx_traj_adam_run(model._h, C.byref(st), C.byref(opt), 1, iters - 7, stream))
+        _lib.check(lib.dcx_traj_adam_run(model._h, C.byref(st), C.byref(opt), iters - 6, 7, stream))  # resumes mid-run
+        torch.cuda.synchronize()
+        outs.append({k: v.clone() for k, v in bufs.items() if k not in ("col_score", "col_grad", "limits")})
+    a, b = outs
+    assert float(b["stats"][:, 7].min()) == 0.0   # no exchange gave up
+    assert int(a["steps"].min()) >= 1 and int(a["steps"].max()) == iters
+    for k in a:
+        assert torch.equal(a[k], b[k]), (k, float((a[k].float() - b[k].float()).abs().max()))
+    assert float((a["path"].cpu() - paths).abs().max()) > 1e-3
+
+
+def test_cluster_form_agrees_with_one_workgroup_per_path(knob):
+    """the rule's choice for a 32-restart shard (8 workgroups per path) against one workgroup per path: a different order
+    of the support sums, so not bitwise - the loss terms of the first iteration agree to fp32 rounding, the first Adam
+    step (lr * sign(g) wherever |g| >> eps) moves the same waypoints the same way"""
+    import ctypes as C
+    from diffco_amd import _lib, _ops
+    rob = make_robot("baxter_left")
+    lib = _lib.require_gpu()
+    g = torch.Generator().manual_seed(11)
+    lim = rob.limits
+    S, R, W, lr = 2000, 32, 50, 0.002
+    sup_q = torch.rand((S, rob.dof), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]
+    desc = rob.fk_desc()
+    sup = _ops.fkine(desc, sup_q.cuda()).reshape(S, -1)
+    model = _ops.ScoreModel(desc, 1, 1.0, 1.0, sup, (0.02 * torch.randn(S, generator=g)).cuda())
+    paths = _random_paths(rob, R, W, seed=3)
+    s0, _ = model.score_grad_raw(paths.reshape(-1, rob.dof).cuda())
+    opt = _lib.TrajOpts(lr, 0.9, 0.999, 1e-8, 1, 10, 10, 10, float(s0.median()), 0.3, 1e9, 0.0)
+    outs = []
+    for tys in (1, -1):
+        knob("traj_ys", tys)
+        st, bufs = _traj_state(model, rob, paths)
+        stream = C.c_void_p(torch.cuda.current_stream(model.dev).cuda_stream)
+        _lib.check(lib.dcx_traj_adam_run(model._h, C.byref(st), C.byref(opt), 1, 1, stream))
+        torch.cuda.synchronize()
+        outs.append({k: v.clone() for k, v in bufs.items()})
+    a, b = outs
+    assert float(b["stats"][:, 7].min()) == 0.0
+    # (a waypoint whose score sits on the margin can fall on either side of the hinge: its gradient enters |grad| or not)
+    assert relerr(b["stats"][:, :7].cpu().numpy(), a["stats"][:, :7].cpu().numpy()) < 1e-4
+    assert relerr(b["stats"][:, 1].cpu().numpy(), a["stats"][:, 1].cpu().numpy()) < 1e-6   # the path length does not see the sweep
+    moved = (a["path"] - b["path"]).abs().cpu()
+    assert float(moved.max()) <= 2.0 * lr * 1.001              # a step is at most lr either way
+    assert float((moved > 1e-6).float().mean()) < 1e-3         # and all but a few sign-of-a-tiny-gradient entries agree
+    assert torch.equal(a["steps"], b["steps"])

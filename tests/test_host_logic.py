@@ -316,3 +316,83 @@ def test_constraint_hessian_from_point_hessians_matches_double_backward():
             raise _lib.DcxUnsupported("frames do not fit")
     Hc = terms._hess_collision_fused(x, torch.from_numpy(v), NoHess())
     assert np.abs(Hc - Hb).max() < 1e-5 * np.abs(Hb).max()  # step^2 / 6 truncation of the central difference
+
+
+def _scipy_fixture():
+    """the SLSQP / trust-constr fixture (tools/make_golden.py gen_optim_scipy: the reference's drivers and their collision
+    constraint, optim.py:166-516) with a float64 torch restatement of its model"""
+    from diffco_amd import optim
+    d = load("optim_scipy_baxter")
+    rob = TorchDHRobot(make_robot("baxter_left"))
+    sup = rob.fkine(torch.from_numpy(d["sup_q"]).double()).reshape(len(d["sup_q"]), -1)
+    w = torch.from_numpy(d["weights"]).double()
+    kern = TorchKernel("poly1", 1, 1.0)
+    dist_est = lambda p: kern(rob.fkine(p).reshape(len(p), -1), sup) @ w[:, None]
+    start, target, init = (torch.from_numpy(d[k]).double() for k in ("start", "target", "init"))
+    opts = {"N_WAYPOINTS": len(init), "NUM_RE_TRIALS": 1, "MAXITER": int(d["slsqp_maxiter"]), "safety_margin": float(d["margin"]),
+            "max_speed": float(d["max_speed"]), "seed": 4321, "history": False, "extra_optimizer_options": {"disp": False},
+            "init_solution": init.clone()}
+    prob = optim._PathProblem(rob, start, target, dict(opts))
+    prob.make_init(0)
+    return d, rob, dist_est, start, target, opts, prob
+
+
+def test_scipy_constraint_terms_against_the_reference_fixture():
+    """row f4: `_ScipyTerms.collision / jac_collision / hess_collision` (autograd route, float64 dist_est) against the
+    reference's con_collision_free, its Jacobian and the Hessian of v . con at the initial path (optim.py:190-218,
+    380-391); `cnt_check` advances by len(dense path) per evaluation as the reference's counter does (:197)"""
+    from diffco_amd import optim
+    d, rob, dist_est, start, target, opts, prob = _scipy_fixture()
+    terms = optim._ScipyTerms(prob, dist_est)
+    x = prob.init_path[1:-1].reshape(-1).numpy()
+    n_dense = int(d["n_dense"])
+    c = terms.collision(x)
+    assert prob.cnt_check == n_dense
+    assert (c < 0).sum() == (d["con0_f64"] < 0).sum() >= 3          # an active constraint
+    assert relerr(c, d["con0_f64"]) < 1e-12 and relerr(c, d["con0_ref"]) < 2e-5
+    J = terms.jac_collision(x)
+    assert prob.cnt_check == 2 * n_dense
+    assert J.shape == d["jac0_f64"].shape and relerr(J, d["jac0_f64"]) < 1e-12 and relerr(J, d["jac0_ref"]) < 2e-5
+    H = terms.hess_collision(x, d["v"])
+    assert prob.cnt_check == 3 * n_dense
+    assert H.shape == d["hess0_f64"].shape and relerr(H, d["hess0_f64"]) < 1e-11 and relerr(H, d["hess0_ref"]) < 5e-5
+
+
+def test_scipy_drivers_reproduce_the_reference_records():
+    """row f4: givengrad_traj_optimize (SLSQP) and trustconstr_traj_optimize on the float64 restatement of the model walk
+    the iterations the reference's drivers walked (optim.py:166-321, 324-516): same cnt_check, cost, solution"""
+    from diffco_amd import optim
+    d, rob, dist_est, start, target, opts, _ = _scipy_fixture()
+    rec = optim.givengrad_traj_optimize(rob, dist_est, start, target, dict(opts))
+    assert rec["success"] == bool(d["slsqp_success"]) and rec["cnt_check"] == int(d["slsqp_cnt_check"])
+    assert abs(rec["cost"] - float(d["slsqp_cost"])) < 1e-5 * float(d["slsqp_cost"])
+    assert relerr(np.array(rec["solution"]), d["slsqp_solution"]) < 1e-5
+    rec = optim.trustconstr_traj_optimize(rob, dist_est, start, target,
+                                          dict(opts, MAXITER=int(d["tc_maxiter"]), constraint_hessian="autograd"))
+    assert rec["success"] == bool(d["tc_success"]) and rec["cnt_check"] == int(d["tc_cnt_check"])
+    assert abs(rec["cost"] - float(d["tc_cost"])) < 1e-5 * float(d["tc_cost"])
+    assert relerr(np.array(rec["solution"]), d["tc_solution"]) < 1e-5
+
+
+def test_fused_constraint_jacobian_chain_rule_on_the_oracle():
+    """row f4: `_jac_collision_fused` - the constraint Jacobian assembled from ONE hinge-gradient evaluation over the dense
+    path, chained through dense_n = p_i + k * max_step * unit(p_{i+1} - p_i) - against the reference's Jacobian, with the
+    C oracle standing in for the HIP launch (the GPU test runs the same comparison through libdcx)"""
+    from diffco_amd import optim
+    from oracle import oracle
+    d, rob, dist_est, start, target, opts, prob = _scipy_fixture()
+    desc = make_robot("baxter_left").fk_desc()
+    sup32 = oracle.fkine(desc, d["sup_q"].astype(np.float64), dtype=np.float64).reshape(len(d["sup_q"]), -1)
+
+    class OracleModel:
+        dev, C = torch.device("cpu"), 1
+
+        def score_hinge_grad_raw(self, q, margin, weight):
+            s, g, _ = oracle.score_grad(desc, 1, 1.0, 1.0, sup32, d["weights"].astype(np.float64).reshape(-1, 1),
+                                        q.double().numpy(), dtype=np.float64)
+            mask = ((s[:, 0] - margin) > 0) * weight
+            return torch.from_numpy(s), torch.from_numpy(g * mask[:, None])
+    terms = optim._ScipyTerms(prob, dist_est)
+    x = prob.init_path[1:-1].reshape(-1).numpy()
+    J = terms._jac_collision_fused(x, OracleModel())
+    assert relerr(J, d["jac0_f64"]) < 2e-6   # (the dense points travel as fp32 to the launch)

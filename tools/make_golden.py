@@ -633,6 +633,87 @@ def gen_optim(out, robots):
          dense_2p0=R.utils.dense_path(path, 2.0))
 
 
+def gen_optim_scipy(out, robots):
+    """Row f4: the reference's SLSQP and trust-constr drivers (optim.py:166-321, 324-516) run end to end on
+    dc.poly_score with `init_solution`, and the collision constraint they build - con_collision_free (:190-207), its
+    Jacobian (:209-218) and the Hessian of v . con (:380-391) - re-evaluated at the initial path through the imported
+    reference dist_est / utils.dense_path (the drivers' closures cannot be called from outside).  The constraint is
+    stored twice: through the reference's own fp32 dist_est (poly_score casts its input, kernel_perceptrons.py:313) and
+    through the same model held in float64 (the tolerance referee)."""
+    gen = torch.Generator().manual_seed(601)
+    rob = robots["baxter_left"]
+    S = 300
+    sup_q = rand_cfgs(rob, S, gen)
+    w = torch.randn(S, generator=gen) * 0.05
+    dc = new_diffco(rob, "poly", (1, 1.0), sup_q, w, "poly")
+    # the same model in float64 (reference classes, double state)
+    dc64 = R.kernel_perceptrons.DiffCo(kernel_func="rq", transform=rob.fkine)
+    dc64.support_points = sup_q.double()
+    dc64.support_transformed = rob.fkine(sup_q.double())
+    dc64.rbf_kernel = make_kernel("poly", (1, 1.0))
+    dc64.rbf_nodes = w.double()
+    start, target = rand_cfgs(rob, 1, gen)[0], rand_cfgs(rob, 1, gen)[0]
+    n_wp, max_speed = 12, 0.3
+    t = torch.linspace(0, 1, n_wp)[:, None].double()
+    init = start.double() * (1 - t) + target.double() * t
+    init[1:-1] += 0.05 * torch.randn((n_wp - 2, 7), generator=gen).double()
+    dense = R.utils.dense_path(init, max_speed)
+    with torch.no_grad():
+        s_dense = dc64.poly_score(dense[1:-1]).reshape(-1)
+    margin = float(s_dense.quantile(0.4))   # ~60 % of the dense points violate the margin: an active constraint
+
+    def con(p, dist_est):  # optim.py:190-207 with return_tensor=True
+        dense_p = R.utils.dense_path(p, max_speed)
+        cost = -(dist_est(dense_p[1:-1]) - margin)
+        cost = torch.clamp(cost, max=0).reshape(-1)
+        n_segment, n_point = len(p) - 1, len(dense_p) - 2
+        mult = n_point // n_segment
+        if n_point % n_segment != 0:
+            mult += 1
+            cost = torch.cat([cost, torch.zeros(n_segment * mult - n_point, dtype=cost.dtype)])
+        return cost.reshape(n_segment, -1).sum(dim=1)
+
+    vvec = torch.rand(n_wp - 1, generator=gen).double()
+    pieces = {}
+    for tag, de in (("ref", dc.poly_score), ("f64", dc64.poly_score)):
+        p = init.clone().requires_grad_(True)
+        c0 = con(p, de).detach()
+        jac = torch.autograd.functional.jacobian(lambda x: con(x, de), p, create_graph=False, strict=False,
+                                                 vectorize=True, strategy="reverse-mode")
+        jac = jac[:, 1:-1].reshape(jac.shape[0], -1)                       # optim.py:217-218
+        vv = vvec.to(c0.dtype)
+        hess = torch.autograd.functional.hessian(lambda x: torch.dot(con(x, de), vv), p, create_graph=False, strict=False,
+                                                 vectorize=True, outer_jacobian_strategy="reverse-mode")
+        hess = hess[1:-1, :, 1:-1, :].reshape((n_wp - 2) * 7, -1)          # optim.py:389-390
+        pieces[tag] = (c0.double(), jac.double(), hess.double())
+    print(f"  constraint at the initial path: {int((pieces['f64'][0] < 0).sum())} of {n_wp - 1} segments active, "
+          f"fp32-vs-fp64 jac {float((pieces['ref'][1] - pieces['f64'][1]).abs().max() / pieces['f64'][1].abs().max()):.2e}, "
+          f"hess {float((pieces['ref'][2] - pieces['f64'][2]).abs().max() / pieces['f64'][2].abs().max()):.2e}")
+    options = {"N_WAYPOINTS": n_wp, "NUM_RE_TRIALS": 1, "MAXITER": 12, "safety_margin": margin, "max_speed": max_speed,
+               "seed": 4321, "history": False, "extra_optimizer_options": {"disp": False}}
+    recs = {}
+    for name, fn in (("slsqp", R.optim.givengrad_traj_optimize), ("trustconstr", R.optim.trustconstr_traj_optimize)):
+        o = dict(options, init_solution=init.clone())
+        if name == "trustconstr":
+            o["MAXITER"] = 6
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            rec = fn(rob, dc.poly_score, start.double(), target.double(), o)
+        recs[name] = rec
+        print(f"  {name}: success={rec['success']} cost={float(rec['cost']):.6f} cnt_check={rec['cnt_check']}")
+    save(out, "optim_scipy_baxter", sup_q=sup_q, weights=w, start=start, target=target, init=init, margin=np.array(margin),
+         max_speed=np.array(max_speed), n_dense=np.array(len(dense)), v=vvec,
+         con0_ref=pieces["ref"][0], jac0_ref=pieces["ref"][1], hess0_ref=pieces["ref"][2],
+         con0_f64=pieces["f64"][0], jac0_f64=pieces["f64"][1], hess0_f64=pieces["f64"][2],
+         slsqp_solution=np.array(recs["slsqp"]["solution"]), slsqp_cost=np.array(float(recs["slsqp"]["cost"])),
+         slsqp_cnt_check=np.array(recs["slsqp"]["cnt_check"]), slsqp_success=np.array(recs["slsqp"]["success"]),
+         slsqp_maxiter=np.array(12),
+         tc_solution=np.array(recs["trustconstr"]["solution"]), tc_cost=np.array(float(recs["trustconstr"]["cost"])),
+         tc_cnt_check=np.array(recs["trustconstr"]["cnt_check"]), tc_success=np.array(recs["trustconstr"]["success"]),
+         tc_maxiter=np.array(6))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
@@ -654,6 +735,8 @@ def main():
         print("old single-class API"); gen_old_single(out, robots)
     if args.only in (None, "all", "hess"):
         print("second derivatives"); gen_hess(out, robots)
+    if args.only in (None, "all", "optim_scipy"):
+        print("SLSQP / trust-constr drivers and their collision constraint"); gen_optim_scipy(out, robots)
     with open(os.path.join(out, "MANIFEST.json"), "w") as f:
         json.dump({"generator": "tools/make_golden.py", "torch": torch.__version__, "numpy": np.__version__,
                    "reference": "ucsdarclab/diffco @ /root/reference (2025-03-21)",

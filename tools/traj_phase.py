@@ -13,8 +13,9 @@ from diffco_amd import _lib  # noqa: E402
 
 lib = _lib.require_gpu()
 dev = torch.device("cuda", 0)
-w = bench.make_workload("cfg5", 256 * 50, dev)
-tst, topt, bufs = bench.traj_state(w, 256, 50, dev)
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 256   # 32: the cluster form (8 workgroups per path), stamps of workgroup (0, 0)
+w = bench.make_workload("cfg5", R * 50, dev)
+tst, topt, bufs = bench.traj_state(w, R, 50, dev)
 st = Ct.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 _lib.check(lib.dcx_traj_adam_run(w["model"]._h, Ct.byref(tst), Ct.byref(topt), 1, 8, st))
 torch.cuda.synchronize()
@@ -22,7 +23,7 @@ n = lib.dcx_debug_ts_words()
 buf = (Ct.c_ulonglong * n)()
 lib.dcx_debug_read_ts.argtypes = [Ct.POINTER(Ct.c_ulonglong)]
 assert lib.dcx_debug_read_ts(buf) == 0
-names = ["iteration start", "after trig+barrier", "after chain+barrier", "after sweep", "partials+barrier", "after fold",
+names = ["iteration start", "after trig+barrier", "after chain+barrier", "after sweep", "partials+barrier", "after fold / exchange",
          "after path terms / R1", "barrier", "after R1b+barrier", "after R2", "barrier", "after Adam"]
 t0 = buf[0]
 for slot, nm in enumerate(names):
