@@ -37,6 +37,8 @@ SYMBOLS = {
     "dcx_traj_adam_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "dcx_train_perceptron": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_float), C.c_float, _c_fp, C.c_int64, C.c_int32, _c_fp,
                                        C.c_int32, _c_fp, _c_fp, _c_fp, C.c_int32, _c_fp, C.c_void_p]),
+    "dcx_train_perceptron_ex": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_float), C.c_float, _c_fp, C.c_int64, C.c_int32, _c_fp,
+                                          C.c_int32, _c_fp, _c_fp, _c_fp, C.c_int32, _c_fp, C.c_int32, C.c_void_p]),
     "dcx_fkine": (C.c_int, [C.c_int, C.POINTER(FkDesc), _c_fp, C.c_int64, _c_fp, C.c_void_p]),
     "dcx_fkine_vjp": (C.c_int, [C.c_int, C.POINTER(FkDesc), _c_fp, _c_fp, C.c_int64, _c_fp, C.c_void_p]),
     "dcx_kernel_matrix": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_float), _c_fp, C.c_int64, _c_fp, C.c_int64,

@@ -114,26 +114,23 @@ def train_perceptron_device(kind, p0, p1, beta, feats, y, gains, hypo, K, max_it
     shape = tuple(y.shape)
     yy = _f32(y.reshape(N, -1), dev)
     Cn = yy.shape[1]
-    def run():
+    def run(flags):
         g = _f32(gains.reshape(N, -1), dev).clone()
         h = _f32(hypo.reshape(N, -1), dev).clone()
         Kd = torch.zeros((N, N), device=dev, dtype=torch.float32) if K is None else _f32(K, dev).clone()
         info = torch.zeros(2, device=dev, dtype=torch.int32)
         with torch.cuda.device(dev):
-            _lib.check(lib.dcx_train_perceptron(dev.index, kind, _kparams(p0, p1), float(beta), _ptr(f), N, D, _ptr(yy), Cn,
-                                                _ptr(g), _ptr(h), _ptr(Kd), int(max_iteration), _ptr(info), _stream(dev)))
+            _lib.check(lib.dcx_train_perceptron_ex(dev.index, kind, _kparams(p0, p1), float(beta), _ptr(f), N, D, _ptr(yy), Cn,
+                                                   _ptr(g), _ptr(h), _ptr(Kd), int(max_iteration), _ptr(info), flags, _stream(dev)))
         it, conv = (int(v) for v in info.tolist())
         return g, h, Kd, it, conv
 
-    g, h, Kd, it, conv = run()
+    g, h, Kd, it, conv = run(0)
     if conv < 0:
         # a grid-wide barrier of the multi-workgroup trainer gave up (another kernel holding CUs for seconds): the run's
-        # buffers are copies, so the whole training simply runs again on the one-workgroup kernels
-        _lib.check(lib.dcx_debug_set(b"train_grid", 0))
-        try:
-            g, h, Kd, it, conv = run()
-        finally:
-            _lib.check(lib.dcx_debug_set(b"train_grid", -1))
+        # buffers are copies, so the whole training simply runs again on the one-workgroup kernels - asked for per call
+        # (DCX_TRAIN_ONE_WORKGROUP), not through the process-wide knob other threads and the tests may have set
+        g, h, Kd, it, conv = run(1)
         if conv < 0:
             raise _lib.DcxError("dcx_train_perceptron: the trainer did not complete")
     return g.reshape(shape), h.reshape(shape), Kd, it, bool(conv)

@@ -720,7 +720,7 @@ int dcx_model_create(dcx_model** out, int device, const dcx_fk_desc* fk, int ker
         // coordinate s - c formed in fp32 exactly as the kernel forms x - c, so that a query that coincides with a support
         // still gives r = 0 exactly
         std::vector<float> centre(m->Dt, 0.0f), rows_xf(rows);
-        rows_xf.resize(rows.size() + 64, 0.0f);
+        rows_xf.resize(rows.size() + 8 * (size_t)m->RS + 16, 0.0f);  // the same tail padding as `rows` below: the two are interchangeable
         const int ss_off = m->Dt + C + (C > 1 ? 1 : 0);
         if (m->fk.kind != DCX_FK_NONE) {
             for (int k = 0; k < D; ++k) {
@@ -846,6 +846,14 @@ int dcx_score_hess(const dcx_model* m, const float* q, int64_t B, const float* u
     if (B < 0 || (B > 0 && (!q || !hess))) return fail(DCX_ERR_INVALID, "q / hess is NULL or B < 0");
     if (int rc = set_device(m->device)) return rc;
     if (B == 0) return DCX_OK;
+    if (m->S_active == 0) {
+        // a model whose weights are all zero (max_num_supports padding before training): the score is identically zero, and
+        // so are its derivatives - nothing to sweep, and no slice size to derive the launch geometry from
+        const size_t dof = (size_t)m->fk.dof;
+        DCX_HIP(hipMemsetAsync(hess, 0, (size_t)B * dof * dof * sizeof(float), (hipStream_t)stream));
+        if (grad) DCX_HIP(hipMemsetAsync(grad, 0, (size_t)B * dof * sizeof(float), (hipStream_t)stream));
+        return DCX_OK;
+    }
     ModelView v{};
     v.rows = m->rows_dev;
     v.fk = m->fk_dev;
@@ -1079,6 +1087,13 @@ int dcx_traj_adam_run(const dcx_model* m, const dcx_traj_state* st, const dcx_tr
 int dcx_train_perceptron(int device, int kernel_kind, const float* kparams, float beta, const float* feats, int64_t N,
                          int32_t D, const float* y, int32_t C, float* gains, float* hypothesis, float* kernel_matrix,
                          int32_t max_iteration, int32_t* info, void* stream) {
+    return dcx_train_perceptron_ex(device, kernel_kind, kparams, beta, feats, N, D, y, C, gains, hypothesis, kernel_matrix,
+                                   max_iteration, info, 0, stream);
+}
+
+int dcx_train_perceptron_ex(int device, int kernel_kind, const float* kparams, float beta, const float* feats, int64_t N,
+                            int32_t D, const float* y, int32_t C, float* gains, float* hypothesis, float* kernel_matrix,
+                            int32_t max_iteration, int32_t* info, int32_t flags, void* stream) {
     if (N < 1 || N > 0x7fffffffLL || D < 1 || C < 1 || C > 31 || max_iteration < 0)
         return fail(DCX_ERR_INVALID, "perceptron trainer: N >= 1, D >= 1, 1 <= C <= 31, max_iteration >= 0");
     if (!feats || !y || !gains || !hypothesis || !kernel_matrix || !info) return fail(DCX_ERR_INVALID, "a trainer pointer is NULL");
@@ -1093,7 +1108,7 @@ int dcx_train_perceptron(int device, int kernel_kind, const float* kparams, floa
     // per thread.  Knob train_grid: 0 = never, 1 = whenever N >= 2048,
     // 2 = the generic kernel whatever the labels.
     const int64_t tg = knobs().train_grid;
-    const bool grid = tg == 0 ? false : (tg > 0 ? N >= 2048 : N > 4096);
+    const bool grid = (flags & DCX_TRAIN_ONE_WORKGROUP) ? false : tg == 0 ? false : (tg > 0 ? N >= 2048 : N > 4096);
     if (tg == 2) sign_labels = false;  // tests: the generic one-workgroup kernel as the referee
     hipError_t e = launch_perceptron(kernel_kind, kparams[0], kparams[1], beta, feats, y, gains, hypothesis, kernel_matrix,
                                      info, (int)N, D, C, max_iteration, sign_labels, grid, (hipStream_t)stream);

@@ -411,8 +411,8 @@ hipError_t launch_hess(const ModelView& m, const float* q, int64_t B, const floa
         if (m.ys_knob >= 1) ys = m.ys_knob < 12 ? m.ys_knob : 12;  // (the hand-over reads at most 12 rows per pass)
         while (ys > 1 && (size_t)nblk * ys * part_row > m.scratch_bytes) --ys;
     }
-    a.s_super = (m.S + ys - 1) / ys;
-    ys = (m.S + a.s_super - 1) / a.s_super;  // no empty blocks
+    a.s_super = std::max(1, (m.S + ys - 1) / ys);            // (dcx_score_hess answers an empty model without a launch)
+    ys = std::max(1, (m.S + a.s_super - 1) / a.s_super);     // no empty blocks
     a.ys = ys;
     a.part = reinterpret_cast<Dual*>(m.scratch);
     a.counters = m.counters;

@@ -622,7 +622,14 @@ hipError_t launch_perceptron(int kind, float kp0, float kp1, float beta, const f
     a.feats = feats; a.y = y; a.gains = gains; a.hypo = hypo; a.K = K; a.info = info;
     a.N = N; a.D = D; a.C = C; a.max_iter = max_iter; a.kind = kind; a.kp0 = kp0; a.kp1 = kp1; a.beta = beta;
     const size_t lds = sizeof(float) * ((D + 3) & ~3) + 16 * sizeof(Best) + 16 * sizeof(int) + 4 * sizeof(float) + sizeof(GridRec);
-    if (grid && sign_labels && C == 1 && perceptron_grid_workgroups(N) <= kGridMaxWg) {
+    // (a stream that is being captured takes the one-workgroup kernels: stream-ordered allocation and a cooperative launch
+    // cannot be recorded, and a refused one could invalidate the capture before the fallback below runs)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess) {
+        (void)hipGetLastError();
+        cap = hipStreamCaptureStatusActive;
+    }
+    if (grid && cap == hipStreamCaptureStatusNone && sign_labels && C == 1 && perceptron_grid_workgroups(N) <= kGridMaxWg) {
         // several workgroups: a stream-ordered scratch for the records and the arrival counter, a cooperative launch
         // (if the cooperative launch is refused - partition mode, resources - the one-workgroup kernels below take over)
         GridSync* gs = nullptr;

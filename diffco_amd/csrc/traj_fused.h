@@ -156,10 +156,10 @@ constexpr int kTrajLim = 32, kTrajFlags = 96, kTrajLowest = 18, kTrajBestValid =
 //   * wave w of every workgroup owns accumulator w (w, w + nw, ...): it folds it over the block's nw partial rows
 //     (row 0 first, like fold_partial_rows), publishes it, polls the ys copies and adds them in the order y = 0, 1, ... -
 //     the sums a split launch of the sweep kernel forms (score_kernel.h), so for equal slicing the cluster form is
-//     bit-identical to the two-launch loop as well.  No barrier inside the exchange;
-//   * what does not need the totals - the path terms, phase R1 of J^T - runs BETWEEN publishing and polling (the one-
-//     workgroup form runs it in front of the sweep, where 125 rows per wave hide it; here a wave sweeps 16): by the time
-//     those waves poll, the rows have arrived.
+//     bit-identical to the two-launch loop as well.  No barrier inside the exchange.
+//   Tried and not kept: the path terms and phase R1 of J^T BETWEEN publishing and polling instead of in front of the sweep
+//   (they do not need the totals).  With twelve waves polling beside it the path-terms wave took 7.4 k cycles instead of
+//   5 k and became the critical path: 12.65 -> 12.85 us per iteration at 32 paths (profiles/r04_traj_cluster.txt).
 // The ys workgroups of a path must be resident together: the host launches the grid cooperatively (n_paths * ys <= CUs).
 // A poll that sees nothing for ~1 s gives up: the launch ends with stats[r][7] = -1, the path and its moments as the
 // launch found them (the loss records may have been touched).
@@ -196,7 +196,7 @@ __device__ __forceinline__ void traj_exchange_publish(const float* sRed, unsigne
     else fold_pub(std::integral_constant<int, 0>{});
 }
 // second half: poll the ys copies of each of this wave's accumulators; totals to row 0 of the scratch (only this wave touches
-// accumulator e's slots).  Whatever a wave does between the two halves hides the rows' way through the memory system.
+// accumulator e's slots)
 template <int ACC>
 __device__ __forceinline__ bool traj_exchange_collect(float* sRed, const unsigned long long* slot, uint32_t tag, int ys, int wave, int lane,
                                                       int nw) {
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
             DCX_TTS(2);
             // What needs the features / frames but not the collision gradient goes in front of the sweep, where the other
             // waves' sweeps hide its latency: the path terms on wave 1, phase R1 of J^T on waves 2 ..
-            if (!CL && b.sc.jt_waves && nw > 1) {   // (cluster form: between the two halves of the exchange, below)
+            if (b.sc.jt_waves && nw > 1) {
                 if (wave == 1) traj_path_terms(b, L, lane);
                 else if (wave >= 2) dh2_vjp_r1_sel(fw.dh, dh, L.sF + lane, L.sJ + lane, wave - 2, 15);
             }
@@ -416,10 +416,6 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
                     unsigned long long* slot = b.exch + ((size_t)(r * 2 + (it & 1)) * b.ys) * ACC * 64 + lane;
                     const uint32_t tag = b.tag_base + (uint32_t)it + 1u;
                     traj_exchange_publish<ACC>(L.sRed, slot, tag, (int)blockIdx.y, wave, lane, nw);
-                    if (jt && nw > 1) {
-                        if (wave == 1) traj_path_terms(b, L, lane);
-                        else if (wave >= 2) dh2_vjp_r1_sel(fw.dh, dh, L.sF + lane, L.sJ + lane, wave - 2, 15);
-                    }
                     if (!traj_exchange_collect<ACC>(L.sRed, slot, tag, b.ys, wave, lane, nw)) L.sR[kTrajAbort] = 1.0f;
                 } else {
                 fold_partial_rows<ACC>(L.sRed, wave, lane, nw);

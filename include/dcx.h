@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DCX_VERSION 103 /* 0.1.3: dcx_fk_desc carries the DCX_FK_TREE section; 32 control points, D <= 96 */
+#define DCX_VERSION 104 /* 0.1.4: dcx_train_perceptron_ex (per-call flags); 0.1.3: dcx_fk_desc carries the DCX_FK_TREE section; 32 control points, D <= 96 */
 
 /* ---- status codes ---------------------------------------------------------------- */
 #define DCX_OK 0
@@ -275,11 +275,19 @@ int dcx_traj_adam_run(const dcx_model* model, const dcx_traj_state* st, const dc
  * per iteration; the same argmin sequence, bit for bit).  Whether the labels really are -1 / +1 is checked by those
  * kernels themselves, on the device (any other label: the generic loop, which uses y as given) - like every entry
  * point of this library the call does not synchronise the caller's stream, and its one-workgroup form can be captured
- * in a HIP graph.  Debug knob "train_grid": 0 = one workgroup only, 1 = several from N = 2048, 2 = the generic
- * one-workgroup kernel whatever the labels.                                                                  */
+ * in a HIP graph (a stream that is being captured never takes the multi-workgroup form).  After info[1] == -1 gains,
+ * hypothesis and kernel_matrix have been partly updated in place: re-initialise them before running again, e.g. with
+ * dcx_train_perceptron_ex(..., DCX_TRAIN_ONE_WORKGROUP, ...), which cannot give up.  Debug knob "train_grid": 0 = one
+ * workgroup only, 1 = several from N = 2048, 2 = the generic one-workgroup kernel whatever the labels.            */
 int dcx_train_perceptron(int device, int kernel_kind, const float* kparams, float beta, const float* feats, int64_t N,
                          int32_t D, const float* y, int32_t C, float* gains, float* hypothesis, float* kernel_matrix,
                          int32_t max_iteration, int32_t* info, void* stream);
+/* the same with per-call flags (thread-safe, unlike the process-wide knob): DCX_TRAIN_ONE_WORKGROUP = never the
+ * multi-workgroup form for this call                                                                          */
+#define DCX_TRAIN_ONE_WORKGROUP 1
+int dcx_train_perceptron_ex(int device, int kernel_kind, const float* kparams, float beta, const float* feats, int64_t N,
+                            int32_t D, const float* y, int32_t C, float* gains, float* hypothesis, float* kernel_matrix,
+                            int32_t max_iteration, int32_t* info, int32_t flags, void* stream);
 
 /* ---- pieces of the path exposed on their own ---------------------------------------- */
 /* X[b] = T(q_b): model.*.fkine (see DCX_FK_*).  q [B, dof] dev -> X [B, n_points*point_dim] dev */

@@ -434,6 +434,9 @@ def test_ragged_empty_and_padding(ops, knob):
     me = ops.ScoreModel(desc, kind, p0, p1, sup[:5], torch.zeros(5, 1))
     se, ge = me.score_grad_raw(q[:70])
     assert float(se.abs().max()) == 0.0 and float(ge.abs().max()) == 0.0
+    # ... with zero second derivatives (this call used to divide by a zero slice size)
+    gh, he = me.score_hess_raw(q[:70].contiguous())
+    assert he.shape == (70, 7, 7) and float(he.abs().max()) == 0.0 and float(gh.abs().max()) == 0.0
 
 
 def test_errors_are_loud(ops):

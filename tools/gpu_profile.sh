@@ -1,15 +1,17 @@
 #!/bin/bash
-# tools/gpu_profile.sh <tag> — run on the GPU box (via gpurun): kernel trace + PMC passes of bench.py's
-# headline workload, written under gpurun_out/<tag>/ ; tools/rocpd_summary.py turns them into the text
+# tools/gpu_profile.sh <tag> [workload [batch]] — run on the GPU box (via gpurun): kernel trace + PMC passes of one of
+# bench.py's workloads (default: headline), written under gpurun_out/<tag>/ ; tools/rocpd_summary.py turns them into the text
 # summaries committed under profiles/.  PMC passes are separate runs with --kernel-trace only (the pool
 # refuses --pmc combined with sys/hip/hsa traces).
 set -u
 TAG=${1:-prof}
+WL=${2:-headline}
+BATCH=${3:-0}
 R=$PWD
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-configs"
+B="python $R/bench.py --workload $WL --batch $BATCH --steps ${STEPS:-100} --warmup 10 --no-cpu-baseline --no-configs"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $B > $OUT/trace.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -o bench -- $B > $OUT/pmc_$C.log 2>&1
