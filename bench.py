@@ -245,41 +245,50 @@ def _torch_dh_fkine(desc):
     return fkine
 
 
-def torch_cpu_baseline(w, budget_s=8.0):
+def torch_cpu_baseline(w, budget_s=6.0):
     """A torch-CPU restatement of the reference EXPRESSION on this box's host cores, as SURVEY.md §8d specifies it: FK ->
     cdist -> kernel -> matmul, `.sum().backward()` down to the joint angles, `torch.set_num_threads(os.cpu_count())`.
-    Secondary information beside `cpu_baseline` (the C/OpenMP oracle)."""
+    torch's intra-op pool does not scale to a 256-thread host at this size (it gets SLOWER), so the expression is timed twice:
+    with every core as specified (`all_cores`) and with 32 threads; `value` is the better of the two.  Secondary
+    information beside `cpu_baseline` (the C/OpenMP oracle)."""
     if w["kspec"][0] not in (0, 1):
         return None
-    nthr = os.cpu_count() or 1
-    torch.set_num_threads(nthr)
     sup = w["sup"].cpu()
     Wt = w["W"]
-    n = min(4096, w["B"])
-    q0 = w["q_cpu"][:n].clone()
     fk = None
     if w["rob_name"] is not None:
         fk = _torch_dh_fkine(w["desc"])
 
-    def run():
-        q = q0.clone().requires_grad_(True)
-        x = q if fk is None else fk(q).reshape(n, -1)
-        if w["kspec"][0] == 0:
-            kv = 1 / (1 + w["kspec"][1] / w["kspec"][2] * torch.cdist(x, sup).square()) ** w["kspec"][2]
-        else:
-            kv = torch.cdist(x, sup) / w["kspec"][2]
-        (kv @ Wt).sum().backward()
-        return q.grad
-    run()
-    best, t_start, reps = 1e30, time.perf_counter(), 0
-    while reps < 5 and time.perf_counter() - t_start < budget_s:
+    def timed(nthr, n, budget):
+        torch.set_num_threads(nthr)
+        q0 = w["q_cpu"][:n].clone()
+
+        def run():
+            q = q0.clone().requires_grad_(True)
+            x = q if fk is None else fk(q).reshape(n, -1)
+            if w["kspec"][0] == 0:
+                kv = 1 / (1 + w["kspec"][1] / w["kspec"][2] * torch.cdist(x, sup).square()) ** w["kspec"][2]
+            else:
+                kv = torch.cdist(x, sup) / w["kspec"][2]
+            (kv @ Wt).sum().backward()
+            return q.grad
         t0 = time.perf_counter()
         run()
-        best = min(best, time.perf_counter() - t0)
-        reps += 1
-    return {"value": round(n / best / 1e6, 5), "unit": "M evals/s", "cores": nthr,
-            "sample": f"{n} configs, torch {torch.__version__} CPU: " + ("FK -> " if fk is not None else "") +
-                      "cdist -> kernel -> matmul -> backward to q, best of " + str(reps)}
+        first = time.perf_counter() - t0
+        best, t_start, reps = first, time.perf_counter(), 0
+        while reps < 5 and time.perf_counter() - t_start < budget:
+            t0 = time.perf_counter()
+            run()
+            best = min(best, time.perf_counter() - t0)
+            reps += 1
+        return {"value": round(n / best / 1e6, 5), "cores": nthr, "configs": n, "reps": reps + 1}
+    ncpu = os.cpu_count() or 1
+    capped = timed(min(ncpu, 32), min(4096, w["B"]), budget_s / 2)
+    allc = timed(ncpu, min(1024, w["B"]), budget_s / 2) if ncpu > 32 else capped
+    best = max(capped, allc, key=lambda r: r["value"])
+    return {"value": best["value"], "unit": "M evals/s", "cores": best["cores"], "all_cores": allc, "capped_32": capped,
+            "sample": f"torch {torch.__version__} CPU: " + ("FK -> " if fk is not None else "") +
+                      f"cdist -> kernel -> matmul -> backward to q, {best['configs']} configs, best of {best['reps']}"}
 
 
 def load_profile_json(fname):

@@ -32,6 +32,8 @@ struct dcx_model {
     int32_t D = 0, Dt = 0, C = 0, RS = 0;
     int32_t kind = 0, kf = 0;
     float kp0 = 0, kp1 = 0;
+    float kp0_sweep = 0;           // what the sweeps get as ScoreArgs::kp0: 2/gamma for RQ2 (constants folded, score_kernel.h sweep_eval), else kp0
+    int32_t xf_rq_ok = 0;          // RQ2: the centred features are small enough for the expanded form (score_kernel.h xf_applies)
     int32_t frame_floats = 0;
     int32_t prog_floats = 0;       // LDS floats of the staged FK program
     launch_fn launch = nullptr;
@@ -461,7 +463,8 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
     const int64_t nblk = (B + 63) / 64;
     // the split rule sees nz launches' worth of tiles: the classes fill the chip too
     // the expanded form of the sweep (centred data, score_kernel.h) where it is compiled and not switched off
-    const bool xf_able = knobs().xf != 0 && xf_applies(m->Dt, m->C, m->kf) && m->rows_xf_dev != nullptr;
+    const bool xf_able = knobs().xf != 0 && xf_applies(m->Dt, m->C, m->kf) && m->rows_xf_dev != nullptr &&
+                         (m->kf != KF_RQ2 || m->xf_rq_ok || knobs().xf >= 2);   // (knob xf = 2 forces it past the rule: tools/xf_rq_rule.py)
     Geometry g = pick_geometry(m, B * nz, acc, true);
     float* part = nullptr;
     if (g.ys > 1) {
@@ -501,7 +504,7 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
     a.one_hot = one_hot;
     a.nz = nz;
     a.grad_stride = grad_stride;
-    a.kp0 = m->kp0;
+    a.kp0 = m->kp0_sweep;
     a.kp1 = m->kp1;
     a.hinge = hinge.on;
     a.hinge_margin = hinge.margin;
@@ -648,6 +651,7 @@ int dcx_model_create(dcx_model** out, int device, const dcx_fk_desc* fk, int ker
     m->kf = (kernel_kind == DCX_K_RQ && kparams[1] == 2.0f)     ? KF_RQ2
             : (kernel_kind == DCX_K_POLY && kparams[0] == 1.0f) ? KF_POLY1
                                                                 : KF_GEN;
+    m->kp0_sweep = (m->kf == KF_RQ2) ? 2.0f / m->kp0 : m->kp0;
     m->frame_floats = fk_frame_floats(desc);
     m->prog_floats = fk_prog_floats(desc);
     m->launch = launch_for(m->Dt);
@@ -671,7 +675,8 @@ int dcx_model_create(dcx_model** out, int device, const dcx_fk_desc* fk, int ker
     }
     // support rows: [D coords | zero pad to Dt | C weights | (C>1) row sum | |s|^2 | pad]; all-zero-weight rows dropped.
     // Polyharmonic(k=1): the 1/eps factor is folded into the weights (score and gradient are linear in them).
-    const float fold = (m->kf == KF_POLY1) ? 1.0f / m->kp1 : 1.0f;
+    // RQKernel(p = 2): (2/gamma)^2 is folded into them (score_kernel.h sweep_eval; one rounding per weight, like 1/eps).
+    const float fold = (m->kf == KF_POLY1) ? 1.0f / m->kp1 : (m->kf == KF_RQ2) ? (float)(4.0 / ((double)m->kp0 * (double)m->kp0)) : 1.0f;
     std::vector<float> rows;
     rows.reserve((size_t)S * m->RS);
     int32_t kept = 0;
@@ -729,6 +734,7 @@ int dcx_model_create(dcx_model** out, int device, const dcx_fk_desc* fk, int ker
                 centre[k] = (float)(acc / (double)kept);
             }
         }
+        double ss_max = 0.0;
         for (int32_t j = 0; j < kept; ++j) {
             float* cen = &rows_xf[(size_t)j * m->RS];
             double ss = 0.0;
@@ -736,8 +742,15 @@ int dcx_model_create(dcx_model** out, int device, const dcx_fk_desc* fk, int ker
                 cen[k] = cen[k] - centre[k];
                 ss += (double)cen[k] * (double)cen[k];
             }
-            cen[ss_off] = (float)ss;
+            ss_max = std::max(ss_max, ss);
+            // RQ2: the expanded sweep's t = d2 + 2/gamma takes its seed from this column (one rounding for the sum)
+            cen[ss_off] = (m->kf == KF_RQ2) ? (float)(ss + (double)m->kp0_sweep) : (float)ss;
         }
+        // RQ2 in the expanded form: features an FK transform produced, centred, with gamma * max |s - c|^2 <= 32.  The error
+        // of the expanded form grows linearly in that number (tools/xf_rq_rule.py, profiles/r04_xf_rq_rule.txt: Baxter and
+        // Panda, gamma 2 .. 80: 2e-6 / 2.5e-6 against float64 at 29, 3.5e-6 / 7e-6 at 58, 1e-5 at 117; the direct form
+        // stays at 3e-7 .. 1e-6): 32 keeps it a factor of four inside the 1e-5 bar.  Larger gamma or workspace: direct form.
+        m->xf_rq_ok = (m->kf == KF_RQ2 && m->fk.kind != DCX_FK_NONE && (double)m->kp0 * ss_max <= 32.0) ? 1 : 0;
         // XM sweep: the centred coordinates split into three bf16 planes by truncation and laid out as the A operands of
         // v_mfma_f32_16x16x32_bf16: [16-row block][chunk c][support m][k'][8], K slot 8 k' + e of chunk c = term 2c + slot / 16,
         // feature slot % 16; terms hi.hi hi.mid mid.hi hi.lo lo.hi mid.mid take the s planes hi mid hi lo hi mid
@@ -867,7 +880,7 @@ int dcx_score_hess(const dcx_model* m, const float* q, int64_t B, const float* u
     v.prog_floats = m->prog_floats;
     v.kind = m->kind;
     v.kf = m->kf;
-    v.kp0 = m->kp0;
+    v.kp0 = m->kp0_sweep;
     v.kp1 = m->kp1;
     v.n_cu = m->n_cu;
     v.ys_knob = (int32_t)knobs().hess_ys;
@@ -924,7 +937,7 @@ int dcx_score_jac(const dcx_model* m, const float* q, int64_t B, float* score, f
         a.d_fk = d_fk;
         a.frame_floats = m->frame_floats;
         a.kind = m->kind;
-        a.kp0 = m->kp0;
+        a.kp0 = m->kp0_sweep;
         a.kp1 = m->kp1;
         a.grad_stride = (int64_t)m->C * m->fk.dof;
         const size_t lds = sizeof(float) * (size_t)(lds_plan_jac(a.dof, d_fk, m->frame_floats, m->C * m->Dt + m->C, m->C).total + m->prog_floats);
@@ -1026,7 +1039,7 @@ int dcx_traj_adam_run(const dcx_model* m, const dcx_traj_state* st, const dcx_tr
             a.sc.d_fk = d_fk;
             a.sc.frame_floats = m->frame_floats;
             a.sc.kind = m->kind;
-            a.sc.kp0 = m->kp0;
+            a.sc.kp0 = m->kp0_sweep;
             a.sc.kp1 = m->kp1;
             a.sc.xf = (knobs().xf != 0 && m->kf == KF_POLY1 && xf_applies(m->Dt, 1, KF_POLY1) && m->rows_xf_dev) ? 1 : 0;
             if (a.sc.xf) {

@@ -66,11 +66,14 @@ __device__ __forceinline__ void kernel_eval_h(const HessArgs& a, float d2, float
         h = on ? -(ri * ri) * ri : 0.0f;
         return;
     }
-    if (KFT == KF_RQ2 || (KFT == KF_GEN && a.kf == KF_RQ2)) {  // (1 + gamma/2 d2)^-2: g = -2 gamma u^3, h = 6 gamma^2 u^4 with u = 1 / t (v_rcp)
-        const float u = __builtin_amdgcn_rcpf(fmaf(0.5f * a.kp0, d2, 1.0f));
+    if (KFT == KF_RQ2 || (KFT == KF_GEN && a.kf == KF_RQ2)) {
+        // (1 + gamma/2 d2)^-2 with the constants folded as in the sweeps (score_kernel.h sweep_eval): the rows of an RQ2 model
+        // carry w (2/gamma)^2 and a.kp0 = 2/gamma, so with u = 1 / (d2 + 2/gamma):  g w = -2 gamma (1 + gamma/2 d2)^-3 w =
+        // -4 u^3 w',  h w = 6 gamma^2 (1 + gamma/2 d2)^-4 w = 24 u^4 w'
+        const float u = __builtin_amdgcn_rcpf(d2 + a.kp0);
         const float u3 = (u * u) * u;
-        g = -2.0f * a.kp0 * u3;
-        h = 6.0f * a.kp0 * a.kp0 * (u3 * u);
+        g = -4.0f * u3;
+        h = 24.0f * (u3 * u);
         return;
     }
     if constexpr (KFT != KF_GEN) {

@@ -56,8 +56,9 @@ __device__ __forceinline__ void sweep_rows_jac(const ScoreArgs& a, const float (
         constexpr int NA = DCX_D2_ACCS(D);
         v2f acc[NA], dp[D / 2 + 1];
         float dl = 0.0f;
+        acc[0] = v2f{d2_seed<KF>(a), 0.0f};   // (RQ2: constants folded, score_kernel.h sweep_eval)
 #pragma unroll
-        for (int i = 0; i < NA; ++i) acc[i] = v2f{0.0f, 0.0f};
+        for (int i = 1; i < NA; ++i) acc[i] = v2f{0.0f, 0.0f};
 #pragma unroll
         for (int k = 0; k + 1 < D; k += 2) {
             const v2f xv = {x[k], x[k + 1]};
@@ -73,7 +74,7 @@ __device__ __forceinline__ void sweep_rows_jac(const ScoreArgs& a, const float (
             d2 = fmaf(dl, dl, d2);
         }
         float val, g;
-        kernel_eval<KF>(d2, a, val, g);
+        sweep_eval<KF>(d2, a, val, g);
 #pragma unroll
         for (int c = 0; c < CC; ++c) {
             const float w = r[L::W_OFF + c];
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void score
         for (int c = 0; c < CC; ++c) {
 #pragma unroll
             for (int k = 0; k < D; ++k)
-                if (k < a.d_fk) sG[(c * a.d_fk + k) * 64 + lane] = tot[CC + c * D + k] * 1.0f;
+                if (k < a.d_fk) sG[(c * a.d_fk + k) * 64 + lane] = tot[CC + c * D + k] * kGradScale<KF>;
         }
     }
     __syncthreads();

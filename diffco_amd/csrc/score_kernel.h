@@ -159,6 +159,10 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define DCX_D2_MULTI 1
 #endif
 #define DCX_D2_ACCS(D) (!DCX_D2_MULTI ? 1 : (D) >= 32 ? 4 : (D) >= 16 ? 2 : 1)
+// rows fetched in whole groups of four floats by the four-row pipeline (see load_row)
+#ifndef DCX_LOAD_GROUPS
+#define DCX_LOAD_GROUPS 1
+#endif
 
 // value K(d2) and g with dK/dx = g * (x - s)
 // CLAMPED: the caller guarantees d2 >= 1e-30 (the expanded-form sweep clamps at its near threshold)
@@ -205,6 +209,32 @@ __device__ __forceinline__ void kernel_eval(float d2, const ScoreArgs& a, float&
             val = v2 * rv;
             g = rv * ie2;
         }
+    }
+}
+
+// ---- RQKernel(p = 2) inside the sweeps: constants folded (round 4) --------------------------------------------------------
+// K = (1 + gamma/2 d2)^-2 = (2/gamma)^2 / t^2 with t = d2 + 2/gamma, and dK/dx = -2 gamma (1 + gamma/2 d2)^-3 (x - s) =
+// -4 (2/gamma)^2 / t^3 (x - s).  dcx_model_create stores the row weights of an RQ2 model as w (2/gamma)^2; the squared-
+// distance accumulator of a pair starts at 2/gamma instead of zero (ScoreArgs::kp0 carries 2/gamma for these launches), so
+// t costs nothing; the pair body is u = 1/t, val = u u, g = val u (3 instead of 5 instructions), and the feature gradient
+// is multiplied by -4 ONCE per lane after the sweep (exact).  17 -> 15 VALU instructions per pair at D = 6 (config #4),
+// 28 -> 26 at D = 12, C = 5.  kernel_eval<KF_RQ2> above stays the textbook form (dcx_kernel_matrix uses it).
+template <int KF>
+__device__ __forceinline__ float d2_seed(const ScoreArgs& a) {
+    if constexpr (KF == KF_RQ2) return a.kp0;
+    else return 0.0f;
+}
+template <int KF>
+inline constexpr float kGradScale = (KF == KF_RQ2) ? -4.0f : 1.0f;
+// value and gradient coefficient inside a sweep; `t` = the accumulated d2 INCLUDING d2_seed
+template <int KF, bool CLAMPED = false>
+__device__ __forceinline__ void sweep_eval(float t, const ScoreArgs& a, float& val, float& g) {
+    if constexpr (KF == KF_RQ2) {
+        const float u = __builtin_amdgcn_rcpf(t);
+        val = u * u;
+        g = val * u;
+    } else {
+        kernel_eval<KF, CLAMPED>(t, a, val, g);
     }
 }
 
@@ -284,6 +314,25 @@ __device__ __forceinline__ const __attribute__((address_space(4))) ScoreArgs& re
         (dst).shared_q = (src).shared_q; \
     } while (0)
 
+// ---- the two-buffer pipeline of wide rows, round 4 ---------------------------------------------------------------------
+// C > 1 rows (18-20 floats) run  wait -> issue B -> consume A -> wait -> issue A -> consume B  between sched_barriers.  The
+// machine scheduler respects those, but the IR reached it already rearranged (rocprofv3 counters of config #3 at B = 65536:
+// 47 % of wave-cycles in s_waitcnt, VALU 62 % busy, 10 SALU per row: profiles/r04_direct_pre_cfg3_b65536_rocprof_summary.txt):
+//   * the SLP vectoriser paired row A's kernel function and coefficient with row B's (v_pk_mul across the two rows).  That
+//     ties A's gradient fold to B's distance: row B's s_load_dwordx8 pair ended up BELOW `consume A`, next to its first
+//     use - every second row waited out a full scalar-cache / L2 round trip - and A's coordinates lived on in twelve
+//     s_mov copies.  row_opaque below makes a row's kernel values and coefficient opaque where they are formed, so a body
+//     is complete before the next begins, and the loads stay where the source puts them.
+//   * nothing reads the class scores before the end of the sweep, so their updates were sunk into the loop latch, again
+//     with the rows' weights kept alive in copies: explicit packed accumulators, pinned (sweep_rows add_scores).
+// Tried and dropped: issuing the row loads as `asm volatile` s_load (program order binding, explicit wait, values handed
+// over through an empty asm).  Order was right, but the compiler does not know a register is still in flight: a phi copy
+// of the x8 tail in front of the wait (D = 21, C = 1) read it before the data had landed - wrong results, caught by
+// tools/xf_rq_rule.py.  Loads the compiler tracks itself cannot have that problem.  (-mllvm -pre-RA-sched=source also
+// restores the order, but once the bodies no longer pair up the default scheduler leaves it alone too.)
+// keeps the SLP vectoriser from pairing one row's kernel function with the next row's
+__device__ __forceinline__ void row_opaque(float& u, float& v) { asm volatile("" : "+v"(u), "+v"(v)); }
+
 // ---- the sweep: supports [j0, j1) against this lane's configuration, rows broadcast through SGPRs ---------------
 // Accumulates into sc[] (scores) and gx[] (feature gradient; untouched for MODE_SCORE).  A function of its own so that
 // kernel variants can share it (e.g. the two-tile helper-wave experiment of DESIGN.md 3.1).
@@ -329,8 +378,15 @@ __device__ __forceinline__ const __attribute__((address_space(4))) ScoreArgs& re
 constexpr bool xf_applies(int D, int CC, int KF) {
     const int used = D + CC + (CC > 1 ? 1 : 0);
     const int parts = (4 * used <= (CC > 1 ? DCX_P0_MAX_MULTI : DCX_P0_MAX_SINGLE)) ? 0 : (used + 37) / 38;
-    return KF == KF_POLY1 && used + 1 <= 38 && parts <= 1;
+    return (KF == KF_POLY1 || KF == KF_RQ2) && used + 1 <= 38 && parts <= 1;
 }
+// Round 4: RQKernel(p = 2) takes the expanded form as well, on FK-CENTRED features only (the host's rule, dcx_api.hip
+// xf_rq_ok: gamma * max |s - c|^2 <= 32, a transform present).  The kernel is smooth at d2 = 0, so there is no near-pair
+// block: the expanded distance's absolute error 2^-23 (|x - c|^2 + |s - c|^2) moves K by at most gamma times that (~2e-6
+// at arm scale, measured 1.7e-6 on config #3 against 3.8e-7 for the direct form: inside the 1e-5 bar with a margin),
+// and the pair body drops the six packed differences AND the clamp / ballot: 28 -> 22 VALU instructions at D = 12, C = 5.
+// The rows of the centred copy carry |s - c|^2 + 2/gamma in their last column (sweep_eval's t needs no add).  Raw-input
+// models (config #4: |x| ~ 10) keep the direct form: there the same error would be 5e-4.
 
 // NACC > 0 overrides the number of independent squared-distance accumulator pairs of the expanded form (callers that run
 // at few waves per SIMD trade one packed add per row for a shorter dependent chain)
@@ -348,6 +404,31 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
     constexpr bool XFA = XF && xf_applies(D, CC, KF);
     constexpr int USED = USED_DIRECT + (XFA ? 1 : 0);
     constexpr int RSTRIDE = L::RS;
+    // (how a row travels through the SGPRs: 0 = four whole rows in flight, 1 = two whole rows, >= 2 = parts of a row; see below)
+    constexpr int PARTS = (4 * USED <= (CC > 1 ? DCX_P0_MAX_MULTI : DCX_P0_MAX_SINGLE)) ? 0 : (USED + 37) / 38;  // parts of <= 38 floats
+    // Two-buffer pipeline, several classes: the class scores accumulate as explicit packed pairs.  Left as CC scalar fmaf
+    // chains the SLP vectoriser packs them itself - across BOTH rows of the loop body, which moves row A's score updates
+    // behind row B's body and keeps A's weights alive in copies (see row_opaque).  Same sums, class by class.
+    constexpr bool SC2 = (CC > 1 && PARTS == 1);
+    v2f sc2[CC / 2 + 1];
+#pragma unroll
+    for (int i = 0; i < CC / 2 + 1; ++i) sc2[i] = v2f{0.0f, 0.0f};
+    auto add_scores = [&](auto weight_of, float val) __attribute__((always_inline)) {
+        if constexpr (SC2) {
+            const v2f v2 = {val, val};
+#pragma unroll
+            for (int c = 0; c + 1 < CC; c += 2) sc2[c / 2] = __builtin_elementwise_fma(v2f{weight_of(c), weight_of(c + 1)}, v2, sc2[c / 2]);
+            if constexpr (CC & 1) sc[CC - 1] = fmaf(weight_of(CC - 1), val, sc[CC - 1]);
+            // pinned where they stand: nothing reads the score accumulators before the end of the sweep, so LLVM sinks these
+            // updates into the loop latch (behind the flush branch) - with the row's weights kept alive in copies
+#pragma unroll
+            for (int c = 0; c + 1 < CC; c += 2) asm volatile("" : "+v"(sc2[c / 2]));
+            if constexpr (CC & 1) asm volatile("" : "+v"(sc[CC - 1]));
+        } else {
+#pragma unroll
+            for (int c = 0; c < CC; ++c) sc[c] = fmaf(weight_of(c), val, sc[c]);
+        }
+    };
 
     // expanded-form state: -2 x (packed), |x|^2, the near threshold (also the hot path's clamp), H and the run's sum(c)
     v2f xm[D / 2 + 1], ga[D / 2 + 1];
@@ -379,7 +460,8 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
         for (int i = 1; i < NA; ++i) acc[0] += acc[i];
         float d2 = acc[0].x + acc[0].y;
         if constexpr (D & 1) d2 = fmaf(xm_tail, r[D - 1], d2);
-        return fmaxf(d2, thr);
+        if constexpr (KF == KF_POLY1) return fmaxf(d2, thr);
+        else return d2;   // RQ2: t = d2 + 2/gamma (the seed rides in the row's last column), no clamp, no near pairs
     };
     auto coef_of = [&](const auto& r, float g) __attribute__((always_inline)) -> float {
         if constexpr (MODE == MODE_GRAD_ROW) {
@@ -396,16 +478,17 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
     auto apply_x = [&](const auto& r, float d2c, auto sign, bool keep) __attribute__((always_inline)) {
         constexpr int SIGN = decltype(sign)::value;
         float val, g;
-        kernel_eval<KF, true>(d2c, a, val, g);
+        sweep_eval<KF, true>(d2c, a, val, g);
+        if constexpr (PARTS == 1) row_opaque(val, g);   // (two-buffer pipeline: this row's body must not pair up with the next row's)
         // one class, row weight: w r = (w / r) d2 — the score rides on the gradient coefficient (one multiply fewer)
         constexpr bool SCORE_BY_COEF = (KF == KF_POLY1 && CC == 1 && MODE == MODE_GRAD_ROW);
         if constexpr (!SCORE_BY_COEF) {
             if constexpr (SIGN < 0) val = keep ? -val : 0.0f;
-#pragma unroll
-            for (int c = 0; c < CC; ++c) sc[c] = fmaf(r[L::W_OFF + c], val, sc[c]);
+            add_scores([&](int c) __attribute__((always_inline)) { return r[L::W_OFF + c]; }, val);
         }
         if constexpr (GRAD) {
             float coef = coef_of(r, g);
+            if constexpr (PARTS == 1) asm volatile("" : "+v"(coef));
             if constexpr (SIGN < 0) coef = keep ? -coef : 0.0f;
             if constexpr (SCORE_BY_COEF) sc[0] = fmaf(coef, d2c, sc[0]);
             const v2f c2 = {coef, coef};
@@ -464,6 +547,11 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
     // mask straight away (the distances are not kept: the rare block recomputes them, bit for bit), one scalar branch
     // per stage.
     auto stage_x = [&](const auto& r0, const auto& r1) __attribute__((always_inline)) {
+        if constexpr (KF != KF_POLY1) {
+            (void)pair_x(r0);
+            (void)pair_x(r1);
+            return;
+        }
         const auto m0 = __builtin_amdgcn_ballot_w64(pair_x(r0) <= thr);
         const auto m1 = __builtin_amdgcn_ballot_w64(pair_x(r1) <= thr);
         if (__builtin_expect((m0 | m1) != 0, 0)) {
@@ -472,6 +560,10 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
         }
     };
     auto single_x = [&](const auto& r0) __attribute__((always_inline)) {
+        if constexpr (KF != KF_POLY1) {
+            (void)pair_x(r0);
+            return;
+        }
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(pair_x(r0) <= thr) != 0, 0)) fix_near(r0, d2_x(r0));
     };
     // fold the run's x * sum(c) into H in place: H <- H - x A = H + (-2 x) (A / 2), bit for bit the same product
@@ -494,8 +586,9 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
             // chain, and wide shapes run at 2-4 waves per SIMD, too few to hide it
             constexpr int NA = DCX_D2_ACCS(D);
             v2f acc[NA];
+            acc[0] = v2f{d2_seed<KF>(a), 0.0f};
 #pragma unroll
-            for (int i = 0; i < NA; ++i) acc[i] = v2f{0.0f, 0.0f};
+            for (int i = 1; i < NA; ++i) acc[i] = v2f{0.0f, 0.0f};
 #pragma unroll
             for (int k = 0; k + 1 < D; k += 2) {
                 const v2f xv = {x[k], x[k + 1]};
@@ -512,7 +605,7 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
             }
         }
         float val, g;
-        kernel_eval<KF>(d2, a, val, g);
+        sweep_eval<KF>(d2, a, val, g);
 #pragma unroll
         for (int c = 0; c < CC; ++c) sc[c] = fmaf(r[L::W_OFF + c], val, sc[c]);
         if constexpr (GRAD) {
@@ -531,10 +624,15 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
             if constexpr (D & 1) gx[D - 1] = fmaf(coef, dl[D - 1], gx[D - 1]);
         }
     };
+    // (whole groups of four floats: the padding of the row stride is readable, and 7 floats fetched as 8 are ONE s_load_dwordx8
+    // instead of x4 + x2 + x1, 14 as 16 one x16 instead of x8 + x4 + x2)
+    constexpr int USED4 = (USED + 3) / 4 * 4;
+    static_assert(USED4 <= L::RS, "the row stride covers whole groups of four");
+    constexpr int NLOAD = DCX_LOAD_GROUPS ? USED4 : USED;
     auto load_row = [&](float (&dst)[L::RS], int j) __attribute__((always_inline)) {
         cfloat_ptr r = rows + (size_t)j * RSTRIDE;
 #pragma unroll
-        for (int e = 0; e < USED; ++e) dst[e] = r[e];
+        for (int e = 0; e < NLOAD; ++e) dst[e] = r[e];
     };
 
     // How many SGPRs a pipeline may keep in flight: ~100 exist, the kernel needs a dozen for itself.  Four whole rows
@@ -542,7 +640,6 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
     // (<= 38 floats), over half rows, or over thirds of a row (D > 75).  Before this split the compiler kept the four-row pipeline
     // alive for every width by parking SGPRs in VGPR lanes: D=24 +37 %, D=42 +75 %, D=60 +97 % VALU instructions
     // (v_writelane / v_readlane) inside the sweep.
-    constexpr int PARTS = (4 * USED <= (CC > 1 ? DCX_P0_MAX_MULTI : DCX_P0_MAX_SINGLE)) ? 0 : (USED + 37) / 38;  // parts of <= 38 floats
     static_assert(!XFA || PARTS <= 1, "expanded form: whole rows only");
     if constexpr (XM) {
     // ---- XM: the expanded form with x . s^T on the matrix cores (round 3) ---------------------------------------------------
@@ -742,7 +839,7 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
         float wsum = 0.0f;
         auto load_part = [&](float (&dst)[PS], int j, auto pc) __attribute__((always_inline)) {
             constexpr int P0 = decltype(pc)::value * PS;
-            constexpr int LEN = (USED - P0 < PS) ? (USED - P0) : PS;
+            constexpr int LEN = (PARTS == 1 && DCX_LOAD_GROUPS) ? PS : (USED - P0 < PS) ? (USED - P0) : PS;
             cfloat_ptr r = rows + (size_t)j * RSTRIDE + P0;
 #pragma unroll
             for (int e = 0; e < LEN; ++e) dst[e] = r[e];
@@ -755,8 +852,9 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
             constexpr int P0 = decltype(pc)::value * PS;
             constexpr int LEN = (USED - P0 < PS) ? (USED - P0) : PS;
             if constexpr (decltype(pc)::value == 0) {
+                acc[0] = v2f{d2_seed<KF>(a), 0.0f};
 #pragma unroll
-                for (int i = 0; i < NA; ++i) acc[i] = v2f{0.0f, 0.0f};
+                for (int i = 1; i < NA; ++i) acc[i] = v2f{0.0f, 0.0f};
             }
 #pragma unroll
             for (int e = 0; e < LEN; ++e) {
@@ -780,9 +878,9 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
                 float d2 = acc[0].x + acc[0].y;
                 if constexpr (D & 1) d2 = fmaf(tail_d, tail_d, d2);
                 float val, g;
-                kernel_eval<KF>(d2, a, val, g);
-#pragma unroll
-                for (int c = 0; c < CC; ++c) sc[c] = fmaf(wv[c], val, sc[c]);
+                sweep_eval<KF>(d2, a, val, g);
+                if constexpr (PARTS == 1) row_opaque(val, g);
+                add_scores([&](int c) __attribute__((always_inline)) { return wv[c]; }, val);
                 if constexpr (GRAD) {
                     float coef;
                     if constexpr (MODE == MODE_GRAD_ROW) {
@@ -793,6 +891,7 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
                         for (int c = 0; c < CC; ++c) wb = fmaf(up[c], wv[c], wb);
                         coef = g * wb;
                     }
+                    if constexpr (PARTS == 1) asm volatile("" : "+v"(coef));
                     const v2f c2 = {coef, coef};
 #pragma unroll
                     for (int k = 0; k + 1 < D; k += 2) gx2[k / 2] = __builtin_elementwise_fma(c2, dp[k / 2], gx2[k / 2]);
@@ -806,6 +905,7 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
             const int jl = j1 - 1;
             if constexpr (PARTS == 1) {
                 // two whole-row buffers: wait -> issue B -> consume A -> wait -> issue A -> consume B
+                static_assert(PS <= RSTRIDE, "a whole row in groups of four floats stays inside its stride");
                 load_part(bufA, j0, P0c{});
                 int j = j0;
                 for (; j + 1 < j1; j += 2) {
@@ -903,6 +1003,17 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
             gx[k + 1] += gx2[k / 2].y;
         }
     }
+    if constexpr (SC2) {
+#pragma unroll
+        for (int c = 0; c + 1 < CC; c += 2) {
+            sc[c] += sc2[c / 2].x;
+            sc[c + 1] += sc2[c / 2].y;
+        }
+    }
+    if constexpr (GRAD && kGradScale<KF> != 1.0f) {   // the folded constant of the gradient (sweep_eval), once per lane
+#pragma unroll
+        for (int k = 0; k < D; ++k) gx[k] *= kGradScale<KF>;
+    }
 }
 
 // ---- the sweep with the (configurations x supports) . (supports x features) contraction on the matrix cores ------
@@ -962,7 +1073,7 @@ __device__ __forceinline__ void sweep_rows_mfma(const ScoreArgs& a, const float 
         }
         const float d2 = d2a.x + d2a.y;
         float g;
-        kernel_eval<KF>(d2, a, val, g);
+        sweep_eval<KF>(d2 + d2_seed<KF>(a), a, val, g);
         if constexpr (!KW) sc[0] = fmaf(r[L::W_OFF], val, sc[0]);
         float coef;
         if constexpr (MODE == MODE_GRAD_ROW) {
@@ -1113,6 +1224,10 @@ __device__ __forceinline__ void sweep_rows_mfma(const ScoreArgs& a, const float 
             if constexpr (KW) contract_kw(v0, v1, v2, 0.0f, wcur);
         }
         flush();
+    }
+    if constexpr (kGradScale<KF> != 1.0f) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) gx[k] *= kGradScale<KF>;
     }
 }
 

@@ -147,12 +147,15 @@ int dcx_device_count(void);
  * block), "min_rows" (supports per wave slice), "split_finish_kernel" (1 = finish split launches with a second
  * launch), "inlaunch_tiles", "jac_per_class" (1 = one launch per class in dcx_score_jac), "mfma" (0 = never use the
  * MFMA contraction, 1 = use it wherever it is compiled), "xf" (0 = the sweep in its direct form everywhere, 1 / rule =
- * the expanded form wherever it is compiled: Polyharmonic(1), rows of <= 37 floats; the two forms agree to ~1e-6),
+ * the expanded form wherever it is compiled and the model qualifies: Polyharmonic(1), or RQKernel(p = 2) behind an FK
+ * transform with gamma * max |s - centroid|^2 <= 32; rows of <= 37 floats; the two forms agree to ~1e-6; 2 = also for RQ
+ * models outside that rule: measurements only),
  * "traj_fused" (0 = dcx_traj_adam_run as two launches per iteration), "jac_one_sweep" (0 = dcx_score_jac never takes the
  * one-sweep kernel, 1 = whenever it is compiled and the batch is beyond the one-launch-per-all-classes regime),
  * "train_grid" (see dcx_train_perceptron), "fkk" (which FK walk a DH arm takes: 2 / rule = the step table, 1 = the FK
  * program through scalar loads, 0 = the FK program from its LDS copy; bit-identical results), "jt_waves" (0 = the chain and
- * J^T phases of a DH arm on one wave instead of several; bit-identical), "hess_ys" (blocks per tile of dcx_score_hess; 1 =
+ * J^T phases of a DH arm on one wave instead of several; bit-identical), "traj_ys" (workgroups per path of the persistent
+ * trajectory kernel: 1 = one, k = k; rule = what fills the chip, at most 8), "hess_ys" (blocks per tile of dcx_score_hess; 1 =
  * never split the supports), "xm" (1 = the expanded form takes its distance GEMM from the matrix cores, bf16x3 split
  * operands, where compiled: one class, Polyharmonic(1), even D <= 16; agrees with the VALU form to ~1e-6, measured slower).
  * value < 0 restores the rule.  The initial values come from the DCX_YS / DCX_NW / DCX_XF / ... environment variables,

@@ -141,7 +141,7 @@ def test_score_grad_vs_oracle_and_reference(ops, name):
 
 
 @pytest.mark.parametrize("name", ["cfg2_baxter_poly1", "cfg3_baxter_rq_c5", "misc_dualpanda_rq"])
-def test_support_slicing_is_invariant(ops, name, knob):
+def test_support_slicing_is_invariant(ops, name, knob, fold_pipe):
     """every launch geometry — waves per block (support slices meeting in LDS) x support super-chunks across
     blocks (split launch + finish kernel) — gives the same answer"""
     d = load(name)
@@ -159,9 +159,12 @@ def test_support_slicing_is_invariant(ops, name, knob):
             outs.append((_n(s), _n(g), _n(s0), _n(jac)))
     knob("nw", -1)
     knob("ys", -1)
+    # (under the "mfma" parametrisation one wave per block has no matrix-core form and takes the default one: for an RQ model
+    # that is the expanded sweep since round 4, 2e-6 from the direct arithmetic of the matrix-core form - two forms are compared)
+    tol = 8e-6 if (fold_pipe == "mfma" and "rq" in name) else 3e-6
     for o in outs[1:]:
         for a, b in zip(o, outs[0]):
-            assert relerr(a, b) < 3e-6
+            assert relerr(a, b) < tol
 
 
 @pytest.mark.parametrize("name", ["cfg2_baxter_poly1", "cfg3_baxter_rq_c5"])
@@ -473,7 +476,7 @@ def _rand_q(rob, B, g):
 
 @pytest.mark.parametrize("B,S,C,kspec", [(65536, 2000, 1, (1, 1.0, 1.0)), (65536, 2000, 5, (0, 10.0, 2.0)),
                                           (4096, 1000, 1, (0, 10.0, 2.0))])
-def test_full_size_properties(ops, B, S, C, kspec, knob):
+def test_full_size_properties(ops, B, S, C, kspec, knob, fold_pipe):
     """headline / config #2 / config #3 sizes: linearity in the weights, additivity over a support
     split, invariance to batch order, and an fp64 spot check of 64 random rows."""
     from oracle import oracle
@@ -487,8 +490,11 @@ def test_full_size_properties(ops, B, S, C, kspec, knob):
     h = S // 3
     s1, g1 = ops.ScoreModel(desc, *kspec, sup[:h], W[:h]).score_grad_raw(q)
     s2, g2 = ops.ScoreModel(desc, *kspec, sup[h:], W[h:]).score_grad_raw(q)
-    assert float((s1 + s2 - s).abs().max()) < 3e-6 * scale_s
-    assert float((g1 + g2 - gr).abs().max()) < 3e-6 * scale_g
+    # (RQ in the expanded form, round 4: each of the three models is centred on its own supports and carries the form's
+    # ~2e-6 against float64 - the last assertion of this test - so the residual of three evaluations is a few of those)
+    tol_add = 8e-6 if (kspec[0] == 0 and fold_pipe != "direct") else 3e-6
+    assert float((s1 + s2 - s).abs().max()) < tol_add * scale_s
+    assert float((g1 + g2 - gr).abs().max()) < tol_add * scale_g
     # linearity in the weights: a power-of-two scale is exact in fp32, so the results are bit-identical
     s3, g3 = ops.ScoreModel(desc, *kspec, sup, -4.0 * W).score_grad_raw(q)
     assert torch.equal(s3, -4.0 * s) and torch.equal(g3, -4.0 * gr)

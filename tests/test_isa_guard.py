@@ -85,6 +85,66 @@ def test_expanded_form_instruction_count(isa):
     assert 48 <= ks[1]["v_pk_fma_f32"] <= 70 and ks[1]["v_rsq_f32"] <= 6 and valu[1] <= 135, (ks[1], valu[1])
 
 
+SRC_R4 = """#include "dcx_internal.h"
+namespace dcx {
+template __global__ void score_kernel<12, KF_RQ2, 5, MODE_GRAD_ROW, 1024, false, true>(const ScoreArgs);
+template __global__ void score_kernel<12, KF_RQ2, 5, MODE_GRAD_ROW, 1024, false, false>(const ScoreArgs);
+template __global__ void score_kernel<12, KF_RQ2, 1, MODE_GRAD_ROW, 1024, false, true>(const ScoreArgs);
+template __global__ void score_kernel<6, KF_RQ2, 1, MODE_GRAD_ROW, 1024, false, false>(const ScoreArgs);
+}
+"""
+
+
+def test_round4_sweeps_rq_folded_expanded_and_the_two_buffer_pipeline(tmp_path):
+    """Round 4 (score_kernel.h, "the two-buffer pipeline", sweep_eval): what the counter passes of config #3 / #4 led to,
+    held in the generated code.  (a) RQKernel(p = 2) with its constants folded: 15 VALU instructions per pair at D = 6
+    (config #4; 17 before), no multiply by gamma left in the loop; (b) config #3's loop (D = 12, C = 5) in the expanded
+    form: 22 per pair (28 in round 3's direct form) and in the direct form 26; (c) its pipeline intact: each row's scalar
+    loads stand BEFORE the other row's body (two v_rcp per iteration, each preceded by the loads of the row after it), and
+    no s_mov copies of row registers, no lane parking"""
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    src, out = tmp_path / "k.hip", tmp_path / "k.s"
+    src.write_text(SRC_R4)
+    subprocess.run(["hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I", CSRC, "-S", "--cuda-device-only",
+                    str(src), "-o", str(out)], check=True, stderr=subprocess.DEVNULL)
+    ks = {(k["D"], k["C"], k["XF"]): k for k in _kernels(out.read_text())}
+    assert set(ks) == {(12, 5, 1), (12, 5, 0), (12, 1, 1), (6, 1, 0)}
+
+    def loop(key):
+        k = ks[key]
+        labels = {m.group(1): n for n, l in enumerate(k["body"]) if (m := re.match(r"^(\.LBB\d+_\d+):", l))}
+        best = None
+        for n, l in enumerate(k["body"]):
+            m = re.search(r"s_c?branch\w* (\.LBB\d+_\d+)", l)
+            if m and m.group(1) in labels and labels[m.group(1)] < n:
+                seg = [x.strip() for x in k["body"][labels[m.group(1)]:n + 1]]
+                seg = [x for x in seg if x and not x.startswith((".", ";"))]
+                if sum("v_rcp_f32" in x for x in seg) >= 2 and sum("s_load_dword" in x for x in seg) >= 2 and (best is None or len(seg) < len(best)):
+                    best = seg
+        assert best is not None
+        return best
+
+    def per_row(seg):
+        rows = sum("v_rcp_f32" in x for x in seg)
+        return sum(x.startswith("v_") for x in seg) / rows, sum(x.startswith("s_mov") for x in seg), rows
+
+    v, movs, rows = per_row(loop((6, 1, 0)))
+    assert rows == 4 and v <= 15.0 and movs <= 2, (v, movs)
+    v, movs, rows = per_row(loop((12, 1, 1)))
+    assert rows == 4 and v <= 19.0, v                     # incl. the flush block's share (direct form: 24)
+    for key, vmax in (((12, 5, 1), 25.0), ((12, 5, 0), 26.0)):   # the expanded loop range holds the flush block (7 VALU / 2 rows)
+        seg = loop(key)
+        v, movs, rows = per_row(seg)
+        assert rows == 2 and v <= vmax and movs <= 2, (key, v, movs)
+        assert not any("v_readlane" in x or "v_writelane" in x for x in seg)
+        # load placement: [loads of row B] ... rcp(A) ... [loads of row A'] ... rcp(B)
+        marks = [("L" if "s_load_dword" in x else "R") for x in seg if "s_load_dword" in x or "v_rcp_f32" in x]
+        compact = "".join(c for n, c in enumerate(marks) if n == 0 or marks[n - 1] != c)
+        assert compact == "LRLR", (key, "".join(marks))
+        assert ks[key]["vgpr"] <= 64 and ks[key]["scratch_bytes"] <= 44
+
+
 def test_handover_publishes_write_through_and_drains_before_the_counter(isa):
     """The in-launch hand-over of a split launch (score_kernel.h) orders the partial-row stores before the arrival
     counter WITHOUT a release fence: it relies on gfx942 / gfx950 lowering agent-scope atomic stores to `global_store sc1`

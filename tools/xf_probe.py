@@ -72,7 +72,7 @@ for name, B in cases:
     up = torch.randn((B, w["C"]), device=dev) if w["C"] > 1 else None
     res = {}
     for mode in (0, 1, 0, 1):
-        lib.dcx_debug_set(b"xf", mode)
+        lib.dcx_debug_set(b"xf", 2 if (mode and os.environ.get("XF_FORCE")) else mode)   # XF_FORCE=1: past the RQ rule (dcx_api.hip xf_rq_ok)
         for _ in range(5):
             s, g = m.score_grad_raw(q, up)
         torch.cuda.synchronize()
