@@ -25,6 +25,9 @@ SYMBOLS = {
     "dcx_debug_set": (C.c_int, [C.c_char_p, C.c_int64]),
     "dcx_model_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(FkDesc), C.c_int, C.POINTER(C.c_float),
                                    _c_fp, _c_fp, C.c_int64, C.c_int32, C.c_int32]),
+    "dcx_model_create_ex": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(FkDesc), C.c_int, C.POINTER(C.c_float),
+                                      _c_fp, _c_fp, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
+    "dcx_model_update": (C.c_int, [C.c_void_p, _c_fp, _c_fp, C.c_int64, C.c_void_p]),
     "dcx_model_destroy": (None, [C.c_void_p]),
     "dcx_model_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                  C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

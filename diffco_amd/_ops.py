@@ -138,26 +138,55 @@ def train_perceptron_device(kind, p0, p1, beta, feats, y, gains, hypo, K, max_it
 
 # ----------------------------------------------------------------------------- fused score model
 class ScoreModel:
-    """Owns one ``dcx_model`` (device copy of support rows + FK parameters).  Immutable."""
+    """Owns one ``dcx_model`` (device copy of support rows + FK parameters).  `update()` refills it in place with new
+    supports / weights (same transform, kernel and class count): no reallocation while they fit `capacity`."""
 
-    def __init__(self, desc, kind, p0, p1, support_feat, weights, device=None):
-        lib = _lib.require_gpu()
-        self.dev = _device(device)
-        self.desc = desc if desc is not None else none_desc(int(support_feat.reshape(len(support_feat), -1).shape[1]))
+    @staticmethod
+    def _rows(support_feat, weights, dev):
         sf = support_feat.detach().reshape(len(support_feat), -1).to(dtype=torch.float32).contiguous()
         w = weights.detach().to(dtype=torch.float32)
         w = (w.reshape(-1, 1) if w.ndim == 1 else w).contiguous()
         if len(sf) != len(w):
             raise ValueError(f"{len(sf)} supports but {len(w)} weight rows")
+        # tensors already on the model's GPU are packed there by one kernel (dcx_model_create_ex); CPU tensors take the
+        # library's host path; another GPU's tensors come over first
+        if sf.is_cuda and sf.device != dev:
+            sf = sf.to(dev)
+        if w.is_cuda and w.device != dev:
+            w = w.to(dev)
+        if sf.is_cuda != w.is_cuda:
+            sf, w = sf.to(dev), w.to(dev)
+        return sf, w
+
+    def __init__(self, desc, kind, p0, p1, support_feat, weights, device=None, capacity=0):
+        lib = _lib.require_gpu()
+        self.dev = _device(device)
+        self.desc = desc if desc is not None else none_desc(int(support_feat.reshape(len(support_feat), -1).shape[1]))
+        sf, w = self._rows(support_feat, weights, self.dev)
         self.S, self.C, self.dof, self.D = len(sf), int(w.shape[1]), self.desc.dof, self.desc.feature_dim
         if len(sf) and sf.shape[1] != self.D:
             raise ValueError(f"supports have {sf.shape[1]} features, the transform produces {self.D}")
+        self.kernel = (int(kind), float(p0), float(p1))
+        self.capacity = max(int(capacity), self.S)
         handle = C.c_void_p()
         with torch.cuda.device(self.dev):
-            _lib.check(lib.dcx_model_create(C.byref(handle), self.dev.index, C.byref(self.desc), kind,
-                                            _kparams(p0, p1), _ptr(sf), _ptr(w), self.S, self.D, self.C))
+            _lib.check(lib.dcx_model_create_ex(C.byref(handle), self.dev.index, C.byref(self.desc), kind,
+                                               _kparams(p0, p1), _ptr(sf), _ptr(w), self.S, self.D, self.C,
+                                               self.capacity, _stream(self.dev)))
         self._h = handle
         self._lib = lib
+
+    def update(self, support_feat, weights):
+        """new supports / weights into the same model (dcx_model_update): what train / fit_poly / update do to a checker's
+        state every round of an active-learning loop"""
+        sf, w = self._rows(support_feat, weights, self.dev)
+        if int(w.shape[1]) != self.C or (len(sf) and sf.shape[1] != self.D):
+            raise ValueError("update() keeps the model's feature width and class count")
+        with torch.cuda.device(self.dev):
+            _lib.check(self._lib.dcx_model_update(self._h, _ptr(sf), _ptr(w), len(sf), _stream(self.dev)))
+        self.S = len(sf)
+        self.capacity = max(self.capacity, self.S)
+        return self
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None

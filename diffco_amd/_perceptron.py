@@ -7,6 +7,8 @@ foreign kernel callable the same algorithm runs as a host loop below, filling ke
 the reference does.  Behaviour restated from the reference: DiffCo.train_perceptron
 kernel_perceptrons.py:98-137 and MultiDiffCo.train_perceptron deprecated/MultiDiffCo.py:50-83.
 """
+import sys
+
 import torch
 
 from . import _ops
@@ -167,6 +169,7 @@ class FusedScorer:
 
     def __init__(self):
         self._key, self._model, self._sup, self._w = None, None, None, None
+        self._struct, self._retired = None, None
 
     def model(self, transform, kernel_func, support_feat, weights, device=None):
         spec = kernel_spec(kernel_func)
@@ -174,7 +177,21 @@ class FusedScorer:
         key = (None if desc is None else desc.key(), spec, support_feat._version, weights._version,
                tuple(support_feat.shape), tuple(weights.shape), str(device))
         if self._model is None or self._sup is not support_feat or self._w is not weights or key != self._key:
-            self._model = _ops.ScoreModel(desc, spec[0], spec[1], spec[2], support_feat, weights, device=device)
+            old = self._model if self._model is not None else self._retired
+            # (refilled in place only while this cache is the model's sole owner: a ShardedAdamRun or an optimiser's terms
+            # object that still holds it keeps the rows it was built with)
+            same_shape = (old is not None and self._struct == (key[0], spec, int(weights.reshape(len(weights), -1).shape[1]), str(device))
+                          and len(support_feat) <= 4 * max(old.capacity, 1) and sys.getrefcount(old) <= 3)
+            if same_shape:
+                # the same transform / kernel / class count with new supports or weights (train, fit_poly, update): the
+                # model is refilled in place (dcx_model_update) - its storage, FK tables and per-stream scratch stay
+                self._model = old.update(support_feat, weights)
+            else:
+                # (room to grow: an active-learning loop adds supports round by round)
+                self._model = _ops.ScoreModel(desc, spec[0], spec[1], spec[2], support_feat, weights, device=device,
+                                              capacity=len(support_feat) + len(support_feat) // 4)
+            self._struct = (key[0], spec, self._model.C, str(device))
+            self._retired = None
             self._key, self._sup, self._w = key, support_feat, weights
         return self._model
 
@@ -190,4 +207,7 @@ class FusedScorer:
         return m.score(point.reshape(-1, m.dof))
 
     def invalidate(self):
+        # the state changed behind the version counters: the next call refills the model (kept aside) instead of rebuilding it
+        if self._model is not None:
+            self._retired = self._model
         self._key, self._model, self._sup, self._w = None, None, None, None

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(64) void score_finish_kernel(const FinishArgs a) {
         if (c0 == 0) score0 = v[0];
 #pragma unroll
         for (int u = 0; u < EC; ++u)
-            if (u < n && a.score != nullptr && lane < nb) a.score[(b0 + lane) * a.C + c0 + u] = v[u];
+            if (u < n && c0 + u < a.c_out && a.score != nullptr && lane < nb) a.score[(b0 + lane) * a.c_out + c0 + u] = v[u];
     }
     if (!a.want_grad) return;
     const fk_cptr fk = stage_fk_prog(a.fk, smem + lp.fk, lane, 64);

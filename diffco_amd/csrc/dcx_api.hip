@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "dcx_internal.h"
+#include "pack_kernels.h"
 
 using namespace dcx;
 
@@ -29,7 +30,13 @@ struct dcx_model {
     float* centre_dev = nullptr;   // [Dt]: the support centroid for features an FK transform produced, zero for raw inputs
     int64_t S_in = 0;
     int32_t S_active = 0;
+    int64_t cap = 0;               // supports the row storage holds (dcx_model_create_ex capacity; dcx_model_update refills in place)
+    size_t aplanes_cap = 0;
+    float fold = 1.0f;             // factor folded into the row weights: 1/eps (Polyharmonic(1)), (2/gamma)^2 (RQ2), else 1
+    int32_t* info_dev = nullptr;   // 16 bytes the packing kernel reports in (kept rows, max |s - c|^2) ...
+    int32_t* info_host = nullptr;  // ... and their pinned host copy
     int32_t D = 0, Dt = 0, C = 0, RS = 0;
+    int32_t Cc = 0;                // the class count the kernels are compiled for (compiled_classes(C) >= C): row layout, accumulators
     int32_t kind = 0, kf = 0;
     float kp0 = 0, kp1 = 0;
     float kp0_sweep = 0;           // what the sweeps get as ScoreArgs::kp0: 2/gamma for RQ2 (constants folded, score_kernel.h sweep_eval), else kp0
@@ -345,7 +352,7 @@ Geometry pick_geometry(const dcx_model* m, int64_t B, int acc_floats, bool allow
         // Wide shapes (URDF hands, dual arms): nw partial rows of D + C floats per lane would leave one or two waves
         // per CU.  Fold through ONE row instead (LDS no longer grows with nw) and take the block size that keeps the
         // most waves resident: registers allow 4 * wps waves per CU, LDS 160 KB / block.
-        const int wps = sweep_min_waves(m->Dt, m->C, m->kf);
+        const int wps = sweep_min_waves(m->Dt, m->Cc, m->kf);
         int best_nw = 1, best_waves = 0;
         for (int nw = g.nw; nw >= 1; nw /= 2) {
             const size_t lds = lds_bytes(nw, 1);
@@ -379,7 +386,7 @@ float* split_scratch(const dcx_model* m, hipStream_t st, size_t bytes) {
         if (sc.stream == st) return sc.bytes >= bytes ? sc.ptr : nullptr;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
-    const size_t fixed = kScratchHead + (size_t)2 * m->n_cu * (m->Dt + m->C) * 64 * sizeof(float);
+    const size_t fixed = kScratchHead + (size_t)2 * m->n_cu * (m->Dt + m->Cc) * 64 * sizeof(float);
     if (bytes > fixed) return nullptr;
     float* p = nullptr;
     if (hipMalloc((void**)&p, fixed) != hipSuccess) {
@@ -459,11 +466,11 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
               int mode, int one_hot, int64_t grad_stride, hipStream_t st, Hinge hinge = Hinge(), int nz = 1) {
     if (B == 0) return DCX_OK;
     const int d_fk = m->fk.n_points * m->fk.point_dim;
-    const int acc = (mode == MODE_SCORE ? 0 : m->Dt) + m->C;
+    const int acc = (mode == MODE_SCORE ? 0 : m->Dt) + m->Cc;
     const int64_t nblk = (B + 63) / 64;
     // the split rule sees nz launches' worth of tiles: the classes fill the chip too
     // the expanded form of the sweep (centred data, score_kernel.h) where it is compiled and not switched off
-    const bool xf_able = knobs().xf != 0 && xf_applies(m->Dt, m->C, m->kf) && m->rows_xf_dev != nullptr &&
+    const bool xf_able = knobs().xf != 0 && xf_applies(m->Dt, m->Cc, m->kf) && m->rows_xf_dev != nullptr &&
                          (m->kf != KF_RQ2 || m->xf_rq_ok || knobs().xf >= 2);   // (knob xf = 2 forces it past the rule: tools/xf_rq_rule.py)
     Geometry g = pick_geometry(m, B * nz, acc, true);
     float* part = nullptr;
@@ -501,6 +508,7 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
     a.d_fk = d_fk;
     a.frame_floats = m->frame_floats;
     a.kind = m->kind;
+    a.c_out = m->C;
     a.one_hot = one_hot;
     a.nz = nz;
     a.grad_stride = grad_stride;
@@ -514,7 +522,7 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
     a.xf = xf_able ? 1 : 0;
     // MFMA form of the gradient fold: compiled for even D <= 16 with the two specialised kernel functions; needs every
     // wave to own a slice of the LDS reduction scratch (nw > 1, parallel fold)
-    a.mfma = (mode != MODE_SCORE && (m->C == 1 || m->C == 5 || m->C == 8) && m->Dt <= 16 && (m->Dt % 2) == 0 && m->kf != KF_GEN && g.nw > 1 && g.red_slots == g.nw &&
+    a.mfma = (mode != MODE_SCORE && (m->Cc == 1 || m->Cc == 5 || m->Cc == 8) && (m->Dt == 12 || m->Dt == 16) && (m->Dt % 2) == 0 && m->kf != KF_GEN && g.nw > 1 && g.red_slots == g.nw &&
               knobs().mfma != 0 && knobs().mfma > 0) ? 1 : 0;
     if (a.mfma) a.xf = 0;
     if (a.xf) {  // the XF kernel: the centred rows and the centroid
@@ -523,7 +531,7 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
     }
     // XM: the expanded form's distance on the matrix cores (score_kernel.h sweep_rows, XM).  Slices then start on the
     // 16-row blocks of the A planes.
-    a.xm = (a.xf && mode == MODE_GRAD_ROW && m->aplanes_dev != nullptr && xm_applies(m->Dt, m->C, m->kf) && knobs().xm > 0) ? 1 : 0;
+    a.xm = (a.xf && mode == MODE_GRAD_ROW && m->aplanes_dev != nullptr && xm_applies(m->Dt, m->Cc, m->kf) && knobs().xm > 0) ? 1 : 0;
     if (a.xm) {
         a.aplanes = m->aplanes_dev;
         a.s_super = (a.s_super + 15) / 16 * 16;
@@ -543,14 +551,14 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
 #endif
     size_t lds = sizeof(float) * (lds_plan(a.dof, d_fk, m->frame_floats, g.nw > 1 ? g.red_slots : 0, acc, true).total + m->prog_floats);
     if (g.ys == 1) {
-        hipError_t e = m->launch(m->kf, m->C, mode, g.nw, lds, nblk, a, st);
+        hipError_t e = m->launch(m->kf, m->Cc, mode, g.nw, lds, nblk, a, st);
         if (e != hipSuccess) return fail_hip(e, "score kernel launch");
         return DCX_OK;
     }
     if (nz > 1 && counters == nullptr) return DCX_ERR_UNSUPPORTED;  // score_finish_kernel has no class dimension
     a.partial = part;
     a.tile_done = counters;
-    hipError_t e = m->launch(m->kf, m->C, mode, g.nw, lds, nblk, a, st);
+    hipError_t e = m->launch(m->kf, m->Cc, mode, g.nw, lds, nblk, a, st);
     if (e == hipSuccess && counters == nullptr) {
         FinishArgs f{};
         f.partial = part;
@@ -563,7 +571,8 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
         f.grad_stride = grad_stride;
         f.ys = g.ys;
         f.acc = acc;
-        f.C = m->C;
+        f.C = m->Cc;
+        f.c_out = m->C;
         f.Dt = m->Dt;
         f.dof = m->fk.dof;
         f.d_fk = d_fk;
@@ -613,8 +622,214 @@ int dcx_device_count(void) {
     return n;
 }
 
+// ---- the model's rows: storage for `cap` supports, filled from host staging or by the packing kernel ---------------------
+static constexpr double kXfRqRule = 32.0;   // RQ2 takes the expanded form iff gamma * max |s - c|^2 <= this (see model_fill_host)
+static size_t rows_tail_floats(const dcx_model* m) { return 8 * (size_t)m->RS + 16; }  // the MFMA B-operand loads run up to 7 rows + 15 floats ahead
+static size_t aplane_shorts(int64_t rows) { return ((size_t)(rows + 15) / 16 + 2) * 3 * 16 * 4 * 8; }
+
+static void model_free_rows(dcx_model* m) {
+    if (m->rows_dev) (void)hipFree(m->rows_dev);
+    if (m->rows_xf_dev) (void)hipFree(m->rows_xf_dev);
+    if (m->aplanes_dev) (void)hipFree(m->aplanes_dev);
+    m->rows_dev = m->rows_xf_dev = nullptr;
+    m->aplanes_dev = nullptr;
+    m->cap = 0;
+}
+
+// room for `cap` rows (both copies, the same tail padding: the two are interchangeable), the centroid, the read-back words
+static int model_alloc_rows(dcx_model* m, int64_t cap) {
+    if (cap < 1) cap = 1;
+    if (cap <= m->cap && m->rows_dev) return DCX_OK;
+    model_free_rows(m);
+    const size_t floats = (size_t)cap * m->RS + rows_tail_floats(m);
+    hipError_t e = hipMalloc((void**)&m->rows_dev, floats * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&m->rows_xf_dev, floats * sizeof(float));
+    if (e == hipSuccess && !m->centre_dev) e = hipMalloc((void**)&m->centre_dev, (size_t)m->Dt * sizeof(float));
+    if (e == hipSuccess && !m->info_dev) e = hipMalloc((void**)&m->info_dev, 16);
+    if (e == hipSuccess && !m->info_host) e = hipHostMalloc((void**)&m->info_host, 16, hipHostMallocDefault);
+    if (e != hipSuccess) return fail_hip(e, "device allocation of the model");
+    m->cap = cap;
+    return DCX_OK;
+}
+
+// Device inputs (round 4): one packing launch on the caller's stream (pack_kernels.hip) and a 16-byte read-back - the kept
+// row count decides the launch geometry of everything that follows.  No bulk copy in either direction.
+static int model_fill_device(dcx_model* m, const float* feat_dev, const float* w_dev, int64_t S, hipStream_t stream) {
+    PackArgs a{};
+    a.feat = feat_dev;
+    a.w = w_dev;
+    a.rows = m->rows_dev;
+    a.rows_xf = m->rows_xf_dev;
+    a.centre = m->centre_dev;
+    a.info = m->info_dev;
+    a.S = S;
+    a.D = m->D;
+    a.Dt = m->Dt;
+    a.C = m->C;
+    a.Cl = m->Cc;
+    a.RS = m->RS;
+    a.tail_floats = (int32_t)rows_tail_floats(m);
+    a.centred = (m->fk.kind != DCX_FK_NONE) ? 1 : 0;
+    a.rq2 = (m->kf == KF_RQ2) ? 1 : 0;
+    a.fold = m->fold;
+    a.seed = m->kp0_sweep;
+    hipError_t e = launch_pack_rows(a, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(m->info_host, m->info_dev, 16, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return fail_hip(e, "packing of the support rows");
+    double ss_max;
+    std::memcpy(&ss_max, reinterpret_cast<const char*>(m->info_host) + 8, sizeof(double));
+    m->S_in = S;
+    m->S_active = m->info_host[0];
+    m->xf_rq_ok = (m->kf == KF_RQ2 && m->fk.kind != DCX_FK_NONE && (double)m->kp0 * ss_max <= kXfRqRule) ? 1 : 0;
+    return DCX_OK;
+}
+
+// Host inputs (or the XM planes asked for: their bf16 split is done here): staged and packed on the host, one copy per array
+// into the model's storage.  pack_rows_kernel restates exactly this arithmetic.
+static int model_fill_host(dcx_model* m, const float* support_feat, const float* weights, int64_t S, hipStream_t stream) {
+    const int32_t D = m->D, C = m->C, Cl = m->Cc;
+    std::vector<float> feat((size_t)S * D), w((size_t)S * C);
+    if (S > 0) {
+        hipError_t e = hipStreamSynchronize(stream);   // (device inputs: whatever produced them on this stream is done)
+        if (e == hipSuccess) e = hipMemcpy(feat.data(), support_feat, feat.size() * sizeof(float), hipMemcpyDefault);
+        if (e == hipSuccess) e = hipMemcpy(w.data(), weights, w.size() * sizeof(float), hipMemcpyDefault);
+        if (e != hipSuccess) return fail_hip(e, "copy of supports/weights");
+    }
+    // support rows: [D coords | zero pad to Dt | C weights | (C>1) row sum | |s|^2 | pad]; all-zero-weight rows dropped.
+    const float fold = m->fold;
+    std::vector<float> rows;
+    rows.reserve((size_t)S * m->RS + rows_tail_floats(m));
+    int32_t kept = 0;
+    for (int64_t j = 0; j < S; ++j) {
+        bool any = false;
+        for (int c = 0; c < C; ++c) any |= (w[j * C + c] != 0.0f);
+        if (!any) continue;
+        const size_t base = rows.size();
+        rows.resize(base + m->RS, 0.0f);
+        for (int k = 0; k < D; ++k) rows[base + k] = feat[j * D + k];
+        float sum = 0.0f;
+        for (int c = 0; c < C; ++c) {
+            const float v = w[j * C + c] * fold;
+            rows[base + m->Dt + c] = v;
+            sum += v;
+        }
+        if (Cl > 1) rows[base + m->Dt + Cl] = sum;   // (columns C .. Cl-1: zero weights of the padding classes)
+        double ss = 0.0;  // |s|^2 of the fp32 coordinates, rounded once (RowLayout::SS_OFF; the expanded-form sweep)
+        for (int k = 0; k < D; ++k) ss += (double)feat[j * D + k] * (double)feat[j * D + k];
+        rows[base + m->Dt + Cl + (Cl > 1 ? 1 : 0)] = (float)ss;
+        ++kept;
+    }
+    m->S_in = S;
+    m->S_active = kept;
+    m->xf_rq_ok = 0;
+    // the centred copy for the expanded-form sweeps: c = mean of the kept supports (float64, rounded once); every
+    // coordinate s - c formed in fp32 exactly as the kernel forms x - c, so that a query that coincides with a support
+    // still gives r = 0 exactly
+    std::vector<float> centre(m->Dt, 0.0f), rows_xf(rows);
+    const int ss_off = m->Dt + Cl + (Cl > 1 ? 1 : 0);
+    if (m->fk.kind != DCX_FK_NONE && kept > 0) {
+        for (int k = 0; k < D; ++k) {
+            double acc = 0.0;
+            for (int32_t j = 0; j < kept; ++j) acc += (double)rows[(size_t)j * m->RS + k];
+            centre[k] = (float)(acc / (double)kept);
+        }
+    }
+    double ss_max = 0.0;
+    for (int32_t j = 0; j < kept; ++j) {
+        float* cen = &rows_xf[(size_t)j * m->RS];
+        double ss = 0.0;
+        for (int k = 0; k < D; ++k) {
+            cen[k] = cen[k] - centre[k];
+            ss += (double)cen[k] * (double)cen[k];
+        }
+        ss_max = std::max(ss_max, ss);
+        // RQ2: the expanded sweep's t = d2 + 2/gamma takes its seed from this column (one rounding for the sum)
+        cen[ss_off] = (m->kf == KF_RQ2) ? (float)(ss + (double)m->kp0_sweep) : (float)ss;
+    }
+    // RQ2 in the expanded form: features an FK transform produced, centred, with gamma * max |s - c|^2 <= 32.  The error
+    // of the expanded form grows linearly in that number (tools/xf_rq_rule.py, profiles/r04_xf_rq_rule.txt: Baxter and
+    // Panda, gamma 2 .. 80: 2e-6 / 2.5e-6 against float64 at 29, 3.5e-6 / 7e-6 at 58, 1e-5 at 117; the direct form
+    // stays at 3e-7 .. 1e-6): 32 keeps it a factor of four inside the 1e-5 bar.  Larger gamma or workspace: direct form.
+    m->xf_rq_ok = (m->kf == KF_RQ2 && m->fk.kind != DCX_FK_NONE && (double)m->kp0 * ss_max <= kXfRqRule) ? 1 : 0;
+    std::vector<unsigned short> aplanes;
+    if (kept > 0) {
+        // XM sweep: the centred coordinates split into three bf16 planes by truncation and laid out as the A operands of
+        // v_mfma_f32_16x16x32_bf16: [16-row block][chunk c][support m][k'][8], K slot 8 k' + e of chunk c = term 2c + slot / 16,
+        // feature slot % 16; terms hi.hi hi.mid mid.hi hi.lo lo.hi mid.mid take the s planes hi mid hi lo hi mid
+        if (xm_applies(m->Dt, C, m->kf)) {
+            const int splane_of_term[6] = {0, 1, 0, 2, 0, 1};
+            aplanes.assign(aplane_shorts(kept), 0);
+            for (int32_t j = 0; j < kept; ++j) {
+                unsigned short pl[3][16] = {};
+                for (int k = 0; k < D; ++k) {
+                    float r = rows_xf[(size_t)j * m->RS + k];
+                    for (int p = 0; p < 3; ++p) {
+                        uint32_t u;
+                        std::memcpy(&u, &r, 4);
+                        u &= 0xFFFF0000u;
+                        float h;
+                        std::memcpy(&h, &u, 4);
+                        pl[p][k] = (unsigned short)(u >> 16);
+                        r -= h;
+                    }
+                }
+                for (int c = 0; c < 3; ++c)
+                    for (int kq = 0; kq < 4; ++kq)
+                        for (int e2 = 0; e2 < 8; ++e2) {
+                            const int slot = 8 * kq + e2, term = 2 * c + slot / 16, kk = slot % 16;
+                            aplanes[((((size_t)(j / 16) * 3 + c) * 16 + (j % 16)) * 4 + kq) * 8 + e2] = pl[splane_of_term[term]][kk];
+                        }
+            }
+        }
+    }
+    rows.resize(rows.size() + rows_tail_floats(m), 0.0f);
+    rows_xf.resize(rows.size(), 0.0f);
+    hipError_t e = hipMemcpy(m->rows_dev, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(m->rows_xf_dev, rows_xf.data(), rows_xf.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(m->centre_dev, centre.data(), centre.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess && !aplanes.empty()) {
+        if (m->aplanes_dev && m->aplanes_cap < aplanes.size()) {
+            (void)hipFree(m->aplanes_dev);
+            m->aplanes_dev = nullptr;
+        }
+        if (!m->aplanes_dev) {
+            m->aplanes_cap = aplane_shorts(m->cap);
+            e = hipMalloc((void**)&m->aplanes_dev, m->aplanes_cap * sizeof(unsigned short));
+        }
+        if (e == hipSuccess) e = hipMemcpy(m->aplanes_dev, aplanes.data(), aplanes.size() * sizeof(unsigned short), hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) return fail_hip(e, "upload of the model's rows");
+    return DCX_OK;
+}
+
+// device memory?  (a pageable host pointer is unknown to the runtime: that is an error code here, not a failure)
+static bool is_device_ptr(const void* p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return at.type == hipMemoryTypeDevice;
+}
+
+// (re)fill the rows of a model whose storage holds >= S supports
+static int model_fill(dcx_model* m, const float* support_feat, const float* weights, int64_t S, hipStream_t stream) {
+    // the XM planes (knob xm > 0: measurements only) are split on the host
+    const bool on_device = S > 0 && is_device_ptr(support_feat) && is_device_ptr(weights) &&
+                           !(knobs().xm > 0 && xm_applies(m->Dt, m->Cc, m->kf));
+    if (on_device) return model_fill_device(m, support_feat, weights, S, stream);
+    return model_fill_host(m, support_feat, weights, S, stream);
+}
+
 int dcx_model_create(dcx_model** out, int device, const dcx_fk_desc* fk, int kernel_kind, const float* kparams,
                      const float* support_feat, const float* weights, int64_t S, int32_t D, int32_t C) {
+    return dcx_model_create_ex(out, device, fk, kernel_kind, kparams, support_feat, weights, S, D, C, 0, nullptr);
+}
+
+int dcx_model_create_ex(dcx_model** out, int device, const dcx_fk_desc* fk, int kernel_kind, const float* kparams,
+                        const float* support_feat, const float* weights, int64_t S, int32_t D, int32_t C,
+                        int64_t capacity, void* stream) {
     if (!out) return fail(DCX_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (S < 0 || S > 0x7fffffffLL) return fail(DCX_ERR_INVALID, "S out of range");
@@ -644,7 +859,8 @@ int dcx_model_create(dcx_model** out, int device, const dcx_fk_desc* fk, int ker
     m->D = D;
     m->Dt = template_d_for(D);
     m->C = C;
-    m->RS = row_stride(m->Dt, C);
+    m->Cc = compiled_classes(C);
+    m->RS = row_stride(m->Dt, m->Cc);
     m->kind = kernel_kind;
     m->kp0 = kparams[0];
     m->kp1 = kparams[1];
@@ -663,43 +879,9 @@ int dcx_model_create(dcx_model** out, int device, const dcx_fk_desc* fk, int ker
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) m->n_cu = prop.multiProcessorCount;
 
-    // host staging of the inputs (they may be device pointers)
-    std::vector<float> feat((size_t)S * D), w((size_t)S * C);
-    if (S > 0) {
-        hipError_t e = hipMemcpy(feat.data(), support_feat, feat.size() * sizeof(float), hipMemcpyDefault);
-        if (e == hipSuccess) e = hipMemcpy(w.data(), weights, w.size() * sizeof(float), hipMemcpyDefault);
-        if (e != hipSuccess) {
-            delete m;
-            return fail_hip(e, "copy of supports/weights");
-        }
-    }
-    // support rows: [D coords | zero pad to Dt | C weights | (C>1) row sum | |s|^2 | pad]; all-zero-weight rows dropped.
     // Polyharmonic(k=1): the 1/eps factor is folded into the weights (score and gradient are linear in them).
     // RQKernel(p = 2): (2/gamma)^2 is folded into them (score_kernel.h sweep_eval; one rounding per weight, like 1/eps).
-    const float fold = (m->kf == KF_POLY1) ? 1.0f / m->kp1 : (m->kf == KF_RQ2) ? (float)(4.0 / ((double)m->kp0 * (double)m->kp0)) : 1.0f;
-    std::vector<float> rows;
-    rows.reserve((size_t)S * m->RS);
-    int32_t kept = 0;
-    for (int64_t j = 0; j < S; ++j) {
-        bool any = false;
-        for (int c = 0; c < C; ++c) any |= (w[j * C + c] != 0.0f);
-        if (!any) continue;
-        const size_t base = rows.size();
-        rows.resize(base + m->RS, 0.0f);
-        for (int k = 0; k < D; ++k) rows[base + k] = feat[j * D + k];
-        float sum = 0.0f;
-        for (int c = 0; c < C; ++c) {
-            const float v = w[j * C + c] * fold;
-            rows[base + m->Dt + c] = v;
-            sum += v;
-        }
-        if (C > 1) rows[base + m->Dt + C] = sum;
-        double ss = 0.0;  // |s|^2 of the fp32 coordinates, rounded once (RowLayout::SS_OFF; the expanded-form sweep)
-        for (int k = 0; k < D; ++k) ss += (double)feat[j * D + k] * (double)feat[j * D + k];
-        rows[base + m->Dt + C + (C > 1 ? 1 : 0)] = (float)ss;
-        ++kept;
-    }
-    m->S_active = kept;
+    m->fold = (m->kf == KF_POLY1) ? 1.0f / m->kp1 : (m->kf == KF_RQ2) ? (float)(4.0 / ((double)m->kp0 * (double)m->kp0)) : 1.0f;
     if (int rc = upload_fk_prog(m->fk, &m->fk_dev)) {
         dcx_model_destroy(m);
         return rc;
@@ -719,83 +901,33 @@ int dcx_model_create(dcx_model** out, int device, const dcx_fk_desc* fk, int ker
             m->dh = dh_args_of(dh, m->dh_dev);
         }
     }
-    hipError_t e = hipSuccess;
-    if (kept > 0) {
-        // the centred copy for the expanded-form sweeps: c = mean of the kept supports (float64, rounded once); every
-        // coordinate s - c formed in fp32 exactly as the kernel forms x - c, so that a query that coincides with a support
-        // still gives r = 0 exactly
-        std::vector<float> centre(m->Dt, 0.0f), rows_xf(rows);
-        rows_xf.resize(rows.size() + 8 * (size_t)m->RS + 16, 0.0f);  // the same tail padding as `rows` below: the two are interchangeable
-        const int ss_off = m->Dt + C + (C > 1 ? 1 : 0);
-        if (m->fk.kind != DCX_FK_NONE) {
-            for (int k = 0; k < D; ++k) {
-                double acc = 0.0;
-                for (int32_t j = 0; j < kept; ++j) acc += (double)rows[(size_t)j * m->RS + k];
-                centre[k] = (float)(acc / (double)kept);
-            }
-        }
-        double ss_max = 0.0;
-        for (int32_t j = 0; j < kept; ++j) {
-            float* cen = &rows_xf[(size_t)j * m->RS];
-            double ss = 0.0;
-            for (int k = 0; k < D; ++k) {
-                cen[k] = cen[k] - centre[k];
-                ss += (double)cen[k] * (double)cen[k];
-            }
-            ss_max = std::max(ss_max, ss);
-            // RQ2: the expanded sweep's t = d2 + 2/gamma takes its seed from this column (one rounding for the sum)
-            cen[ss_off] = (m->kf == KF_RQ2) ? (float)(ss + (double)m->kp0_sweep) : (float)ss;
-        }
-        // RQ2 in the expanded form: features an FK transform produced, centred, with gamma * max |s - c|^2 <= 32.  The error
-        // of the expanded form grows linearly in that number (tools/xf_rq_rule.py, profiles/r04_xf_rq_rule.txt: Baxter and
-        // Panda, gamma 2 .. 80: 2e-6 / 2.5e-6 against float64 at 29, 3.5e-6 / 7e-6 at 58, 1e-5 at 117; the direct form
-        // stays at 3e-7 .. 1e-6): 32 keeps it a factor of four inside the 1e-5 bar.  Larger gamma or workspace: direct form.
-        m->xf_rq_ok = (m->kf == KF_RQ2 && m->fk.kind != DCX_FK_NONE && (double)m->kp0 * ss_max <= 32.0) ? 1 : 0;
-        // XM sweep: the centred coordinates split into three bf16 planes by truncation and laid out as the A operands of
-        // v_mfma_f32_16x16x32_bf16: [16-row block][chunk c][support m][k'][8], K slot 8 k' + e of chunk c = term 2c + slot / 16,
-        // feature slot % 16; terms hi.hi hi.mid mid.hi hi.lo lo.hi mid.mid take the s planes hi mid hi lo hi mid
-        std::vector<unsigned short> aplanes;
-        if (xm_applies(m->Dt, C, m->kf)) {
-            const int splane_of_term[6] = {0, 1, 0, 2, 0, 1};
-            aplanes.assign(((size_t)(kept + 15) / 16 + 2) * 3 * 16 * 4 * 8, 0);
-            for (int32_t j = 0; j < kept; ++j) {
-                unsigned short pl[3][16] = {};
-                for (int k = 0; k < D; ++k) {
-                    float r = rows_xf[(size_t)j * m->RS + k];
-                    for (int p = 0; p < 3; ++p) {
-                        uint32_t u;
-                        std::memcpy(&u, &r, 4);
-                        u &= 0xFFFF0000u;
-                        float h;
-                        std::memcpy(&h, &u, 4);
-                        pl[p][k] = (unsigned short)(u >> 16);
-                        r -= h;
-                    }
-                }
-                for (int c = 0; c < 3; ++c)
-                    for (int kq = 0; kq < 4; ++kq)
-                        for (int e2 = 0; e2 < 8; ++e2) {
-                            const int slot = 8 * kq + e2, term = 2 * c + slot / 16, kk = slot % 16;
-                            aplanes[((((size_t)(j / 16) * 3 + c) * 16 + (j % 16)) * 4 + kq) * 8 + e2] = pl[splane_of_term[term]][kk];
-                        }
-            }
-        }
-        rows.resize(rows.size() + 8 * (size_t)m->RS + 16, 0.0f);  // the MFMA B-operand loads run up to 7 rows + 15 floats ahead
-        e = hipMalloc((void**)&m->rows_dev, rows.size() * sizeof(float));
-        if (e == hipSuccess) e = hipMemcpy(m->rows_dev, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMalloc((void**)&m->rows_xf_dev, rows_xf.size() * sizeof(float));
-        if (e == hipSuccess) e = hipMemcpy(m->rows_xf_dev, rows_xf.data(), rows_xf.size() * sizeof(float), hipMemcpyHostToDevice);
-        if (e == hipSuccess && !aplanes.empty()) e = hipMalloc((void**)&m->aplanes_dev, aplanes.size() * sizeof(unsigned short));
-        if (e == hipSuccess && !aplanes.empty()) e = hipMemcpy(m->aplanes_dev, aplanes.data(), aplanes.size() * sizeof(unsigned short), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMalloc((void**)&m->centre_dev, centre.size() * sizeof(float));
-        if (e == hipSuccess) e = hipMemcpy(m->centre_dev, centre.data(), centre.size() * sizeof(float), hipMemcpyHostToDevice);
-    }
-    if (e != hipSuccess) {
+    if (capacity > 0x7fffffffLL) capacity = 0x7fffffffLL;
+    int rc = model_alloc_rows(m, std::max<int64_t>(S, capacity));
+    if (rc == DCX_OK) rc = model_fill(m, support_feat, weights, S, (hipStream_t)stream);
+    if (rc != DCX_OK) {
+        const std::string msg = g_err;
         dcx_model_destroy(m);
-        return fail_hip(e, "device allocation of the model");
+        g_err = msg;
+        return rc;
     }
     *out = m;
     return DCX_OK;
+}
+
+int dcx_model_update(dcx_model* m, const float* support_feat, const float* weights, int64_t S, void* stream) {
+    if (!m) return fail(DCX_ERR_INVALID, "model is NULL");
+    if (S < 0 || S > 0x7fffffffLL) return fail(DCX_ERR_INVALID, "S out of range");
+    if (S > 0 && (!support_feat || !weights)) return fail(DCX_ERR_INVALID, "support_feat / weights is NULL");
+    if (int rc = set_device(m->device)) return rc;
+    std::lock_guard<std::mutex> lock(m->mu);
+    if (S > m->cap) {
+        // more supports than the storage holds: new storage (blocking; ask dcx_model_create_ex for capacity to avoid it).
+        // Launches already enqueued may still read the old rows: wait for them first.
+        hipError_t e = hipDeviceSynchronize();
+        if (e != hipSuccess) return fail_hip(e, "dcx_model_update");
+        if (int rc = model_alloc_rows(m, S)) return rc;
+    }
+    return model_fill(m, support_feat, weights, S, (hipStream_t)stream);
 }
 
 void dcx_model_destroy(dcx_model* m) {
@@ -807,6 +939,8 @@ void dcx_model_destroy(dcx_model* m) {
     if (m->rows_xf_dev) (void)hipFree(m->rows_xf_dev);
     if (m->centre_dev) (void)hipFree(m->centre_dev);
     if (m->aplanes_dev) (void)hipFree(m->aplanes_dev);
+    if (m->info_dev) (void)hipFree(m->info_dev);
+    if (m->info_host) (void)hipHostFree(m->info_host);
     for (auto& sc : m->scratch)
         if (sc.ptr) (void)hipFree(sc.ptr);
     for (auto& ex : m->traj_exch)
@@ -872,7 +1006,8 @@ int dcx_score_hess(const dcx_model* m, const float* q, int64_t B, const float* u
     v.fk = m->fk_dev;
     v.S = m->S_active;
     v.Dt = m->Dt;
-    v.C = m->C;
+    v.C = m->Cc;
+    v.c_out = m->C;
     v.RS = m->RS;
     v.dof = m->fk.dof;
     v.d_fk = m->fk.n_points * m->fk.point_dim;
@@ -890,7 +1025,7 @@ int dcx_score_hess(const dcx_model* m, const float* q, int64_t B, const float* u
         v.n_counters = (int32_t)kTileCounters;
         v.counter_stride = kCounterStride;
         v.scratch = sc + kScratchHead / sizeof(float);
-        v.scratch_bytes = (size_t)2 * m->n_cu * (m->Dt + m->C) * 64 * sizeof(float);
+        v.scratch_bytes = (size_t)2 * m->n_cu * (m->Dt + m->Cc) * 64 * sizeof(float);
     }
     const hipError_t e = launch_hess(v, q, B, upstream, grad, hess, (hipStream_t)stream);
     if (e == hipErrorInvalidValue) return fail(DCX_ERR_UNSUPPORTED, "dcx_score_hess: the transform's feature row does not fit the LDS in duals");
@@ -914,7 +1049,7 @@ int dcx_score_jac(const dcx_model* m, const float* q, int64_t B, float* score, f
     // A chip-filling batch: every class in ONE sweep (jac_kernel.h) where it is compiled (D * C + C <= 104 accumulators per
     // lane).  Knob jac_one_sweep: 0 = never, 1 = also for small batches (tests).
     const int64_t one_sweep = knobs().jac_one_sweep;
-    if (jac_applies(m->Dt, m->C) && B > 0 && one_sweep != 0 && !(knobs().jac_per_class > 0) &&
+    if (jac_applies(m->Dt, m->Cc) && B > 0 && one_sweep != 0 && !(knobs().jac_per_class > 0) &&
         (one_sweep > 0 || (B + 63) / 64 * m->C > 2 * (int64_t)m->n_cu)) {
         const int d_fk = m->fk.n_points * m->fk.point_dim;
         int nw = std::min(16, m->max_threads / 64);
@@ -940,10 +1075,11 @@ int dcx_score_jac(const dcx_model* m, const float* q, int64_t B, float* score, f
         a.kp0 = m->kp0_sweep;
         a.kp1 = m->kp1;
         a.grad_stride = (int64_t)m->C * m->fk.dof;
-        const size_t lds = sizeof(float) * (size_t)(lds_plan_jac(a.dof, d_fk, m->frame_floats, m->C * m->Dt + m->C, m->C).total + m->prog_floats);
+        a.c_out = m->C;
+        const size_t lds = sizeof(float) * (size_t)(lds_plan_jac(a.dof, d_fk, m->frame_floats, m->Cc * m->Dt + m->Cc, m->Cc).total + m->prog_floats);
         jac_fn fn = jac_for(m->Dt);
         if (fn && lds <= 150 * 1024) {
-            hipError_t e = fn(m->kf, m->C, nw, lds, (B + 63) / 64, a, (hipStream_t)stream);
+            hipError_t e = fn(m->kf, m->Cc, nw, lds, (B + 63) / 64, a, (hipStream_t)stream);
             if (e == hipSuccess) return DCX_OK;
             if (e != hipErrorNotSupported) return fail_hip(e, "Jacobian launch");
             (void)hipGetLastError();
@@ -1011,6 +1147,8 @@ int dcx_traj_adam_run(const dcx_model* m, const dcx_traj_state* st, const dcx_tr
             while (2 * ys <= want) ys *= 2;
             int min_rows = 15;
             if (const int64_t v = knobs().min_rows; v >= 1) min_rows = (int)v;
+            // (tried: TWO 8-wave workgroups per CU at 256 paths, so that one path's lone-wave phases run beside another path's
+            // sweep - 31.8 us per iteration against 28.4 for one 16-wave workgroup: profiles/r04_traj_cluster.txt)
             while (ys > 1 && (m->S_active / (ys * nw) < min_rows || (int64_t)ys * st->n_paths > m->n_cu)) ys /= 2;
         }
         while (nw > 1 && m->S_active / (ys * nw) < 15) nw /= 2;
@@ -1039,6 +1177,7 @@ int dcx_traj_adam_run(const dcx_model* m, const dcx_traj_state* st, const dcx_tr
             a.sc.d_fk = d_fk;
             a.sc.frame_floats = m->frame_floats;
             a.sc.kind = m->kind;
+            a.sc.c_out = 1;
             a.sc.kp0 = m->kp0_sweep;
             a.sc.kp1 = m->kp1;
             a.sc.xf = (knobs().xf != 0 && m->kf == KF_POLY1 && xf_applies(m->Dt, 1, KF_POLY1) && m->rows_xf_dev) ? 1 : 0;

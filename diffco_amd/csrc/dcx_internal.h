@@ -22,6 +22,11 @@ inline int template_d_for(int D) {
 // the ~3*D live registers of the sweep
 inline int max_threads_for(int Dt) { return Dt <= 16 ? 1024 : (Dt <= 48 ? 512 : 256); }
 
+// class counts the sweeps are compiled for: 3 runs as 4, 6 and 7 as 8 - the extra classes are zero weight columns in the
+// rows, never read from `upstream` and never written to `score` (ScoreArgs::c_out).  Five is BASELINE config #3's count.
+// (Round 4: eight compiled class counts x 21 widths x 3 kernel functions x modes x forms had grown to 115 MB and 10 minutes.)
+inline int compiled_classes(int C) { return C <= 2 ? C : C <= 4 ? 4 : C == 5 ? 5 : 8; }
+
 inline int row_stride(int Dt, int C) { return (Dt + C + (C > 1 ? 1 : 0) + 1 + 3) / 4 * 4; }  // RowLayout<Dt, C>::RS
 
 // one entry point per compiled D (score_inst.hip, built once per width)
@@ -70,7 +75,8 @@ hipError_t launch_kernel_matrix(int kind, float kp0, float kp1, const float* x, 
 struct ModelView {
     const float* rows;
     const FkProg* fk;
-    int32_t S, Dt, C, RS, dof, d_fk, frame_floats, prog_floats, kind, kf;
+    int32_t S, Dt, C, RS, dof, d_fk, frame_floats, prog_floats, kind, kf;   // C: the compiled class count (row layout)
+    int32_t c_out = 0;      // the caller's class count
     float kp0, kp1;
     // this stream's split-launch scratch (dcx_api.hip split_scratch) or null: partial rows + zeroed arrival counters
     float* scratch = nullptr;

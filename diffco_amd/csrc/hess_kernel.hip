@@ -33,7 +33,8 @@ struct HessArgs {
     float* grad;            // [B][dof] or null
     float* hess;            // [B][dof][dof]
     int64_t n_lanes;        // B * dof
-    int32_t S, D, C, RS, w_off, wsum_off;
+    int32_t S, D, C, RS, w_off, wsum_off;   // C: the compiled class count (row layout)
+    int32_t c_out;                          // the caller's class count (row stride of upstream)
     int32_t dof, d_fk, frame_floats;
     int32_t kind, kf;
     int32_t fk_dh;          // 1: a DH arm - the chain and its reverse sweep read the FK program with scalar loads (fk_*_dh_k)
@@ -119,7 +120,7 @@ __device__ __forceinline__ void kernel_eval_h(const HessArgs& a, float d2, float
 __device__ __forceinline__ float pair_weight(const HessArgs& a, const float* r, const float* up) {
     if (!up) return r[a.C > 1 ? a.wsum_off : a.w_off];
     float w = 0.0f;
-    for (int c = 0; c < a.C; ++c) w = fmaf(up[c], r[a.w_off + c], w);
+    for (int c = 0; c < a.c_out; ++c) w = fmaf(up[c], r[a.w_off + c], w);
     return w;
 }
 
@@ -170,7 +171,7 @@ __device__ __forceinline__ void sweep_hess_regs(const HessArgs& a, const Dual* s
     auto weight = [&](cfloat_ptr r) __attribute__((always_inline)) {
         if (!up) return r[C > 1 ? a.wsum_off : w_off];
         float w = 0.0f;
-        for (int c = 0; c < C; ++c) w = fmaf(up[c], r[w_off + c], w);
+        for (int c = 0; c < a.c_out; ++c) w = fmaf(up[c], r[w_off + c], w);
         return w;
     };
     constexpr int NV = NP + (ODD ? 1 : 0);
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(SMALL ? 1024 : 512) void score_hess_kernel(const He
     const int yend = (ybase + a.s_super < a.S) ? ybase + a.s_super : a.S;
     const int j0 = (ybase + wave * a.s_chunk < yend) ? ybase + wave * a.s_chunk : yend;
     const int j1 = (j0 + a.s_chunk < yend) ? j0 + a.s_chunk : yend;
-    const float* up = a.upstream ? a.upstream + b * a.C : nullptr;
+    const float* up = a.upstream ? a.upstream + b * a.c_out : nullptr;
 #define DCX_HESS_CASE(W) case W: sweep_hess_regs<W, KFT>(a, sX, sAcc, up, j0, j1); break;
     auto sweep = [&](auto kft) __attribute__((always_inline)) {
         constexpr int KFT = decltype(kft)::value;
@@ -384,6 +385,7 @@ hipError_t launch_hess(const ModelView& m, const float* q, int64_t B, const floa
     a.S = m.S;
     a.D = m.Dt;
     a.C = m.C;
+    a.c_out = m.c_out;
     a.RS = m.RS;
     a.w_off = m.Dt;
     a.wsum_off = m.Dt + m.C;

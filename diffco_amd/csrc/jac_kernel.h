@@ -181,7 +181,8 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void score
     if (wave == 0) {
         if (a.score != nullptr && lane < nb) {
 #pragma unroll
-            for (int c = 0; c < CC; ++c) a.score[(b0 + lane) * CC + c] = tot[c];
+            for (int c = 0; c < CC; ++c)
+                if (c < a.c_out) a.score[(b0 + lane) * a.c_out + c] = tot[c];
         }
 #pragma unroll
         for (int c = 0; c < CC; ++c) {
@@ -204,9 +205,9 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void score
         for (int i = lane; i < n; i += 64) gdst[(int64_t)(i / dof) * a.grad_stride + (i % dof)] = gq[i];
     };
     if (parallel) {
-        if (wave < CC) finish_class(wave);
+        if (wave < a.c_out) finish_class(wave);      // (classes beyond the caller's are zero padding: no output row)
     } else if (wave == 0) {
-        for (int c = 0; c < CC; ++c) finish_class(c);
+        for (int c = 0; c < a.c_out; ++c) finish_class(c);
     }
 }
 

@@ -14,8 +14,9 @@
 //     (one lane per feature - the host's order, so the same float), s - c in fp32, |s - c|^2 (+ 2/gamma for RQ2) in the last
 //     column, and the largest |s - c|^2 for the RQ rule (dcx_api.hip xf_rq_ok).
 // The host reads back 16 bytes (kept rows, max |s - c|^2) - the launch geometry depends on the row count - and nothing else.
-// One workgroup: a model is a few thousand rows; the packing is latency, not bandwidth (S = 2000: ~40 us).
-#include "dcx_internal.h"
+// One workgroup: a model is a few thousand rows; the packing is latency, not bandwidth
+// (dcx_model_update at S = 2000: ~0.1 ms including the read-back; profiles/r04_model_latency.txt).
+#include "pack_kernels.h"
 
 namespace dcx {
 namespace {
@@ -27,7 +28,7 @@ __global__ __launch_bounds__(kPackThreads) void pack_rows_kernel(const PackArgs 
     __shared__ int s_base;
     __shared__ double s_max[kPackThreads / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ss_off = a.Dt + a.C + (a.C > 1 ? 1 : 0);
+    const int ss_off = a.Dt + a.Cl + (a.Cl > 1 ? 1 : 0);
     if (tid == 0) s_base = 0;
     __syncthreads();
     // ---- compaction + direct rows ---------------------------------------------------------------------------------------
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(kPackThreads) void pack_rows_kernel(const PackArgs 
                 r[a.Dt + c] = v;
                 sum += v;
             }
-            if (a.C > 1) r[a.Dt + a.C] = sum;
+            if (a.Cl > 1) r[a.Dt + a.Cl] = sum;
             r[ss_off] = (float)ss;
         }
         __syncthreads();
@@ -83,12 +84,12 @@ __global__ __launch_bounds__(kPackThreads) void pack_rows_kernel(const PackArgs 
             double acc = 0.0;
             const float* col = a.rows + tid;
             int j = 0;
-            for (; j + 8 <= kept; j += 8) {
-                float v[8];
+            for (; j + 32 <= kept; j += 32) {   // 32 loads in flight, the additions in row order
+                float v[32];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = col[(size_t)(j + u) * a.RS];
+                for (int u = 0; u < 32; ++u) v[u] = col[(size_t)(j + u) * a.RS];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) acc += (double)v[u];
+                for (int u = 0; u < 32; ++u) acc += (double)v[u];
             }
             for (; j < kept; ++j) acc += (double)col[(size_t)j * a.RS];
             c = (float)(acc / (double)kept);

@@ -28,7 +28,7 @@ constexpr int kMaxT = kD <= 16 ? 1024 : (kD <= 48 ? 512 : 256);
 // (one, five and eight classes: the developer knob takes it for those models, dcx_api.hip; with C > 1 the weight
 // contraction K . W runs on the matrix cores beside the gradient fold)
 template <int KF, int CC, int MODE>
-constexpr bool kHasMfma = (kD <= 16) && (kD % 2 == 0) && (CC == 1 || CC == 5 || CC == 8) && (MODE != MODE_SCORE) && (KF != KF_GEN);
+constexpr bool kHasMfma = (kD == 12 || kD == 16) && (CC == 1 || CC == 5 || CC == 8) && (MODE != MODE_SCORE) && (KF != KF_GEN);
 
 // Shapes with an expanded form (score_kernel.h, XF: Polyharmonic(1), rows of <= 37 floats) run it by default, on the
 // centred row pairs the host passes with it (ScoreArgs::centre).  The direct form is compiled for them as well and
@@ -76,11 +76,8 @@ hipError_t by_cc(int cc, int mode, int nw, size_t lds, int64_t nblk, const Score
     case 1: return by_mode<KF, 1>(mode, nw, lds, nblk, a, st);
     case 5: return by_mode<KF, 5>(mode, nw, lds, nblk, a, st);
 #ifndef DCX_DEV_FAST  // developer builds (EXTRA=-DDCX_DEV_FAST): one and five classes only
-    case 2: return by_mode<KF, 2>(mode, nw, lds, nblk, a, st);
-    case 3: return by_mode<KF, 3>(mode, nw, lds, nblk, a, st);
+    case 2: return by_mode<KF, 2>(mode, nw, lds, nblk, a, st);   // (3 runs as 4, 6 and 7 as 8: dcx_internal.h compiled_classes)
     case 4: return by_mode<KF, 4>(mode, nw, lds, nblk, a, st);
-    case 6: return by_mode<KF, 6>(mode, nw, lds, nblk, a, st);
-    case 7: return by_mode<KF, 7>(mode, nw, lds, nblk, a, st);
     case 8: return by_mode<KF, 8>(mode, nw, lds, nblk, a, st);
 #endif
     default: return hipErrorInvalidValue;
@@ -123,10 +120,7 @@ hipError_t jac_by_cc(int cc, int nw, size_t lds, int64_t nblk, const ScoreArgs& 
     case 5: return jac_go<KF, 5>(nw, lds, nblk, a, st);
 #ifndef DCX_DEV_FAST
     case 2: return jac_go<KF, 2>(nw, lds, nblk, a, st);
-    case 3: return jac_go<KF, 3>(nw, lds, nblk, a, st);
     case 4: return jac_go<KF, 4>(nw, lds, nblk, a, st);
-    case 6: return jac_go<KF, 6>(nw, lds, nblk, a, st);
-    case 7: return jac_go<KF, 7>(nw, lds, nblk, a, st);
     case 8: return jac_go<KF, 8>(nw, lds, nblk, a, st);
 #endif
     default: return hipErrorNotSupported;

@@ -58,6 +58,8 @@ struct ScoreArgs {
     int32_t d_fk;             // features the FK writes (<= D; the rest are zero padding)
     int32_t frame_floats;     // per-lane LDS floats for FK frames
     int32_t kind;             // DCX_K_* (used by KF_GEN)
+    int32_t c_out;            // classes the CALLER has (<= the compiled CC: 3 runs as 4, 6 and 7 as 8 with zero weight columns -
+                              // dcx_api.hip compiled_classes): row stride of upstream / score, and the columns written
     int32_t one_hot;          // MODE_GRAD_UP: >= 0 selects upstream = e_{one_hot} (Jacobian rows); -1 = use upstream[]
     int32_t nz;               // MODE_GRAD_UP, > 1: gridDim.z = nz classes in ONE launch, block z takes upstream = e_z and writes
                               // grad + z * dof (all Jacobian rows at once: the per-class sweeps of a small batch run side by side)
@@ -269,7 +271,8 @@ __host__ __device__ inline LdsPlan lds_plan(int dof, int d_fk, int frame_floats,
 #endif
 // The XM sweep (round 3): the expanded form with its distance GEMM x . s^T on v_mfma_f32_16x16x32_bf16 in split operands
 // (sweep_rows, XM).  One class, Polyharmonic(1), even D <= 16 (a term's 16 K slots hold the features).
-constexpr bool xm_applies(int D, int CC, int KF) { return KF == 1 /* KF_POLY1 */ && CC == 1 && D <= 16 && (D % 2) == 0 && D >= 4; }
+// (compiled for the two widths it was measured at: profiles/r03_mfma_ab.txt - measured slower, kept as evidence)
+constexpr bool xm_applies(int D, int CC, int KF) { return KF == 1 /* KF_POLY1 */ && CC == 1 && (D == 12 || D == 16); }
 constexpr int sweep_min_waves(int D, int CC, int KF, bool MF = false, bool XM = false) {
     if (XM) return 4;  // 48 VGPRs of loop-invariant B fragments + 16 distances in flight: 128 VGPRs
     // KF_GEN calls powf/logf; the MFMA form adds 16 accumulator registers per contraction + the operand fragments
@@ -1343,7 +1346,7 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF, MF, XM)) void scor
         const int64_t bl = b0 + (lane < nb ? lane : nb - 1);
         const int hot = (a.nz > 1) ? (int)blockIdx.z : a.one_hot;
 #pragma unroll
-        for (int c = 0; c < CC; ++c) up[c] = (hot >= 0) ? (c == hot ? 1.0f : 0.0f) : a.upstream[bl * CC + c];
+        for (int c = 0; c < CC; ++c) up[c] = (hot >= 0) ? (c == hot ? 1.0f : 0.0f) : (c < a.c_out ? a.upstream[bl * a.c_out + c] : 0.0f);
     }
 
     // ---- the sweep: this wave's slice of the supports ----------------------------------------
@@ -1493,7 +1496,8 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF, MF, XM)) void scor
         DCX_TS(4);
         if (wave == 0 && b.score != nullptr && lane < nb && blockIdx.z == 0) {
 #pragma unroll
-            for (int c = 0; c < CC; ++c) b.score[(b0 + lane) * CC + c] = sRed[c * 64 + lane];
+            for (int c = 0; c < CC; ++c)
+                if (c < b.c_out) b.score[(b0 + lane) * b.c_out + c] = sRed[c * 64 + lane];
         }
         if constexpr (!GRAD) {
             return;
@@ -1656,7 +1660,8 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF, MF, XM)) void scor
 
     if (b.score != nullptr && lane < nb && blockIdx.z == 0) {
 #pragma unroll
-        for (int c = 0; c < CC; ++c) b.score[(b0 + lane) * CC + c] = sc[c];
+        for (int c = 0; c < CC; ++c)
+            if (c < b.c_out) b.score[(b0 + lane) * b.c_out + c] = sc[c];
     }
     }  // one-wave forms
 
@@ -1711,7 +1716,8 @@ struct FinishArgs {
     float* grad;
     int64_t B;
     int64_t grad_stride;
-    int32_t ys, acc, C, Dt, dof, d_fk, frame_floats, want_grad;
+    int32_t ys, acc, C, Dt, dof, d_fk, frame_floats, want_grad;   // C: the compiled class count (layout of the partial rows)
+    int32_t c_out;           // the caller's class count (score row stride, columns written)
     int32_t hinge;
     float hinge_margin, hinge_weight;
 };

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DCX_VERSION 104 /* 0.1.4: dcx_train_perceptron_ex (per-call flags); 0.1.3: dcx_fk_desc carries the DCX_FK_TREE section; 32 control points, D <= 96 */
+#define DCX_VERSION 105 /* 0.1.5: dcx_model_create_ex / dcx_model_update (rows packed on the device); 0.1.4: dcx_train_perceptron_ex (per-call flags); 0.1.3: dcx_fk_desc carries the DCX_FK_TREE section; 32 control points, D <= 96 */
 
 /* ---- status codes ---------------------------------------------------------------- */
 #define DCX_OK 0
@@ -135,7 +135,7 @@ typedef struct dcx_fk_desc {
     float t_axis[DCX_MAX_TREE_JOINTS][3];
 } dcx_fk_desc;
 
-typedef struct dcx_model dcx_model; /* opaque; immutable after create */
+typedef struct dcx_model dcx_model; /* opaque; changed only by dcx_model_update */
 
 /* ---- library ----------------------------------------------------------------------- */
 int dcx_version(void);
@@ -175,6 +175,20 @@ int dcx_debug_set(const char* name, int64_t value);
 int dcx_model_create(dcx_model** out, int device, const dcx_fk_desc* fk, int kernel_kind,
                      const float* kparams, const float* support_feat, const float* weights,
                      int64_t S, int32_t D, int32_t C);
+/* The same on a stream, with room to grow (round 4).  When support_feat and weights are DEVICE pointers the rows are packed
+ * by one kernel on `stream` (dropping zero rows, folding the kernel's constants, building the centred copy) and 16 bytes
+ * come back - no bulk copy through the host; `stream` is synchronised for that read-back (the number of kept rows decides
+ * the launch geometry of every later call).  Host pointers take the host path.  capacity >= S reserves storage so that
+ * dcx_model_update can refill the model in place (0 = exactly S).  Results are bit-identical to dcx_model_create's. */
+int dcx_model_create_ex(dcx_model** out, int device, const dcx_fk_desc* fk, int kernel_kind,
+                        const float* kparams, const float* support_feat, const float* weights,
+                        int64_t S, int32_t D, int32_t C, int64_t capacity, void* stream);
+/* New supports / weights for an existing model (same transform, kernel, D, C): what DiffCo.train / fit_poly / update do to
+ * the state every round of the reference's active-learning loop (collision_checkers.py:220-252).  Reuses the model's
+ * storage when S <= its capacity (else reallocates after a device synchronisation) and every per-stream scratch buffer.
+ * The model must not be in use by launches on OTHER streams or threads while it is updated; launches enqueued earlier on
+ * `stream` are ordered before the refill, later ones see the new rows.                                               */
+int dcx_model_update(dcx_model* m, const float* support_feat, const float* weights, int64_t S, void* stream);
 void dcx_model_destroy(dcx_model* m);
 /* any out pointer may be NULL; S_active = supports kept after dropping all-zero rows */
 int dcx_model_info(const dcx_model* m, int64_t* S_active, int32_t* D, int32_t* C, int32_t* dof,

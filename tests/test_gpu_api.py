@@ -326,6 +326,90 @@ def test_scipy_constraint_and_drivers_against_the_reference_fixture():
     assert relerr(np.array(rec["solution"]), d["tc_solution"]) < 1e-3
 
 
+@pytest.mark.parametrize("rob_name,kspec,C,zero_frac", [("baxter_left", (1, 1.0, 1.0), 1, 0.0), ("baxter_left", (0, 10.0, 2.0), 5, 0.4),
+                                                         ("panda", (0, 5.0, 2.0), 1, 0.3), (None, (0, 10.0, 2.0), 1, 0.0),
+                                                         ("se3", (1, 3.0, 2.0), 2, 0.5), ("planar3", (2, 0.7, 0.0), 1, 0.2)])
+def test_rows_packed_on_the_device_equal_the_host_packing(rob_name, kspec, C, zero_frac, knob):
+    """dcx_model_create_ex from device tensors (one packing kernel: zero rows dropped in order, constants folded, centred
+    copy, 16 bytes read back) against the host packing of dcx_model_create (CPU tensors in): every output bit-identical in
+    both sweep forms; then dcx_model_update into the same storage - fewer rows, more rows than the capacity, all weights
+    zero - against fresh models"""
+    from diffco_amd import _fkdesc, _ops
+    g = torch.Generator().manual_seed(17)
+    S, B = 700, 300
+    if rob_name is None:
+        desc, dof = _fkdesc.none_desc(6), 6
+        sup = torch.rand((S, 6), generator=g) * 4 - 2
+        q = (torch.rand((B, 6), generator=g) * 4 - 2).cuda()
+    else:
+        rob = make_robot(rob_name)
+        desc, lim = rob.fk_desc(), rob.limits
+        sq = torch.rand((S, rob.dof), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]
+        sup = _ops.fkine(desc, sq.cuda()).reshape(S, -1).cpu()
+        q = (torch.rand((B, rob.dof), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]).cuda()
+    W = torch.randn((S, C), generator=g)
+    W[torch.rand(S, generator=g) < zero_frac] = 0.0           # rows that are dropped (max_num_supports padding)
+    knob("nw", 4)
+    up = torch.randn((B, C), generator=g).cuda() if C > 1 else None
+
+    def outputs(m):
+        res = []
+        for form in (1, 0):
+            knob("xf", form)
+            s, gr = m.score_grad_raw(q, up)
+            res += [s, gr, m.score_jac_raw(q)[1]]
+        knob("xf", -1)
+        return res
+
+    host = _ops.ScoreModel(desc, *kspec, sup, W)                 # CPU tensors: staged and packed on the host
+    devm = _ops.ScoreModel(desc, *kspec, sup.cuda(), W.cuda())   # device tensors: packed by pack_rows_kernel
+    for a, b in zip(outputs(host), outputs(devm)):
+        assert torch.equal(a, b)
+    # refill in place: a smaller support set, then one beyond the capacity, then nothing active
+    for n, scale in ((250, 1.0), (S, -0.5), (40, 0.0)):
+        sup2, W2 = sup[:n].cuda().contiguous(), (scale * W[:n]).cuda().contiguous()
+        devm.update(sup2, W2)
+        fresh = _ops.ScoreModel(desc, *kspec, sup2.cpu(), W2.cpu())
+        for a, b in zip(outputs(fresh), outputs(devm)):
+            assert torch.equal(a, b), (n, scale)
+    assert devm.capacity >= S and float(devm.score_raw(q).abs().max()) == 0.0
+
+
+def test_checker_refills_its_model_in_place():
+    """the FusedScorer behind a checker keeps ONE dcx_model across train / fit_poly style state changes (same transform,
+    kernel, class count): new weights or supports are packed into it (dcx_model_update); a model someone else still
+    holds is left alone"""
+    from diffco_amd import kernel
+    from diffco_amd.kernel_perceptrons import DiffCo
+    rob = make_robot("baxter_left")
+    lim = rob.limits
+    g = torch.Generator().manual_seed(3)
+    S = 400
+    sq = (torch.rand((S, 7), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]).cuda()
+    q = (torch.rand((64, 7), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]).cuda()
+    dc = DiffCo(transform=rob.fkine)
+    dc.support_points, dc.support_transformed = sq, rob.fkine(sq)
+    dc.rbf_kernel, dc.rbf_nodes = kernel.Polyharmonic(1, 1.0), torch.randn(S, generator=g).cuda()
+    s1 = dc.poly_score(q)
+    h1 = dc._poly_fused._model._h.value
+    dc.rbf_nodes = torch.randn(S, generator=g).cuda()                       # fit_poly's output of the next round
+    s2 = dc.poly_score(q)
+    assert dc._poly_fused._model._h.value == h1 and not torch.equal(s1, s2)    # the same dcx_model, refilled
+    ref = DiffCo(transform=rob.fkine)
+    ref.support_points, ref.support_transformed = sq, rob.fkine(sq)
+    ref.rbf_kernel, ref.rbf_nodes = kernel.Polyharmonic(1, 1.0), dc.rbf_nodes.clone()
+    assert torch.equal(ref.poly_score(q), s2)
+    dc.support_points, dc.support_transformed = sq[:300], rob.fkine(sq[:300])  # supports retired
+    dc.rbf_nodes = dc.rbf_nodes[:300].clone()
+    dc._poly_fused.invalidate()
+    s3 = dc.poly_score(q)
+    assert dc._poly_fused._model._h.value == h1 and s3.shape == s2.shape
+    held = dc._poly_fused._model                                            # e.g. an optimiser's terms object
+    dc.rbf_nodes = torch.randn(300, generator=g).cuda()
+    s4 = dc.poly_score(q)
+    assert dc._poly_fused._model is not held and torch.equal(held.score(q), s3) and not torch.equal(s4, s3)
+
+
 def test_device_trainer_equals_host_trainer_and_reference(monkeypatch):
     """f1: the persistent-workgroup trainer (dcx_train_perceptron) walks the same sequence as the host loop — same
     supports in the same order as the reference's model — for the single- and the multi-class perceptron."""

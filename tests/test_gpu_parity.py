@@ -442,6 +442,51 @@ def test_ragged_empty_and_padding(ops, knob):
     assert he.shape == (70, 7, 7) and float(he.abs().max()) == 0.0 and float(gh.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("C", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("rob_name,kspec", [("baxter_left", (0, 10.0, 2.0)), ("baxter_left", (1, 1.0, 1.0)), ("planar3", (2, 0.8, 0.0))])
+def test_every_class_count(ops, C, rob_name, kspec, knob):
+    """C = 1 .. 8 (DCX_MAX_C): the sweeps are compiled for 1, 2, 4, 5 and 8 classes - 3 runs as 4, 6 and 7 as 8 with zero
+    weight columns that are neither read from `upstream` nor written to `score` / `jac` (dcx_internal.h compiled_classes).
+    Score, vjp with a random upstream, the full Jacobian and the Hessian against the float64 oracle, small (split) and
+    larger batches; the output buffers are exactly [B, C] wide (a guard band behind them stays untouched)"""
+    from oracle import oracle
+    rob, desc, sup, W, g = _rand_setup(ops, rob_name, 500, C, kspec, seed=C)
+    m = ops.ScoreModel(desc, *kspec, sup, W)
+    for B in (70, 3000):
+        q = _rand_q(rob, B, g)
+        up = torch.randn((B, C), generator=g).cuda()
+        so, go, jo = oracle.score_grad(desc, *kspec, _n(sup).astype(np.float64), _n(W).astype(np.float64), _n(q).astype(np.float64),
+                                       upstream=_n(up).astype(np.float64), want_jac=True, dtype=np.float64)
+        s, gr = m.score_grad_raw(q, up)
+        assert s.shape == (B, C) and relerr(_n(s), so) < TOL and relerr(_n(gr), go) < TOL
+        s1, g1 = m.score_grad_raw(q)                         # upstream = ones: the row-sum weight column
+        assert relerr(_n(g1), jo.sum(axis=1)) < TOL and torch.equal(s1, s)
+        for one_sweep in (0, 1):
+            knob("jac_one_sweep", one_sweep)
+            sj, jac = m.score_jac_raw(q)
+            assert jac.shape == (B, C, rob.dof) and relerr(_n(jac), jo) < TOL and relerr(_n(sj), so) < TOL
+        knob("jac_one_sweep", -1)
+        assert relerr(_n(m.score_raw(q)), so) < TOL
+    # guard band: a [B, C] score buffer carved out of a larger one
+    B = 130
+    q = _rand_q(rob, B, g)
+    big = torch.full((B * C + 64,), 7.0, device="cuda")
+    out = big[:B * C].view(B, C)
+    grad = torch.empty((B, rob.dof), device="cuda")
+    import ctypes as Ct
+    from diffco_amd import _lib
+    _lib.check(m._lib.dcx_score_grad(m._h, Ct.c_void_p(q.data_ptr()), B, None, Ct.c_void_p(out.data_ptr()), Ct.c_void_p(grad.data_ptr()),
+                                     Ct.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    assert float(big[B * C:].min()) == 7.0 and float(big[B * C:].max()) == 7.0
+    assert relerr(_n(out), _n(m.score_raw(q))) < 3e-6       # (the score-only launch may take another form of the sweep)
+    if rob_name == "baxter_left" and kspec[0] == 0:
+        q40, up40 = q[:40].contiguous(), torch.randn((40, C), generator=g).cuda()
+        gh, hs = m.score_hess_raw(q40, up40)                 # the second-derivative kernel reads the same rows and upstream
+        _, g40 = m.score_grad_raw(q40, up40)
+        assert hs.shape == (40, rob.dof, rob.dof) and torch.isfinite(hs).all() and relerr(_n(gh), _n(g40)) < 1e-5
+
+
 def test_errors_are_loud(ops):
     from diffco_amd._lib import DcxError
     d = load("cfg2_baxter_poly1")
