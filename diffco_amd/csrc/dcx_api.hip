@@ -259,7 +259,7 @@ int fk_device_copy(int device, const dcx_fk_desc& fk, FkProg** out) {
 struct Knobs {
     std::atomic<int64_t> ys{-1}, nw{-1}, min_rows{-1}, split_finish_kernel{-1}, inlaunch_tiles{-1}, jac_per_class{-1},
         mfma{-1}, traj_fused{-1}, xf{-1}, jac_one_sweep{-1}, train_grid{-1}, fkk{-1}, jt_waves{-1}, hess_ys{-1}, xm{-1},
-        traj_ys{-1};
+        traj_ys{-1}, traj_across{-1};
     Knobs() {
         auto rd = [](const char* name, std::atomic<int64_t>& dst, bool flag) {
             if (const char* e = std::getenv(name)) dst = flag ? 1 : std::atoll(e);
@@ -280,6 +280,7 @@ struct Knobs {
         rd("DCX_HESS_YS", hess_ys, false);
         rd("DCX_XM", xm, false);
         rd("DCX_TRAJ_YS", traj_ys, false);
+        rd("DCX_TRAJ_ACROSS", traj_across, false);
     }
 };
 Knobs& knobs() {
@@ -608,7 +609,7 @@ int dcx_debug_set(const char* name, int64_t value) {
     const std::string n(name);
     std::atomic<int64_t>* dst = n == "ys" ? &k.ys : n == "nw" ? &k.nw : n == "min_rows" ? &k.min_rows
         : n == "split_finish_kernel" ? &k.split_finish_kernel : n == "inlaunch_tiles" ? &k.inlaunch_tiles
-        : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : n == "traj_fused" ? &k.traj_fused : n == "xf" ? &k.xf : n == "jac_one_sweep" ? &k.jac_one_sweep : n == "train_grid" ? &k.train_grid : n == "fkk" ? &k.fkk : n == "jt_waves" ? &k.jt_waves : n == "hess_ys" ? &k.hess_ys : n == "xm" ? &k.xm : n == "traj_ys" ? &k.traj_ys : nullptr;
+        : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : n == "traj_fused" ? &k.traj_fused : n == "xf" ? &k.xf : n == "jac_one_sweep" ? &k.jac_one_sweep : n == "train_grid" ? &k.train_grid : n == "fkk" ? &k.fkk : n == "jt_waves" ? &k.jt_waves : n == "hess_ys" ? &k.hess_ys : n == "xm" ? &k.xm : n == "traj_ys" ? &k.traj_ys : n == "traj_across" ? &k.traj_across : nullptr;
     if (!dst) return fail(DCX_ERR_INVALID, "unknown knob: " + n);
     *dst = value;
     return DCX_OK;
@@ -1202,6 +1203,7 @@ int dcx_traj_adam_run(const dcx_model* m, const dcx_traj_state* st, const dcx_tr
                     a.exch = traj_exchange_rows(m, (hipStream_t)stream, (size_t)st->n_paths * 2 * ys * (m->Dt + 1) * 64 * sizeof(unsigned long long),
                                                 &a.tag_base);
                     if (a.exch) a.ys = ys;
+                    a.cl_across = knobs().traj_across > 0 ? 1 : 0;
                 }
                 if (a.ys != ys) {  // no exchange rows right now: one workgroup per path, the whole support set each
                     ys = 1;

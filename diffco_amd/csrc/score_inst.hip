@@ -150,8 +150,8 @@ hipError_t DCX_CAT(launch_traj_fused_D, DCX_INST_D)(int kf, int nw, size_t lds, 
             // resident at once - a cooperative launch checks that and keeps other cooperative grids off the device meanwhile
             TrajFusedArgs copy = a;
             void* params[] = {&copy};
-            return hipLaunchCooperativeKernel((const void*)kern, dim3((unsigned)n_paths, (unsigned)a.ys), dim3(64 * nw), params,
-                                              (unsigned int)lds, st);
+            const dim3 grid = a.cl_across ? dim3((unsigned)a.ys, (unsigned)n_paths) : dim3((unsigned)n_paths, (unsigned)a.ys);
+            return hipLaunchCooperativeKernel((const void*)kern, grid, dim3(64 * nw), params, (unsigned int)lds, st);
         }
         kern<<<dim3((unsigned)n_paths), dim3(64 * nw), lds, st>>>(a);
         return hipGetLastError();

@@ -17,12 +17,17 @@
 //     instruction at all.  The path is fp32-VALU bound, and this layout
 //     spends VALU slots only on the algorithmic sub/fma/rsq work.
 //   * one block = the same 64 configurations x NW waves, each wave on its own support slice
-//     (fills the chip when B is small); partial sums meet in LDS and wave 0 finishes.
-//   * prologue / epilogue (wave 0): q rows staged coalesced through LDS, FK chain evaluated
-//     per lane with frames kept in LDS (fk_device.h), J^T applied to the feature gradient,
-//     gradient rows staged back through LDS for a coalesced store.
-// Distances use direct differences (x - s)^2, never the |x|^2+|s|^2-2x.s GEMM form: that
-// form is what makes the reference's own fp32 result ~1e-5 off.
+//     (fills the chip when B is small); partial sums meet in LDS, every wave folds its share.
+//   * prologue / epilogue: q rows staged coalesced through LDS, FK chain evaluated per lane with
+//     frames kept in LDS (fk_device.h; DH arms: on several waves), J^T applied to the feature
+//     gradient, gradient rows staged back through LDS for a coalesced store.
+// Two forms of the pair body.  DIRECT: differences (x - s), squared, scaled by the coefficient - every
+// kernel function, every input.  EXPANDED (XF, the default where it applies): d2 = |x|^2 + |s|^2 - 2 x.s
+// and gX = x sum(c) - sum(c s) on data CENTRED on the support centroid, with a direct-form correction
+// for near pairs where the kernel is not smooth (Polyharmonic(1)) and no correction where it is
+// (RQKernel(2), FK-centred features only) - see "the expanded form" below.  This is NOT the reference's
+// unguarded |x|^2+|s|^2-2x.s cdist GEMM, which is what puts its own fp32 result ~1e-5 off on raw
+// coordinates: raw-input models with a sharp kernel (config #4) stay direct.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <type_traits>

@@ -71,6 +71,9 @@ struct TrajFusedArgs {
     int32_t ys, s_super;            // block y sweeps supports [y * s_super, (y + 1) * s_super), its waves s_chunk each
     unsigned long long* exch;       // [n_paths][2 (iteration parity)][ys][D + 1][64] (value, tag) words, see traj_exchange
     uint32_t tag_base;              // tags of this launch: tag_base + iteration + 1 (unique per launch on this buffer)
+    int32_t cl_across;              // 1: grid (ys, n_paths) - consecutive workgroup ids = the ys members of a path, which the
+                                    // dispatcher deals out to DIFFERENT XCDs; 0: grid (n_paths, ys) - with n_paths a multiple of
+                                    // 8 the members of a path land on ONE XCD and exchange through its L2 (see traj_exchange)
     float bias1[kTrajFusedMaxIters];       // 1 - beta1^t          (host double arithmetic, like launch_traj_adam_step)
     float bias2_sqrt[kTrajFusedMaxIters];  // sqrt(1 - beta2^t)
 };
@@ -285,7 +288,8 @@ template <int D, int KF, int MAXT, bool XF = false, bool CL = false>
 __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_fused_kernel(const TrajFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int ACC = D + 1;
-    const int r = blockIdx.x;
+    const int r = (CL && a.cl_across) ? blockIdx.y : blockIdx.x;
+    const int ycl = CL ? (a.cl_across ? (int)blockIdx.x : (int)blockIdx.y) : 0;   // this workgroup's place among the path's ys
     if (a.st.done[r]) return;  // frozen path (cluster form: the ys workgroups of a path all see the same flag - it is only
                                // ever written by a workgroup that leaves, and none leaves before all have passed here)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -361,7 +365,7 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
             }
             // this wave's slice of the supports (the sweep's slicing: wave w takes [w * s_chunk, (w + 1) * s_chunk))
             if constexpr (CL) {  // ... of this workgroup's share [y * s_super, (y + 1) * s_super) (score_kernel's split slicing)
-                const int ybase = (int)blockIdx.y * b.s_super;
+                const int ybase = ycl * b.s_super;
                 const int yend = (ybase + b.s_super < b.sc.S) ? ybase + b.s_super : b.sc.S;
                 j0 = (ybase + wave * b.sc.s_chunk < yend) ? ybase + wave * b.sc.s_chunk : yend;
                 j1 = (j0 + b.sc.s_chunk < yend) ? j0 + b.sc.s_chunk : yend;
@@ -415,7 +419,7 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
                 if constexpr (CL) {
                     unsigned long long* slot = b.exch + ((size_t)(r * 2 + (it & 1)) * b.ys) * ACC * 64 + lane;
                     const uint32_t tag = b.tag_base + (uint32_t)it + 1u;
-                    traj_exchange_publish<ACC>(L.sRed, slot, tag, (int)blockIdx.y, wave, lane, nw);
+                    traj_exchange_publish<ACC>(L.sRed, slot, tag, ycl, wave, lane, nw);
                     if (!traj_exchange_collect<ACC>(L.sRed, slot, tag, b.ys, wave, lane, nw)) L.sR[kTrajAbort] = 1.0f;
                 } else {
                 fold_partial_rows<ACC>(L.sRed, wave, lane, nw);
@@ -557,7 +561,7 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
             if constexpr (CL) {
                 if (L.sR[kTrajAbort] != 0.0f) flags = 8;  // an exchange gave up in this workgroup: leave, state untouched
             }
-            if ((flags & 3) && (!CL || blockIdx.y == 0)) {
+            if ((flags & 3) && (!CL || ycl == 0)) {
                 float* lo = b.st.lowest_path + (size_t)r * W * dof;
                 float* bv = b.st.best_valid_path + (size_t)r * W * dof;
                 for (int i = tid; i < W * dof; i += blockDim.x) {
@@ -578,14 +582,14 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
             }
         }
         if (flags & 4) {
-            if (tid == 0 && (!CL || blockIdx.y == 0)) a.st.done[r] = 1;
+            if (tid == 0 && (!CL || ycl == 0)) a.st.done[r] = 1;
             ++it;
             break;
         }
     }
     (void)it;
     if constexpr (CL) {
-        if (blockIdx.y != 0) return;  // workgroup 0 of the cluster writes the state back
+        if (ycl != 0) return;  // workgroup 0 of the cluster writes the state back
     }
     // ---- state back to HBM ------------------------------------------------------------------------------------------
     {

@@ -10,9 +10,12 @@ kernels of libdcx.  `fused_adam_traj_optimize` (diffco_amd/traj.py) is the batch
 Differences worth knowing:
   * the straight-line initial path is built with numpy from array views of the endpoints (the reference's
     `torch.from_numpy(np.linspace(tensor, tensor))` breaks under numpy 2 / torch 2.10 — SURVEY.md §8c);
-  * trust-constr's collision-constraint Hessian (the reference double-backwards through dist_est) is built from
-    central differences of the fused analytic gradient, chained exactly through the dense-path geometry
-    (`_ScipyTerms.hess_collision`); a BFGS model when dist_est is not a fusable diffco_amd score.
+  * for a fusable dist_est (a diffco_amd checker's score of this robot) the collision constraint's Jacobian comes from ONE
+    hinge-gradient launch over the densified path and its Hessian (the reference double-backwards through dist_est) from
+    the analytic per-point Hessians of `dcx_score_hess`, both chained exactly through the dense-path geometry in fp64
+    tensor ops on the device (`_ScipyTerms.jac_collision / hess_collision`); a foreign callable keeps the reference's
+    autograd route (BFGS model for the Hessian by default).  Pinned to the reference's own constraint values, Jacobian,
+    Hessian and SLSQP / trust-constr records (tests/golden/optim_scipy_baxter.npz, tools/make_golden.py gen_optim_scipy).
 """
 import time
 from typing import Dict
@@ -234,21 +237,25 @@ class _ScipyTerms:
         pts, seg, step = dense[1:-1], seg[1:-1], step[1:-1]
         n_seg, n_pt = W - 1, len(pts)
         per = -(-n_pt // n_seg) if n_pt else 0
-        J = torch.zeros((n_seg, W, dof), dtype=torch.float64)
+        dev = model.dev
+        J = torch.zeros((n_seg, W, dof), dtype=torch.float64, device=dev)
         if n_pt:
-            q32 = pts.to(device=model.dev, dtype=torch.float32).contiguous()
+            # the chain rule stays on the device (round 4): one launch, a handful of fp64 tensor ops, ONE copy back - the
+            # [n_seg, (W-2) dof] array scipy asked for
+            q32 = pts.to(device=dev, dtype=torch.float32).contiguous()
             _, h = model.score_hinge_grad_raw(q32, prob.safety_margin, -1.0)  # h_n = d c_n / d dense_n
-            h = h.double().cpu()
-            delta = p[1:] - p[:-1]
+            h = h.double()
+            pd, segd, stepd = p.to(dev), seg.to(dev), step.to(dev)
+            delta = pd[1:] - pd[:-1]
             length = delta.norm(dim=1)
             unit = delta / length[:, None]
-            u = unit[seg]                                                   # [n_pt, dof]
-            scale = (step * ms / length[seg])[:, None]
+            u = unit[segd]                                                  # [n_pt, dof]
+            scale = (stepd * ms / length[segd])[:, None]
             a = scale * (h - u * (u * h).sum(dim=1, keepdim=True))          # part carried by p_{i+1}
-            row = torch.arange(n_pt) // per
-            J.index_put_((row, seg), h - a, accumulate=True)
-            J.index_put_((row, seg + 1), a, accumulate=True)
-        return J[:, 1:-1].numpy().reshape(n_seg, -1)
+            row = torch.arange(n_pt, device=dev) // per
+            J.index_put_((row, segd), h - a, accumulate=True)
+            J.index_put_((row, segd + 1), a, accumulate=True)
+        return J[:, 1:-1].cpu().numpy().reshape(n_seg, -1)
 
     HESS_FD_STEP = 4e-3  # rad (or m); only where dcx_score_hess reports DCX_ERR_UNSUPPORTED
 
@@ -284,10 +291,11 @@ class _ScipyTerms:
             return np.zeros(((W - 2) * dof, (W - 2) * dof))
         per = -(-n_pt // n_seg)
         q32 = pts.to(device=model.dev, dtype=torch.float32).contiguous()
+        dev = model.dev
         s, g = model.score_grad_raw(q32)
         try:
             _, S = model.score_hess_raw(q32)
-            S = S.double().cpu()
+            S = S.double()
         except _lib.DcxUnsupported:
             # a feature row too wide for the Hessian kernel's LDS in (value, tangent) pairs (none of the reference's robots
             # since round 3: the 23-joint iiwa7 + Allegro tree pages its frames to global memory): central differences of
@@ -296,20 +304,23 @@ class _ScipyTerms:
             eps = self.HESS_FD_STEP
             probes = pts[:, None, None, :] + eps * torch.stack([torch.eye(dof), -torch.eye(dof)]).to(pts.dtype)[None]
             _, gp = model.score_grad_raw(probes.reshape(-1, dof).to(device=model.dev, dtype=torch.float32).contiguous())
-            gp = gp.double().cpu().reshape(n_pt, 2, dof, dof)
+            gp = gp.double().reshape(n_pt, 2, dof, dof)
             S = (gp[:, 0] - gp[:, 1]) / (2 * eps)
-        s, g = s.double().cpu()[:, 0], g.double().cpu()
-        active = -((s - prob.safety_margin) > 0).double() * v[torch.arange(n_pt) // per]  # d(v.c)/d score_n
+        # everything below stays on the device in fp64 (round 4): the second-order surrogate is differentiated twice there
+        # and only the [(W-2) dof]^2 result comes back
+        s, g = s.double()[:, 0], g.double()
+        segd, stepd, ptsd, vd = seg.to(dev), step.to(dev), pts.to(dev), v.to(dev)
+        active = -((s - prob.safety_margin) > 0).double() * vd[torch.arange(n_pt, device=dev) // per]  # d(v.c)/d score_n
         S = 0.5 * (S + S.transpose(1, 2)) * active[:, None, None]
         h = g * active[:, None]
 
         def taylor(z):
             delta = z[1:] - z[:-1]
             unit = delta / delta.norm(dim=1, keepdim=True)
-            d = z[seg] + (step * ms)[:, None] * unit[seg] - pts
+            d = z[segd] + (stepd * ms)[:, None] * unit[segd] - ptsd
             return (h * d).sum() + 0.5 * torch.einsum('ni,nij,nj->', d, S, d)
-        H = torch.autograd.functional.hessian(taylor, p, vectorize=True)
-        return H[1:-1, :, 1:-1, :].numpy().reshape((W - 2) * dof, -1)
+        H = torch.autograd.functional.hessian(taylor, p.to(dev), vectorize=True)
+        return H[1:-1, :, 1:-1, :].cpu().numpy().reshape((W - 2) * dof, -1)
 
     def joint_limit(self, x):
         return -self.prob.joint_limit_violation(self.prob.full(x).detach()).item()
