@@ -538,6 +538,8 @@ def primary_line(args, w, loop, world, multi, ranks_reported, wall, kern_ms, n_s
     ach_tf = F * B / (kern_ms * 1e-3) / 1e12
     ach_gbs = bytes_per_eval(dof, C) * B / (kern_ms * 1e-3) / 1e9
     pmc = load_profile_json(f"pmc_{name}.json")
+    if pmc is not None and pmc.get("batch_per_gpu") not in (None, B):
+        pmc = None   # (the counters were collected at another batch size: bytes per launch do not carry over)
     mfc = load_profile_json("mfma_contractions.json") or {}
     forms = mfc.get("forms") or {}
     head_form = next((v for k, v in forms.items() if k.startswith("headline")), {})
@@ -574,7 +576,11 @@ def primary_line(args, w, loop, world, multi, ranks_reported, wall, kern_ms, n_s
                                     "expanded (XF: d2 = |x|^2+|s|^2-2x.s, gX = x*sum(c)-sum(c s); 20 VALU/pair at D=12)"
                                     if (w["kspec"][0] == 1 and w["kspec"][1] == 1.0 and w["D"] + C + (C > 1) + 1 <= 38
                                         and os.environ.get("DCX_XF", "") != "0" and not mfma_on)
-                                    else "direct (differences; 24 VALU/pair at D=12)"),
+                                    else "expanded where libdcx's rule admits it (RQ2 behind an FK transform, gamma*max|s-c|^2 <= 32: it does for "
+                                         "the Baxter workloads; 22 VALU/pair at D=12, C=5), else direct with the RQ constants folded"
+                                    if (w["kspec"][0] == 0 and w["kspec"][2] == 2.0 and w["rob_name"] is not None
+                                        and os.environ.get("DCX_XF", "") != "0" and not mfma_on)
+                                    else "direct (differences; RQ2: constants folded, 15 VALU/pair at D=6)"),
                      "kernel_ms": round(kern_ms, 5), "flops_per_eval": F,
                      "note": "fp32 VALU bound (peak == fp32 MFMA peak 157.3 TFLOP/s); algorithmic flops "
                              "S*(5D+4C+6)+800 per eval (SURVEY.md §8d)",
@@ -744,7 +750,7 @@ def main():
     configs = None
     if world == 1 and not multi and name == "headline" and not args.batch and not args.no_configs:
         configs = {}
-        for cname, csteps in (("cfg2", 200), ("cfg2_panda", 200), ("cfg3", 200), ("cfg3_b65536", 100), ("cfg3_poly", 200), ("cfg4", 12),
+        for cname, csteps in (("cfg2", 200), ("cfg2_panda", 200), ("cfg3", 200), ("cfg3_b65536", 200), ("cfg3_poly", 200), ("cfg4", 12),
                               ("cfg5", 200), ("cfg5_shard32", 200), ("headline_rq", 100)):
             try:
                 wname = cname.split("_shard")[0].split("_b")[0]

@@ -368,6 +368,10 @@ Geometry pick_geometry(const dcx_model* m, int64_t B, int acc_floats, bool allow
         g.nw = best_nw;
         g.red_slots = 1;
     }
+    // (Round 4, tried: for a chip-filling batch of a C > 1 model the fold through ONE row instead of nw - 31 KB instead of 63 KB
+    // per 8-wave block at config #3, i.e. four resident blocks per CU instead of two.  Same time (95.7 vs 96.8 us at B = 65536;
+    // 4- and 16-wave blocks 102 / 97 us): residency is not what holds that sweep at 61 % VALU-busy - the two-row depth of its
+    // scalar pipeline is, and a third row buffer does not fit the SGPRs.  profiles/r04_cfg3_residency.txt)
     return g;
 }
 
