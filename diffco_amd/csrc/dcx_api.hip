@@ -259,7 +259,7 @@ int fk_device_copy(int device, const dcx_fk_desc& fk, FkProg** out) {
 struct Knobs {
     std::atomic<int64_t> ys{-1}, nw{-1}, min_rows{-1}, split_finish_kernel{-1}, inlaunch_tiles{-1}, jac_per_class{-1},
         mfma{-1}, traj_fused{-1}, xf{-1}, jac_one_sweep{-1}, train_grid{-1}, fkk{-1}, jt_waves{-1}, hess_ys{-1}, xm{-1},
-        traj_ys{-1}, traj_across{-1};
+        traj_ys{-1}, traj_across{-1}, owner_poll{-1};
     Knobs() {
         auto rd = [](const char* name, std::atomic<int64_t>& dst, bool flag) {
             if (const char* e = std::getenv(name)) dst = flag ? 1 : std::atoll(e);
@@ -281,6 +281,7 @@ struct Knobs {
         rd("DCX_XM", xm, false);
         rd("DCX_TRAJ_YS", traj_ys, false);
         rd("DCX_TRAJ_ACROSS", traj_across, false);
+        rd("DCX_OWNER_POLL", owner_poll, false);
     }
 };
 Knobs& knobs() {
@@ -391,15 +392,17 @@ float* split_scratch(const dcx_model* m, hipStream_t st, size_t bytes) {
         if (sc.stream == st) return sc.bytes >= bytes ? sc.ptr : nullptr;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
-    const size_t fixed = kScratchHead + (size_t)2 * m->n_cu * (m->Dt + m->Cc) * 64 * sizeof(float);
-    if (bytes > fixed) return nullptr;
+    // [counters | float rows of the counter protocol | 8-byte (value, tag) words of the owner-polls protocol (score_kernel.h)]
+    const size_t rows_bytes = (size_t)2 * m->n_cu * (m->Dt + m->Cc) * 64 * sizeof(float);
+    const size_t fixed = kScratchHead + 3 * rows_bytes;
+    if (bytes > kScratchHead + rows_bytes) return nullptr;
     float* p = nullptr;
     if (hipMalloc((void**)&p, fixed) != hipSuccess) {
         (void)hipGetLastError();
         return nullptr;
     }
-    // zero the arrival counters on the SAME stream (the kernels leave them at zero themselves afterwards)
-    if (hipMemsetAsync(p, 0, kScratchHead, st) != hipSuccess) {
+    // zero the arrival counters and the tag words on the SAME stream (the kernels leave them at zero themselves afterwards)
+    if (hipMemsetAsync(p, 0, fixed, st) != hipSuccess) {
         (void)hipGetLastError();
         (void)hipFree(p);
         return nullptr;
@@ -563,6 +566,13 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
     if (nz > 1 && counters == nullptr) return DCX_ERR_UNSUPPORTED;  // score_finish_kernel has no class dimension
     a.partial = part;
     a.tile_done = counters;
+    // the owner-polls hand-over (score_kernel.h): in-launch finish, the parallel epilogue, every block resident at once
+    // (a split launch is one block per CU) with owners on at most half the CUs.  Knob owner_poll = 0: the counter protocol.
+    // Measured (profiles/r04_owner_poll.txt): config #2 11.57 -> 11.06 us, config #3's shard 20.6 -> 20.1, Polyharmonic nodes
+    // 22.35 -> 21.8; Panda (22 accumulators on 8 waves: three dependent polls per wave) 15.4 -> 15.6, hence acc <= 2 nw.
+    if (counters != nullptr && g.red_slots == g.nw && g.nw > 1 && knobs().owner_poll != 0 && (acc <= 2 * g.nw || knobs().owner_poll > 0) &&
+        nblk * nz * g.ys <= (int64_t)m->n_cu && 2 * nblk * nz <= (int64_t)m->n_cu)
+        a.pwords = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(part) + (size_t)2 * m->n_cu * (m->Dt + m->Cc) * 64 * sizeof(float));
     hipError_t e = m->launch(m->kf, m->Cc, mode, g.nw, lds, nblk, a, st);
     if (e == hipSuccess && counters == nullptr) {
         FinishArgs f{};
@@ -613,7 +623,7 @@ int dcx_debug_set(const char* name, int64_t value) {
     const std::string n(name);
     std::atomic<int64_t>* dst = n == "ys" ? &k.ys : n == "nw" ? &k.nw : n == "min_rows" ? &k.min_rows
         : n == "split_finish_kernel" ? &k.split_finish_kernel : n == "inlaunch_tiles" ? &k.inlaunch_tiles
-        : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : n == "traj_fused" ? &k.traj_fused : n == "xf" ? &k.xf : n == "jac_one_sweep" ? &k.jac_one_sweep : n == "train_grid" ? &k.train_grid : n == "fkk" ? &k.fkk : n == "jt_waves" ? &k.jt_waves : n == "hess_ys" ? &k.hess_ys : n == "xm" ? &k.xm : n == "traj_ys" ? &k.traj_ys : n == "traj_across" ? &k.traj_across : nullptr;
+        : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : n == "traj_fused" ? &k.traj_fused : n == "xf" ? &k.xf : n == "jac_one_sweep" ? &k.jac_one_sweep : n == "train_grid" ? &k.train_grid : n == "fkk" ? &k.fkk : n == "jt_waves" ? &k.jt_waves : n == "hess_ys" ? &k.hess_ys : n == "xm" ? &k.xm : n == "traj_ys" ? &k.traj_ys : n == "traj_across" ? &k.traj_across : n == "owner_poll" ? &k.owner_poll : nullptr;
     if (!dst) return fail(DCX_ERR_INVALID, "unknown knob: " + n);
     *dst = value;
     return DCX_OK;

@@ -75,6 +75,8 @@ struct ScoreArgs {
     unsigned int* tile_done;  // split launch: per-tile arrival counters (zero between launches).  Non-null: the LAST of a
                               // tile's ys blocks to arrive adds the partial rows and finishes in this launch; null: a
                               // second launch (score_finish_kernel) does
+    unsigned long long* pwords;  // split launch, owner-polls hand-over (round 4): per (tile, y >= 1) rows of 8-byte (value, tag)
+                              // words [(tile*ys + y)][ACC][64], all zero between launches; non-null selects that protocol
     int32_t ys;               // support super-chunks (gridDim.y); block y sweeps [y*s_super, (y+1)*s_super)
     int32_t s_super;
     int32_t red_slots;        // LDS rows for the cross-wave fold: nw (all waves write, fold in parallel) or 1 (waves
@@ -1416,7 +1418,19 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF, MF, XM)) void scor
         }
         __syncthreads();
         DCX_TS(16);
-        float* out = split ? b.partial + (tile * b.ys + blockIdx.y) * ACC * 64 + lane : nullptr;
+        // Round 4, the owner-polls hand-over (b.pwords != null; the host selects it when every block of the launch is resident
+        // at once and at most half the CUs hold owners): block y = 0 OWNS its tile.  The other blocks publish each partial value
+        // as ONE 8-byte (value, tag = 1) word - single-copy atomic, so a reader that sees the tag sees the value - and leave: no
+        // drain, no arrival counter, no barrier.  The owner folds its own row, runs phase R1 of J^T, then polls the words of
+        // y = 1, 2, ... per accumulator (the wave that owns it), adds them in that order - the order of the counter protocol,
+        // bit for bit - and puts the zeros back for the next launch (or graph replay).  The counter protocol below paid
+        // publish -> drain -> atomic round trip -> re-read in EVERY block: 5.6 k of a config-#2 block's 25 k cycles
+        // (profiles/r04_phase_cfg2.txt).  Blocks that do not own never wait, so the owners' polling cannot deadlock while
+        // fewer than all CUs hold owners.
+        const bool opoll = split && b.pwords != nullptr;
+        const bool publisher = opoll && blockIdx.y != 0;
+        unsigned long long* wout = opoll ? b.pwords + ((tile * b.ys + blockIdx.y) * ACC) * 64 + lane : nullptr;
+        float* out = (split && !opoll) ? b.partial + (tile * b.ys + blockIdx.y) * ACC * 64 + lane : nullptr;
         auto fold_mine = [&](auto nwc) __attribute__((always_inline)) {
             constexpr int NWC = decltype(nwc)::value;
             const int nwr = NWC > 0 ? NWC : nw;
@@ -1433,7 +1447,8 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF, MF, XM)) void scor
                     v = sRed[e * 64 + lane];
                     for (int w = 1; w < nw; ++w) v += sRed[((size_t)w * ACC + e) * 64 + lane];
                 }
-                if (split) __hip_atomic_store(out + e * 64, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (publisher) __hip_atomic_store(wout + e * 64, ((unsigned long long)1u << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else if (split && !opoll) __hip_atomic_store(out + e * 64, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 else sRed[e * 64 + lane] = v;  // row 0's slot of accumulator e: only this wave reads or writes it
             }
         };
@@ -1443,7 +1458,44 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF, MF, XM)) void scor
         else if (nw == 2) fold_mine(std::integral_constant<int, 2>{});
         else fold_mine(std::integral_constant<int, 0>{});
         DCX_TS(17);
-        if (split) {
+        if (opoll) {
+            if (publisher) return;
+            __syncthreads();   // every wave has folded: rows 1 .. of the scratch are free for J^T's phase R1
+            const bool jt_here = GRAD && b.jt_waves;
+            r1_done = jt_here && nw >= 2 + 2 * dhb.n_chains;
+            if (r1_done && wave >= 2) dh2_vjp_r1_sel(fw.dh, dhb, sF + lane, sRed + (size_t)ACC * 64 + lane, wave - 2);
+            const unsigned long long* wtile = b.pwords + (tile * b.ys) * ACC * 64 + lane;
+            for (int e = wave; e < ACC; e += nw) {
+                float tot = 0.0f;
+                int spins = 0;
+                for (;;) {
+                    tot = sRed[e * 64 + lane];   // this block's own row (y = 0), then y = 1, 2, ...
+                    bool all = true;
+                    for (int y = 1; y < b.ys; y += 8) {
+                        unsigned long long wv[8];
+#pragma unroll
+                        for (int v = 0; v < 8; ++v)
+                            if (y + v < b.ys) wv[v] = __hip_atomic_load(wtile + ((size_t)(y + v) * ACC + e) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                        for (int v = 0; v < 8; ++v)
+                            if (y + v < b.ys) {
+                                all = all && ((unsigned int)(wv[v] >> 32) != 0u);
+                                tot += __uint_as_float((unsigned int)wv[v]);
+                            }
+                    }
+                    if (__builtin_amdgcn_ballot_w64(!all) == 0) break;
+                    if (++spins > (1 << 21)) {   // seconds: a peer never ran.  Loud, not silent: the tile's results are NaN
+                        tot = __builtin_nanf("");
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                for (int y = 1; y < b.ys; ++y)   // zeros back: the next launch on this stream (or graph replay) starts clean
+                    __hip_atomic_store(const_cast<unsigned long long*>(wtile) + ((size_t)y * ACC + e) * 64, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sRed[e * 64 + lane] = tot;
+            }
+            DCX_FK_TS(11, 2);
+        } else if (split) {
             // Every value of the row left as an agent-scope atomic store (global_store sc1: written through to where the
             // other XCDs see it), and this wave stored nothing else.  Waiting for those stores to be acknowledged orders
             // them before the counter increment; a release fence's buffer_wbl2 would write back OTHER dirty lines and has

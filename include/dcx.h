@@ -155,7 +155,10 @@ int dcx_device_count(void);
  * "train_grid" (see dcx_train_perceptron), "fkk" (which FK walk a DH arm takes: 2 / rule = the step table, 1 = the FK
  * program through scalar loads, 0 = the FK program from its LDS copy; bit-identical results), "jt_waves" (0 = the chain and
  * J^T phases of a DH arm on one wave instead of several; bit-identical), "traj_ys" (workgroups per path of the persistent
- * trajectory kernel: 1 = one, k = k; rule = what fills the chip, at most 8), "hess_ys" (blocks per tile of dcx_score_hess; 1 =
+ * trajectory kernel: 1 = one, k = k; rule = what fills the chip, at most 8), "traj_across" (1 = a path's workgroups dealt
+ * across XCDs instead of onto one: a measurement), "owner_poll" (the split launch's hand-over: 0 = arrival counters, last
+ * block to arrive finishes; 1 / rule = block y = 0 owns its tile and polls its peers' (value, tag) words - bit-identical;
+ * the rule takes it when every block of the launch is resident at once), "hess_ys" (blocks per tile of dcx_score_hess; 1 =
  * never split the supports), "xm" (1 = the expanded form takes its distance GEMM from the matrix cores, bf16x3 split
  * operands, where compiled: one class, Polyharmonic(1), even D <= 16; agrees with the VALU form to ~1e-6, measured slower).
  * value < 0 restores the rule.  The initial values come from the DCX_YS / DCX_NW / DCX_XF / ... environment variables,

@@ -167,6 +167,28 @@ def test_support_slicing_is_invariant(ops, name, knob, fold_pipe):
             assert relerr(a, b) < tol
 
 
+@pytest.mark.parametrize("name", ["cfg2_baxter_poly1", "cfg3_baxter_rq_c5", "cfg2_panda_poly1"])
+def test_owner_polls_handover_equals_the_counter_protocol_bitwise(ops, name, knob):
+    """round 4: the split launch's hand-over with block y = 0 owning its tile and polling its peers' (value, tag) words
+    (score_kernel.h, knob owner_poll = 1) against the arrival-counter protocol (knob 0): the same sums in the same order ->
+    bit-identical score, gradient and Jacobian, launch after launch (the owner puts the zeros back), ragged batches"""
+    d = load(name)
+    kind, p0, p1 = case_kernel(d)
+    m = ops.ScoreModel(desc_for(CASE_ROBOT[name]), kind, p0, p1, _t(d["sup_x32"].reshape(len(d["sup_x32"]), -1)), _t(d["weights"]))
+    for n in (150, 64, 333):
+        q = _t(d["q"][:n])
+        up = _t(d["upstream"][:n]) if m.C > 1 and "upstream" in d.files else None
+        knob("owner_poll", 0)
+        s0, g0 = m.score_grad_raw(q, up)
+        j0 = m.score_jac_raw(q)[1]
+        knob("owner_poll", 1)
+        for _ in range(3):
+            s1, g1 = m.score_grad_raw(q, up)
+            assert torch.equal(s0, s1) and torch.equal(g0, g1), n
+        assert torch.equal(j0, m.score_jac_raw(q)[1])
+    knob("owner_poll", -1)
+
+
 @pytest.mark.parametrize("name", ["cfg2_baxter_poly1", "cfg3_baxter_rq_c5"])
 def test_split_launch_finish_modes_agree_bitwise(ops, name, knob):
     """small batches split the supports across blocks; the rows are added either by the last block to arrive

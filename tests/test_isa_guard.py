@@ -159,20 +159,27 @@ def test_handover_publishes_write_through_and_drains_before_the_counter(isa):
         assert atomics, "arrival counter not found"
         for at in atomics:
             back = body[:at]
-            st = max(n for n, l in enumerate(back) if l.startswith("global_store_dword") and " sc1" in l)
+            # (4-byte stores: the 8-byte `global_store_dwordx2 ... sc1` belong to the owner-polls protocol, checked below)
+            st = max(n for n, l in enumerate(back) if l.startswith("global_store_dword ") and " sc1" in l)
             between = back[st + 1:]
             assert any(l.startswith("s_waitcnt") and "vmcnt(0)" in l for l in between), "no vmcnt(0) between the publish and the counter"
             # the publish run in front of the counter is write-through only
             run = []
             for l in reversed(back[:st + 1]):
-                if l.startswith("global_store_dword"):
+                if l.startswith("global_store_dword "):
                     run.append(l)
+                elif l.startswith("global_store_dwordx2"):
+                    continue
                 elif l.startswith(("s_waitcnt", "v_", "s_", ";", "ds_")) or not l:
                     continue
                 else:
                     break
             assert run and all(" sc1" in l for l in run), run
-        assert any(l.startswith("global_load_dword") and " sc1" in l for l in body), "the re-read must use agent-scope (sc1) loads"
+        assert any(l.startswith("global_load_dword ") and " sc1" in l for l in body), "the re-read must use agent-scope (sc1) loads"
+        # round 4, the owner-polls protocol: value and tag travel as ONE 8-byte agent-scope store / load (single-copy atomic:
+        # that is the whole ordering argument), in the same kernels
+        assert any(l.startswith("global_store_dwordx2") and " sc1" in l for l in body), "(value, tag) words must be 8-byte sc1 stores"
+        assert any(l.startswith("global_load_dwordx2") and " sc1" in l for l in body), "(value, tag) words must be polled with 8-byte sc1 loads"
         assert not any(l.startswith(("buffer_wbl2", "buffer_inv")) for l in body)
         seen += 1
     assert seen == 4

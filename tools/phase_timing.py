@@ -24,7 +24,7 @@ m, q = w["model"], w["q"]
 for _ in range(3):
     s, g = m.score_grad_raw(q)
 torch.cuda.synchronize()
-buf = (Ct.c_ulonglong * 512)()
+buf = (Ct.c_ulonglong * max(512, lib.dcx_debug_ts_words()))()   # (the library copies ALL its stamp words: phase slots + per-block stamps)
 lib.dcx_debug_read_ts.argtypes = [Ct.POINTER(Ct.c_ulonglong)]
 assert lib.dcx_debug_read_ts(buf) == 0
 NWV = 16
