@@ -118,8 +118,11 @@ class LineKeeper:
         self._send("F", obj)
 
     def close(self):
-        self.proc.stdin.close()
-        self.proc.wait(timeout=30)
+        try:
+            self.proc.stdin.close()
+            self.proc.wait(timeout=30)
+        except Exception:   # noqa: BLE001  (the line is the keeper's business from here on; never turn it into a failed run)
+            pass
 
 
 def _fault(where):

@@ -829,6 +829,17 @@ static bool is_device_ptr(const void* p) {
 }
 
 // (re)fill the rows of a model whose storage holds >= S supports
+// Building or refilling a model allocates and ends in a synchronisation of `stream` (the kept row count comes back to the
+// host): refused, before anything is touched, while the stream is being captured.
+static int refuse_capture(hipStream_t stream) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return fail(DCX_ERR_UNSUPPORTED, "a model cannot be built or refilled on a stream that is being captured (the kept row count is read back)");
+    }
+    return DCX_OK;
+}
+
 static int model_fill(dcx_model* m, const float* support_feat, const float* weights, int64_t S, hipStream_t stream) {
     // the XM planes (knob xm > 0: measurements only) are split on the host
     const bool on_device = S > 0 && is_device_ptr(support_feat) && is_device_ptr(weights) &&
@@ -865,6 +876,7 @@ int dcx_model_create_ex(dcx_model** out, int device, const dcx_fk_desc* fk, int 
     if (int rc = check_fk(desc)) return rc;
     if (desc.n_points * desc.point_dim != D) return fail(DCX_ERR_INVALID, "D does not match the transform's feature width");
     if (int rc = set_device(device)) return rc;
+    if (int rc = refuse_capture((hipStream_t)stream)) return rc;
 
     dcx_model* m = new (std::nothrow) dcx_model();
     if (!m) return fail(DCX_ERR_INVALID, "out of host memory");
@@ -934,6 +946,7 @@ int dcx_model_update(dcx_model* m, const float* support_feat, const float* weigh
     if (S < 0 || S > 0x7fffffffLL) return fail(DCX_ERR_INVALID, "S out of range");
     if (S > 0 && (!support_feat || !weights)) return fail(DCX_ERR_INVALID, "support_feat / weights is NULL");
     if (int rc = set_device(m->device)) return rc;
+    if (int rc = refuse_capture((hipStream_t)stream)) return rc;
     std::lock_guard<std::mutex> lock(m->mu);
     if (S > m->cap) {
         // more supports than the storage holds: new storage (blocking; ask dcx_model_create_ex for capacity to avoid it).

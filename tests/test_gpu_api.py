@@ -375,6 +375,34 @@ def test_rows_packed_on_the_device_equal_the_host_packing(rob_name, kspec, C, ze
     assert devm.capacity >= S and float(devm.score_raw(q).abs().max()) == 0.0
 
 
+def test_model_build_is_refused_while_the_stream_is_captured():
+    """dcx_model_create_ex / dcx_model_update allocate and read 16 bytes back: on a capturing stream they return
+    DCX_ERR_UNSUPPORTED before touching anything (the capture stays valid), instead of invalidating the graph"""
+    from diffco_amd import _lib, _ops
+    rob = make_robot("baxter_left")
+    desc = rob.fk_desc()
+    g = torch.Generator().manual_seed(5)
+    sup = torch.randn((50, 12), generator=g).cuda()
+    w = torch.randn((50, 1), generator=g).cuda()
+    q = torch.zeros((8, 7), device="cuda")
+    m = _ops.ScoreModel(desc, 1, 1.0, 1.0, sup, w)
+    s0 = m.score_raw(q)
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        m.score_raw(q)                       # (this stream's scratch exists before the capture)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+        with pytest.raises(_lib.DcxUnsupported):
+            m.update(sup, 2 * w)
+        with pytest.raises(_lib.DcxUnsupported):
+            _ops.ScoreModel(desc, 1, 1.0, 1.0, sup, w)
+        s1 = m.score_raw(q)                  # launches themselves can be captured
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(s1, s0)
+
+
 def test_checker_refills_its_model_in_place():
     """the FusedScorer behind a checker keeps ONE dcx_model across train / fit_poly style state changes (same transform,
     kernel, class count): new weights or supports are packed into it (dcx_model_update); a model someone else still
