@@ -375,6 +375,77 @@ def test_rows_packed_on_the_device_equal_the_host_packing(rob_name, kspec, C, ze
     assert devm.capacity >= S and float(devm.score_raw(q).abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("S,C,pattern", [(2500, 1, "random"), (3100, 5, "blocks"), (1024, 2, "last"), (1025, 8, "first"), (4097, 1, "none")])
+def test_device_packing_across_scan_chunks(S, C, pattern):
+    """the packing kernel compacts 1024 rows per pass: support sets that span several passes, with the dropped rows at
+    random, in whole blocks, only the last / first row kept, and nothing dropped - bit-identical to the host packing"""
+    from diffco_amd import _ops
+    rob = make_robot("baxter_left")
+    desc, lim = rob.fk_desc(), rob.limits
+    g = torch.Generator().manual_seed(S + C)
+    sq = torch.rand((S, 7), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]
+    sup = _ops.fkine(desc, sq.cuda()).reshape(S, -1).cpu()
+    W = torch.randn((S, C), generator=g)
+    keep = torch.ones(S, dtype=torch.bool)
+    if pattern == "random":
+        keep = torch.rand(S, generator=g) > 0.37
+    elif pattern == "blocks":
+        keep[500:1600] = False
+        keep[2049:2050] = False
+    elif pattern == "last":
+        keep[:-1] = False
+    elif pattern == "first":
+        keep[1:] = False
+    W[~keep] = 0.0
+    q = (torch.rand((257, 7), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]).cuda()
+    up = torch.randn((257, C), generator=g).cuda() if C > 1 else None
+    host = _ops.ScoreModel(desc, 0, 10.0, 2.0, sup, W)
+    devm = _ops.ScoreModel(desc, 0, 10.0, 2.0, sup.cuda(), W.cuda())
+    import ctypes as Ct
+    n_host, n_dev = Ct.c_int64(), Ct.c_int64()
+    host._lib.dcx_model_info(host._h, Ct.byref(n_host), None, None, None, None)
+    devm._lib.dcx_model_info(devm._h, Ct.byref(n_dev), None, None, None, None)
+    assert n_host.value == n_dev.value == int(keep.sum())
+    for a, b in zip(host.score_grad_raw(q, up), devm.score_grad_raw(q, up)):
+        assert torch.equal(a, b)
+    assert torch.equal(host.score_jac_raw(q)[1], devm.score_jac_raw(q)[1])
+
+
+def test_rq_takes_the_expanded_form_only_inside_its_rule(knob):
+    """RQKernel(2) behind an FK transform: gamma * max |s - c|^2 <= 32 -> the expanded sweep (2e-6 from float64), beyond it
+    the direct one (bit-identical to knob xf = 0); raw-input models never take it; both stay inside 1e-5"""
+    from diffco_amd import _fkdesc, _ops
+    from oracle import oracle
+    rob = make_robot("baxter_left")
+    desc, lim = rob.fk_desc(), rob.limits
+    g = torch.Generator().manual_seed(9)
+    S, B = 1500, 1024
+    sq = torch.rand((S, 7), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]
+    sup = _ops.fkine(desc, sq.cuda()).reshape(S, -1)
+    W = torch.randn((S, 1), generator=g).cuda()
+    q = (torch.rand((B, 7), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]).cuda()
+    ss_max = float(((sup - sup.mean(0)) ** 2).sum(1).max())
+    for gamma, expanded in ((0.9 * 32.0 / ss_max, True), (1.15 * 32.0 / ss_max, False)):
+        m = _ops.ScoreModel(desc, 0, gamma, 2.0, sup, W)
+        s, gr = m.score_grad_raw(q)
+        knob("xf", 0)
+        s0, g0 = m.score_grad_raw(q)
+        knob("xf", -1)
+        assert (not torch.equal(s, s0)) == expanded, gamma           # the rule's side of the line
+        so, go, _ = oracle.score_grad(desc, 0, gamma, 2.0, sup.cpu().numpy().astype(np.float64), W.cpu().numpy().astype(np.float64),
+                                      q.cpu().numpy().astype(np.float64), dtype=np.float64)
+        assert relerr(s.cpu().numpy(), so) < 1e-5 and relerr(gr.cpu().numpy(), go) < 1e-5
+        assert relerr(s0.cpu().numpy(), so) < 3e-6 and relerr(g0.cpu().numpy(), go) < 3e-6
+    raw = _fkdesc.none_desc(12)
+    m = _ops.ScoreModel(raw, 0, 1.0, 2.0, sup, W)                        # the same numbers as raw inputs: always direct
+    x = sup[:B].contiguous() + 0.01
+    s, gr = m.score_grad_raw(x)
+    knob("xf", 0)
+    s0, g0 = m.score_grad_raw(x)
+    knob("xf", -1)
+    assert torch.equal(s, s0) and torch.equal(gr, g0)
+
+
 def test_model_build_is_refused_while_the_stream_is_captured():
     """dcx_model_create_ex / dcx_model_update allocate and read 16 bytes back: on a capturing stream they return
     DCX_ERR_UNSUPPORTED before touching anything (the capture stays valid), instead of invalidating the graph"""

@@ -370,3 +370,48 @@ def test_cluster_form_agrees_with_one_workgroup_per_path(knob):
     assert float(moved.max()) <= 2.0 * lr * 1.001              # a step is at most lr either way
     assert float((moved > 1e-6).float().mean()) < 1e-3         # and all but a few sign-of-a-tiny-gradient entries agree
     assert torch.equal(a["steps"], b["steps"])
+
+
+@pytest.mark.parametrize("R,W,expect_cluster", [(256, 12, False), (129, 12, False), (128, 12, True), (37, 64, True), (3, 2 + 1, True), (1, 50, True)])
+def test_cluster_rule_edges(R, W, expect_cluster, knob):
+    """the rule that picks the workgroups per path (largest power of two <= min(8, CUs / R)): path counts around the
+    boundaries, a path that fills its 64-lane tile, three-waypoint paths, a single path - each against the two-launch loop
+    split the same way (bit-identical), and the rule's choice against one workgroup per path (same step counts, loss
+    terms to rounding)"""
+    import ctypes as C
+    from diffco_amd import _lib, _ops
+    rob = make_robot("baxter_left")
+    lib = _lib.require_gpu()
+    g = torch.Generator().manual_seed(R + W)
+    lim = rob.limits
+    S = 1200
+    sup_q = torch.rand((S, rob.dof), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]
+    desc = rob.fk_desc()
+    sup = _ops.fkine(desc, sup_q.cuda()).reshape(S, -1)
+    model = _ops.ScoreModel(desc, 1, 1.0, 1.0, sup, (0.02 * torch.randn(S, generator=g)).cuda())
+    paths = _random_paths(rob, R, W, seed=R * W)
+    s0, _ = model.score_grad_raw(paths.reshape(-1, rob.dof).cuda())
+    srt = s0.reshape(-1).sort().values
+    margin = float(0.5 * (srt[len(srt) // 2] + srt[len(srt) // 2 + 1])) if len(srt) > 2 else float(srt.mean())
+    opt = _lib.TrajOpts(0.02, 0.9, 0.999, 1e-8, 1, 10, 10, 10, margin, 0.3, 1e9, 0.0)
+    ys_rule = 1
+    while 2 * ys_rule <= min(8, 256 // R) and S // (2 * ys_rule * 16) >= 15:
+        ys_rule *= 2
+    assert (ys_rule > 1) == expect_cluster
+    outs = {}
+    for label, fused, tys, ys in (("rule", 1, -1, None), ("two-launch", 0, 1, ys_rule), ("one", 1, 1, None)):
+        knob("traj_fused", fused)
+        knob("traj_ys", tys)
+        knob("nw", 16)
+        knob("ys", ys if ys is not None else -1)
+        st, bufs = _traj_state(model, rob, paths)
+        stream = C.c_void_p(torch.cuda.current_stream(model.dev).cuda_stream)
+        _lib.check(lib.dcx_traj_adam_run(model._h, C.byref(st), C.byref(opt), 1, 12, stream))
+        torch.cuda.synchronize()
+        outs[label] = {k: v.clone() for k, v in bufs.items() if k not in ("col_score", "col_grad", "limits")}
+    a, b, c = outs["rule"], outs["two-launch"], outs["one"]
+    assert float(a["stats"][:, 7].min()) == 0.0
+    for k in a:
+        assert torch.equal(a[k], b[k]), (k, float((a[k].float() - b[k].float()).abs().max()))
+    assert torch.equal(a["steps"], c["steps"]) and int(a["steps"].min()) == 12
+    assert torch.equal(a["path"][:, 0].cpu(), paths[:, 0]) and torch.equal(a["path"][:, -1].cpu(), paths[:, -1])
