@@ -61,3 +61,35 @@ for reuse in (True, False):
         with torch.no_grad():
             return dc.poly_score(q)
     print(f"new rbf_nodes -> poly_score(50 waypoints), {'model refilled in place' if reuse else 'model rebuilt        '}: {timeit(round_):8.1f} us", flush=True)
+
+# the reference's recommended facade: ForwardKinematicsDiffCo.update (collision_checkers.py:220-252) on a URDF Panda with a
+# synthetic ground truth (a sphere the hand must avoid) - the whole round: sampling, ground truth, device trainer, fit_poly,
+# verification scores - with the model refilled in place and rebuilt
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from helpers import urdf_robot  # noqa: E402
+from diffco_amd.collision_checkers import ForwardKinematicsDiffCo  # noqa: E402
+
+urob = urdf_robot("urdf_panda")
+k_tip = urob.unique_position_link_names.index("panda_virtual_ee_link")
+centre = torch.tensor([0.35, 0.0, 0.55], device=dev)
+
+
+def ground_truth(qq):
+    return ((urob.fkine(qq.to(dev))[:, :, k_tip] - centre).norm(dim=1) < 0.35).float().cpu()
+
+
+for reuse in (True, False, True, False):
+    torch.manual_seed(0)
+    fk = ForwardKinematicsDiffCo(robot=urob, gamma=10, gt_check_func=ground_truth)
+    fk.fit(num_samples=1500, verify_ratio=0.2, fix_joints=[7], fix_joint_values=[0.04])
+    fk.update(num_samples=200, verify=0.2)
+    torch.cuda.synchronize()
+    t0, n = time.perf_counter(), 12
+    for _ in range(n):
+        if not reuse:
+            fk.perceptron._poly_fused._retired = None
+            fk.perceptron._poly_fused._model = None
+        fk.update(num_samples=200, verify=0.2)
+    torch.cuda.synchronize()
+    print(f"ForwardKinematicsDiffCo.update (200 new samples, {len(fk.perceptron.gains)} supports), "
+          f"{'model refilled in place' if reuse else 'model rebuilt        '}: {(time.perf_counter() - t0) / n * 1e3:8.2f} ms per round", flush=True)
