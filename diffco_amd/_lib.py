@@ -46,6 +46,9 @@ SYMBOLS = {
     "dcx_fkine_vjp": (C.c_int, [C.c_int, C.POINTER(FkDesc), _c_fp, _c_fp, C.c_int64, _c_fp, C.c_void_p]),
     "dcx_kernel_matrix": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_float), _c_fp, C.c_int64, _c_fp, C.c_int64,
                                     C.c_int32, _c_fp, C.c_void_p]),
+    "dcx_solve_work_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
+    "dcx_solve": (C.c_int, [C.c_int, _c_fp, _c_fp, C.c_int64, C.c_int64, _c_fp, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int32,
+                            C.c_void_p]),
 }
 
 

@@ -92,14 +92,71 @@ def kernel_matrix(kind, p0, p1, x: torch.Tensor, s: torch.Tensor) -> torch.Tenso
     return K.to(device=x.device, dtype=x.dtype)
 
 
+SOLVE_MAX_N = 2560   # dcx_solve takes up to DCX_SOLVE_MAX_N = 4096; beyond ~2600 unknowns the library LU is the faster one
+SOLVE_MAX_RHS = 64
+
+
+def _solve_device(a32: torch.Tensor, b32: torch.Tensor) -> torch.Tensor:
+    """dcx_solve on device fp32 tensors a32 [n, n], b32 [n, r]: x [n, r] (device fp32).  Raises torch's LinAlgError on an
+    exactly singular matrix, as torch.linalg.solve does."""
+    lib = _lib.require_gpu()
+    dev = a32.device
+    n, r = b32.shape
+    nbytes = int(lib.dcx_solve_work_bytes(n, r))
+    work = torch.empty((nbytes + 7) // 8, device=dev, dtype=torch.float64)
+    x = torch.empty((n, r), device=dev, dtype=torch.float32)
+    info = torch.zeros(2, device=dev, dtype=torch.int32)
+    with torch.cuda.device(dev):
+        for flags in (0, 1):
+            _lib.check(lib.dcx_solve(dev.index, _ptr(a32), _ptr(b32), n, r, _ptr(x), _ptr(work), nbytes, _ptr(info), flags,
+                                     _stream(dev)))
+            code = int(info[0].item())
+            if code >= 0:
+                break
+            # a grid barrier gave up (another kernel held the CUs): the inputs are untouched, run again as one workgroup
+    if code < 0:
+        raise _lib.DcxError("dcx_solve: the solve did not complete")
+    if code > 0:
+        raise torch.linalg.LinAlgError(f"dcx_solve: the matrix is singular (pivot {code} is exactly zero)")
+    return x
+
+
 def solve(kmat: torch.Tensor, rhs: torch.Tensor) -> torch.Tensor:
-    """x with kmat @ x = rhs, solved on the GPU (LU through torch's hipSOLVER/rocSOLVER binding — a plain library
-    factorisation, the S x S system of fit_poly: reference kernel_perceptrons.py:283, deprecated/MultiDiffCo.py:149);
-    result on kmat's device and dtype.  Like every other op here it needs the GPU."""
+    """x with kmat @ x = rhs, solved on the GPU: the S x S system of fit_poly (reference kernel_perceptrons.py:283,
+    deprecated/MultiDiffCo.py:149).  Up to 2560 unknowns: dcx_solve, one launch (LU with partial pivoting in fp64,
+    csrc/solve_kernels.hip); beyond, or for more than 64 right-hand sides, torch's hipSOLVER binding - a plain library
+    factorisation.  Result on kmat's device and dtype.  Like every other op here it needs the GPU."""
     _lib.require_gpu()
     dev = _device(kmat.device)
+    n = kmat.shape[-1]
+    if kmat.dim() == 2 and rhs.dim() in (1, 2) and 1 <= n <= SOLVE_MAX_N and rhs.shape[0] == n \
+            and 1 <= rhs.numel() // n <= SOLVE_MAX_RHS:
+        x = _solve_device(_f32(kmat, dev), _f32(rhs.reshape(n, -1), dev))
+        return x.reshape(rhs.shape).to(device=kmat.device, dtype=kmat.dtype)
     x = torch.linalg.solve(kmat.detach().to(dev), rhs.detach().to(device=dev, dtype=kmat.dtype))
     return x.to(device=kmat.device)
+
+
+def fit_nodes(kind, p0, p1, feats: torch.Tensor, targets: torch.Tensor, reg: float = 0.0) -> torch.Tensor:
+    """fit_poly in one piece: nodes with (K(feats, feats) + reg I) nodes = targets, the kernel matrix built and solved on
+    the device without leaving it (dcx_kernel_matrix + dcx_solve).  feats [S, ...], targets [S] or [S, C]; result on
+    targets' device and dtype."""
+    lib = _lib.require_gpu()
+    dev = _device(feats.device)
+    f = _f32(feats.reshape(len(feats), -1), dev)
+    S, D = f.shape
+    if S > SOLVE_MAX_N or targets.numel() // max(S, 1) > SOLVE_MAX_RHS:
+        K = kernel_matrix(kind, p0, p1, f, f)
+        if reg:
+            K = K + reg * torch.eye(S, device=dev, dtype=K.dtype)
+        return solve(K, _f32(targets, dev)).to(device=targets.device, dtype=targets.dtype)
+    K = torch.empty((S, S), device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        _lib.check(lib.dcx_kernel_matrix(dev.index, kind, _kparams(p0, p1), _ptr(f), S, _ptr(f), S, D, _ptr(K), _stream(dev)))
+    if reg:
+        K.diagonal().add_(reg)
+    x = _solve_device(K, _f32(targets.reshape(S, -1), dev))
+    return x.reshape(targets.shape).to(device=targets.device, dtype=targets.dtype)
 
 
 # ----------------------------------------------------------------------------- perceptron trainer

@@ -134,6 +134,19 @@ def solve_system(kernel_func, kmat, rhs):
     return torch.linalg.solve(kmat, rhs.to(kmat.dtype))
 
 
+def fit_system(kernel_func, feats, targets, reg=0.0):
+    """fit_poly's nodes: (K(feats, feats) + reg I) nodes = targets.  For a diffco_amd kernel on plain feature rows the
+    matrix is built and solved on the device in one go (`_ops.fit_nodes`: dcx_kernel_matrix + dcx_solve, nothing but the
+    nodes comes back); anything else builds the matrix through the callable and goes through solve_system."""
+    spec = kernel_func.dcx_spec() if isinstance(kernel_func, KernelFunc) else None
+    if spec is not None and len(feats) >= 1:
+        return _ops.fit_nodes(spec[0], spec[1], spec[2], feats, targets, reg)
+    kmat = kernel_func(feats, feats)
+    if reg:
+        kmat = kmat + reg * torch.eye(len(kmat), dtype=kmat.dtype, device=kmat.device)
+    return solve_system(kernel_func, kmat, targets.to(kmat.dtype))
+
+
 def sub_block(K, idx, device, dtype):
     """K[idx][:, idx] gathered where K lives, then moved to (device, dtype)"""
     i = idx.to(K.device)

@@ -115,9 +115,12 @@ class RBFDiffCo(CollisionChecker):
                 fresh = torch.nonzero(~exist_mask.cpu()).reshape(-1)
                 verify_mask[fresh[torch.randperm(len(fresh))[:num_verify]]] = True
                 exist_mask = exist_mask[~verify_mask.to(exist_mask.device)]
-            q_train, q_verify = q[~verify_mask], q[verify_mask]
-            labels_train, labels_verify = labels[~verify_mask], labels[verify_mask]
-            dists_train = dists[~verify_mask]
+            # (index_select: see kernel_perceptrons.train_perceptron)
+            i_train, i_verify = torch.where(~verify_mask)[0], torch.where(verify_mask)[0]
+            pick = lambda t, i: t.index_select(0, i.to(t.device))  # noqa: E731
+            q_train, q_verify = pick(q, i_train), pick(q, i_verify)
+            labels_train, labels_verify = pick(labels, i_train), pick(labels, i_verify)
+            dists_train = pick(dists, i_train)
         elif verify_ratio:
             raise ValueError(f'verify_ratio should be in (0, 1), got {verify_ratio}')
         else:

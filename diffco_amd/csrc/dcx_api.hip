@@ -13,6 +13,7 @@
 
 #include "dcx_internal.h"
 #include "pack_kernels.h"
+#include "solve_kernels.h"
 
 using namespace dcx;
 
@@ -259,7 +260,7 @@ int fk_device_copy(int device, const dcx_fk_desc& fk, FkProg** out) {
 struct Knobs {
     std::atomic<int64_t> ys{-1}, nw{-1}, min_rows{-1}, split_finish_kernel{-1}, inlaunch_tiles{-1}, jac_per_class{-1},
         mfma{-1}, traj_fused{-1}, xf{-1}, jac_one_sweep{-1}, train_grid{-1}, fkk{-1}, jt_waves{-1}, hess_ys{-1}, xm{-1},
-        traj_ys{-1}, traj_across{-1}, owner_poll{-1};
+        traj_ys{-1}, traj_across{-1}, owner_poll{-1}, solve_threads{-1};
     Knobs() {
         auto rd = [](const char* name, std::atomic<int64_t>& dst, bool flag) {
             if (const char* e = std::getenv(name)) dst = flag ? 1 : std::atoll(e);
@@ -282,6 +283,7 @@ struct Knobs {
         rd("DCX_TRAJ_YS", traj_ys, false);
         rd("DCX_TRAJ_ACROSS", traj_across, false);
         rd("DCX_OWNER_POLL", owner_poll, false);
+        rd("DCX_SOLVE_THREADS", solve_threads, false);
     }
 };
 Knobs& knobs() {
@@ -623,7 +625,7 @@ int dcx_debug_set(const char* name, int64_t value) {
     const std::string n(name);
     std::atomic<int64_t>* dst = n == "ys" ? &k.ys : n == "nw" ? &k.nw : n == "min_rows" ? &k.min_rows
         : n == "split_finish_kernel" ? &k.split_finish_kernel : n == "inlaunch_tiles" ? &k.inlaunch_tiles
-        : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : n == "traj_fused" ? &k.traj_fused : n == "xf" ? &k.xf : n == "jac_one_sweep" ? &k.jac_one_sweep : n == "train_grid" ? &k.train_grid : n == "fkk" ? &k.fkk : n == "jt_waves" ? &k.jt_waves : n == "hess_ys" ? &k.hess_ys : n == "xm" ? &k.xm : n == "traj_ys" ? &k.traj_ys : n == "traj_across" ? &k.traj_across : n == "owner_poll" ? &k.owner_poll : nullptr;
+        : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : n == "traj_fused" ? &k.traj_fused : n == "xf" ? &k.xf : n == "jac_one_sweep" ? &k.jac_one_sweep : n == "train_grid" ? &k.train_grid : n == "fkk" ? &k.fkk : n == "jt_waves" ? &k.jt_waves : n == "hess_ys" ? &k.hess_ys : n == "xm" ? &k.xm : n == "traj_ys" ? &k.traj_ys : n == "traj_across" ? &k.traj_across : n == "owner_poll" ? &k.owner_poll : n == "solve_threads" ? &k.solve_threads : nullptr;
     if (!dst) return fail(DCX_ERR_INVALID, "unknown knob: " + n);
     *dst = value;
     return DCX_OK;
@@ -1336,6 +1338,31 @@ int dcx_kernel_matrix(int device, int kernel_kind, const float* kparams, const f
                                             (hipStream_t)stream);
         if (e != hipSuccess) return fail_hip(e, "kernel_matrix launch");
     }
+    return DCX_OK;
+}
+
+size_t dcx_solve_work_bytes(int64_t n, int64_t nrhs) {
+    if (n < 1 || nrhs < 1) return 0;
+    return solve_work_bytes(n, nrhs);
+}
+
+int dcx_solve(int device, const float* A, const float* B, int64_t n, int64_t nrhs, float* X, void* work, size_t work_bytes,
+              int32_t* info, int32_t flags, void* stream) {
+    if (n < 1 || n > DCX_SOLVE_MAX_N || nrhs < 1 || nrhs > 64) return fail(DCX_ERR_INVALID, "solve: 1 <= n <= 4096, 1 <= nrhs <= 64");
+    if (!A || !B || !X || !work || !info) return fail(DCX_ERR_INVALID, "a solve pointer is NULL");
+    if (work_bytes < solve_work_bytes(n, nrhs) || (reinterpret_cast<uintptr_t>(work) & 15))
+        return fail(DCX_ERR_INVALID, "solve: the workspace is smaller than dcx_solve_work_bytes(n, nrhs) or not 16-byte aligned");
+    if (int rc = set_device(device)) return rc;
+    static int n_cu_of[64] = {0};
+    int n_cu = (device >= 0 && device < 64) ? n_cu_of[device] : 0;
+    if (n_cu == 0) {
+        hipDeviceProp_t prop;
+        n_cu = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 64;
+        if (device >= 0 && device < 64) n_cu_of[device] = n_cu;
+    }
+    hipError_t e = launch_solve(A, B, X, (int)n, (int)nrhs, work, info, n_cu, (flags & DCX_SOLVE_ONE_WORKGROUP) != 0,
+                                knobs().solve_threads == 256 ? 256 : knobs().solve_threads == 512 ? 512 : 0, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "solve launch");
     return DCX_OK;
 }
 

@@ -13,7 +13,7 @@ from time import time
 import torch
 
 from . import kernel
-from ._perceptron import FusedScorer, run_trainer, solve_system, sub_block
+from ._perceptron import FusedScorer, fit_system, run_trainer, solve_system, sub_block
 
 
 class CollisionChecker:
@@ -136,8 +136,7 @@ class DiffCo(CollisionChecker):
 
     def fit_poly(self, kernel_func=None, target='hypo', fkine=None):
         X, t = self._fit_inputs(kernel_func, target, fkine)
-        kmat = self.rbf_kernel(X, X)
-        self.rbf_nodes = solve_system(self.rbf_kernel, kmat, t.reshape(len(X), 1).to(kmat.dtype)).reshape(-1)
+        self.rbf_nodes = fit_system(self.rbf_kernel, X, t.reshape(len(X), 1).to(X.dtype)).reshape(-1)
         if self._cuda:
             self.cuda()
 

@@ -18,8 +18,9 @@ from time import time
 
 import torch as th
 
-from . import kernel
-from ._perceptron import FusedScorer, run_trainer, solve_system, sub_block
+from . import _ops, kernel
+from .kernel import KernelFunc
+from ._perceptron import FusedScorer, fit_system, run_trainer, sub_block
 
 
 class Perceptron:
@@ -113,9 +114,16 @@ class DiffCo(Perceptron):
         """Warm start for active learning: rows flagged in exist_mask are the current supports (same
         order); the rest are new samples whose hypothesis is the current score."""
         n = len(X)
-        dev = th.device('cpu') if n <= 10000 else X.device
+        # (the reference assembles the warm start on the host for n <= 10000; the trainer and fit_poly run on the GPU here,
+        # so state that already lives there stays there: on a many-core host the CPU tensor ops of this function - an n x n
+        # zero fill, three masked scatters - cost more than the training itself, 20 of a 57 ms update round)
+        # `home`: where the reference keeps the result (and where the caller finds the state afterwards); `dev`: where the
+        # assembly runs - the trainer's GPU for our kernels
+        home = th.device('cpu') if n <= 10000 else X.device
+        ours = isinstance(self.kernel_func, KernelFunc) and self.kernel_func.dcx_spec() is not None
+        dev = X.device if X.is_cuda else (_ops._device(None) if (ours and th.cuda.is_available()) else home)
         exist_mask = exist_mask.to(th.bool)
-        novel = X[~exist_mask]
+        novel = X.index_select(0, th.where(~exist_mask)[0].to(X.device))   # (not X[~mask]: see train_perceptron)
         v = self.valid_supports
         assert n - len(novel) == v
         hypo = th.zeros(n, dtype=X.dtype, device=dev)
@@ -137,7 +145,9 @@ class DiffCo(Perceptron):
         gains[exist_mask.to(dev)] = self.gains[:v].to(dev)
         check = K @ gains
         assert th.allclose(check, hypo, atol=1e-4), f"diff: {th.abs(check - hypo).max()}"
-        return gains, X.to(dev), Xt, K, hypo, y.to(dev).reshape(-1)
+        # (the n x n matrix stays where it was assembled: the trainer takes it from there and callers only ever gather
+        # the support sub-block of it)
+        return gains.to(home), X.to(home), Xt.to(home), K, hypo.to(home), y.to(home).reshape(-1)
 
     def train_perceptron(self, X, y, update=False, exist_mask=None, max_iteration=1000, verbose=False):
         if update:
@@ -164,12 +174,15 @@ class DiffCo(Perceptron):
             keep[th.where(~keep)[0][0]] = True
         idx = th.where(keep)[0]
         if self.max_num_supports is None:
-            self.support_points = X[keep]
-            self.support_transformed = Xt[keep]
-            self.hypothesis = hypo[keep]
-            self.y = y[keep]
-            self.distance = self.distance.to(keep.device)[keep] if self.distance is not None else None
-            self.gains = gains[keep]
+            # (index_select on the kept rows, not boolean-mask indexing: on CPU tensors the latter opens an OpenMP region
+            #  for the [n, m, d] features, and on a 128-thread host waking the pool costs more than the training - 13 ms
+            #  of an update round, tools/facade_lines.py)
+            self.support_points = X.index_select(0, idx)
+            self.support_transformed = Xt.index_select(0, idx)
+            self.hypothesis = hypo.index_select(0, idx)
+            self.y = y.index_select(0, idx)
+            self.distance = self.distance.to(keep.device).index_select(0, idx) if self.distance is not None else None
+            self.gains = gains.index_select(0, idx)
             self.rbf_nodes = self.gains.new_zeros(len(self.gains))
             self.kernel_matrix = sub_block(K, idx, gains.device, gains.dtype)
             self._valid_supports = len(self.support_points)
@@ -231,9 +244,8 @@ class DiffCo(Perceptron):
         self._invalidate_fused()
         v = self.valid_supports
         Xs = self.support_transformed[:v]
-        kmat = self.rbf_kernel(Xs, Xs)
         self.rbf_nodes.zero_()
-        self.rbf_nodes[:v] = solve_system(self.rbf_kernel, kmat, t[:v, None].to(kmat.dtype)).reshape(-1)
+        self.rbf_nodes[:v] = fit_system(self.rbf_kernel, Xs, t[:v, None].to(Xs.dtype)).reshape(-1)
         if self._cuda:
             self.cuda()
 

@@ -26,13 +26,14 @@
 #ifndef DCX_H
 #define DCX_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define DCX_VERSION 105 /* 0.1.5: dcx_model_create_ex / dcx_model_update (rows packed on the device); 0.1.4: dcx_train_perceptron_ex (per-call flags); 0.1.3: dcx_fk_desc carries the DCX_FK_TREE section; 32 control points, D <= 96 */
+#define DCX_VERSION 106 /* 0.1.5: dcx_model_create_ex / dcx_model_update (rows packed on the device); 0.1.4: dcx_train_perceptron_ex (per-call flags); 0.1.3: dcx_fk_desc carries the DCX_FK_TREE section; 32 control points, D <= 96 */
 
 /* ---- status codes ---------------------------------------------------------------- */
 #define DCX_OK 0
@@ -160,7 +161,8 @@ int dcx_device_count(void);
  * block to arrive finishes; 1 / rule = block y = 0 owns its tile and polls its peers' (value, tag) words - bit-identical;
  * the rule takes it when every block of the launch is resident at once), "hess_ys" (blocks per tile of dcx_score_hess; 1 =
  * never split the supports), "xm" (1 = the expanded form takes its distance GEMM from the matrix cores, bf16x3 split
- * operands, where compiled: one class, Polyharmonic(1), even D <= 16; agrees with the VALU form to ~1e-6, measured slower).
+ * operands, where compiled: one class, Polyharmonic(1), even D <= 16; agrees with the VALU form to ~1e-6, measured slower),
+ * "solve_threads" (dcx_solve's workgroup size: 256 or 512; rule = 256 up to 768 unknowns; same pivots, same arithmetic).
  * value < 0 restores the rule.  The initial values come from the DCX_YS / DCX_NW / DCX_XF / ... environment variables,
  * read once at library load; no launch calls getenv.   */
 int dcx_debug_set(const char* name, int64_t value);
@@ -319,6 +321,19 @@ int dcx_fkine_vjp(int device, const dcx_fk_desc* fk, const float* q, const float
  * row fill kernel_perceptrons.py:117-119 and fit_poly :271-287).  x [B, D], s [S, D] dev -> K [B, S] dev */
 int dcx_kernel_matrix(int device, int kernel_kind, const float* kparams, const float* x, int64_t B,
                       const float* s, int64_t S, int32_t D, float* K, void* stream);
+
+/* x with A x = B: the S x S system fit_poly ends in (torch.linalg.solve at kernel_perceptrons.py:283, deprecated/DiffCo.py:162,
+ * deprecated/MultiDiffCo.py:151 - add `reg` to A's diagonal first).  LU with partial pivoting in fp64, ONE launch.
+ * A [n, n], B [n, nrhs] -> X [n, nrhs], all row-major fp32 on the device; 1 <= n <= DCX_SOLVE_MAX_N, 1 <= nrhs <= 64.
+ * work: dcx_solve_work_bytes(n, nrhs) bytes of device memory, the caller's (no allocation, no synchronisation here; the
+ * stream may be under capture).  info [2] int32 on the device: info[0] = 0, or k > 0 when the k-th pivot is exactly zero
+ * (LAPACK's info; X is then not a solution), or -1 when a grid barrier gave up (another kernel held the CUs for seconds):
+ * call again with DCX_SOLVE_ONE_WORKGROUP in flags.  */
+#define DCX_SOLVE_MAX_N 4096
+#define DCX_SOLVE_ONE_WORKGROUP 1
+size_t dcx_solve_work_bytes(int64_t n, int64_t nrhs);
+int dcx_solve(int device, const float* A, const float* B, int64_t n, int64_t nrhs, float* X, void* work, size_t work_bytes,
+              int32_t* info, int32_t flags, void* stream);
 
 #ifdef __cplusplus
 }

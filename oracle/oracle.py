@@ -98,3 +98,12 @@ def score_grad(desc, kind, p0, p1, sup, W, q, upstream=None, want_jac=False, dty
                                                     C.c_int(D), C.c_int(Cn), _p(q), C.c_int64(B), _p(up), _p(score),
                                                     _p(grad), _p(jac))
     return score, grad, jac
+
+
+def solve(kmat, rhs, dtype=np.float64):
+    """x with kmat x = rhs: the S x S system fit_poly ends in (reference kernel_perceptrons.py:283, deprecated/DiffCo.py:162,
+    deprecated/MultiDiffCo.py:151: torch.linalg.solve = LAPACK gesv, LU with partial pivoting).  numpy's solve is the same
+    LAPACK routine; `dtype=np.float32` is the reference's arithmetic, float64 the referee."""
+    a = np.ascontiguousarray(kmat, dtype=dtype)
+    b = np.ascontiguousarray(rhs, dtype=dtype)
+    return np.linalg.solve(a, b.reshape(len(a), -1)).reshape(b.shape)

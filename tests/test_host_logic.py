@@ -46,6 +46,28 @@ def test_new_api_trainer_matches_reference_supports():
     assert torch.equal(dc2["gains"], dc.gains)
 
 
+def test_oracle_solve_against_the_reference_nodes():
+    """oracle.solve (LAPACK gesv, what torch.linalg.solve calls) on the reference's own supports and targets reproduces the
+    nodes the reference's fit_poly stored (trained_baxter.npz), in its fp32 arithmetic and - within the conditioning of the
+    polyharmonic system, see above - as the fp64 referee the HIP solve is held to (tests/test_gpu_solve.py)"""
+    from helpers import KIND
+    d = load("trained_baxter")
+    S = d["support_transformed"].reshape(len(d["support_transformed"]), -1)
+    for tgt, vals in (("label", d["sup_y"]), ("hypo", d["hypothesis"]), ("dist", d["sup_dist"])):
+        K32 = oracle.kernel_matrix(KIND["poly"], 1, 1.0, S, S)
+        n32 = oracle.solve(K32, vals, np.float32)
+        n64 = oracle.solve(oracle.kernel_matrix(KIND["poly"], 1, 1.0, S, S, dtype=np.float64), vals)
+        assert n32.shape == vals.shape
+        assert relerr(n32, d[f"rbf_nodes_{tgt}"]) < 2e-2 and relerr(n64, d[f"rbf_nodes_{tgt}"]) < 2e-2, tgt
+        # both interpolate the targets
+        assert np.abs(K32.astype(np.float64) @ n64 - vals).max() < 2e-3 * np.abs(vals).max(), tgt
+    # several right-hand sides at once, and a 1 x 1 system
+    rhs = np.stack([d["sup_y"], d["hypothesis"]], axis=1)
+    both = oracle.solve(K32, rhs)
+    assert both.shape == rhs.shape and relerr(both[:, 0], oracle.solve(K32, d["sup_y"])) < 1e-9
+    assert oracle.solve(np.array([[4.0]]), np.array([2.0]))[0] == 0.5
+
+
 def test_max_num_supports_padding():
     from diffco_amd.kernel_perceptrons import DiffCo
     d = load("trained_baxter")
