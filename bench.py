@@ -616,6 +616,31 @@ def primary_line(args, w, loop, world, multi, ranks_reported, wall, kern_ms, n_s
     return out
 
 
+def solve_times(dev):
+    """K x = y for the Polyharmonic(1) kernel matrix of S supports in 24 features, as fit_poly builds it (dcx_kernel_matrix):
+    dcx_solve (one launch, diffco_amd._ops.solve) and torch.linalg.solve (hipSOLVER) on the SAME device matrix, milliseconds
+    of wall time per call in a loop of 10, device-synchronised; the residual max|K x - y| in float64 beside each"""
+    from diffco_amd import _ops
+    out = {"unit": "ms", "what": "S x S solve of fit_poly, one right-hand side, fp32 in / out"}
+    for S in (438, 2000):
+        g = torch.Generator().manual_seed(S)
+        feats = torch.rand((S, 24), generator=g).to(dev)
+        y = torch.sign(torch.randn(S, generator=g)).to(dev)
+        K = _ops.kernel_matrix(1, 1.0, 1.0, feats, feats)   # DCX_K_POLY, k = 1, epsilon = 1
+        res = {}
+        for key, fn in (("dcx_solve", lambda: _ops.solve(K, y)), ("hipsolver", lambda: torch.linalg.solve(K, y))):
+            x = fn()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(10):
+                x = fn()
+            torch.cuda.synchronize(dev)
+            res[key] = round((time.perf_counter() - t0) / 10 * 1e3, 4)
+            res[key + "_residual"] = float((K.double() @ x.double() - y.double()).abs().max())
+        out[f"S{S}"] = res
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -774,6 +799,15 @@ def main():
             except Exception as exc:  # noqa: BLE001  (a side measurement never takes the primary line down)
                 configs[cname] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
 
+    # the caller next to the path: fit_poly's S x S solve, one launch (dcx_solve), the library route beside it
+    callers = None
+    if configs is not None:
+        callers = {}
+        try:
+            callers["fit_poly_solve"] = solve_times(dev)
+        except Exception as exc:  # noqa: BLE001
+            callers["fit_poly_solve"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+
     if rank == 0:
         if multi:
             none_ms = ((variants or {}).get("gather_none") or {}).get("ms_per_step")
@@ -783,6 +817,7 @@ def main():
                 out["variants"] = variants
         if configs is not None:
             out["configs"] = configs
+            out["callers"] = callers
         keeper.final(out)
     if multi:
         dist.destroy_process_group()

@@ -84,6 +84,11 @@ def test_headline_line_carries_every_baseline_config():
     # the 8-GPU shard of config #5 runs its paths on several workgroups each (cluster form): well under the 256-restart time
     assert cf["cfg5_shard32"]["ms_per_step"] < 0.7 * cf["cfg5"]["ms_per_step"]
     assert d["settle_steps"] > 0
+    # the caller beside the path: fit_poly's solve in one launch, a solution (residual of K x = y) and not slower than the library
+    fs = d["callers"]["fit_poly_solve"]
+    for key in ("S438", "S2000"):
+        assert 0 < fs[key]["dcx_solve"] < 1.1 * fs[key]["hipsolver"], fs
+        assert fs[key]["dcx_solve_residual"] <= max(1e-4, fs[key]["hipsolver_residual"]), fs   # (fp64 inside: the smaller one)
     for name, c in cf.items():
         assert "error" not in c, (name, c)
         assert c["value"] > 0 and 0 < c["frac"] < 1 and c["kernel_ms"] <= c["ms_per_step"] * 1.05, (name, c)

@@ -199,3 +199,35 @@ def test_measurement_tools_still_compile_for_gfx950(tmp_path, src, flags):
         assert text.count("v_mfma_f32_16x16x4_f32") >= 8 and "v_mfma_f32_16x16x32_bf16" in text
     elif "mfma_coissue" in src:
         assert ("v_mfma_f32_16x16x32_bf16" if flags else "v_mfma_f32_16x16x4_f32") in text and "s_getreg_b32" in text
+
+
+def test_dense_solve_keeps_its_panel_in_registers(tmp_path):
+    """csrc/solve_kernels.hip (dcx_solve), both workgroup sizes: what profiles/r04_solve.txt relies on.  The panel's 64
+    doubles per thread are registers (three source forms ended in scratch: a column loop indexes the array dynamically,
+    `if (r == rp) v[r]` chains become v[rp], non-inlined phases spill callee-saved registers per call); the pivot search is a
+    DPP reduction (no shuffle through LDS in the kernel at all); the pivot row is published by plain ds_write_b64 and read
+    back wide; the rank-nb update is fp64 FMAs against LDS reads, never more than its budget of registers."""
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    out = tmp_path / "s.s"
+    subprocess.run(["hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I", CSRC, "-S", "--cuda-device-only",
+                    os.path.join(CSRC, "solve_kernels.hip"), "-o", str(out)], check=True, stderr=subprocess.DEVNULL)
+    txt = out.read_text()
+    kernels = list(re.finditer(r"^(_ZN3dcx\S*nt(256|512)\S*lu_solve_kernel\S*):", txt, re.M))
+    assert sorted(m.group(2) for m in kernels) == ["256", "512"]
+    for m in kernels:
+        body = txt[m.end():txt.index(".Lfunc_end", m.end())]
+        meta = txt[txt.index(".name:           " + m.group(1)):]
+        scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", meta).group(1))
+        vgpr = int(re.search(r"\.vgpr_count:\s+(\d+)", meta).group(1))
+        spills = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", meta).group(1))
+        nt = int(m.group(2))
+        # 256 threads: one wave per SIMD, the whole file; 512: two waves, 256 registers each - a handful of spills tolerated
+        assert vgpr <= 512 and scratch <= (0 if nt == 256 else 64) and spills <= (0 if nt == 256 else 12), (nt, vgpr, scratch, spills)
+        ops = Counter(l.split()[0] for l in body.split("\n") if l.startswith("\t") and not l.startswith("\t."))
+        assert ops["ds_bpermute_b32"] == 0 and ops["ds_permute_b32"] == 0, "a wave reduction went back through the LDS crossbar"
+        assert sum(v for k, v in ops.items() if k.endswith("_dpp")) >= 12 * 60, "the pivot search lost its DPP reduction"
+        assert ops["ds_max_u64"] == 32 + 16 + 8 + 4, ops["ds_max_u64"]          # one per panel column and width
+        assert ops["v_rcp_f64_e32"] >= 60 and ops["v_div_scale_f64"] == 0, "a pivot reciprocal became an IEEE division"
+        assert ops["scratch_load_dwordx2"] + ops["scratch_load_dwordx4"] <= (0 if nt == 256 else 16)
+        assert ops["v_fma_f64"] + ops["v_fmac_f64_e32"] > 2500                    # the unrolled panel columns and updates
