@@ -260,7 +260,7 @@ int fk_device_copy(int device, const dcx_fk_desc& fk, FkProg** out) {
 struct Knobs {
     std::atomic<int64_t> ys{-1}, nw{-1}, min_rows{-1}, split_finish_kernel{-1}, inlaunch_tiles{-1}, jac_per_class{-1},
         mfma{-1}, traj_fused{-1}, xf{-1}, jac_one_sweep{-1}, train_grid{-1}, fkk{-1}, jt_waves{-1}, hess_ys{-1}, xm{-1},
-        traj_ys{-1}, traj_across{-1}, owner_poll{-1}, solve_threads{-1};
+        traj_ys{-1}, traj_across{-1}, owner_poll{-1}, solve_threads{-1}, qt{-1};
     Knobs() {
         auto rd = [](const char* name, std::atomic<int64_t>& dst, bool flag) {
             if (const char* e = std::getenv(name)) dst = flag ? 1 : std::atoll(e);
@@ -284,6 +284,7 @@ struct Knobs {
         rd("DCX_TRAJ_ACROSS", traj_across, false);
         rd("DCX_OWNER_POLL", owner_poll, false);
         rd("DCX_SOLVE_THREADS", solve_threads, false);
+        rd("DCX_QT", qt, false);
     }
 };
 Knobs& knobs() {
@@ -477,12 +478,47 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
     if (B == 0) return DCX_OK;
     const int d_fk = m->fk.n_points * m->fk.point_dim;
     const int acc = (mode == MODE_SCORE ? 0 : m->Dt) + m->Cc;
-    const int64_t nblk = (B + 63) / 64;
+    int64_t nblk = (B + 63) / 64;
     // the split rule sees nz launches' worth of tiles: the classes fill the chip too
     // the expanded form of the sweep (centred data, score_kernel.h) where it is compiled and not switched off
     const bool xf_able = knobs().xf != 0 && xf_applies(m->Dt, m->Cc, m->kf) && m->rows_xf_dev != nullptr &&
                          (m->kf != KF_RQ2 || m->xf_rq_ok || knobs().xf >= 2);   // (knob xf = 2 forces it past the rule: tools/xf_rq_rule.py)
-    Geometry g = pick_geometry(m, B * nz, acc, true);
+    // The 16-configuration tile (score_kernel.h QT, round 4): a batch of at most 16 configurations per CU runs as blocks of 16
+    // that sweep ALL the supports from an LDS copy - one block per CU, no cross-block hand-over.  One class with row weights,
+    // D = 12 / 24, the specialised kernel functions; the rows and the block's own state must fit the CU's LDS with all 16 waves
+    // (config #2: 64 + 53 KB; a 2000-row model does not fit and keeps the split launch).  Measured (profiles/r04_qt.txt): config #2's
+    // model 10.9 - 11.0 -> 10.2 - 10.4 us at every batch from 256 to 4096.  Knob qt: 0 = never, 1 = whenever it is compiled and
+    // fits with at least 4 waves.
+    constexpr int QT_SLICES = kQtSlices;   // row slices per wave (score_kernel.h)
+    Geometry g{};
+    bool qt = false;
+    int qt_per = 0;
+    size_t qt_lds = 0;
+    // (a knob that asks for a particular form of the split launch or of the sweep - tests, A/B tools - is honoured: the rule yields)
+    const Knobs& kn0 = knobs();
+    const bool asked_otherwise = kn0.ys >= 1 || kn0.xf >= 0 || kn0.mfma > 0 || kn0.xm > 0 || kn0.owner_poll >= 0 || kn0.split_finish_kernel > 0 ||
+                                 kn0.inlaunch_tiles >= 0 || kn0.min_rows >= 1;
+    if (const int64_t kq = kn0.qt; kq != 0 && (kq > 0 || !asked_otherwise) && qt_applies(m->Dt, m->Cc, m->kf, mode) && nz == 1 &&
+                                   m->S_active >= 64 && B <= 16LL * m->n_cu) {
+        int nw = std::min(16, m->max_threads / 64);
+        if (const int64_t v = knobs().nw; v >= 2) nw = (int)std::min<int64_t>(v, m->max_threads / 64);
+        const int nw_rule = nw;
+        for (; nw >= 4; nw /= 2) {
+            qt_per = (m->S_active + QT_SLICES * nw - 1) / (QT_SLICES * nw);
+            const size_t plan = lds_plan(m->fk.dof, d_fk, m->frame_floats, nw, acc, true).total + m->prog_floats;
+            qt_lds = sizeof(float) * (((plan + 3) & ~(size_t)3) + (size_t)QT_SLICES * nw * (qt_per * row_stride(m->Dt, m->Cc) + 4) +
+                                      (size_t)(12 * m->dh.n_pt + 1) * 64);   // + J^T's own scratch columns (phase R1 beside the sweep)
+            if (qt_lds <= 156 * 1024 && qt_per >= 2) break;
+            if (kq < 0) { nw = 0; break; }   // (the rule: all the waves or not at all)
+        }
+        if (nw >= 4 && (kq > 0 || nw == nw_rule)) {
+            qt = true;
+            g.nw = nw;
+            g.ys = 1;
+            g.red_slots = nw;
+        }
+    }
+    if (!qt) g = pick_geometry(m, B * nz, acc, true);
     float* part = nullptr;
     if (g.ys > 1) {
         part = split_scratch(m, st, (size_t)nblk * nz * g.ys * acc * 64 * sizeof(float));
@@ -534,6 +570,20 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
     // wave to own a slice of the LDS reduction scratch (nw > 1, parallel fold)
     a.mfma = (mode != MODE_SCORE && (m->Cc == 1 || m->Cc == 5 || m->Cc == 8) && (m->Dt == 12 || m->Dt == 16) && (m->Dt % 2) == 0 && m->kf != KF_GEN && g.nw > 1 && g.red_slots == g.nw &&
               knobs().mfma != 0 && knobs().mfma > 0) ? 1 : 0;
+    if (qt) {   // 16-configuration blocks, the direct form on the model's own rows
+        a.mfma = 0;
+        a.xf = 0;
+        a.qt = 1;
+        a.qt_per = qt_per;
+        a.qt_off = (int32_t)((lds_plan(a.dof, d_fk, m->frame_floats, g.nw, acc, true).total + m->prog_floats + 3) & ~3);
+        a.qt_scr = a.qt_off + QT_SLICES * g.nw * (qt_per * row_stride(m->Dt, m->Cc) + 4);
+        // rows copied before the first barrier: ~45 % (the FK chain hides the rest behind its 2 k cycles; tried: the loads of that part
+        // issued before anything else - the FK description's own wait then waits for them too: 10.46 -> 11.5 us).  Knob qt >= 100:
+        // qt - 100 percent.
+        const int64_t kq = knobs().qt;
+        a.qt_front = (int32_t)((int64_t)QT_SLICES * g.nw * qt_per * (kq >= 100 ? std::min<int64_t>(kq - 100, 100) : 45) / 100);
+        nblk = (B + 15) / 16;
+    }
     if (a.mfma) a.xf = 0;
     if (a.xf) {  // the XF kernel: the centred rows and the centroid
         a.rows = m->rows_xf_dev;
@@ -560,6 +610,7 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
     a.ts_block = std::getenv("DCX_TS_BLOCK") ? (unsigned)std::atoi(std::getenv("DCX_TS_BLOCK")) : 0u;
 #endif
     size_t lds = sizeof(float) * (lds_plan(a.dof, d_fk, m->frame_floats, g.nw > 1 ? g.red_slots : 0, acc, true).total + m->prog_floats);
+    if (qt) lds = qt_lds;
     if (g.ys == 1) {
         hipError_t e = m->launch(m->kf, m->Cc, mode, g.nw, lds, nblk, a, st);
         if (e != hipSuccess) return fail_hip(e, "score kernel launch");
@@ -625,7 +676,7 @@ int dcx_debug_set(const char* name, int64_t value) {
     const std::string n(name);
     std::atomic<int64_t>* dst = n == "ys" ? &k.ys : n == "nw" ? &k.nw : n == "min_rows" ? &k.min_rows
         : n == "split_finish_kernel" ? &k.split_finish_kernel : n == "inlaunch_tiles" ? &k.inlaunch_tiles
-        : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : n == "traj_fused" ? &k.traj_fused : n == "xf" ? &k.xf : n == "jac_one_sweep" ? &k.jac_one_sweep : n == "train_grid" ? &k.train_grid : n == "fkk" ? &k.fkk : n == "jt_waves" ? &k.jt_waves : n == "hess_ys" ? &k.hess_ys : n == "xm" ? &k.xm : n == "traj_ys" ? &k.traj_ys : n == "traj_across" ? &k.traj_across : n == "owner_poll" ? &k.owner_poll : n == "solve_threads" ? &k.solve_threads : nullptr;
+        : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : n == "traj_fused" ? &k.traj_fused : n == "xf" ? &k.xf : n == "jac_one_sweep" ? &k.jac_one_sweep : n == "train_grid" ? &k.train_grid : n == "fkk" ? &k.fkk : n == "jt_waves" ? &k.jt_waves : n == "hess_ys" ? &k.hess_ys : n == "xm" ? &k.xm : n == "traj_ys" ? &k.traj_ys : n == "traj_across" ? &k.traj_across : n == "owner_poll" ? &k.owner_poll : n == "solve_threads" ? &k.solve_threads : n == "qt" ? &k.qt : nullptr;
     if (!dst) return fail(DCX_ERR_INVALID, "unknown knob: " + n);
     *dst = value;
     return DCX_OK;

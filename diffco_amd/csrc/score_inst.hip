@@ -47,6 +47,9 @@ hipError_t go(int nw, size_t lds, int64_t nblk, const ScoreArgs& a, hipStream_t 
         kern<<<grid, dim3(64 * nw), lds, st>>>(a);
         return hipGetLastError();
     };
+    if constexpr (qt_applies(kD, CC, KF, MODE)) {   // the quarter tile (16 configurations per block, rows from LDS): nblk counts ITS blocks
+        if (a.qt) return launch(score_kernel<kD, KF, CC, MODE, kMaxT, false, false, false, true>);
+    }
     if constexpr (xf_applies(kD, CC, KF) && xm_applies(kD, CC, KF) && MODE == MODE_GRAD_ROW) {
         if (!a.mfma && a.xf && a.xm) return launch(score_kernel<kD, KF, CC, MODE, kMaxT, false, true, true>);
     }

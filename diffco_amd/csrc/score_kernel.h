@@ -97,6 +97,11 @@ struct ScoreArgs {
                               // point step (+ 1): J^T runs on several waves (fk_device.h dh2_vjp_r1_sel / r1b / r2_sel)
     int32_t hinge;            // C == 1: gradient of weight * clamp(score - margin, 0) instead of the score's
     float hinge_margin, hinge_weight;
+    int32_t qt;               // 1: the quarter-tile form (score_kernel<..., QT>): 16 configurations per block, rows from LDS
+    int32_t qt_off;           // ... float offset of the rows' copy inside the block's LDS
+    int32_t qt_per;           // ... rows per slice (kQtSlices * nw slices; a slice starts four banks behind the one before)
+    int32_t qt_scr;           // ... float offset of J^T's own scratch columns (phase R1 runs beside the sweep's tail)
+    int32_t qt_front;         // ... rows copied into LDS before the first barrier (the rest during the FK chain)
 };
 
 template <int D, int CC>
@@ -280,7 +285,8 @@ __host__ __device__ inline LdsPlan lds_plan(int dof, int d_fk, int frame_floats,
 // (sweep_rows, XM).  One class, Polyharmonic(1), even D <= 16 (a term's 16 K slots hold the features).
 // (compiled for the two widths it was measured at: profiles/r03_mfma_ab.txt - measured slower, kept as evidence)
 constexpr bool xm_applies(int D, int CC, int KF) { return KF == 1 /* KF_POLY1 */ && CC == 1 && (D == 12 || D == 16); }
-constexpr int sweep_min_waves(int D, int CC, int KF, bool MF = false, bool XM = false) {
+constexpr int sweep_min_waves(int D, int CC, int KF, bool MF = false, bool XM = false, bool QT = false) {
+    if (QT) return 4;  // one block per CU (the rows fill its LDS), at most 16 waves: two row buffers in VGPRs + the direct body
     if (XM) return 4;  // 48 VGPRs of loop-invariant B fragments + 16 distances in flight: 128 VGPRs
     // KF_GEN calls powf/logf; the MFMA form adds 16 accumulator registers per contraction + the operand fragments
     const int need = 3 * D + 2 * CC + 16 + DCX_MINW_SLACK + (KF == 2 ? 40 : 0) + (MF ? (CC > 1 ? 48 : 24) : 0);
@@ -1026,6 +1032,89 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
     }
 }
 
+// ---- the 16-configuration tile (QT, round 4): rows from LDS, lane = (configuration, row slice) -----------------------------
+// a batch with fewer 64-configuration tiles than CUs splits the supports over several blocks per tile and
+// pays a cross-block hand-over (4.5 k of a config-#2 block's 24 k cycles even with the owner polling).  Here a block takes 16
+// configurations and ALL the rows: 4096 configurations = 256 blocks, one per CU, no arrival counter, no second FK, the
+// partial sums meet inside the block (the usual fold over the waves, then two lane exchanges over the four slices of a wave).
+// The row operands cannot be wave-uniform any more (a wave sweeps four rows at once to have 64 lanes of work), so they come
+// from an LDS copy of the rows: three ds_read_b128 + one ds_read_b32 per pair and lane, each row broadcast to its 16 lanes.
+// The pair body is the DIRECT form (differences; the same operations in the same order as sweep_rows' `pair`), on the
+// model's own rows: no centred data, no near-pair block.
+// What the stamps of a config-#2 block say (profiles/r04_qt.txt): the hand-over's 4.2 k cycles are gone, the copy of the rows
+// adds 1.4 k (45 % of it rides with the q rows, the rest is done by the idle waves during the FK chain), the sweep is 9.2 k
+// against 8.6 k - it is bound by the four waves a SIMD has to cover the LDS latency and the body's dependent chains, not by
+// the LDS pipe (6.7 k) or the VALU count: the EXPANDED body (17 instead of 24 VALU instructions, one more ds_read_b32 and a
+// ballot per pair) came out SLOWER, 10.6 k, and two configurations per lane (half the LDS reads per pair) 10.4 k.  Net:
+// config #2 11.2 -> 10.5 us.
+// One class, row weights (MODE_GRAD_ROW), the two specialised kernel functions, D = 12 / 24; the host takes it for batches of
+// at most 16 configurations per CU when the rows fit the LDS (dcx_api.hip run_score).
+constexpr int kQtSlices = 4;   // row slices per wave
+constexpr bool qt_applies(int D, int CC, int KF, int MODE) {
+    return (D == 12 || D == 24) && CC == 1 && MODE == 1 /* MODE_GRAD_ROW */ && KF != 2 /* KF_GEN */;
+}
+template <int D, int KF>
+__device__ __forceinline__ void sweep_rows_lds(const ScoreArgs& a, const float (&x)[D], const float* slice, int per, float& sc0,
+                                               float (&gx)[D]) {
+    static_assert(D % 4 == 0, "rows are read as whole float4s");
+    using L = RowLayout<D, 1>;
+    v2f g2[D / 2];
+#pragma unroll
+    for (int k = 0; k < D / 2; ++k) g2[k] = v2f{0.0f, 0.0f};
+    typedef float v4f_t __attribute__((ext_vector_type(4)));
+    auto load_row = [&](float (&r)[D + 1], int jj) __attribute__((always_inline)) {
+        const float* p = slice + (size_t)jj * L::RS;
+#pragma unroll
+        for (int q = 0; q < D / 4; ++q) {
+            const v4f_t v = *reinterpret_cast<const v4f_t*>(p + 4 * q);
+            r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+        }
+        r[D] = p[L::W_OFF];
+    };
+    auto pair = [&](const float (&r)[D + 1]) __attribute__((always_inline)) {
+        v2f dp[D / 2];
+        constexpr int NA = DCX_D2_ACCS(D);
+        v2f acc[NA];
+        acc[0] = v2f{d2_seed<KF>(a), 0.0f};
+#pragma unroll
+        for (int i = 1; i < NA; ++i) acc[i] = v2f{0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k + 1 < D; k += 2) {
+            const v2f xv = {x[k], x[k + 1]};
+            const v2f rv = {r[k], r[k + 1]};
+            dp[k / 2] = xv - rv;
+            acc[(k / 2) % NA] = __builtin_elementwise_fma(dp[k / 2], dp[k / 2], acc[(k / 2) % NA]);
+        }
+#pragma unroll
+        for (int i = 1; i < NA; ++i) acc[0] += acc[i];
+        const float d2 = acc[0].x + acc[0].y;
+        float val, g;
+        sweep_eval<KF>(d2, a, val, g);
+        sc0 = fmaf(r[D], val, sc0);
+        const float coef = g * r[D];
+        const v2f c2 = {coef, coef};
+#pragma unroll
+        for (int k = 0; k + 1 < D; k += 2) g2[k / 2] = __builtin_elementwise_fma(c2, dp[k / 2], g2[k / 2]);
+    };
+    // two row buffers: the next row's reads are in flight while this one is consumed (every slice holds `per` rows: the
+    // staging pads the short ones with zero-weight rows)
+    float ra[D + 1], rb[D + 1];
+    load_row(ra, 0);
+    int jj = 0;
+    for (; jj + 2 <= per; jj += 2) {
+        load_row(rb, jj + 1);
+        pair(ra);
+        load_row(ra, jj + 2 < per ? jj + 2 : jj + 1);
+        pair(rb);
+    }
+    if (jj < per) pair(ra);
+#pragma unroll
+    for (int k = 0; k + 1 < D; k += 2) {
+        gx[k] += g2[k / 2].x * kGradScale<KF>;
+        gx[k + 1] += g2[k / 2].y * kGradScale<KF>;
+    }
+}
+
 // ---- the sweep with the (configurations x supports) . (supports x features) contraction on the matrix cores ------
 // The gradient fold  gX[b, :] = sum_j coef_bj (x_b - s_j)  is  x_b * (sum_j coef_bj) - (coef[B, S] . s[S, D])[b, :].
 // The second term is a dense GEMM; here it runs on v_mfma_f32_16x16x4_f32 (exact fp32, an fmaf chain in k order — the
@@ -1275,18 +1364,20 @@ __device__ __forceinline__ void fold_partial_rows(float* sRed, int wave, int lan
 }
 
 
-template <int D, int KF, int CC, int MODE, int MAXT, bool MF = false, bool XF = false, bool XM = false>
-__global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF, MF, XM)) void score_kernel(const ScoreArgs a) {
+template <int D, int KF, int CC, int MODE, int MAXT, bool MF = false, bool XF = false, bool XM = false, bool QT = false>
+__global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF, MF, XM, QT)) void score_kernel(const ScoreArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr bool GRAD = (MODE != MODE_SCORE);
     constexpr int ACC = (GRAD ? D : 0) + CC;
+    constexpr int TILE = QT ? 16 : 64;   // configurations per block (QT: lane l works for configuration l & 15)
+    static_assert(!QT || (!MF && !XF && !XM && qt_applies(D, CC, KF, MODE)), "the quarter tile: direct form, one class, row weights");
 
     int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nw = blockDim.x >> 6;
-    const int64_t b0 = (int64_t)blockIdx.x * 64;
+    const int64_t b0 = (int64_t)blockIdx.x * TILE;
     const size_t tile = (size_t)blockIdx.x * gridDim.z + blockIdx.z;  // scratch rows / arrival counter of this (tile, class)
-    const int nb = (int)((a.B - b0) < 64 ? (a.B - b0) : 64);
+    const int nb = (int)((a.B - b0) < TILE ? (a.B - b0) : TILE);
     const int dof = a.dof;
     const LdsPlan lp = lds_plan(dof, a.d_fk, a.frame_floats, nw > 1 ? a.red_slots : 0, ACC, true);
     float* sQ = smem + lp.q;
@@ -1295,6 +1386,25 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF, MF, XM)) void scor
     float* sF = smem + lp.f;
     float* sRed = smem + lp.red;
 
+    // QT: all the rows go into LDS, slice by slice (4 nw slices of qt_per rows; short slices end in zero rows: weight 0) - the
+    // first qt_front rows with the q rows below (their loads ride on the same round trip), the rest by the waves that have no
+    // part in the FK chain, meanwhile.  (Staged up front in one piece the copy cost 2.4 k cycles of a config-#2 block.)
+    auto stage_rows = [&](int first_wave, int row0, int row1) __attribute__((always_inline)) {
+        if constexpr (QT) {
+            constexpr int RS4 = RowLayout<D, CC>::RS / 4;
+            typedef float v4f_t __attribute__((ext_vector_type(4)));
+            const v4f_t* src = reinterpret_cast<const v4f_t*>(a.rows);
+            const int per = a.qt_per, stride = per * RowLayout<D, CC>::RS + 4;
+            float* dst = smem + a.qt_off;
+            for (int e = row0 * RS4 + (int)threadIdx.x - 64 * first_wave; e < row1 * RS4; e += (int)blockDim.x - 64 * first_wave) {
+                const int row = e / RS4, q4 = e - row * RS4;   // row = slice * per + jj: consecutive rows of the model
+                const int sl = row / per, jj = row - sl * per;
+                v4f_t v = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (row < a.S) v = src[(size_t)row * RS4 + q4];
+                *reinterpret_cast<v4f_t*>(dst + sl * stride + jj * RowLayout<D, CC>::RS + 4 * q4) = v;
+            }
+        }
+    };
     DCX_TS(0);
     DCX_TSB(0);
     // ---- prologue: stage the FK description and the q rows (coalesced), FK per lane on wave 0 ----
@@ -1305,7 +1415,17 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF, MF, XM)) void scor
     {
         const float* qsrc = a.q + b0 * dof;
         const int n = nb * dof;
-        for (int i = threadIdx.x; i < 64 * dof; i += blockDim.x) sQ[i] = qsrc[i < n ? i : (i % dof) + (nb - 1) * dof];
+        if constexpr (QT) {
+            // lane l of every wave walks the arm of configuration l & 15 (the four quarters redundantly: same cost, and each
+            // ends with the features its slice of the sweep needs)
+            for (int i = threadIdx.x; i < 64 * dof; i += blockDim.x) {
+                const int c = (i / dof) & 15;
+                sQ[i] = qsrc[(c < nb ? c : nb - 1) * dof + (i % dof)];
+            }
+            stage_rows(0, 0, a.qt_front);
+        } else {
+            for (int i = threadIdx.x; i < 64 * dof; i += blockDim.x) sQ[i] = qsrc[i < n ? i : (i % dof) + (nb - 1) * dof];
+        }
     }
     __syncthreads();
     DCX_TS(1);
@@ -1318,8 +1438,11 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF, MF, XM)) void scor
     if (a.fkk == 2 && a.jt_rows) {
         // the step table, chains of <= kDhUnroll steps: every chain split by rows over two waves, chains side by side
         dh2_chain_rows_sel(fw.dh, a.dh, sX + lane, sF + lane, wave);
+        if (QT && wave >= 2 * a.dh.n_chains) stage_rows(2 * a.dh.n_chains, a.qt_front, kQtSlices * nw * a.qt_per);
     } else if (wave == 0) {
         fk_chain_sel(fw, a.dh, sQ + lane * dof, sX + lane, sF + lane);
+    } else {
+        stage_rows(1, a.qt_front, kQtSlices * nw * a.qt_per);
     }
 #endif
     __syncthreads();
@@ -1369,7 +1492,12 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF, MF, XM)) void scor
     const int j1 = (j0 + a.s_chunk < yend) ? (j0 + a.s_chunk) : yend;
 
     DCX_TSB(1);
-    if constexpr (MF) {
+    if constexpr (QT) {
+        // this lane's slice of the rows: four per wave
+        const int sl = wave * kQtSlices + (lane >> 4);
+        const float* slice = smem + a.qt_off + sl * (a.qt_per * RowLayout<D, CC>::RS + 4);
+        sweep_rows_lds<D, KF>(a, x, slice, a.qt_per, sc[0], gx);
+    } else if constexpr (MF) {
         // this wave's slice of the reduction scratch doubles as its transpose buffer (X is dead, the fold comes later)
         sweep_rows_mfma<D, KF, CC, MODE>(a, x, up, j0, j1, sc, gx, sRed + (size_t)wave * ACC * 64, lane);
     } else {
@@ -1381,9 +1509,9 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF, MF, XM)) void scor
     int lane = fresh_lane();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nw = blockDim.x >> 6;
-    const int64_t b0 = (int64_t)blockIdx.x * 64;
+    const int64_t b0 = (int64_t)blockIdx.x * TILE;
     const size_t tile = (size_t)blockIdx.x * gridDim.z + blockIdx.z;
-    const int nb = (int)((b.B - b0) < 64 ? (b.B - b0) : 64);
+    const int nb = (int)((b.B - b0) < TILE ? (b.B - b0) : TILE);
     const int dof = b.dof;
     const LdsPlan lp = lds_plan(dof, b.d_fk, b.frame_floats, nw > 1 ? b.red_slots : 0, ACC, true);
     float* sQ = smem + lp.q;
@@ -1408,6 +1536,15 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF, MF, XM)) void scor
     const bool split = b.partial != nullptr;
     const bool par_tail = nw > 1 && b.red_slots != 1 && (!split || b.tile_done != nullptr);
     bool r1_done = false;
+    if constexpr (QT && GRAD) {
+        // QT: phase R1 of J^T needs the frames only - the waves that carry it are the first to leave the sweep (the LDS pipe
+        // serves the oldest wave first: they finish ~5 k cycles before the last), so it runs HERE, into its own scratch columns,
+        // instead of behind the fold's barrier (1.4 k cycles of a config-#2 block)
+        if (b.jt_waves && b.qt_scr > 0) {
+            r1_done = true;
+            dh2_vjp_r1_sel(fw.dh, dhb, sF + lane, smem + b.qt_scr + lane, wave);
+        }
+    }
     if (par_tail) {
         float* mine = sRed + (size_t)wave * ACC * 64 + lane;
 #pragma unroll
@@ -1425,7 +1562,7 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF, MF, XM)) void scor
         // y = 1, 2, ... per accumulator (the wave that owns it), adds them in that order - the order of the counter protocol,
         // bit for bit - and puts the zeros back for the next launch (or graph replay).  The counter protocol below paid
         // publish -> drain -> atomic round trip -> re-read in EVERY block: 5.6 k of a config-#2 block's 25 k cycles
-        // (profiles/r04_phase_cfg2.txt).  Blocks that do not own never wait, so the owners' polling cannot deadlock while
+        // (profiles/r04_qt.txt, first table).  Blocks that do not own never wait, so the owners' polling cannot deadlock while
         // fewer than all CUs hold owners.
         const bool opoll = split && b.pwords != nullptr;
         const bool publisher = opoll && blockIdx.y != 0;
@@ -1446,6 +1583,10 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF, MF, XM)) void scor
                 } else {
                     v = sRed[e * 64 + lane];
                     for (int w = 1; w < nw; ++w) v += sRed[((size_t)w * ACC + e) * 64 + lane];
+                }
+                if constexpr (QT) {   // the four quarters of a configuration sit 16 lanes apart
+                    v += __shfl_xor(v, 16, 64);
+                    v += __shfl_xor(v, 32, 64);
                 }
                 if (publisher) __hip_atomic_store(wout + e * 64, ((unsigned long long)1u << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 else if (split && !opoll) __hip_atomic_store(out + e * 64, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1567,7 +1708,7 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF, MF, XM)) void scor
                     if (b.hinge) scale = (sRed[lane] - b.hinge_margin > 0.0f) ? b.hinge_weight : 0.0f;
                 }
                 float* gq = smem + lp.q;
-                float* scr = sRed + (size_t)ACC * 64 + lane;
+                float* scr = (QT && r1_done) ? smem + b.qt_scr + lane : sRed + (size_t)ACC * 64 + lane;
                 if (!r1_done) {  // unsplit launches (and blocks too small to run it beside the counter)
                     dh2_vjp_r1_sel(fw.dh, dhb, sF + lane, scr, wave);
                     __syncthreads();

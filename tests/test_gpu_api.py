@@ -439,10 +439,12 @@ def test_rq_takes_the_expanded_form_only_inside_its_rule(knob):
     raw = _fkdesc.none_desc(12)
     m = _ops.ScoreModel(raw, 0, 1.0, 2.0, sup, W)                        # the same numbers as raw inputs: always direct
     x = sup[:B].contiguous() + 0.01
+    knob("qt", 0)   # (this batch would otherwise run as 16-configuration tiles - direct too, in another summation order)
     s, gr = m.score_grad_raw(x)
     knob("xf", 0)
     s0, g0 = m.score_grad_raw(x)
     knob("xf", -1)
+    knob("qt", -1)
     assert torch.equal(s, s0) and torch.equal(gr, g0)
 
 

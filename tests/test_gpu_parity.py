@@ -809,3 +809,78 @@ def test_expanded_form_se3_bodies_across_the_workspace(ops, knob, spread):
         s, gr = m.score_grad_raw(q.cuda())
         es, eg = relerr(_n(s), so), relerr(_n(gr), go)
         assert es < TOL and eg < TOL, (spread, form, es, eg)
+
+
+@pytest.mark.parametrize("name", ["cfg2_baxter_poly1", "cfg2_baxter_rq", "headline_baxter_poly1_s2000"])
+def test_tile_of_16_configurations_against_the_split_launch_and_the_oracle(ops, name, knob):
+    """round 4: small batches of a one-class D = 12 model run as blocks of 16 configurations that sweep
+    ALL the rows from an LDS copy (score_kernel.h QT; knob qt = 1 forces it wherever it fits, 0 = the split launch).  Same
+    pairs, direct form, another summation order: both sit at the oracle, ragged batches included, score-and-gradient,
+    upstream scaling, the hinge gradient and the C = 1 Jacobian."""
+    d = load(name)
+    kind, p0, p1 = case_kernel(d)
+    S = min(len(d["sup_x32"]), 1000)   # (a 2000-row model does not fit the LDS beside 16 waves' partial rows: its first 1000)
+    m = ops.ScoreModel(desc_for(CASE_ROBOT[name]), kind, p0, p1, _t(d["sup_x32"][:S].reshape(S, -1)), _t(d["weights"][:S]))
+    from oracle import oracle
+    for n in (1, 15, 16, 17, 100, 256):
+        q = _t(d["q"][:n])
+        knob("qt", 0)
+        s0, g0 = m.score_grad_raw(q)
+        knob("qt", 1)
+        s1, g1 = m.score_grad_raw(q)
+        assert not torch.equal(g0, g1) or n == 1, "the knob did not change the launch"
+        so, go, _ = oracle.score_grad(desc_for(CASE_ROBOT[name]), kind, p0, p1, d["sup_x32"][:S], d["weights"][:S], d["q"][:n], dtype=np.float64)
+        assert relerr(_n(s1), so) < TOL and relerr(_n(g1), go) < TOL, (n, relerr(_n(g1), go))
+        # (the split launch it is compared with may be the EXPANDED form - RQ: ~2e-6 from the referee itself; the tile is direct)
+        assert relerr(_n(s1), _n(s0)) < 8e-6 and relerr(_n(g1), _n(g0)) < 8e-6
+        up = torch.linspace(-1.5, 2.0, n, device=q.device)[:, None]
+        a, b = m.score_grad_raw(q, up)[1], None
+        knob("qt", 0)
+        b = m.score_grad_raw(q, up)[1]
+        assert relerr(_n(a), _n(b)) < 8e-6
+        h0 = m.score_hinge_grad_raw(q, 0.1, 2.0)
+        j0 = m.score_jac_raw(q)[1]
+        knob("qt", 1)
+        if h0 is not None:
+            h1 = m.score_hinge_grad_raw(q, 0.1, 2.0)
+            clear = (h0[0][:, 0] - 0.1).abs() > 1e-3   # (rows whose score sits on the hinge may switch with the rounding)
+            if bool(clear.any()):
+                assert relerr(_n(h1[1][clear]), _n(h0[1][clear])) < 8e-6
+        assert relerr(_n(m.score_jac_raw(q)[1]), _n(j0)) < 8e-6
+    knob("qt", -1)
+
+
+def test_tile_of_16_configurations_is_bit_stable_across_batch_order(ops, knob):
+    """a configuration's result does not depend on where it stands in the batch, on its neighbours in the block, or on the
+    launch: the tile's sums have a fixed order (slices of the rows, waves, the four slices of a wave)"""
+    d = load("cfg2_baxter_poly1")
+    kind, p0, p1 = case_kernel(d)
+    m = ops.ScoreModel(desc_for("baxter_left"), kind, p0, p1, _t(d["sup_x32"].reshape(len(d["sup_x32"]), -1)), _t(d["weights"]))
+    g = torch.Generator().manual_seed(5)
+    q = _t(d["q"][:200])
+    knob("qt", 1)
+    s0, g0 = m.score_grad_raw(q)
+    for _ in range(3):
+        perm = torch.randperm(200, generator=g).to(q.device)
+        s1, g1 = m.score_grad_raw(q[perm].contiguous())
+        assert torch.equal(s1, s0[perm]) and torch.equal(g1, g0[perm])
+    s2, g2 = m.score_grad_raw(q[37:38].contiguous())   # alone in its block
+    assert torch.equal(s2, s0[37:38]) and torch.equal(g2, g0[37:38])
+    knob("qt", -1)
+
+
+@pytest.mark.parametrize("S", [64, 65, 130, 1023, 1100])
+def test_tile_of_16_configurations_row_counts(ops, knob, S):
+    """slices of unequal length end in zero-weight rows; the largest model that fits beside 16 waves' partial rows"""
+    from oracle import oracle
+    g = np.random.default_rng(S)
+    desc = desc_for("baxter_left")
+    q = g.uniform(-1.5, 1.5, (70, 7)).astype(np.float32)
+    sup = oracle.fkine(desc, g.uniform(-1.5, 1.5, (S, 7)).astype(np.float32)).reshape(S, -1)
+    w = g.standard_normal((S, 1)).astype(np.float32)
+    m = ops.ScoreModel(desc, KIND["poly"], 1, 1.0, _t(sup), _t(w))
+    knob("qt", 1)
+    s1, g1 = m.score_grad_raw(_t(q))
+    so, go, _ = oracle.score_grad(desc, KIND["poly"], 1, 1.0, sup, w, q, dtype=np.float64)
+    assert relerr(_n(s1), so) < TOL and relerr(_n(g1), go) < TOL
+    knob("qt", -1)
