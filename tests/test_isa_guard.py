@@ -38,7 +38,7 @@ def isa(tmp_path_factory):
 
 
 def _kernels(txt):
-    for m in re.finditer(r"^(_ZN3dcx12score_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi1024ELb0ELb(\d)ELb0EEEvNS_9ScoreArgsE):", txt, re.M):
+    for m in re.finditer(r"^(_ZN3dcx12score_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi1024ELb0ELb(\d)ELb0ELb0EEEvNS_9ScoreArgsE):", txt, re.M):
         body = txt[m.end():txt.index(".Lfunc_end", m.end())].split("\n")
         meta = txt[txt.index(".name:           " + m.group(1)):]
         yield dict(D=int(m.group(2)), KF=int(m.group(3)), C=int(m.group(4)), MODE=int(m.group(5)), XF=int(m.group(6)), body=body,
@@ -231,3 +231,39 @@ def test_dense_solve_keeps_its_panel_in_registers(tmp_path):
         assert ops["v_rcp_f64_e32"] >= 60 and ops["v_div_scale_f64"] == 0, "a pivot reciprocal became an IEEE division"
         assert ops["scratch_load_dwordx2"] + ops["scratch_load_dwordx4"] <= (0 if nt == 256 else 16)
         assert ops["v_fma_f64"] + ops["v_fmac_f64_e32"] > 2500                    # the unrolled panel columns and updates
+
+
+def test_tile_of_16_configurations_sweeps_from_lds_without_scratch(tmp_path):
+    """score_kernel<..., QT> (round 4): the rows come from LDS as whole float4s (three ds_read_b128 + the weight per pair at
+    D = 12), two row buffers in registers, no scratch and no lane parking inside the sweep loop."""
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    src, out = tmp_path / "q.hip", tmp_path / "q.s"
+    src.write_text('#include "dcx_internal.h"\nnamespace dcx {\n'
+                   "template __global__ void score_kernel<12, KF_POLY1, 1, MODE_GRAD_ROW, 1024, false, false, false, true>(const ScoreArgs);\n"
+                   "template __global__ void score_kernel<12, KF_RQ2, 1, MODE_GRAD_ROW, 1024, false, false, false, true>(const ScoreArgs);\n}\n")
+    subprocess.run(["hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I", CSRC, "-S", "--cuda-device-only",
+                    str(src), "-o", str(out)], check=True, stderr=subprocess.DEVNULL)
+    txt = out.read_text()
+    names = re.findall(r"^(_ZN3dcx12score_kernelILi12ELi\dELi1ELi1ELi1024ELb0ELb0ELb0ELb1EEEvNS_9ScoreArgsE):", txt, re.M)
+    assert len(names) == 2
+    for name in names:
+        start = txt.index(name + ":")
+        body = txt[start:txt.index(".Lfunc_end", start)].split("\n")
+        meta = txt[txt.index(".name:           " + name):]
+        assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", meta).group(1)) <= 160   # (the FK tree's own frame)
+        assert int(re.search(r"\.vgpr_count:\s+(\d+)", meta).group(1)) <= 128                   # four waves per SIMD
+        ops = Counter(l.split()[0] for l in body if l.startswith("\t") and not l.startswith("\t."))
+        assert ops["ds_read_b128"] + ops["ds_read2_b64"] >= 6      # two row buffers x three float4s
+        # the sweep loop: backward branch range holding the LDS row reads and the kernel function's quarter-rate op
+        labels = {m.group(1): n for n, l in enumerate(body) if (m := re.match(r"^(\.LBB\d+_\d+):", l))}
+        loops = []
+        for n, l in enumerate(body):
+            m = re.search(r"s_c?branch\w* (\.LBB\d+_\d+)", l)
+            if m and m.group(1) in labels and labels[m.group(1)] < n:
+                seg = body[labels[m.group(1)]:n + 1]
+                if sum("ds_read_b128" in x for x in seg) >= 6 and any(("v_rsq_f32" in x) or ("v_rcp_f32" in x) for x in seg):
+                    loops.append(seg)
+        assert loops, "no sweep loop over LDS rows found"
+        seg = min(loops, key=len)
+        assert not any(("scratch_" in x) or ("v_readlane" in x) or ("v_writelane" in x) for x in seg)
