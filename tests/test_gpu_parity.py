@@ -884,3 +884,30 @@ def test_tile_of_16_configurations_row_counts(ops, knob, S):
     so, go, _ = oracle.score_grad(desc, KIND["poly"], 1, 1.0, sup, w, q, dtype=np.float64)
     assert relerr(_n(s1), so) < TOL and relerr(_n(g1), go) < TOL
     knob("qt", -1)
+
+
+@pytest.mark.parametrize("kspec", [("poly", 1, 1.0), ("rq", 10.0, 2.0)])
+def test_tile_of_16_configurations_on_raw_inputs(ops, knob, kspec):
+    """no transform (DCX_FK_NONE, D = 12): the tile form is the direct form on the caller's own numbers - exact differences,
+    a query sitting ON a support included (r = 0: value 0, sub-gradient 0 for Polyharmonic)"""
+    from diffco_amd import _fkdesc
+    from oracle import oracle
+    kind, p0, p1 = KIND[kspec[0]], kspec[1], kspec[2]
+    g = np.random.default_rng(12)
+    S, B = 700, 333
+    sup = g.uniform(-3, 3, (S, 12)).astype(np.float32)
+    w = g.standard_normal((S, 1)).astype(np.float32)
+    x = g.uniform(-3, 3, (B, 12)).astype(np.float32)
+    x[:40] = sup[:40]                      # r = 0 pairs
+    x[40:80] = sup[40:80] + 1e-4           # and near ones
+    raw = _fkdesc.none_desc(12)
+    m = ops.ScoreModel(raw, kind, p0, p1, _t(sup), _t(w))
+    knob("qt", 1)
+    s1, g1 = m.score_grad_raw(_t(x))
+    knob("qt", 0)
+    s0, g0 = m.score_grad_raw(_t(x))
+    knob("qt", -1)
+    so, go, _ = oracle.score_grad(raw, kind, p0, p1, sup, w, x, dtype=np.float64)
+    assert not torch.equal(g0, g1)
+    assert relerr(_n(s1), so) < TOL and relerr(_n(g1), go) < TOL
+    assert torch.isfinite(g1).all()

@@ -197,3 +197,23 @@ def test_solve_inside_a_stream_capture():
     graph.replay()
     torch.cuda.synchronize()
     assert relerr(X.cpu().numpy(), oracle.solve(a, 2 * b)) < 2e-7
+
+
+def test_solves_on_two_streams_at_once():
+    """two cooperative launches from two streams (each its own workspace): both complete, both right - a solve that could not
+    get its workgroups resident in time reports -1 and the wrapper runs it again as one workgroup"""
+    from diffco_amd import _ops
+    from oracle import oracle
+    g = np.random.default_rng(77)
+    mats = [(g.standard_normal((n, n)).astype(np.float32), g.standard_normal((n, 1)).astype(np.float32)) for n in (500, 900)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [None, None]
+    for rep in range(3):
+        for i, (a, b) in enumerate(mats):
+            A, Bm = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+            torch.cuda.synchronize()
+            with torch.cuda.stream(streams[i]):
+                outs[i] = _ops.solve(A, Bm)
+        torch.cuda.synchronize()
+        for (a, b), x in zip(mats, outs):
+            assert relerr(x.cpu().numpy(), oracle.solve(a, b)) < 2e-7
