@@ -92,7 +92,7 @@ def kernel_matrix(kind, p0, p1, x: torch.Tensor, s: torch.Tensor) -> torch.Tenso
     return K.to(device=x.device, dtype=x.dtype)
 
 
-SOLVE_MAX_N = 2560   # dcx_solve takes up to DCX_SOLVE_MAX_N = 4096; beyond ~2600 unknowns the library LU is the faster one
+SOLVE_MAX_N = 3072   # dcx_solve takes up to DCX_SOLVE_MAX_N = 4096; beyond ~3000 unknowns the library LU is the faster one
 SOLVE_MAX_RHS = 64
 
 
@@ -123,7 +123,7 @@ def _solve_device(a32: torch.Tensor, b32: torch.Tensor) -> torch.Tensor:
 
 def solve(kmat: torch.Tensor, rhs: torch.Tensor) -> torch.Tensor:
     """x with kmat @ x = rhs, solved on the GPU: the S x S system of fit_poly (reference kernel_perceptrons.py:283,
-    deprecated/MultiDiffCo.py:149).  Up to 2560 unknowns: dcx_solve, one launch (LU with partial pivoting in fp64,
+    deprecated/MultiDiffCo.py:149).  Up to 3072 unknowns: dcx_solve, one launch (LU with partial pivoting in fp64,
     csrc/solve_kernels.hip); beyond, or for more than 64 right-hand sides, torch's hipSOLVER binding - a plain library
     factorisation.  Result on kmat's device and dtype.  Like every other op here it needs the GPU."""
     _lib.require_gpu()

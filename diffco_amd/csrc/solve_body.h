@@ -156,8 +156,8 @@ __device__ __forceinline__ void panel_columns(SolveSync* gs, PanelRegs<NB, 64 / 
 }
 
 template <int NB>
-__device__ __forceinline__ void factor_panel(SolveSync* gs, double* W, size_t ld, int n, int k0, int nb, double* sRowP, unsigned long long* sKey,
-                             int* sCnt, int tid) {
+__device__ __forceinline__ void factor_panel(SolveSync* gs, int buf, double* W, size_t ld, int n, int k0, int nb, double* sRowP,
+                                             unsigned long long* sKey, int* sCnt, int tid) {
     constexpr int R = 64 / NB;
     const int m = n - k0;
     PanelRegs<NB, R> g;
@@ -195,17 +195,17 @@ __device__ __forceinline__ void factor_panel(SolveSync* gs, double* W, size_t ld
             for (int cc = 0; cc < NB; ++cc)
                 if (cc < nb) W[(size_t)(k0 + cc) * ld + k0 + at] = g.v[r][cc];
             // the swaps' net effect: the source row of each top row, and the rows below that received another row's content
-            if (at < nb) gs->top_src[at] = k0 + i;
+            if (at < nb) gs->top_src[buf][at] = k0 + i;
             else if (at != i) {
                 const int slot = atomicAdd(sCnt, 1);
-                gs->low_dst[slot] = k0 + at;
-                gs->low_src[slot] = k0 + i;
+                gs->low_dst[buf][slot] = k0 + at;
+                gs->low_src[buf][slot] = k0 + i;
             }
         }
     }
     DCX_PTS(4);
     __syncthreads();
-    if (tid == 0) gs->n_low = *sCnt;
+    if (tid == 0) gs->n_low[buf] = *sCnt;
     DCX_PTS(5);
 }
 
@@ -415,49 +415,104 @@ __global__ __launch_bounds__(kNT) void lu_solve_kernel(const SolveArgs a) {
     DCX_STS(0);
     bool alive = grid_barrier(a.gs, n_bar, tid);
     DCX_STS(1);
-    int step = 0;   // (only the developer stamps read it)
-    // ---- block steps ----------------------------------------------------------------------------------------------------
-    for (int k0 = 0; k0 < n && alive;) {
-        const int nb = nb_for(n - k0);
-        ++step;
-        DCX_STS(8 * step);
-        if (blockIdx.x == 0) {
-            switch (nbt_for(n - k0)) {
-                case 32: factor_panel<32>(a.gs, a.W, ld, n, k0, nb, sRow, sKey, sCnt, tid); break;
-                case 16: factor_panel<16>(a.gs, a.W, ld, n, k0, nb, sRow, sKey, sCnt, tid); break;
-                case 8: factor_panel<8>(a.gs, a.W, ld, n, k0, nb, sRow, sKey, sCnt, tid); break;
-                default: factor_panel<4>(a.gs, a.W, ld, n, k0, nb, sRow, sKey, sCnt, tid); break;
-            }
+    // ---- block steps, with a look-ahead of one panel ----------------------------------------------------------------------
+    // Step s applies panel s to the trailing columns.  The groups that hold the NEXT panel's columns are updated first (one
+    // workgroup each), workgroup 0 waits for exactly those - a counter, not a barrier - and then factorises that panel while
+    // the other workgroups are still updating the rest: ONE grid barrier per step, and the
+    // panel's dependent chain - 0.7 - 1 us per column on one wave per SIMD - runs beside the trailing update instead of in
+    // front of it.  Every element still sees the same fused multiply-adds in
+    // the same order.  The panels' row-movement lists are double-buffered by step parity.
+    auto factor = [&](int k0, int nb, int buf) __attribute__((always_inline)) {
+        switch (nbt_for(n - k0)) {
+            case 32: factor_panel<32>(a.gs, buf, a.W, ld, n, k0, nb, sRow, sKey, sCnt, tid); break;
+            case 16: factor_panel<16>(a.gs, buf, a.W, ld, n, k0, nb, sRow, sKey, sCnt, tid); break;
+            case 8: factor_panel<8>(a.gs, buf, a.W, ld, n, k0, nb, sRow, sKey, sCnt, tid); break;
+            default: factor_panel<4>(a.gs, buf, a.W, ld, n, k0, nb, sRow, sKey, sCnt, tid); break;
         }
-        DCX_STS(8 * step + 1);
-        alive = grid_barrier(a.gs, n_bar, tid);
-        DCX_STS(8 * step + 2);
-        if (!alive) break;
-        const int jt = k0 + nb;   // first trailing column
-        if (jt < ncol) {
+    };
+    // (tried first: workgroup 0 updating the next panel's columns itself, group after group - at n = 438 four groups in a row
+    // cost more than the overlap returns, 0.87 -> 1.17 ms; with the counter both forms gain: 0.88 -> 0.81 ms at n = 438,
+    // 3.04 -> 2.68 at 1000, 10.6 -> 9.0 at 2000.)  kLookAhead = false is the two-barrier step, kept for A/B.
+    constexpr bool kLookAhead = true;
+    // (iteration 0 applies nothing and factorises panel 0; iteration s >= 1 applies panel s - 1 from list buffer (s - 1) & 1
+    // and factorises panel s into buffer s & 1; the one call site keeps the four unrolled panel bodies in the binary once)
+    int k0 = 0, nb = 0, step = 0;
+    unsigned panel_expected = 0;
+    while (alive) {
+        DCX_STS(8 * (step + 1));
+        const int jt = k0 + nb;   // first trailing column (jt <= n < ncol: the right-hand sides are always there)
+        const int nb1 = jt < n ? nb_for(n - jt) : 0;          // the next panel
+        if (nb > 0) {
+            const int buf = (step - 1) & 1;
             // this step's L11 and row movement into LDS
             for (int e = tid; e < nb * 32; e += kNT) {
                 const int c = e >> 5, d = e & 31;
                 sL[c * 33 + d] = (d < nb && d > c) ? a.W[(size_t)(k0 + c) * ld + k0 + d] : 0.0;
             }
-            const int n_low = a.gs->n_low;
+            const int n_low = a.gs->n_low[buf];
             if (tid < 32) {
-                sTop[tid] = tid < nb ? a.gs->top_src[tid] : 0;
-                sLowDst[tid] = tid < n_low ? a.gs->low_dst[tid] : 0;
-                sLowSrc[tid] = tid < n_low ? a.gs->low_src[tid] : 0;
+                sTop[tid] = tid < nb ? a.gs->top_src[buf][tid] : 0;
+                sLowDst[tid] = tid < n_low ? a.gs->low_dst[buf][tid] : 0;
+                sLowSrc[tid] = tid < n_low ? a.gs->low_src[buf][tid] : 0;
             }
             __syncthreads();
             const int groups = (ncol - jt + kTJ - 1) / kTJ;
-            for (int g = blockIdx.x; g < groups; g += G) {
+            const int gp = (nb1 + kTJ - 1) / kTJ;             // the next panel sits in the first gp groups
+            auto group = [&](int g) __attribute__((always_inline)) {
                 const int j0 = jt + g * kTJ;
                 trailing_group(a, k0, nb, j0, ncol - j0 < kTJ ? ncol - j0 : kTJ, sL, sU, sTop, sLowDst, sLowSrc, n_low, tid);
+            };
+            if (G == 1 || nb1 == 0 || !kLookAhead) {            // shared out evenly
+                for (int g = blockIdx.x; g < groups; g += G) group(g);
+            } else if (G - 1 >= gp) {
+                // look-ahead: workgroups 1 .. gp update the next panel's columns FIRST, one group each, and say so; workgroup 0
+                // waits for those gp groups only (not for a grid barrier) and factorises while everybody else goes on
+                if (blockIdx.x == 0) {
+                    panel_expected += (unsigned)gp;
+                    if (tid == 0) {
+                        const unsigned long long t0 = wall_clock64();
+                        while (__hip_atomic_load(&a.gs->panel_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < panel_expected) {
+                            __builtin_amdgcn_s_sleep(1);
+                            if (__hip_atomic_load(&a.gs->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                            if (wall_clock64() - t0 > 200000000ull) {
+                                __hip_atomic_store(&a.gs->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                break;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                } else {
+                    const int w = (int)blockIdx.x - 1;
+                    if (w < gp) {
+                        group(w);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                        __syncthreads();
+                        if (tid == 0) __hip_atomic_fetch_add(&a.gs->panel_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    // the other groups start behind them (group gp + r goes to workgroup (gp + r) mod (G - 1)): a workgroup that
+                    // did a panel group gets another one only when the groups wrap around the grid
+                    for (int r = ((w - gp) % (G - 1) + (G - 1)) % (G - 1); r < groups - gp; r += G - 1) group(gp + r);
+                }
+            } else {                                              // (a grid smaller than a panel: workgroup 0 takes them itself)
+                if (blockIdx.x == 0) for (int g = 0; g < gp && g < groups; ++g) group(g);
+                else for (int g = gp + (int)blockIdx.x - 1; g < groups; g += G - 1) group(g);
             }
         }
-        k0 += nb;
+        DCX_STS(8 * (step + 1) + 1);
+        if (!kLookAhead && nb > 0 && nb1 > 0 && G > 1) {   // every workgroup's part of the next panel's columns must have landed
+            alive = grid_barrier(a.gs, n_bar, tid);
+            if (!alive) break;
+        }
+        if (blockIdx.x == 0 && nb1 > 0) factor(jt, nb1, step & 1);
+        k0 = jt;
+        nb = nb1;
+        ++step;
+        DCX_STS(8 * step + 2);
+        alive = grid_barrier(a.gs, n_bar, tid);
         DCX_STS(8 * step + 3);
-        if (k0 < n) alive = grid_barrier(a.gs, n_bar, tid);   // (the last step's trailing columns are workgroup-local no more:
-    }                                                        //  the barrier below covers them)
-    alive = grid_barrier(a.gs, n_bar, tid) && alive;
+        if (nb == 0) break;
+    }
     DCX_STS(2);
     if (blockIdx.x == 0) {
         if (alive) back_substitute(a, sL, sU, tid);

@@ -16,15 +16,17 @@
 //     labels.  Two __syncthreads per column: a DPP wave reduction and one LDS atomic find the pivot, its owner publishes the
 //     row through LDS, everybody updates its own rows.  Besides L and U the panel leaves the NET effect of its swaps: which
 //     original row ends in each of the nb top rows, and the (at most nb) displaced rows below them;
-//   * a grid barrier, then every workgroup takes groups of 8 (16) trailing columns: gathers the rows the swaps moved
-//     (reads, barrier, writes: no sequential chain of swaps), forward-substitutes the nb x 8 block in registers (one lane
-//     per element, the solved row broadcast by v_readlane), and applies the rank-nb update to its rows with L's row in
-//     registers and U's block in LDS;
-//   * a second grid barrier; after the last panel, workgroup 0 back-substitutes blockwise and writes X in fp32.
+//   * every workgroup takes groups of 8 (16) trailing columns: gathers the rows the swaps moved (reads, barrier, writes: no
+//     sequential chain of swaps), forward-substitutes the nb x 8 block in registers (one lane per element, the solved row
+//     broadcast by v_readlane), and applies the rank-nb update to its rows with L's row in registers and U's block in LDS;
+//   * LOOK-AHEAD: the groups that hold the next panel's columns are updated first, one workgroup each; workgroup 0 waits for
+//     exactly those (a counter, not a barrier) and factorises the next panel while the others are still updating the rest.
+//     One grid barrier per block step; the panel's dependent chain runs beside the trailing update, not in front of it;
+//   * after the last panel, workgroup 0 back-substitutes blockwise and writes X in fp32.
 // The barriers are the trainer's (arrival counter, agent-scope release/acquire, a time-out that flags instead of hanging).
 // If the cooperative launch is refused (or the stream is being captured) the same kernel runs as ONE workgroup.
-// Measured (profiles/r04_solve.txt): n = 438: 0.87 ms (hipSOLVER through torch 1.80), 1000: 3.1 (4.6), 2000: 10.7 (15.2 -
-// 17.5), 3000: 30 (25): the Python side hands systems beyond 2560 unknowns to the library.
+// Measured (profiles/r04_solve.txt): n = 438: 0.81 ms (hipSOLVER through torch 1.77), 1000: 2.7 (4.8), 2000: 9.1 (15 - 18),
+// 3000: 24.5 (25 - 34), 4000: 52 (44): the Python side hands systems beyond 3072 unknowns to the library.
 #include "solve_kernels.h"
 #include <utility>
 
@@ -46,9 +48,10 @@ __device__ unsigned long long g_solve_ts[8 * 2048];
 #define DCX_PTS(k) do { } while (0)
 #endif
 
-// Two workgroup sizes.  256 threads (one wave per SIMD) has the shorter barriers and is the faster form up to ~600 unknowns;
+// Two workgroup sizes.  256 threads (one wave per SIMD) has the shorter barriers and is the faster form up to ~730 unknowns;
 // 512 threads hold a panel twice as wide in their registers (32 columns up to 1024 rows, 16 up to 2048, 8 up to 4096): half
-// the block steps - grid barriers and passes over the trailing matrix - for the larger systems (n = 2000: 19.1 -> 10.7 ms).
+// the block steps - grid barriers and passes over the trailing matrix - for the larger systems (n = 2000: 19.1 -> 10.7 ms
+// before the look-ahead).
 #define DCX_SOLVE_NT 256
 namespace nt256 {
 #include "solve_body.h"

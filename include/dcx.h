@@ -162,7 +162,7 @@ int dcx_device_count(void);
  * the rule takes it when every block of the launch is resident at once), "hess_ys" (blocks per tile of dcx_score_hess; 1 =
  * never split the supports), "xm" (1 = the expanded form takes its distance GEMM from the matrix cores, bf16x3 split
  * operands, where compiled: one class, Polyharmonic(1), even D <= 16; agrees with the VALU form to ~1e-6, measured slower),
- * "solve_threads" (dcx_solve's workgroup size: 256 or 512; rule = 256 up to 768 unknowns; same pivots, same arithmetic),
+ * "solve_threads" (dcx_solve's workgroup size: 256 or 512; rule = 256 up to 736 unknowns; same pivots, same arithmetic),
  * "qt" (small batches of a one-class D = 12 / 24 model as tiles of 16 configurations that sweep all the rows from an LDS copy
  * instead of the split launch: 0 = never, 1 = wherever it is compiled and fits with >= 4 waves; rule = at most 16
  * configurations per CU and room for all 16 waves, unless another knob asks for a particular form of the launch).

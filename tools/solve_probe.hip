@@ -56,24 +56,20 @@ int main(int argc, char** argv) {
 #ifdef DCX_SOLVE_TS
         std::vector<unsigned long long> ts(8 * 2048);
         CK(hipMemcpyFromSymbol(ts.data(), HIP_SYMBOL(dcx::g_solve_ts), ts.size() * 8));
-        const int steps = (hinfo[1] - 1) / 2;   // barriers: 1 + 2 per step (the last step's second one is the final barrier)
-        double panel = 0, bar1 = 0, trail = 0, bar2 = 0;
+        const int steps = hinfo[1] - 1;   // barriers: 1 after the copy + 1 per iteration (iteration 0 factorises panel 0 only)
+        double trail = 0, panel = 0, bar = 0;
         for (int s = 1; s <= steps; ++s) {
-            panel += (double)(ts[8 * s + 1] - ts[8 * s]);
-            bar1 += (double)(ts[8 * s + 2] - ts[8 * s + 1]);
-            trail += (double)(ts[8 * s + 3] - ts[8 * s + 2]);
-            if (s < steps) bar2 += (double)(ts[8 * (s + 1)] - ts[8 * s + 3]);
+            trail += (double)(ts[8 * s + 1] - ts[8 * s]);             // workgroup 0 waits for the groups that hold the next panel's columns
+            panel += (double)(ts[8 * s + 2] - ts[8 * s + 1]);         // the next panel
+            bar += (double)(ts[8 * s + 3] - ts[8 * s + 2]);           // the grid barrier (waiting for the others included)
         }
         const double tick = 0.01;   // us (100 MHz)
         const double runs = reps + 2;
         const unsigned long long* pt = &ts[8 * 2047];
         printf("   panel columns, per column: search + exchange %.2f us, publish %.2f us, read + update %.2f us; panel load %.1f us per panel\n",
-               pt[0] * tick / runs / n, pt[1] * tick / runs / n, pt[2] * tick / runs / n, pt[3] * tick / runs / ((hinfo[1] - 1) / 2));
-        printf("   per panel: columns (outer clock) %.1f us, write-back issue %.1f us, its completion + barrier %.1f us\n",
-               pt[6] * tick / runs / ((hinfo[1] - 1) / 2), pt[4] * tick / runs / ((hinfo[1] - 1) / 2), pt[5] * tick / runs / ((hinfo[1] - 1) / 2));
-        printf("   %d steps: convert %.1f us | panel %.1f  barrier %.1f  trailing %.1f  barrier %.1f (sums, us) | final barrier + back-substitution %.1f us | total %.1f us\n",
-               steps, (ts[1] - ts[0]) * tick + 0.0, panel * tick, bar1 * tick, trail * tick, bar2 * tick,
-               (double)(ts[3] - ts[8 * steps + 3]) * tick, (double)(ts[3] - ts[0]) * tick);
+               pt[0] * tick / runs / n, pt[1] * tick / runs / n, pt[2] * tick / runs / n, pt[3] * tick / runs / steps);
+        printf("   workgroup 0, %d iterations: copy %.1f us | waiting for the next panel's columns %.1f  that panel %.1f  barrier %.1f (sums, us) | back-substitution %.1f us | total %.1f us\n",
+               steps, (ts[1] - ts[0]) * tick + 0.0, trail * tick, panel * tick, bar * tick, (double)(ts[3] - ts[2]) * tick, (double)(ts[3] - ts[0]) * tick);
 #endif
         hipFree(dA); hipFree(dB); hipFree(dX); hipFree(work); hipFree(info);
     }
