@@ -123,26 +123,30 @@ class DiffCo(Perceptron):
         ours = isinstance(self.kernel_func, KernelFunc) and self.kernel_func.dcx_spec() is not None
         dev = X.device if X.is_cuda else (_ops._device(None) if (ours and th.cuda.is_available()) else home)
         exist_mask = exist_mask.to(th.bool)
-        novel = X.index_select(0, th.where(~exist_mask)[0].to(X.device))   # (not X[~mask]: see train_perceptron)
+        # one pair of index vectors, made where the mask lives and copied once; every scatter below is an index_copy_ with
+        # them (a boolean-mask assignment on a CUDA tensor is a nonzero + a device synchronisation each time: eight of them
+        # were half of this function's 1.5 - 2 ms)
+        ei_h, ni_h = th.where(exist_mask)[0], th.where(~exist_mask)[0]
+        ei, ni = ei_h.to(dev), ni_h.to(dev)
+        novel = X.index_select(0, ni_h.to(X.device))
         v = self.valid_supports
         assert n - len(novel) == v
         hypo = th.zeros(n, dtype=X.dtype, device=dev)
-        hypo[exist_mask.to(dev)] = self.hypothesis[:v].to(dev)
-        hypo[(~exist_mask).to(dev)] = self.score_original(novel).detach().to(dev).reshape(-1)
+        hypo.index_copy_(0, ei, self.hypothesis[:v].to(device=dev, dtype=X.dtype))
+        hypo.index_copy_(0, ni, self.score_original(novel).detach().to(device=dev, dtype=X.dtype).reshape(-1))
         novel_t = (novel if self.transform is None else self.transform(novel)).detach().to(dev)
+        sup_t = self.support_transformed[:v].to(dev)
         K = th.zeros((n, n), dtype=X.dtype, device=dev)
-        ei = th.where(exist_mask)[0].to(dev)
-        ni = th.where(~exist_mask)[0].to(dev)
         K[ei[:, None], ei[None, :]] = self.kernel_matrix[:v, :v].to(dev)
         if len(ni) and len(ei):
-            cross = self.kernel_func(self.support_transformed[:v].to(dev), novel_t).to(dev)
+            cross = self.kernel_func(sup_t, novel_t).to(dev)
             K[ei[:, None], ni[None, :]] = cross.reshape(len(ei), len(ni))
             K[ni[:, None], ei[None, :]] = cross.reshape(len(ei), len(ni)).T
-        Xt = self.support_transformed.new_zeros((n,) + tuple(novel_t.shape[1:])).to(dev)
-        Xt[exist_mask.to(dev)] = self.support_transformed[:v].to(dev)
-        Xt[(~exist_mask).to(dev)] = novel_t
+        Xt = th.zeros((n,) + tuple(novel_t.shape[1:]), dtype=self.support_transformed.dtype, device=dev)
+        Xt.index_copy_(0, ei, sup_t)
+        Xt.index_copy_(0, ni, novel_t.to(Xt.dtype))
         gains = th.zeros(n, dtype=X.dtype, device=dev)
-        gains[exist_mask.to(dev)] = self.gains[:v].to(dev)
+        gains.index_copy_(0, ei, self.gains[:v].to(device=dev, dtype=X.dtype))
         check = K @ gains
         assert th.allclose(check, hypo, atol=1e-4), f"diff: {th.abs(check - hypo).max()}"
         # (the n x n matrix stays where it was assembled: the trainer takes it from there and callers only ever gather
