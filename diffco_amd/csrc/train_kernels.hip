@@ -61,13 +61,25 @@ __device__ __forceinline__ bool takes_max(float bv, int bi, float av, int ai) {
 __device__ __forceinline__ Best better_min(Best a, Best b) { return takes_min(b.v, b.i, a.v, a.i) ? b : a; }
 __device__ __forceinline__ Best better_max(Best a, Best b) { return takes_max(b.v, b.i, a.v, a.i) ? b : a; }
 
+// one step of the wave reduction through DPP (a lane that receives nothing keeps comparing with itself)
+template <bool IS_MIN, int CTRL, int ROW_MASK>
+__device__ __forceinline__ Best dpp_best(Best m) {
+    const Best o{__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, m.v), __builtin_bit_cast(int, m.v), CTRL, ROW_MASK, 0xF, false)),
+                 __builtin_amdgcn_update_dpp(m.i, m.i, CTRL, ROW_MASK, 0xF, false)};
+    return IS_MIN ? better_min(m, o) : better_max(m, o);
+}
 template <bool IS_MIN>
 __device__ Best block_best(Best mine, Best* sB, int tid) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        Best other{__shfl_xor(mine.v, o, 64), __shfl_xor(mine.i, o, 64)};
-        mine = IS_MIN ? better_min(mine, other) : better_max(mine, other);
-    }
+    // four DPP steps inside each row of 16 lanes, two row broadcasts, v_readlane of lane 63: the choice (extreme value, lowest
+    // index on ties) does not depend on the order of the comparisons.  (Six __shfl_xor steps of two words each went through
+    // the LDS crossbar on the dependent chain of every iteration.)
+    mine = dpp_best<IS_MIN, 0xB1, 0xF>(mine);    // quad_perm [1, 0, 3, 2]
+    mine = dpp_best<IS_MIN, 0x4E, 0xF>(mine);    // quad_perm [2, 3, 0, 1]
+    mine = dpp_best<IS_MIN, 0x141, 0xF>(mine);   // row_half_mirror
+    mine = dpp_best<IS_MIN, 0x140, 0xF>(mine);   // row_mirror
+    mine = dpp_best<IS_MIN, 0x142, 0xA>(mine);   // row_bcast15 into rows 1 and 3
+    mine = dpp_best<IS_MIN, 0x143, 0xC>(mine);   // row_bcast31 into rows 2 and 3
+    mine = Best{__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.v), 63)), __builtin_amdgcn_readlane(mine.i, 63)};
     __syncthreads();
     if ((tid & 63) == 0) sB[tid >> 6] = mine;
     __syncthreads();
@@ -265,7 +277,38 @@ __global__ __launch_bounds__(NT) void perceptron_reg_kernel(const TrainArgs a) {
         float kii = sS[2];
         float* Ki = a.K + (size_t)i * N;
         const bool violated = worst.v <= 0.0f;
-        if (kii == 0.0f) {
+        float krow[EPT <= 4 ? EPT : 1];   // EPT <= 4: the row's values this thread just computed (no reload behind the store)
+        bool fresh = false;
+        if (kii == 0.0f && EPT <= 4) {
+            // 2. first use of row i, few samples per thread: computed once, stored in the N x N matrix (row and column), and
+            //    kept in registers for the update below - the reload of a value just written is an L2 round trip per iteration
+            for (int k = tid; k < a.D; k += NT) sX[k] = a.feats[(size_t)i * a.D + k];
+            __syncthreads();
+            fresh = true;
+#pragma unroll
+            for (int e = 0; e < (EPT <= 4 ? EPT : 1); ++e) {
+                const int j = tid + e * NT;
+                krow[e] = 0.0f;
+                if (j < N) {
+                    const float* xj = a.feats + (size_t)j * a.D;
+                    float d2 = 0.f;
+                    for (int k = 0; k < a.D; ++k) {
+                        const float dl = sX[k] - xj[k];
+                        d2 = fmaf(dl, dl, d2);
+                    }
+                    const float kv = kernel_value(a, d2);
+                    krow[e] = kv;
+                    Ki[j] = kv;
+                    a.K[(size_t)j * N + i] = kv;
+                    if (j == i) sS[3] = kv;
+                }
+            }
+            __syncthreads();
+            kii = sS[3];
+#pragma unroll
+            for (int e = 0; e < EPT; ++e)
+                if (tid + e * NT == i) dg[e] = kii;
+        } else if (kii == 0.0f) {
             // 2. first use of row i: compute it once (rolled loop: the kernel function may be a powf/logf body)
             //    and store it in the N x N matrix
             for (int k = tid; k < a.D; k += NT) sX[k] = a.feats[(size_t)i * a.D + k];
@@ -296,7 +339,7 @@ __global__ __launch_bounds__(NT) void perceptron_reg_kernel(const TrainArgs a) {
 #pragma unroll
             for (int e = 0; e < EPT; ++e) {
                 const int j = tid + e * NT;
-                if (j < N) m[e] = add_rn(m[e], ysign(e) * mul_rn(step, Ki[j]));
+                if (j < N) m[e] = add_rn(m[e], ysign(e) * mul_rn(step, (EPT <= 4 && fresh) ? krow[e < (EPT <= 4 ? EPT : 1) ? e : 0] : Ki[j]));
                 if (j == i) yg[e] = add_rn(yg[e], ysign(e) * step);
             }
             __syncthreads();  // sS is rewritten next iteration
