@@ -556,13 +556,17 @@ __global__ __launch_bounds__(NT) void perceptron_grid_kernel(const TrainArgs a, 
         float kii = worst.a1;
         float* Ki = a.K + (size_t)i * N;
         const bool violated = worst.v <= 0.0f;
+        float krow[EPT];
+        bool fresh = false;
         if (kii == 0.0f) {
             // 2. first use of row i: every workgroup fills its own part of the row and of the column
             for (int k = tid; k < a.D; k += NT) sX[k] = a.feats[(size_t)i * a.D + k];
             __syncthreads();
-#pragma unroll 1
+            fresh = true;   // (the values stay in registers for the update below: no reload behind the store, see perceptron_reg_kernel)
+#pragma unroll
             for (int e = 0; e < EPT; ++e) {
                 const int j = base + e * stride;
+                krow[e] = 0.0f;
                 if (j < N) {
                     const float* xj = a.feats + (size_t)j * a.D;
                     float d2 = 0.f;
@@ -571,6 +575,7 @@ __global__ __launch_bounds__(NT) void perceptron_grid_kernel(const TrainArgs a, 
                         d2 = fmaf(dl, dl, d2);
                     }
                     const float kv = kernel_value(a, d2);
+                    krow[e] = kv;
                     Ki[j] = kv;
                     a.K[(size_t)j * N + i] = kv;
                 }
@@ -587,7 +592,7 @@ __global__ __launch_bounds__(NT) void perceptron_grid_kernel(const TrainArgs a, 
 #pragma unroll
             for (int e = 0; e < EPT; ++e) {
                 const int j = base + e * stride;
-                if (j < N) m[e] = add_rn(m[e], ysign(e) * mul_rn(step, Ki[j]));
+                if (j < N) m[e] = add_rn(m[e], ysign(e) * mul_rn(step, fresh ? krow[e] : Ki[j]));
                 if (j == i) yg[e] = add_rn(yg[e], ysign(e) * step);
             }
             __syncthreads();  // sR / sX are rewritten next iteration
