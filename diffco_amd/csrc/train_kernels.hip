@@ -218,14 +218,26 @@ __global__ __launch_bounds__(1024) void perceptron_kernel(const TrainArgs a) {
 // registers for the whole training run; per iteration only the selected kernel row crosses memory (computed and
 // stored on first use, re-loaded from the N x N matrix afterwards).  Everything else is register arithmetic plus
 // two block reductions, so an iteration costs a few microseconds instead of several passes over global arrays.
-template <int EPT, int NT>
+// FL: the features sit in LDS for the whole run (row stride D | 1: consecutive samples in different banks) - the two L2 round
+// trips of a first-use iteration (sample i's features, then every thread's own samples') become LDS reads
+template <int EPT, int NT, bool FL = false>
 __global__ __launch_bounds__(NT) void perceptron_reg_kernel(const TrainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sX = smem;                                         // [D]
     Best* sB = reinterpret_cast<Best*>(sX + ((a.D + 3) & ~3));  // [16]
     int* sCnt = reinterpret_cast<int*>(sB + 16);              // [16]
     float* sS = reinterpret_cast<float*>(sCnt + 16);          // [4] broadcast slots
+    float* sFe = sS + 4;                                      // FL: [N][D | 1]
     const int tid = threadIdx.x, N = a.N;
+    const int fstride = FL ? (a.D | 1) : a.D;
+    const float* feats = FL ? sFe : a.feats;
+    if constexpr (FL) {
+        for (int e = tid; e < N * a.D; e += NT) {
+            const int j = e / a.D, k = e - j * a.D;
+            sFe[j * fstride + k] = a.feats[e];
+        }
+        __syncthreads();
+    }
     {
         // The margin form below needs y in {-1, +1}.  Any other label (0/1 labels, y = 0) takes the generic loop,
         // which computes y*h and beta^((1+y)/2)*y with the actual y like the reference does.
@@ -282,7 +294,7 @@ __global__ __launch_bounds__(NT) void perceptron_reg_kernel(const TrainArgs a) {
         if (kii == 0.0f && EPT <= 4) {
             // 2. first use of row i, few samples per thread: computed once, stored in the N x N matrix (row and column), and
             //    kept in registers for the update below - the reload of a value just written is an L2 round trip per iteration
-            for (int k = tid; k < a.D; k += NT) sX[k] = a.feats[(size_t)i * a.D + k];
+            for (int k = tid; k < a.D; k += NT) sX[k] = feats[(size_t)i * fstride + k];
             __syncthreads();
             fresh = true;
 #pragma unroll
@@ -290,7 +302,7 @@ __global__ __launch_bounds__(NT) void perceptron_reg_kernel(const TrainArgs a) {
                 const int j = tid + e * NT;
                 krow[e] = 0.0f;
                 if (j < N) {
-                    const float* xj = a.feats + (size_t)j * a.D;
+                    const float* xj = feats + (size_t)j * fstride;
                     float d2 = 0.f;
                     for (int k = 0; k < a.D; ++k) {
                         const float dl = sX[k] - xj[k];
@@ -696,9 +708,27 @@ hipError_t launch_perceptron(int kind, float kp0, float kp1, float beta, const f
     if (sign_labels && C == 1 && N <= 768) {
         // an active-learning round trains on a few hundred samples: four waves reduce and synchronise faster than sixteen that
         // mostly hold nothing (N = 300: 0.37 -> 0.32 ms for 58 iterations, N = 640: 0.84 -> 0.78; level at 1000).  Same sequence.
-        perceptron_reg_kernel<4, 256><<<dim3(1), dim3(256), lds, st>>>(a);
+        const size_t lds_fl = lds + sizeof(float) * (size_t)N * (D | 1);
+        if (lds_fl <= 150 * 1024) {   // the features ride in LDS (N = 640, D = 24: 64 KB)
+            auto kern = perceptron_reg_kernel<4, 256, true>;
+            if (lds_fl > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fl) != hipSuccess) {
+                (void)hipGetLastError();
+                perceptron_reg_kernel<4, 256><<<dim3(1), dim3(256), lds, st>>>(a);
+            } else {
+                kern<<<dim3(1), dim3(256), lds_fl, st>>>(a);
+            }
+        } else {
+            perceptron_reg_kernel<4, 256><<<dim3(1), dim3(256), lds, st>>>(a);
+        }
     } else if (sign_labels && C == 1 && N <= 1024 * 4) {
-        perceptron_reg_kernel<4, 1024><<<dim3(1), dim3(1024), lds, st>>>(a);
+        const size_t lds_fl = lds + sizeof(float) * (size_t)N * (D | 1);
+        auto kern = perceptron_reg_kernel<4, 1024, true>;
+        if (lds_fl <= 150 * 1024 && (lds_fl <= 64 * 1024 || hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fl) == hipSuccess)) {
+            kern<<<dim3(1), dim3(1024), lds_fl, st>>>(a);   // (the features in LDS while they fit: N = 1500 at D = 24)
+        } else {
+            (void)hipGetLastError();
+            perceptron_reg_kernel<4, 1024><<<dim3(1), dim3(1024), lds, st>>>(a);
+        }
     } else if (sign_labels && C == 1 && N <= 512 * 20) {   // 8 waves = 2 per SIMD: 256 VGPRs per lane hold 20 samples' state
         perceptron_reg_kernel<20, 512><<<dim3(1), dim3(512), lds, st>>>(a);
     } else {
