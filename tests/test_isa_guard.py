@@ -186,7 +186,9 @@ def test_handover_publishes_write_through_and_drains_before_the_counter(isa):
 
 
 @pytest.mark.parametrize("src,flags", [("tools/contraction_ubench.hip", []), ("tools/mfma_coissue_ubench.hip", []),
-                                       ("tools/mfma_coissue_ubench.hip", ["-DBF16"]), ("tools/lone_wave_ubench.hip", [])])
+                                       ("tools/mfma_coissue_ubench.hip", ["-DBF16"]), ("tools/lone_wave_ubench.hip", []),
+                                       ("tools/tile16_ubench.hip", ["-std=c++17"]),
+                                       ("tools/solve_probe.hip", ["-std=c++17", "-DDCX_SOLVE_TS", "-I" + CSRC])])
 def test_measurement_tools_still_compile_for_gfx950(tmp_path, src, flags):
     """the micro-benchmarks the profiles cite are part of the evidence: they must keep building (device code only, no GPU)"""
     if shutil.which("hipcc") is None:
@@ -197,6 +199,10 @@ def test_measurement_tools_still_compile_for_gfx950(tmp_path, src, flags):
     text = out.read_text()
     if "contraction" in src:   # the three matrix-core variants really issue matrix instructions
         assert text.count("v_mfma_f32_16x16x4_f32") >= 8 and "v_mfma_f32_16x16x32_bf16" in text
+    elif "tile16" in src:      # the LDS-operand sweep reads whole float4s; the scalar one goes through the scalar cache
+        assert "ds_read_b128" in text and "s_load_dwordx" in text
+    elif "solve_probe" in src:  # both workgroup sizes of the solve, with the phase stamps
+        assert text.count("lu_solve_kernel") >= 2 and "s_memrealtime" in text
     elif "mfma_coissue" in src:
         assert ("v_mfma_f32_16x16x32_bf16" if flags else "v_mfma_f32_16x16x4_f32") in text and "s_getreg_b32" in text
 
