@@ -1047,13 +1047,13 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
 // the LDS pipe (6.7 k) or the VALU count: the EXPANDED body (17 instead of 24 VALU instructions, one more ds_read_b32 and a
 // ballot per pair) came out SLOWER, 10.6 k, and two configurations per lane (half the LDS reads per pair) 10.4 k.  Net:
 // config #2 11.2 -> 10.5 us.
-// One class, row weights (MODE_GRAD_ROW), the two specialised kernel functions, D = 12 / 24; the host takes it for batches of
+// One class, row weights (MODE_GRAD_ROW) or the score alone (MODE_SCORE), the two specialised kernel functions, D = 12 / 24; the host takes it for batches of
 // at most 16 configurations per CU when the rows fit the LDS (dcx_api.hip run_score).
 constexpr int kQtSlices = 4;   // row slices per wave
 constexpr bool qt_applies(int D, int CC, int KF, int MODE) {
-    return (D == 12 || D == 24) && CC == 1 && MODE == 1 /* MODE_GRAD_ROW */ && KF != 2 /* KF_GEN */;
+    return (D == 12 || D == 24) && CC == 1 && (MODE == 1 /* MODE_GRAD_ROW */ || MODE == 0 /* MODE_SCORE */) && KF != 2 /* KF_GEN */;
 }
-template <int D, int KF>
+template <int D, int KF, bool GRAD>
 __device__ __forceinline__ void sweep_rows_lds(const ScoreArgs& a, const float (&x)[D], const float* slice, int per, float& sc0,
                                                float (&gx)[D]) {
     static_assert(D % 4 == 0, "rows are read as whole float4s");
@@ -1091,10 +1091,12 @@ __device__ __forceinline__ void sweep_rows_lds(const ScoreArgs& a, const float (
         float val, g;
         sweep_eval<KF>(d2, a, val, g);
         sc0 = fmaf(r[D], val, sc0);
-        const float coef = g * r[D];
-        const v2f c2 = {coef, coef};
+        if constexpr (GRAD) {
+            const float coef = g * r[D];
+            const v2f c2 = {coef, coef};
 #pragma unroll
-        for (int k = 0; k + 1 < D; k += 2) g2[k / 2] = __builtin_elementwise_fma(c2, dp[k / 2], g2[k / 2]);
+            for (int k = 0; k + 1 < D; k += 2) g2[k / 2] = __builtin_elementwise_fma(c2, dp[k / 2], g2[k / 2]);
+        }
     };
     // two row buffers: the next row's reads are in flight while this one is consumed (every slice holds `per` rows: the
     // staging pads the short ones with zero-weight rows)
@@ -1108,10 +1110,12 @@ __device__ __forceinline__ void sweep_rows_lds(const ScoreArgs& a, const float (
         pair(rb);
     }
     if (jj < per) pair(ra);
+    if constexpr (GRAD) {
 #pragma unroll
-    for (int k = 0; k + 1 < D; k += 2) {
-        gx[k] += g2[k / 2].x * kGradScale<KF>;
-        gx[k + 1] += g2[k / 2].y * kGradScale<KF>;
+        for (int k = 0; k + 1 < D; k += 2) {
+            gx[k] += g2[k / 2].x * kGradScale<KF>;
+            gx[k + 1] += g2[k / 2].y * kGradScale<KF>;
+        }
     }
 }
 
@@ -1496,7 +1500,7 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF, MF, XM, QT)) void 
         // this lane's slice of the rows: four per wave
         const int sl = wave * kQtSlices + (lane >> 4);
         const float* slice = smem + a.qt_off + sl * (a.qt_per * RowLayout<D, CC>::RS + 4);
-        sweep_rows_lds<D, KF>(a, x, slice, a.qt_per, sc[0], gx);
+        sweep_rows_lds<D, KF, GRAD>(a, x, slice, a.qt_per, sc[0], gx);
     } else if constexpr (MF) {
         // this wave's slice of the reduction scratch doubles as its transpose buffer (X is dead, the fold comes later)
         sweep_rows_mfma<D, KF, CC, MODE>(a, x, up, j0, j1, sc, gx, sRed + (size_t)wave * ACC * 64, lane);

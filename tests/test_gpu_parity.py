@@ -831,6 +831,7 @@ def test_tile_of_16_configurations_against_the_split_launch_and_the_oracle(ops, 
         assert not torch.equal(g0, g1) or n == 1, "the knob did not change the launch"
         so, go, _ = oracle.score_grad(desc_for(CASE_ROBOT[name]), kind, p0, p1, d["sup_x32"][:S], d["weights"][:S], d["q"][:n], dtype=np.float64)
         assert relerr(_n(s1), so) < TOL and relerr(_n(g1), go) < TOL, (n, relerr(_n(g1), go))
+        assert torch.equal(m.score_raw(q), s1)        # the score-only launch takes the tile too: same sums, no gradient
         # (the split launch it is compared with may be the EXPANDED form - RQ: ~2e-6 from the referee itself; the tile is direct)
         assert relerr(_n(s1), _n(s0)) < 8e-6 and relerr(_n(g1), _n(g0)) < 8e-6
         up = torch.linspace(-1.5, 2.0, n, device=q.device)[:, None]
