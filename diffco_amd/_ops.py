@@ -22,8 +22,35 @@ def _device(dev=None):
     return torch.device("cuda", torch.cuda.current_device())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream(dev):
+    """torch's current stream on `dev` as the C ABI's `void* stream` (the raw handle straight from torch's C layer: building
+    a torch.cuda.Stream object to read its handle cost 5 us per call, tools/api_profile.py)"""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(dev.index))
     return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+class _on_device:
+    """`with _on_device(dev):` = torch.cuda.device(dev) when another device is current, nothing at all otherwise (the library
+    selects the model's device itself; the guard only keeps the CALLER's current device what it was)"""
+    __slots__ = ("guard",)
+
+    def __init__(self, dev):
+        cur = _raw_device() if _raw_device is not None else torch.cuda.current_device()
+        self.guard = None if cur == dev.index else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.guard is not None:
+            self.guard.__enter__()
+
+    def __exit__(self, *exc):
+        if self.guard is not None:
+            self.guard.__exit__(*exc)
+        return False
 
 
 def _f32(t, dev):
@@ -232,18 +259,41 @@ class ScoreModel:
                                                self.capacity, _stream(self.dev)))
         self._h = handle
         self._lib = lib
+        self.leases = 0          # holders that need the rows to stay as they are (acquire / release)
+        self._streams = set()    # raw handles of the streams that have launched this model since the last update()
+
+    def acquire(self):
+        """take a lease: while any is held, a FusedScorer builds a NEW model for changed state instead of refilling this one"""
+        self.leases += 1
+        return self
+
+    def release(self):
+        self.leases = max(0, self.leases - 1)
 
     def update(self, support_feat, weights):
         """new supports / weights into the same model (dcx_model_update): what train / fit_poly / update do to a checker's
-        state every round of an active-learning loop"""
+        state every round of an active-learning loop.  The refill is enqueued on torch's CURRENT stream; launches of this
+        model that went to other streams since the last update are waited for first (device-side, one event each), so a
+        sweep still running elsewhere never reads half-packed rows."""
         sf, w = self._rows(support_feat, weights, self.dev)
         if int(w.shape[1]) != self.C or (len(sf) and sf.shape[1] != self.D):
             raise ValueError("update() keeps the model's feature width and class count")
+        cur = torch.cuda.current_stream(self.dev)
+        for h in self._streams:
+            if h != cur.cuda_stream:
+                cur.wait_stream(torch.cuda.ExternalStream(h, device=self.dev))
+        self._streams.clear()
         with torch.cuda.device(self.dev):
             _lib.check(self._lib.dcx_model_update(self._h, _ptr(sf), _ptr(w), len(sf), _stream(self.dev)))
         self.S = len(sf)
         self.capacity = max(self.capacity, self.S)
         return self
+
+    def _st(self):
+        """torch's current stream as the C ABI wants it, remembered for update()'s cross-stream wait"""
+        st = _stream(self.dev)
+        self._streams.add(st.value or 0)
+        return st
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -257,25 +307,25 @@ class ScoreModel:
     def score_raw(self, q32):
         B = q32.shape[0]
         out = torch.empty((B, self.C), device=self.dev, dtype=torch.float32)
-        with torch.cuda.device(self.dev):
-            _lib.check(self._lib.dcx_score(self._h, _ptr(q32), B, _ptr(out), _stream(self.dev)))
+        with _on_device(self.dev):
+            _lib.check(self._lib.dcx_score(self._h, _ptr(q32), B, _ptr(out), self._st()))
         return out
 
     def score_grad_raw(self, q32, upstream32=None, want_score=True):
         B = q32.shape[0]
         out = torch.empty((B, self.C), device=self.dev, dtype=torch.float32) if want_score else None
         grad = torch.empty((B, self.dof), device=self.dev, dtype=torch.float32)
-        with torch.cuda.device(self.dev):
+        with _on_device(self.dev):
             _lib.check(self._lib.dcx_score_grad(self._h, _ptr(q32), B, _ptr(upstream32), _ptr(out), _ptr(grad),
-                                                _stream(self.dev)))
+                                                self._st()))
         return out, grad
 
     def score_jac_raw(self, q32):
         B = q32.shape[0]
         out = torch.empty((B, self.C), device=self.dev, dtype=torch.float32)
         jac = torch.empty((B, self.C, self.dof), device=self.dev, dtype=torch.float32)
-        with torch.cuda.device(self.dev):
-            _lib.check(self._lib.dcx_score_jac(self._h, _ptr(q32), B, _ptr(out), _ptr(jac), _stream(self.dev)))
+        with _on_device(self.dev):
+            _lib.check(self._lib.dcx_score_jac(self._h, _ptr(q32), B, _ptr(out), _ptr(jac), self._st()))
         return out, jac
 
     def score_hess_raw(self, q32, upstream32=None):
@@ -284,9 +334,9 @@ class ScoreModel:
         B = q32.shape[0]
         grad = torch.empty((B, self.dof), device=self.dev, dtype=torch.float32)
         hess = torch.empty((B, self.dof, self.dof), device=self.dev, dtype=torch.float32)
-        with torch.cuda.device(self.dev):
+        with _on_device(self.dev):
             _lib.check(self._lib.dcx_score_hess(self._h, _ptr(q32), B, _ptr(upstream32), _ptr(grad), _ptr(hess),
-                                                _stream(self.dev)))
+                                                self._st()))
         return grad, hess
 
     def score_hinge_grad_raw(self, q32, margin, weight):
@@ -294,14 +344,19 @@ class ScoreModel:
         B = q32.shape[0]
         out = torch.empty((B, self.C), device=self.dev, dtype=torch.float32)
         grad = torch.empty((B, self.dof), device=self.dev, dtype=torch.float32)
-        with torch.cuda.device(self.dev):
+        with _on_device(self.dev):
             _lib.check(self._lib.dcx_score_hinge_grad(self._h, _ptr(q32), B, float(margin), float(weight), _ptr(out),
-                                                      _ptr(grad), _stream(self.dev)))
+                                                      _ptr(grad), self._st()))
         return out, grad
 
     # autograd-aware ------------------------------------------------------------------------
     def score(self, q: torch.Tensor) -> torch.Tensor:
         """[B, C] scores for q [B, dof]; differentiable w.r.t. q (gradient from the fused HIP pass)."""
+        if not (q.requires_grad and torch.is_grad_enabled()):
+            # nothing to differentiate: the score-only sweep, no autograd.Function around it (its apply() alone cost 10 us of
+            # a 17 us call: profiles/r05_api_latency.txt)
+            s = self.score_raw(_f32(q.reshape(-1, self.dof), self.dev))
+            return s if (s.device == q.device and s.dtype == q.dtype) else s.to(device=q.device, dtype=q.dtype)
         return _ScoreFn.apply(q, self)
 
     def score_and_grad(self, q: torch.Tensor, upstream: torch.Tensor = None):
@@ -337,7 +392,7 @@ class _ScoreFn(torch.autograd.Function):
         ctx.model, ctx.in_shape, ctx.in_dtype, ctx.in_device = model, q.shape, q.dtype, q.device
         if ctx.needs_input_grad[0] and model.C == 1:
             s, jac = model.score_jac_raw(q32)
-            ctx.save_for_backward(jac.to(device=q.device, dtype=q.dtype))
+            ctx.save_for_backward(jac.reshape(-1, model.dof).to(device=q.device, dtype=q.dtype))   # d score / d q  [B, dof]
         else:
             s = model.score_raw(q32)
             ctx.save_for_backward(q32)
@@ -348,8 +403,8 @@ class _ScoreFn(torch.autograd.Function):
     def backward(ctx, gs):
         (saved,) = ctx.saved_tensors
         model = ctx.model
-        if model.C == 1:  # saved = d score / d q  [B, 1, dof]
-            return (gs * saved[:, 0, :]).reshape(ctx.in_shape), None
+        if model.C == 1:  # saved = d score / d q  [B, dof]; gs [B, 1]: ONE elementwise launch
+            return (gs * saved).reshape(ctx.in_shape), None
         q32 = saved
         if _is_batched(gs):
             _, jac = model.score_jac_raw(q32)  # [B, C, dof]

@@ -7,8 +7,6 @@ foreign kernel callable the same algorithm runs as a host loop below, filling ke
 the reference does.  Behaviour restated from the reference: DiffCo.train_perceptron
 kernel_perceptrons.py:98-137 and MultiDiffCo.train_perceptron deprecated/MultiDiffCo.py:50-83.
 """
-import sys
-
 import torch
 
 from . import _ops
@@ -178,23 +176,41 @@ class FusedScorer:
     changes.  The cache holds strong references to the two tensors it was built from and compares by identity plus
     in-place version, so a freed-and-reallocated tensor at the same address can never alias the cached model; edits
     that bypass the version counter (`t.data[...] = ...`, `set_`) must be followed by `invalidate()` — the checkers
-    call it from train / fit_poly / to / filter_support_points_."""
+    call it from train / fit_poly / to / filter_support_points_.
+
+    Ownership (round 5: an explicit count instead of `sys.getrefcount`).  When the checker's state changes but the model's
+    structure (transform, kernel, class count, feature width, device) does not, the cached model is REFILLED in place
+    (`ScoreModel.update`: same storage, FK tables, per-stream scratch) - unless somebody holds a lease on it
+    (`ScoreModel.acquire()` / `release()`: a ShardedAdamRun while it iterates, an optimiser's constraint terms), in which
+    case the holder keeps the rows it started with and the cache builds a new model.  `model()` hands out the cache's own
+    model: a caller that keeps it across a later train / fit_poly and needs it unchanged takes a lease."""
 
     def __init__(self):
         self._key, self._model, self._sup, self._w = None, None, None, None
         self._struct, self._retired = None, None
+        self._fast = None   # (transform, kernel_func, device string, spec) of the cached model: the per-call check
 
     def model(self, transform, kernel_func, support_feat, weights, device=None):
         spec = kernel_spec(kernel_func)
+        # the per-call path (an optimiser asks thousands of times between two state changes): same objects, same in-place
+        # versions, same kernel parameters -> the cached model, without rebuilding the description key (bytes of a 5 KB struct)
+        if (self._model is not None and self._sup is support_feat and self._w is weights and self._fast is not None
+                and self._fast[0] is transform and self._fast[1] is kernel_func and self._fast[3] == spec
+                and self._fast[2] == (device if device is None else str(device))
+                and self._key[2] == support_feat._version and self._key[3] == weights._version
+                and self._key[4] == tuple(support_feat.shape) and self._key[5] == tuple(weights.shape)):
+            return self._model
         desc = transform_desc(transform)
         key = (None if desc is None else desc.key(), spec, support_feat._version, weights._version,
                tuple(support_feat.shape), tuple(weights.shape), str(device))
         if self._model is None or self._sup is not support_feat or self._w is not weights or key != self._key:
             old = self._model if self._model is not None else self._retired
-            # (refilled in place only while this cache is the model's sole owner: a ShardedAdamRun or an optimiser's terms
-            # object that still holds it keeps the rows it was built with)
-            same_shape = (old is not None and self._struct == (key[0], spec, int(weights.reshape(len(weights), -1).shape[1]), str(device))
-                          and len(support_feat) <= 4 * max(old.capacity, 1) and sys.getrefcount(old) <= 3)
+            width = int(support_feat.reshape(len(support_feat), -1).shape[1]) if len(support_feat) else -1
+            struct = (key[0], spec, int(weights.reshape(len(weights), -1).shape[1]), width, str(device))
+            # refilled in place only while nobody holds a lease on the model (see the class docstring), and only for the same
+            # structure INCLUDING the feature width (ADVICE r4: a refit on different-width features must rebuild, not raise)
+            same_shape = (old is not None and self._struct == struct and width == old.D
+                          and len(support_feat) <= 4 * max(old.capacity, 1) and old.leases == 0)
             if same_shape:
                 # the same transform / kernel / class count with new supports or weights (train, fit_poly, update): the
                 # model is refilled in place (dcx_model_update) - its storage, FK tables and per-stream scratch stay
@@ -203,9 +219,10 @@ class FusedScorer:
                 # (room to grow: an active-learning loop adds supports round by round)
                 self._model = _ops.ScoreModel(desc, spec[0], spec[1], spec[2], support_feat, weights, device=device,
                                               capacity=len(support_feat) + len(support_feat) // 4)
-            self._struct = (key[0], spec, self._model.C, str(device))
+            self._struct = (key[0], spec, self._model.C, self._model.D, str(device))
             self._retired = None
             self._key, self._sup, self._w = key, support_feat, weights
+        self._fast = (transform, kernel_func, device if device is None else str(device), spec)
         return self._model
 
     def score(self, transform, kernel_func, support_feat, weights, point):
@@ -223,4 +240,4 @@ class FusedScorer:
         # the state changed behind the version counters: the next call refills the model (kept aside) instead of rebuilding it
         if self._model is not None:
             self._retired = self._model
-        self._key, self._model, self._sup, self._w = None, None, None, None
+        self._key, self._model, self._sup, self._w, self._fast = None, None, None, None, None

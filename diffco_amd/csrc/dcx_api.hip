@@ -52,8 +52,11 @@ struct dcx_model {
     struct Scratch {
         hipStream_t stream;
         float* ptr;
-        size_t bytes;
+        size_t rows_bytes;   // capacity of the float rows region (the (value, tag) words behind it hold twice that)
+        uint32_t epoch;      // launches that used the owner-polls words: their tags never repeat (0 = an empty word)
     };
+    int32_t* giveup_host = nullptr;   // pinned, device-visible: an owner-polls launch that gave up waiting sets it (sticky)
+    int32_t* giveup_dev = nullptr;
     mutable std::mutex mu;
     mutable std::vector<Scratch> scratch;
     // exchange rows of the persistent trajectory kernel's cluster form (traj_fused.h traj_exchange): one buffer per stream,
@@ -388,17 +391,23 @@ Geometry pick_geometry(const dcx_model* m, int64_t B, int acc_floats, bool allow
 // uses the unsplit geometry, which is always valid.
 constexpr size_t kTileCounters = 1024;                       // arrival counters at the head of a scratch buffer
 constexpr size_t kScratchHead = kTileCounters * kCounterStride * sizeof(unsigned int);  // one counter per 128-byte line
-float* split_scratch(const dcx_model* m, hipStream_t st, size_t bytes) {
-    bytes += kScratchHead;
+float* split_scratch(const dcx_model* m, hipStream_t st, size_t bytes, uint32_t* ptag) {
     std::lock_guard<std::mutex> lock(m->mu);
+    // (`bytes` is what the launch's partial ROWS take; an existing buffer is held to the same limit as a new one - its rows
+    // region - so that a knob-sized request can never spill into the tag words behind it, which must stay zero: ADVICE r4)
     for (auto& sc : m->scratch)
-        if (sc.stream == st) return sc.bytes >= bytes ? sc.ptr : nullptr;
+        if (sc.stream == st) {
+            if (sc.rows_bytes < bytes) return nullptr;
+            if (++sc.epoch == 0u) sc.epoch = 1u;
+            *ptag = sc.epoch;
+            return sc.ptr;
+        }
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
     // [counters | float rows of the counter protocol | 8-byte (value, tag) words of the owner-polls protocol (score_kernel.h)]
     const size_t rows_bytes = (size_t)2 * m->n_cu * (m->Dt + m->Cc) * 64 * sizeof(float);
     const size_t fixed = kScratchHead + 3 * rows_bytes;
-    if (bytes > kScratchHead + rows_bytes) return nullptr;
+    if (bytes > rows_bytes) return nullptr;
     float* p = nullptr;
     if (hipMalloc((void**)&p, fixed) != hipSuccess) {
         (void)hipGetLastError();
@@ -410,8 +419,25 @@ float* split_scratch(const dcx_model* m, hipStream_t st, size_t bytes) {
         (void)hipFree(p);
         return nullptr;
     }
-    m->scratch.push_back({st, p, fixed});
+    m->scratch.push_back({st, p, rows_bytes, 1u});
+    *ptag = 1u;
     return p;
+}
+
+// The owner-polls hand-over makes the owning blocks of a launch WAIT for the publishing ones, which is only safe while
+// the publishers can always be dispatched: run_score's rule keeps one launch's owners on at most half the CUs, but launches
+// that run side by side - several streams - add up.  So one stream per device may use the protocol: the first
+// that asks; every other stream keeps the arrival counters, whose blocks never wait for anything.  (Another PROCESS on the
+// same GPU is beyond this rule: there the bounded wait and the sticky give-up flag - dcx_model::giveup_host - apply.)
+std::mutex g_opoll_mu;
+struct OpollOwner { int device; hipStream_t stream; };
+std::vector<OpollOwner> g_opoll_owner;
+bool opoll_stream_ok(int device, hipStream_t st) {
+    std::lock_guard<std::mutex> lock(g_opoll_mu);
+    for (auto& o : g_opoll_owner)
+        if (o.device == device) return o.stream == st;
+    g_opoll_owner.push_back({device, st});
+    return true;
 }
 
 // This stream's exchange rows for the cluster form of the persistent trajectory kernel, and the tag base of the launch that
@@ -520,8 +546,13 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
     }
     if (!qt) g = pick_geometry(m, B * nz, acc, true);
     float* part = nullptr;
+    uint32_t ptag = 0;
+    if (m->giveup_host && *m->giveup_host)
+        return fail(DCX_ERR_HIP, "an earlier split launch of this model gave up waiting for its peer workgroups (owner-polls hand-over: "
+                                 "they were never scheduled - the GPU is shared with another process?); its results were NaN. "
+                                 "dcx_debug_set(\"owner_poll\", 0) selects the hand-over that never waits");
     if (g.ys > 1) {
-        part = split_scratch(m, st, (size_t)nblk * nz * g.ys * acc * 64 * sizeof(float));
+        part = split_scratch(m, st, (size_t)nblk * nz * g.ys * acc * 64 * sizeof(float), &ptag);
         if (!part) g = pick_geometry(m, B * nz, acc, false);
     }
     unsigned int* counters = nullptr;
@@ -624,8 +655,11 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
     // Measured (profiles/r04_owner_poll.txt): config #2 11.57 -> 11.06 us, config #3's shard 20.6 -> 20.1, Polyharmonic nodes
     // 22.35 -> 21.8; Panda (22 accumulators on 8 waves: three dependent polls per wave) 15.4 -> 15.6, hence acc <= 2 nw.
     if (counters != nullptr && g.red_slots == g.nw && g.nw > 1 && knobs().owner_poll != 0 && (acc <= 2 * g.nw || knobs().owner_poll > 0) &&
-        nblk * nz * g.ys <= (int64_t)m->n_cu && 2 * nblk * nz <= (int64_t)m->n_cu)
+        nblk * nz * g.ys <= (int64_t)m->n_cu && 2 * nblk * nz <= (int64_t)m->n_cu && m->giveup_dev != nullptr && opoll_stream_ok(m->device, st)) {
         a.pwords = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(part) + (size_t)2 * m->n_cu * (m->Dt + m->Cc) * 64 * sizeof(float));
+        a.ptag = ptag;           // this launch's tag: words of any other launch never match (score_kernel.h)
+        a.giveup = m->giveup_dev;
+    }
     hipError_t e = m->launch(m->kf, m->Cc, mode, g.nw, lds, nblk, a, st);
     if (e == hipSuccess && counters == nullptr) {
         FinishArgs f{};
@@ -708,14 +742,30 @@ static void model_free_rows(dcx_model* m) {
 static int model_alloc_rows(dcx_model* m, int64_t cap) {
     if (cap < 1) cap = 1;
     if (cap <= m->cap && m->rows_dev) return DCX_OK;
-    model_free_rows(m);
+    // the new buffers first, the old ones freed only when both exist: a failed growth leaves the model as it was (ADVICE r4:
+    // freeing first left rows_dev null beside the old S_active, and the next launch read through it)
     const size_t floats = (size_t)cap * m->RS + rows_tail_floats(m);
-    hipError_t e = hipMalloc((void**)&m->rows_dev, floats * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void**)&m->rows_xf_dev, floats * sizeof(float));
+    float *rows = nullptr, *rows_xf = nullptr;
+    hipError_t e = hipMalloc((void**)&rows, floats * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&rows_xf, floats * sizeof(float));
     if (e == hipSuccess && !m->centre_dev) e = hipMalloc((void**)&m->centre_dev, (size_t)m->Dt * sizeof(float));
     if (e == hipSuccess && !m->info_dev) e = hipMalloc((void**)&m->info_dev, 16);
     if (e == hipSuccess && !m->info_host) e = hipHostMalloc((void**)&m->info_host, 16, hipHostMallocDefault);
-    if (e != hipSuccess) return fail_hip(e, "device allocation of the model");
+    if (e == hipSuccess && !m->giveup_host) {
+        e = hipHostMalloc((void**)&m->giveup_host, sizeof(int32_t), hipHostMallocMapped);
+        if (e == hipSuccess) {
+            *m->giveup_host = 0;
+            e = hipHostGetDevicePointer((void**)&m->giveup_dev, m->giveup_host, 0);
+        }
+    }
+    if (e != hipSuccess) {
+        if (rows) (void)hipFree(rows);
+        if (rows_xf) (void)hipFree(rows_xf);
+        return fail_hip(e, "device allocation of the model");
+    }
+    model_free_rows(m);
+    m->rows_dev = rows;
+    m->rows_xf_dev = rows_xf;
     m->cap = cap;
     return DCX_OK;
 }
@@ -1022,6 +1072,7 @@ void dcx_model_destroy(dcx_model* m) {
     if (m->aplanes_dev) (void)hipFree(m->aplanes_dev);
     if (m->info_dev) (void)hipFree(m->info_dev);
     if (m->info_host) (void)hipHostFree(m->info_host);
+    if (m->giveup_host) (void)hipHostFree(m->giveup_host);
     for (auto& sc : m->scratch)
         if (sc.ptr) (void)hipFree(sc.ptr);
     for (auto& ex : m->traj_exch)
@@ -1101,7 +1152,8 @@ int dcx_score_hess(const dcx_model* m, const float* q, int64_t B, const float* u
     v.n_cu = m->n_cu;
     v.ys_knob = (int32_t)knobs().hess_ys;
     v.fk_dh = (m->fk.kind == DCX_FK_DH && knobs().fkk != 0) ? 1 : 0;
-    if (float* sc = split_scratch(m, (hipStream_t)stream, 0)) {  // small batches split the supports across blocks
+    uint32_t unused_tag = 0;
+    if (float* sc = split_scratch(m, (hipStream_t)stream, 0, &unused_tag)) {  // small batches split the supports across blocks
         v.counters = reinterpret_cast<unsigned int*>(sc);
         v.n_counters = (int32_t)kTileCounters;
         v.counter_stride = kCounterStride;

@@ -27,7 +27,10 @@ inline int max_threads_for(int Dt) { return Dt <= 16 ? 1024 : (Dt <= 48 ? 512 : 
 // (Round 4: eight compiled class counts x 21 widths x 3 kernel functions x modes x forms had grown to 115 MB and 10 minutes.)
 inline int compiled_classes(int C) { return C <= 2 ? C : C <= 4 ? 4 : C == 5 ? 5 : 8; }
 
-inline int row_stride(int Dt, int C) { return (Dt + C + (C > 1 ? 1 : 0) + 1 + 3) / 4 * 4; }  // RowLayout<Dt, C>::RS
+inline int row_stride(int Dt, int C) {   // RowLayout<Dt, C>::RS
+    const int al = C > 1 ? DCX_ROW_ALIGN_MULTI : 4;
+    return (Dt + C + (C > 1 ? 1 : 0) + 1 + al - 1) / al * al;
+}
 
 // one entry point per compiled D (score_inst.hip, built once per width)
 typedef hipError_t (*launch_fn)(int kf, int cc, int mode, int nw, size_t lds_bytes, int64_t n_blocks,

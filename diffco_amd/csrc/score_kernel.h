@@ -77,6 +77,9 @@ struct ScoreArgs {
                               // second launch (score_finish_kernel) does
     unsigned long long* pwords;  // split launch, owner-polls hand-over (round 4): per (tile, y >= 1) rows of 8-byte (value, tag)
                               // words [(tile*ys + y)][ACC][64], all zero between launches; non-null selects that protocol
+    uint32_t ptag;            // ... the tag of THIS launch's words (never 0; the host numbers the launches that use a buffer)
+    int32_t* giveup;          // ... host-visible flag an owner sets when its peers never published (results NaN; the API refuses
+                              // further launches of the model: dcx_api.hip run_score)
     int32_t ys;               // support super-chunks (gridDim.y); block y sweeps [y*s_super, (y+1)*s_super)
     int32_t s_super;
     int32_t red_slots;        // LDS rows for the cross-wave fold: nw (all waves write, fold in parallel) or 1 (waves
@@ -104,12 +107,17 @@ struct ScoreArgs {
     int32_t qt_front;         // ... rows copied into LDS before the first barrier (the rest during the FK chain)
 };
 
+// floats a multi-class row's stride is rounded up to (developer A/B: 16 / 32 put every row on its own 64 / 128-byte lines)
+#ifndef DCX_ROW_ALIGN_MULTI
+#define DCX_ROW_ALIGN_MULTI 4
+#endif
 template <int D, int CC>
 struct RowLayout {
     static constexpr int W_OFF = D;
     static constexpr int WSUM_OFF = D + CC;                   // only present when CC > 1
     static constexpr int SS_OFF = D + CC + (CC > 1 ? 1 : 0);  // |s|^2 (float64 sum rounded once; the expanded-form sweep)
-    static constexpr int RS = (SS_OFF + 1 + 3) / 4 * 4;
+    static constexpr int AL = CC > 1 ? DCX_ROW_ALIGN_MULTI : 4;
+    static constexpr int RS = (SS_OFF + 1 + AL - 1) / AL * AL;
 };
 
 // arrival counters of a split launch sit one per 128-byte line: 256 blocks bumping 64 counters inside one line serialise
@@ -1492,7 +1500,11 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF, MF, XM, QT)) void 
     for (int k = 0; k < D; ++k) gx[k] = 0.0f;
     const int ybase = blockIdx.y * a.s_super;                               // this block's super-chunk
     const int yend = (ybase + a.s_super < a.S) ? (ybase + a.s_super) : a.S;
+#ifdef DCX_EXP_SAME_SLICE   // timing experiment only (wrong results): every wave of a block sweeps the SAME rows (scalar-cache hits)
+    const int j0 = ybase;
+#else
     const int j0 = (ybase + wave * a.s_chunk < yend) ? (ybase + wave * a.s_chunk) : yend;
+#endif
     const int j1 = (j0 + a.s_chunk < yend) ? (j0 + a.s_chunk) : yend;
 
     DCX_TSB(1);
@@ -1567,7 +1579,10 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF, MF, XM, QT)) void 
         // bit for bit - and puts the zeros back for the next launch (or graph replay).  The counter protocol below paid
         // publish -> drain -> atomic round trip -> re-read in EVERY block: 5.6 k of a config-#2 block's 25 k cycles
         // (profiles/r04_qt.txt, first table).  Blocks that do not own never wait, so the owners' polling cannot deadlock while
-        // fewer than all CUs hold owners.
+        // fewer than all CUs hold owners (the host allows ONE stream per device to use this protocol: opoll_stream_ok).
+        // Round 5: the tag is the launch's own number (b.ptag), not a constant: a word that a late publisher of an
+        // abandoned launch leaves behind can never be taken for a word of a later launch; and an owner that gives up says so
+        // in a host-visible flag (b.giveup) besides turning its tile into NaN.
         const bool opoll = split && b.pwords != nullptr;
         const bool publisher = opoll && blockIdx.y != 0;
         unsigned long long* wout = opoll ? b.pwords + ((tile * b.ys + blockIdx.y) * ACC) * 64 + lane : nullptr;
@@ -1592,7 +1607,7 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF, MF, XM, QT)) void 
                     v += __shfl_xor(v, 16, 64);
                     v += __shfl_xor(v, 32, 64);
                 }
-                if (publisher) __hip_atomic_store(wout + e * 64, ((unsigned long long)1u << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (publisher) __hip_atomic_store(wout + e * 64, ((unsigned long long)b.ptag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 else if (split && !opoll) __hip_atomic_store(out + e * 64, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 else sRed[e * 64 + lane] = v;  // row 0's slot of accumulator e: only this wave reads or writes it
             }
@@ -1624,13 +1639,14 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF, MF, XM, QT)) void 
 #pragma unroll
                         for (int v = 0; v < 8; ++v)
                             if (y + v < b.ys) {
-                                all = all && ((unsigned int)(wv[v] >> 32) != 0u);
+                                all = all && ((unsigned int)(wv[v] >> 32) == b.ptag);
                                 tot += __uint_as_float((unsigned int)wv[v]);
                             }
                     }
                     if (__builtin_amdgcn_ballot_w64(!all) == 0) break;
                     if (++spins > (1 << 21)) {   // seconds: a peer never ran.  Loud, not silent: the tile's results are NaN
-                        tot = __builtin_nanf("");
+                        tot = __builtin_nanf("");   // and the host hears of it before the next launch of this model
+                        if (lane == 0) __hip_atomic_store(b.giveup, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         break;
                     }
                     __builtin_amdgcn_s_sleep(1);

@@ -19,8 +19,7 @@ from time import time
 import torch as th
 
 from . import _ops, kernel
-from .kernel import KernelFunc
-from ._perceptron import FusedScorer, fit_system, run_trainer, sub_block
+from ._perceptron import FusedScorer, device_trainer_spec, fit_system, run_trainer, sub_block
 
 
 class Perceptron:
@@ -120,8 +119,11 @@ class DiffCo(Perceptron):
         # `home`: where the reference keeps the result (and where the caller finds the state afterwards); `dev`: where the
         # assembly runs - the trainer's GPU for our kernels
         home = th.device('cpu') if n <= 10000 else X.device
-        ours = isinstance(self.kernel_func, KernelFunc) and self.kernel_func.dcx_spec() is not None
-        dev = X.device if X.is_cuda else (_ops._device(None) if (ours and th.cuda.is_available()) else home)
+        # (the rule is "will the DEVICE trainer run?", not "is the kernel ours / is X on the GPU": the host loop -
+        # a foreign kernel callable, an FKKernel, DCX_HOST_TRAINER=1 - updates hypo / gains on `home` row by row and needs the
+        # matrix it fills beside them, so then everything is assembled on `home`, as the reference does)
+        on_device = device_trainer_spec(self.kernel_func) is not None and th.cuda.is_available()
+        dev = (X.device if X.is_cuda else _ops._device(None)) if on_device else home
         exist_mask = exist_mask.to(th.bool)
         # one pair of index vectors, made where the mask lives and copied once; every scatter below is an index_copy_ with
         # them (a boolean-mask assignment on a CUDA tensor is a nonzero + a device synchronisation each time: eight of them
@@ -149,8 +151,8 @@ class DiffCo(Perceptron):
         gains.index_copy_(0, ei, self.gains[:v].to(device=dev, dtype=X.dtype))
         check = K @ gains
         assert th.allclose(check, hypo, atol=1e-4), f"diff: {th.abs(check - hypo).max()}"
-        # (the n x n matrix stays where it was assembled: the trainer takes it from there and callers only ever gather
-        # the support sub-block of it)
+        # (the n x n matrix stays where it was assembled - the device trainer's GPU, or `home` for the host loop: callers only
+        # ever gather the support sub-block of it)
         return gains.to(home), X.to(home), Xt.to(home), K, hypo.to(home), y.to(home).reshape(-1)
 
     def train_perceptron(self, X, y, update=False, exist_mask=None, max_iteration=1000, verbose=False):

@@ -206,10 +206,16 @@ class _ScipyTerms:
                 from .traj import _resolve_model
                 m = _resolve_model(self.dist_est)
                 if m.C == 1 and m.desc.key() == self.prob.robot.fk_desc().key():
-                    self._model = m
+                    self._model = m.acquire()   # a lease for the lifetime of these terms (released in __del__)
             except Exception:
                 self._model = None
         return self._model
+
+    def __del__(self):
+        m = getattr(self, "_model", None)
+        if m is not None:
+            self._model = None
+            m.release()
 
     def jac_collision(self, x):
         """[n_segments, (W-2)*dof] Jacobian of `collision`.  With a fusable dist_est it is assembled analytically

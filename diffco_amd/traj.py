@@ -74,7 +74,7 @@ class ShardedAdamRun:
         import torch.distributed as dist
         from .sharded import shard_bounds
         self.lib = _lib.require_gpu()
-        self.model, self.group = model, group
+        self.model, self.group = model.acquire(), group   # a lease: the checker's cache must not refill these rows under the run
         self.n_total = len(init_paths)
         self.sharded = (group is not None or bool(sharded)) and dist.is_initialized()
         self.rank, self.world = (dist.get_rank(group), dist.get_world_size(group)) if self.sharded else (0, 1)
@@ -100,12 +100,25 @@ class ShardedAdamRun:
                                  STATIONARY_GRAD_NORM if grad_tol is None else float(grad_tol))
         self.it = 0
 
+    def close(self):
+        """give the model's lease back (idempotent; also done when the run is garbage-collected)"""
+        m, self._released = self.model, getattr(self, "_released", False) or not hasattr(self, "model")
+        if not self._released:
+            self._released = True
+            m.release()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # noqa: BLE001
+            pass
+
     def run(self, n_iters):
         """enqueue n_iters more iterations on torch's current stream (no host synchronisation)"""
         if self.R and n_iters > 0:
             dev = self.model.dev
             with torch.cuda.device(dev):
-                stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+                stream = self.model._st()
                 _lib.check(self.lib.dcx_traj_adam_run(self.model._h, C.byref(self.st), C.byref(self.opt), self.it + 1,
                                                       int(n_iters), stream))
         self.it += n_iters
@@ -168,6 +181,7 @@ def fused_adam_traj_optimize(robot, dist_est, start_cfg, target_cfg, options, gr
             break
     # ---- gather the per-restart summaries (and paths) and apply the reference's selection policy ----------
     summ, best_valid_path, lowest_path = run.finish()
+    run.close()
     bvo, lol, loo, nst = summ[:, 0], summ[:, 1], summ[:, 2], summ[:, 3]
     t_win, found, cost, cnt = select_trial(bvo, lol, loo, nst, W)
     solution = (best_valid_path if found else lowest_path)[t_win]

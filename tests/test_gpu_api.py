@@ -505,10 +505,59 @@ def test_checker_refills_its_model_in_place():
     dc._poly_fused.invalidate()
     s3 = dc.poly_score(q)
     assert dc._poly_fused._model._h.value == h1 and s3.shape == s2.shape
-    held = dc._poly_fused._model                                            # e.g. an optimiser's terms object
+    held = dc._poly_fused._model.acquire()                                  # a lease: e.g. an optimiser's terms object
     dc.rbf_nodes = torch.randn(300, generator=g).cuda()
     s4 = dc.poly_score(q)
     assert dc._poly_fused._model is not held and torch.equal(held.score(q), s3) and not torch.equal(s4, s3)
+    held.release()
+    # the holders inside the package take that lease themselves: a sharded Adam run, the scipy drivers' constraint terms
+    from diffco_amd.traj import ShardedAdamRun
+    m5 = dc._poly_fused._model
+    run = ShardedAdamRun(m5, rob.limits, q[:40].reshape(2, 20, 7).clone(), 0.05, 0.0, 0.3)
+    assert m5.leases == 1
+    dc.rbf_nodes = torch.randn(300, generator=g).cuda()
+    dc.poly_score(q)
+    assert dc._poly_fused._model is not m5                                  # not refilled under the run
+    run.close()
+    run.close()
+    assert m5.leases == 0
+    # a refit on features of ANOTHER width is a rebuild, not an error: transform=None, raw 7-wide rows
+    raw = DiffCo(transform=None)
+    raw.support_points = raw.support_transformed = sq[:100].clone()
+    raw.rbf_kernel, raw.rbf_nodes = kernel.Polyharmonic(1, 1.0), torch.randn(100, generator=g).cuda()
+    a = raw.poly_score(q)
+    wide = torch.cat([sq[:100], sq[100:200]], dim=1)                        # 14-wide rows, same count
+    raw.support_points = raw.support_transformed = wide
+    raw._poly_fused.invalidate()
+    b = raw.poly_score(torch.cat([q, q], dim=1))
+    assert a.shape == b.shape == (64, 1) and raw._poly_fused._model.D == 14
+
+
+def test_refill_waits_for_launches_on_other_streams():
+    """dcx_model_update runs on the current stream; a sweep of the same model still running on ANOTHER torch stream
+    must have read its rows before they are repacked.  Many long sweeps on a side stream, then the refill on the default
+    stream: every side-stream result equals the first (the old rows), the next default-stream result is the new model's."""
+    from diffco_amd import _ops
+    rob = make_robot("baxter_left")
+    lim = rob.limits
+    g = torch.Generator().manual_seed(8)
+    S, B = 2000, 65536
+    desc = rob.fk_desc()
+    sup = _ops.fkine(desc, (torch.rand((S, 7), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]).cuda()).reshape(S, -1)
+    w0, w1 = torch.randn(S, generator=g).cuda(), torch.randn(S, generator=g).cuda()
+    q = (torch.rand((B, 7), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]).cuda()
+    m = _ops.ScoreModel(desc, 1, 1.0, 1.0, sup, w0)
+    want0 = m.score_grad_raw(q)[0].clone()
+    want1 = _ops.ScoreModel(desc, 1, 1.0, 1.0, sup, w1).score_raw(q).clone()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        outs = [m.score_grad_raw(q)[0] for _ in range(40)]   # ~3.5 ms of sweeps queued on the side stream
+    m.update(sup, w1)                                         # default stream: must wait for them
+    got1 = m.score_raw(q)
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, want0) for o in outs)
+    assert torch.equal(got1, want1)
 
 
 def test_device_trainer_equals_host_trainer_and_reference(monkeypatch):
@@ -617,6 +666,42 @@ def test_device_trainer_all_equal_labels_then_update(mns, n):
     v = dc.valid_supports
     assert torch.all((dc.hypothesis[:v] > 0) == (dc.y[:v] > 0))
     assert torch.allclose(dc.kernel_matrix @ dc.gains, dc.hypothesis, atol=1e-4)
+
+
+@pytest.mark.parametrize("where", ["cpu", "cuda"])
+def test_update_round_through_the_host_loop(where, monkeypatch):
+    """jump_start_initialize assembled the n x n matrix on the GPU whenever the kernel was ours or X was a CUDA
+    tensor, while gains / hypothesis went `home` (the CPU for n <= 10000) - fine for the device trainer, a device mismatch in
+    the host loop (DCX_HOST_TRAINER=1; a foreign kernel callable never gets this far: the score path that seeds the new
+    samples' hypothesis is HIP-only and rejects it).  The host loop must train the update round, from CPU and from CUDA
+    inputs, and agree with the device trainer on the same data."""
+    from diffco_amd import kernel
+    from diffco_amd.kernel_perceptrons import DiffCo
+    rob = make_robot("baxter_left")
+    g = torch.Generator().manual_seed(11)
+    lim = rob.limits
+    label = lambda q: torch.where(rob.fkine(q)[:, -1, 2] > 0.3, 1.0, -1.0)
+    X = torch.rand((400, 7), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]
+    Xn = torch.rand((150, 7), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]
+    yX, yXn = label(X).cpu(), label(Xn).cpu()
+
+    def two_rounds(dev):
+        dc = DiffCo(kernel_func=kernel.RQKernel(10.0), beta=1.0, transform=rob.fkine)
+        dc.train(X.to(dev), yX.to(dev), max_iteration=1500)
+        v = dc.valid_supports
+        Xa = torch.cat([Xn.to(dev), dc.support_points[:v].to(dev)])
+        ya = torch.cat([yXn.to(dev), dc.y[:v].to(dev)])
+        mask = torch.cat([torch.zeros(len(Xn), dtype=torch.bool), torch.ones(v, dtype=torch.bool)]).to(dev)
+        dc.train(Xa, ya, update=True, exist_mask=mask, max_iteration=1500)
+        assert torch.allclose(dc.kernel_matrix @ dc.gains, dc.hypothesis, atol=1e-4)
+        return dc
+
+    ref = two_rounds("cpu")   # the device trainer
+    monkeypatch.setenv("DCX_HOST_TRAINER", "1")
+    got = two_rounds(where)
+    monkeypatch.delenv("DCX_HOST_TRAINER")
+    np.testing.assert_array_equal(_np(got.support_points), _np(ref.support_points))
+    assert relerr(_np(got.gains), _np(ref.gains)) < 1e-3 and relerr(_np(got.hypothesis), _np(ref.hypothesis)) < 1e-3
 
 
 def test_device_trainer_labels_outside_plus_minus_one():
