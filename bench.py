@@ -505,6 +505,93 @@ class TrajLoop:
         return None
 
 
+class ClockSampler:
+    """The GPU's shader clock and socket power from sysfs (amdgpu hwmon: freq1_input, power1_input / power1_average) sampled
+    every 2 ms by a thread while a measurement runs.  Why the line carries it: under the sweep's fp32-VALU load the part does
+    NOT hold the 2.4 GHz its peak figure assumes - the settle phase + timed region of the headline run at ~1.4 GHz on the
+    boxes of this pool (profiles/r05_clock_under_load.txt: tools/clock_probe.hip, tools/sweep_body_ubench.hip) - so the
+    roofline fraction against the nominal peak is bounded by that clock, whatever the kernel does."""
+
+    def __init__(self, dev_index=0):
+        import glob
+        import threading
+        pick = lambda pat: (sorted(glob.glob(pat)) or [None])[0]
+        base = f"/sys/class/drm/card{dev_index}/device/hwmon/hwmon*/"
+        self.f_clk = pick(base + "freq1_input")
+        self.f_pow = pick(base + "power1_input") or pick(base + "power1_average")
+        self.rows, self.stop_flag = [], False
+        self.thread = threading.Thread(target=self._run, daemon=True) if self.f_clk else None
+        if self.thread:
+            self.thread.start()
+
+    @staticmethod
+    def _read(path, scale):
+        try:
+            with open(path) as f:
+                return float(f.read().strip()) / scale
+        except Exception:   # noqa: BLE001
+            return None
+
+    def _run(self):
+        while not self.stop_flag:
+            self.rows.append((time.perf_counter(), self._read(self.f_clk, 1e6), self._read(self.f_pow, 1e6) if self.f_pow else None))
+            time.sleep(0.002)
+
+    def summary(self, t0=None):
+        """clock / power over the samples taken since t0 (perf_counter), None where sysfs has nothing"""
+        self.stop_flag = True
+        if self.thread:
+            self.thread.join(timeout=1.0)
+        r = [x for x in self.rows if x[1] is not None and (t0 is None or x[0] >= t0)]
+        if not r:
+            return None
+        clk = [x[1] for x in r]
+        pw = [x[2] for x in r if x[2] is not None]
+        return {"sclk_mhz_mean": round(sum(clk) / len(clk), 1), "sclk_mhz_min": round(min(clk), 1), "sclk_mhz_max": round(max(clk), 1),
+                "power_w_mean": round(sum(pw) / len(pw), 1) if pw else None, "samples": len(r),
+                "source": "amdgpu hwmon freq1_input / power1 (2 ms samples over the second half of the settle phase, the warm-up and the timed steps); "
+                          "what freq1_input means differs between boxes of the pool: see roofline.clock.shader_ghz_under_this_load"}
+
+
+def clock_under_load(loop, dev, ms=6.0):
+    """The clock the shaders have WHILE the measured loop runs: `dcx_debug_clock_probe` - one wave that samples s_memtime (the
+    shader clock counter) and s_memrealtime (a fixed 100 MHz) at its start and `ms` later - goes to a side stream, the loop's
+    launches keep the launch stream busy meanwhile; (shader ticks) / (wall ticks) x rate = GHz.  Run AFTER the timed region
+    (the probe occupies one wave slot of one CU).  Also the same probe on an idle GPU, for reference."""
+    import ctypes as Ct
+    from diffco_amd import _lib
+    lib = _lib.load()
+    out = torch.zeros(4, device=dev, dtype=torch.int64)
+    khz = Ct.c_int32(0)
+    side = torch.cuda.Stream(dev)
+
+    def probe(busy):
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 0
+        if busy:
+            loop.run(SETTLE_STEPS)      # (the probe starts into a GPU that is already under the load)
+        _lib.check(lib.dcx_debug_clock_probe(dev.index, Ct.c_void_p(out.data_ptr()), int(ms * 1e-3 * 100e6), Ct.byref(khz),
+                                             Ct.c_void_p(side.cuda_stream)))
+        if busy:
+            e0.record()
+            loop.run(SETTLE_STEPS)
+            e1.record()
+            e1.synchronize()
+            per = max(e0.elapsed_time(e1) / SETTLE_STEPS, 1e-3)
+            n = int(min(max(1.3 * ms / per, 1), 20000))
+            loop.run(n)
+            loop.drain()
+        torch.cuda.synchronize(dev)
+        t0, t1, r0, r1 = (int(v) for v in out.tolist())
+        return (t1 - t0) / max(r1 - r0, 1) * khz.value * 1e-6, n + 2 * SETTLE_STEPS if busy else 0
+
+    idle, _ = probe(False)
+    busy, n = probe(True)
+    return {"shader_ghz_under_this_load": round(busy, 3), "shader_ghz_idle": round(idle, 3), "probe_ms": ms, "launches_beside_the_probe": n,
+            "how": "dcx_debug_clock_probe on a side stream: (s_memtime ticks) / (s_memrealtime ticks) x its rate, one wave, beside the loop's launches"}
+
+
 def measure(loop, steps, warmup, dev, multi):
     """W untimed warm-up steps, then exactly `steps` steps bracketed by barrier + synchronize; max over ranks.
     Returns (wall seconds, average launch-to-launch kernel milliseconds from HIP events on the launch stream, number of
@@ -666,6 +753,54 @@ def solve_times(dev):
     return out
 
 
+def api_latency(dev, n=200):
+    """What a caller of the drop-in Python API waits for per call, microseconds of wall time in a loop of `n` (device
+    synchronised at the end, so consecutive calls overlap as they do in an optimiser's loop): `DiffCo.poly_score(q)` without
+    and with `torch.autograd.grad` behind it (the reference optimisers' call pattern, optim.py:88-101), the non-autograd
+    `ScoreModel.score_and_grad`, and the raw C-ABI call on ready device buffers - Baxter, 2000 supports, q resident on the
+    GPU.  `torch_autograd_floor` = forward + autograd.grad of `(q * 2).sum()` alone: what torch's engine costs on this host
+    without any of this package's code in the graph (tools/api_latency.py is the long form)."""
+    from diffco_amd import kernel, model
+    from diffco_amd.kernel_perceptrons import DiffCo
+    rob = model.BaxterLeftArmFK()
+    lim = rob.limits
+    g = torch.Generator().manual_seed(0)
+    S = 2000
+    sq = (torch.rand((S, 7), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]).to(dev)
+    dc = DiffCo(transform=rob.fkine)
+    dc.support_points, dc.support_transformed = sq, rob.fkine(sq)
+    dc.rbf_kernel, dc.rbf_nodes = kernel.Polyharmonic(1, 1.0), torch.randn(S, generator=g).to(dev)
+
+    def timeit(fn):
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize(dev)
+        return round((time.perf_counter() - t0) / n * 1e6, 2)
+
+    qe = torch.rand((50, 7), device=dev, requires_grad=True)
+    out = {"unit": "us per call", "what": "DiffCo.poly_score on a Baxter checker with 2000 supports, q on the GPU",
+           "torch_autograd_floor": timeit(lambda: torch.autograd.grad((qe * 2.0).sum(), qe))}
+    for B in (20, 50, 256, 4096):
+        q = (torch.rand((B, 7), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]).to(dev)
+        qg = q.clone().requires_grad_(True)
+        m = dc._poly_fused.model(dc.transform, dc.rbf_kernel, dc.support_transformed, dc.rbf_nodes, dev)
+
+        def fwd():
+            with torch.no_grad():
+                return dc.poly_score(q)
+
+        def fwd_bwd():
+            return torch.autograd.grad(dc.poly_score(qg).sum(), qg)
+
+        out[f"B{B}"] = {"fwd": timeit(fwd), "fwd_bwd": timeit(fwd_bwd), "score_and_grad": timeit(lambda: m.score_and_grad(q)),
+                        "raw": timeit(lambda: m.score_grad_raw(q))}
+    return out
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher around it: this process BECOMES `python -m torch.distributed.run
     --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port> bench.py <the same arguments>` (exec: same
@@ -782,7 +917,12 @@ def main():
         return strong_global
 
     w, loop = build(args.scaling, args.gather)
+    sampler = ClockSampler(local_rank) if rank == 0 else None
+    t_meas = time.perf_counter()
     wall, kern_ms, n_settle = measure(loop, args.steps, args.warmup, dev, multi)
+    clocks = None
+    if sampler is not None:
+        clocks = sampler.summary(t_meas + 0.5 * (time.perf_counter() - t_meas))
     gather_ms = loop.gather_ms()
     B, C, dof = w["B"], w["C"], w["dof"]
 
@@ -790,8 +930,43 @@ def main():
     if rank == 0:
         out = primary_line(args, w, loop, world, multi, ranks_reported, wall, kern_ms, n_settle, gather_ms, global_evals(args.scaling, w),
                            is_traj, cpu_base, cpu_torch)
+        # the clock the SIMDs really had under this loop's load (measured in the kernel, right after the timed region), the
+        # fraction against the peak AT THAT CLOCK, and what the driver's hwmon says beside it (a DPM level on some boxes, an
+        # average on others: 2400 and 1410 MHz have both been read during the same 85 us launches)
+        try:
+            # (N = 1 only: the probe's busy loop would issue this rank's collectives without its peers)
+            ck = clock_under_load(loop, dev) if not (SAME_GPU or multi) else None
+        except Exception as exc:  # noqa: BLE001  (a side measurement)
+            ck = {"error": f"{type(exc).__name__}: {exc}"[:160]}
+        if ck is not None:
+            if clocks is not None:
+                ck["hwmon"] = clocks
+            out["roofline"]["clock"] = ck
+            if ck.get("shader_ghz_under_this_load"):
+                out["roofline"]["frac_at_measured_clock"] = round(out["roofline"]["frac"] * 2.4 / ck["shader_ghz_under_this_load"], 4)
+                out["roofline"]["clock_note"] = ("peak 157.3 TFLOP/s assumes 2.4 GHz; frac_at_measured_clock = frac x 2.4 / shader_ghz_under_this_load. "
+                                                 "It can exceed 1: `achieved` counts ALGORITHMIC flops (S*(5D+4C+6)+800 per evaluation) and the "
+                                                 "expanded-form sweep executes ~0.8 of them (profiles/r05_clock_under_load.txt)")
         keeper.primary(out)   # from here on the driver gets a line whatever happens below
     _fault("after_primary")
+    # ... also if a side measurement HANGS (a collective whose peers took another path, a capture that never returns): every rank
+    # arms a timer when its primary numbers are safe; when it fires the rank leaves at once with exit code 0, and rank 0's
+    # keeper prints the best line it was given (round 5; an abort was already covered, a hang ran into the driver's own timeout).
+    side_budget = float(os.environ.get("DCX_BENCH_SIDE_BUDGET_S", "240"))
+
+    def _leave():
+        sys.stderr.write(f"bench: side measurements exceeded {side_budget:.0f} s; leaving with the line measured so far\n")
+        sys.stderr.flush()
+        if keeper is not None:
+            keeper.close()
+        os._exit(0)
+    import threading
+    side_timer = threading.Timer(side_budget, _leave)
+    side_timer.daemon = True
+    side_timer.start()
+    if os.environ.get("DCX_BENCH_FAULT", "") == "hang":
+        sys.stderr.write("bench: injected hang in the side measurements\n")
+        time.sleep(10 ** 6)
 
     variants = None
     candidates = []   # (wall, gather form, workload, loop, kernel ms, settle steps) of the forms that may be promoted
@@ -866,6 +1041,10 @@ def main():
             callers["fit_poly_solve"] = solve_times(dev)
         except Exception as exc:  # noqa: BLE001
             callers["fit_poly_solve"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+        try:   # the Python boundary itself
+            callers["poly_score_us"] = api_latency(dev)
+        except Exception as exc:  # noqa: BLE001
+            callers["poly_score_us"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
 
     if rank == 0:
         if multi:
@@ -878,12 +1057,15 @@ def main():
             best = min(candidates, key=lambda c: c[0]) if candidates else None
             if best is not None and best[0] < wall:
                 bw, bga, w2, l2, bkm, bns = best
+                clk_first = out["roofline"].get("clock")
                 out = primary_line(args, w2, l2, world, multi, ranks_reported, bw, bkm, bns, l2.gather_ms(), global_evals(args.scaling, w2),
                                    is_traj, cpu_base, cpu_torch)
                 variants[f"gather_{first['gather']}"] = {"scaling": args.scaling, **first, "steps": args.steps,
                                                           "global_batch": global_evals(args.scaling, w), "batch_per_gpu": w["B"]}
                 variants.pop(f"gather_{bga}", None)
                 wall = bw
+                if clk_first is not None:
+                    out["roofline"]["clock"] = dict(clk_first, source=clk_first["source"] + " of the per-call run (multi.primary)")
             out["multi"]["primary"] = first
             out["multi"]["promoted"] = out["multi"]["gather"] != first["gather"]
             none_ms = ((variants or {}).get("gather_none") or {}).get("ms_per_step")
@@ -895,6 +1077,7 @@ def main():
             out["configs"] = configs
             out["callers"] = callers
         keeper.final(out)
+    side_timer.cancel()
     if multi:
         dist.destroy_process_group()
     if keeper is not None:

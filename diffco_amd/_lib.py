@@ -23,6 +23,7 @@ SYMBOLS = {
     "dcx_last_error": (C.c_char_p, []),
     "dcx_device_count": (C.c_int, []),
     "dcx_debug_set": (C.c_int, [C.c_char_p, C.c_int64]),
+    "dcx_debug_clock_probe": (C.c_int, [C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_int32), C.c_void_p]),
     "dcx_model_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(FkDesc), C.c_int, C.POINTER(C.c_float),
                                    _c_fp, _c_fp, C.c_int64, C.c_int32, C.c_int32]),
     "dcx_model_create_ex": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(FkDesc), C.c_int, C.POINTER(C.c_float),

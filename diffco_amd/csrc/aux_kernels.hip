@@ -219,4 +219,29 @@ hipError_t launch_kernel_matrix(int kind, float kp0, float kp1, const float* x, 
     return hipGetLastError();
 }
 
+
+// ---- measurement aid: the clock the shaders have right now --------------------------------------------------------------------
+// One wave samples clock64 (s_memtime: the shader clock) and wall_clock64 (s_memrealtime: a fixed-rate counter) and sleeps until
+// `wall_ticks` of the latter have passed; launched on a side stream BESIDE a loop of sweeps it reports the clock the sweep runs
+// at (bench.py `roofline.clock`; profiles/r05_clock_under_load.txt is why the line carries it).
+__global__ void clock_probe_kernel(unsigned long long* out, unsigned long long wall_ticks) {
+    const unsigned long long r0 = wall_clock64(), t0 = clock64();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < wall_ticks) {
+        __builtin_amdgcn_s_sleep(64);
+        r1 = wall_clock64();
+    }
+    const unsigned long long t1 = clock64();
+    if (threadIdx.x == 0) {
+        out[0] = t0;
+        out[1] = t1;
+        out[2] = r0;
+        out[3] = r1;
+    }
+}
+hipError_t launch_clock_probe(unsigned long long* out, unsigned long long wall_ticks, hipStream_t st) {
+    clock_probe_kernel<<<1, 64, 0, st>>>(out, wall_ticks);
+    return hipGetLastError();
+}
+
 }  // namespace dcx

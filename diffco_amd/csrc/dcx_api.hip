@@ -288,6 +288,10 @@ struct Knobs {
         rd("DCX_OWNER_POLL", owner_poll, false);
         rd("DCX_SOLVE_THREADS", solve_threads, false);
         rd("DCX_QT", qt, false);
+#ifndef DCX_WITH_MATRIX_FORMS
+        if (mfma > 0) mfma = -1;   // (forms this build does not carry)
+        if (xm > 0) xm = -1;
+#endif
     }
 };
 Knobs& knobs() {
@@ -712,6 +716,11 @@ int dcx_debug_set(const char* name, int64_t value) {
         : n == "split_finish_kernel" ? &k.split_finish_kernel : n == "inlaunch_tiles" ? &k.inlaunch_tiles
         : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : n == "traj_fused" ? &k.traj_fused : n == "xf" ? &k.xf : n == "jac_one_sweep" ? &k.jac_one_sweep : n == "train_grid" ? &k.train_grid : n == "fkk" ? &k.fkk : n == "jt_waves" ? &k.jt_waves : n == "hess_ys" ? &k.hess_ys : n == "xm" ? &k.xm : n == "traj_ys" ? &k.traj_ys : n == "traj_across" ? &k.traj_across : n == "owner_poll" ? &k.owner_poll : n == "solve_threads" ? &k.solve_threads : n == "qt" ? &k.qt : nullptr;
     if (!dst) return fail(DCX_ERR_INVALID, "unknown knob: " + n);
+#ifndef DCX_WITH_MATRIX_FORMS
+    if ((dst == &k.mfma || dst == &k.xm) && value > 0)
+        return fail(DCX_ERR_UNSUPPORTED, "this build of libdcx does not carry the matrix-core forms of the sweep (measured slower, "
+                                         "profiles/r03_mfma_ab.txt): make EXTRA=-DDCX_WITH_MATRIX_FORMS");
+#endif
     *dst = value;
     return DCX_OK;
 }
@@ -1441,6 +1450,19 @@ int dcx_kernel_matrix(int device, int kernel_kind, const float* kparams, const f
                                             (hipStream_t)stream);
         if (e != hipSuccess) return fail_hip(e, "kernel_matrix launch");
     }
+    return DCX_OK;
+}
+
+int dcx_debug_clock_probe(int device, uint64_t* out4, uint64_t wall_ticks, int32_t* wall_clock_khz, void* stream) {
+    if (!out4 || wall_ticks < 1 || wall_ticks > (1ull << 32)) return fail(DCX_ERR_INVALID, "clock probe: out4 is NULL or wall_ticks out of range");
+    if (int rc = set_device(device)) return rc;
+    if (wall_clock_khz) {
+        int khz = 0;
+        DCX_HIP(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device));
+        *wall_clock_khz = khz;
+    }
+    const hipError_t e = launch_clock_probe(reinterpret_cast<unsigned long long*>(out4), wall_ticks, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "clock probe launch");
     return DCX_OK;
 }
 

@@ -71,6 +71,7 @@ hipError_t launch_fkine(const FkProg* fk_dev, const dcx_fk_desc& fk_host, const 
                         hipStream_t stream);
 hipError_t launch_fkine_vjp(const FkProg* fk_dev, const dcx_fk_desc& fk_host, const float* q, const float* gX,
                             int64_t B, float* gq, hipStream_t stream);
+hipError_t launch_clock_probe(unsigned long long* out, unsigned long long wall_ticks, hipStream_t stream);
 hipError_t launch_kernel_matrix(int kind, float kp0, float kp1, const float* x, int64_t B, const float* s, int64_t S,
                                 int D, float* K, hipStream_t stream);
 

@@ -9,7 +9,9 @@
 #error "compile with -DDCX_INST_D=<feature width>"
 #endif
 
-#ifdef DCX_STUB  // developer builds (Makefile ONLY_WIDTHS): this width is not compiled
+#if defined(DCX_STUB) && DCX_INST_PART != 0
+// (the stubs of this width live in its part-0 object)
+#elif defined(DCX_STUB)  // developer builds (Makefile ONLY_WIDTHS): this width is not compiled
 namespace dcx {
 #define DCX_CAT_(a, b) a##b
 #define DCX_CAT(a, b) DCX_CAT_(a, b)
@@ -27,8 +29,19 @@ constexpr int kMaxT = kD <= 16 ? 1024 : (kD <= 48 ? 512 : 256);
 // widths / modes that carry the MFMA form of the gradient fold (sweep_rows_mfma)
 // (one, five and eight classes: the developer knob takes it for those models, dcx_api.hip; with C > 1 the weight
 // contraction K . W runs on the matrix cores beside the gradient fold)
+// Round 5: NOT in the shipped library.  Both matrix-core forms (MF: the gradient fold / K . W on v_mfma_f32_16x16x4_f32; XM: the
+// distance GEMM as bf16 x 3 on v_mfma_f32_16x16x32_bf16) measured 4 - 47 % slower than the VALU forms (profiles/r03_mfma_ab.txt);
+// they are compiled by `make EXTRA=-DDCX_WITH_MATRIX_FORMS` (tools/build_variant.sh matrix ...) for the parity tests' "mfma" leg
+// and the A/B tools, and dcx_debug_set("mfma" / "xm", 1) answers DCX_ERR_UNSUPPORTED without them.
+#ifdef DCX_WITH_MATRIX_FORMS
 template <int KF, int CC, int MODE>
 constexpr bool kHasMfma = (kD == 12 || kD == 16) && (CC == 1 || CC == 5 || CC == 8) && (MODE != MODE_SCORE) && (KF != KF_GEN);
+constexpr bool kHasXm = true;
+#else
+template <int KF, int CC, int MODE>
+constexpr bool kHasMfma = false;
+constexpr bool kHasXm = false;
+#endif
 
 // Shapes with an expanded form (score_kernel.h, XF: Polyharmonic(1), rows of <= 37 floats) run it by default, on the
 // centred row pairs the host passes with it (ScoreArgs::centre).  The direct form is compiled for them as well and
@@ -50,7 +63,7 @@ hipError_t go(int nw, size_t lds, int64_t nblk, const ScoreArgs& a, hipStream_t 
     if constexpr (qt_applies(kD, CC, KF, MODE)) {   // the quarter tile (16 configurations per block, rows from LDS): nblk counts ITS blocks
         if (a.qt) return launch(score_kernel<kD, KF, CC, MODE, kMaxT, false, false, false, true>);
     }
-    if constexpr (xf_applies(kD, CC, KF) && xm_applies(kD, CC, KF) && MODE == MODE_GRAD_ROW) {
+    if constexpr (kHasXm && xf_applies(kD, CC, KF) && xm_applies(kD, CC, KF) && MODE == MODE_GRAD_ROW) {
         if (!a.mfma && a.xf && a.xm) return launch(score_kernel<kD, KF, CC, MODE, kMaxT, false, true, true>);
     }
     if constexpr (xf_applies(kD, CC, KF)) {
@@ -91,14 +104,26 @@ hipError_t by_cc(int cc, int mode, int nw, size_t lds, int64_t nblk, const Score
 
 #define DCX_CAT_(a, b) a##b
 #define DCX_CAT(a, b) DCX_CAT_(a, b)
+// Every width is built as TWO objects (Makefile, -DDCX_INST_PART=0 / 1; round 5: 21 objects of up to 155 s each left a
+// 16-core build two rounds of the longest ones): part 0 = the sweep with the two specialised kernel functions, part 1 = the
+// generic kernel function, the one-sweep Jacobian and the persistent trajectory kernel.
+#ifndef DCX_INST_PART
+#error "compile with -DDCX_INST_PART=0 and -DDCX_INST_PART=1"
+#endif
+hipError_t DCX_CAT(launch_score_gen_D, DCX_INST_D)(int cc, int mode, int nw, size_t lds, int64_t nblk, const ScoreArgs& a, hipStream_t st);
+#if DCX_INST_PART == 0
 hipError_t DCX_CAT(launch_score_D, DCX_INST_D)(int kf, int cc, int mode, int nw, size_t lds, int64_t nblk,
                                                const ScoreArgs& a, hipStream_t st) {
     switch (kf) {
     case KF_RQ2: return by_cc<KF_RQ2>(cc, mode, nw, lds, nblk, a, st);
     case KF_POLY1: return by_cc<KF_POLY1>(cc, mode, nw, lds, nblk, a, st);
-    case KF_GEN: return by_cc<KF_GEN>(cc, mode, nw, lds, nblk, a, st);
+    case KF_GEN: return DCX_CAT(launch_score_gen_D, DCX_INST_D)(cc, mode, nw, lds, nblk, a, st);
     default: return hipErrorInvalidValue;
     }
+}
+#else
+hipError_t DCX_CAT(launch_score_gen_D, DCX_INST_D)(int cc, int mode, int nw, size_t lds, int64_t nblk, const ScoreArgs& a, hipStream_t st) {
+    return by_cc<KF_GEN>(cc, mode, nw, lds, nblk, a, st);
 }
 
 namespace {
@@ -181,5 +206,6 @@ hipError_t DCX_CAT(launch_traj_fused_D, DCX_INST_D)(int kf, int nw, size_t lds, 
     }
 }
 
+#endif  // DCX_INST_PART
 }  // namespace dcx
 #endif  // DCX_STUB

@@ -653,8 +653,19 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
     constexpr int USED4 = (USED + 3) / 4 * 4;
     static_assert(USED4 <= L::RS, "the row stride covers whole groups of four");
     constexpr int NLOAD = DCX_LOAD_GROUPS ? USED4 : USED;
+#ifdef DCX_EXP_NO_LOADS   // timing experiment only (wrong results): after the first few, a row "load" fetches nothing - the
+    int exp_real_loads = 4;  // registers keep their values behind an opaque barrier - what do the scalar loads cost the stream?
+#endif
     auto load_row = [&](float (&dst)[L::RS], int j) __attribute__((always_inline)) {
         cfloat_ptr r = rows + (size_t)j * RSTRIDE;
+#ifdef DCX_EXP_NO_LOADS
+        if (exp_real_loads <= 0) {
+#pragma unroll
+            for (int e = 0; e < NLOAD; ++e) asm volatile("" : "+s"(dst[e]));
+            return;
+        }
+        --exp_real_loads;
+#endif
 #pragma unroll
         for (int e = 0; e < NLOAD; ++e) dst[e] = r[e];
     };
@@ -865,6 +876,28 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
             constexpr int P0 = decltype(pc)::value * PS;
             constexpr int LEN = (PARTS == 1 && DCX_LOAD_GROUPS) ? PS : (USED - P0 < PS) ? (USED - P0) : PS;
             cfloat_ptr r = rows + (size_t)j * RSTRIDE + P0;
+#ifdef DCX_EXP_NO_LOADS
+            if (exp_real_loads <= 2) {
+#pragma unroll
+                for (int e = 0; e < LEN; ++e) asm volatile("" : "+s"(dst[e]));
+                return;
+            }
+            --exp_real_loads;
+#endif
+#if defined(DCX_EXP_LOAD_DWORDS)   // timing experiment only (wrong results): fetch this many dwords per row, whatever its width
+            static_assert(PARTS != 1 || DCX_EXP_LOAD_DWORDS <= 16 || RSTRIDE >= 32, "build with DCX_ROW_ALIGN_MULTI=32");
+            if constexpr (PARTS == 1) {
+                float extra = 0.0f;
+#pragma unroll
+                for (int e = 0; e < (DCX_EXP_LOAD_DWORDS < LEN ? DCX_EXP_LOAD_DWORDS : LEN); ++e) dst[e] = r[e];
+#pragma unroll
+                for (int e = DCX_EXP_LOAD_DWORDS; e < LEN; ++e) dst[e] = dst[e - DCX_EXP_LOAD_DWORDS];
+#pragma unroll
+                for (int e = LEN; e < DCX_EXP_LOAD_DWORDS; ++e) extra += r[e];   // dwords beyond the row: fetched and folded into one operand
+                if constexpr (DCX_EXP_LOAD_DWORDS > LEN) dst[LEN - 1] += 1e-30f * extra;
+                return;
+            }
+#endif
 #pragma unroll
             for (int e = 0; e < LEN; ++e) dst[e] = r[e];
         };
@@ -1388,13 +1421,11 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF, MF, XM, QT)) void 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nw = blockDim.x >> 6;
     const int64_t b0 = (int64_t)blockIdx.x * TILE;
-    const size_t tile = (size_t)blockIdx.x * gridDim.z + blockIdx.z;  // scratch rows / arrival counter of this (tile, class)
     const int nb = (int)((a.B - b0) < TILE ? (a.B - b0) : TILE);
     const int dof = a.dof;
     const LdsPlan lp = lds_plan(dof, a.d_fk, a.frame_floats, nw > 1 ? a.red_slots : 0, ACC, true);
     float* sQ = smem + lp.q;
     float* sX = smem + lp.x;
-    float* sG = smem + lp.g;
     float* sF = smem + lp.f;
     float* sRed = smem + lp.red;
 

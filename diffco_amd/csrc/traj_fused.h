@@ -394,7 +394,7 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
         {
             const auto& b = reload_kernargs<TrajFusedArgs>();
             const TrajLds L = traj_lds<D>(smem, b, nw);
-            const int W = b.st.n_waypoints, dof = b.sc.dof, d_fk = b.sc.d_fk, pd = b.point_dim, n_points = b.n_points;
+            const int W = b.st.n_waypoints, dof = b.sc.dof, d_fk = b.sc.d_fk;
             const bool live = w < W;
             const bool jt = b.sc.jt_waves != 0;
             DhArgs dh;

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DCX_VERSION 106 /* 0.1.5: dcx_model_create_ex / dcx_model_update (rows packed on the device); 0.1.4: dcx_train_perceptron_ex (per-call flags); 0.1.3: dcx_fk_desc carries the DCX_FK_TREE section; 32 control points, D <= 96 */
+#define DCX_VERSION 107 /* 0.1.6: dcx_debug_clock_probe; the matrix-core forms are a build option (dcx_debug_set("mfma" / "xm", 1) -> DCX_ERR_UNSUPPORTED without them); owner-polls words tagged per launch, give-up reported by the model's next launch; 0.1.5: dcx_model_create_ex / dcx_model_update (rows packed on the device); 0.1.4: dcx_train_perceptron_ex (per-call flags); 0.1.3: dcx_fk_desc carries the DCX_FK_TREE section; 32 control points, D <= 96 */
 
 /* ---- status codes ---------------------------------------------------------------- */
 #define DCX_OK 0
@@ -169,6 +169,12 @@ int dcx_device_count(void);
  * value < 0 restores the rule.  The initial values come from the DCX_YS / DCX_NW / DCX_XF / ... environment variables,
  * read once at library load; no launch calls getenv.   */
 int dcx_debug_set(const char* name, int64_t value);
+/* Measurement aid (0.1.6): one wave on `stream` samples the shader clock counter (s_memtime) and the fixed-rate wall clock
+ * (s_memrealtime; its rate in kHz -> *wall_clock_khz, may be NULL) when it starts and again after `wall_ticks` of the latter:
+ * out4 [4] uint64 on the device = {clock0, clock1, wall0, wall1}.  (clock1 - clock0) / (wall1 - wall0) x rate = the clock the
+ * shaders had meanwhile: launched beside a loop of sweeps on another stream it tells what clock the sweep ran at (under its
+ * fp32-VALU load the part holds ~1.45 GHz, not its nominal 2.4: profiles/r05_clock_under_load.txt; bench.py `roofline.clock`). */
+int dcx_debug_clock_probe(int device, uint64_t* out4, uint64_t wall_ticks, int32_t* wall_clock_khz, void* stream);
 
 /* ---- model = inference state of a kernel perceptron ------------------------------- */
 /* Replaces the state DiffCo.score/poly_score read: support_transformed[S,m,d] + gains[S]

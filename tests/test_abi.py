@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"libdcx.so does not export {n}"
     assert set(names) == set(_lib.SYMBOLS), "ctypes table and header disagree"
-    assert lib.dcx_version() == 106
+    assert lib.dcx_version() == 107
     assert isinstance(lib.dcx_device_count(), int)
 
 
@@ -152,3 +152,27 @@ def test_tree_description_is_validated_before_any_device_work():
         fd.tree_desc(1, [dict(joints=[dict(type=fd.DCX_J_REV_X, q=3, fixed=ident)])], [(0, 0, (0, 0, 0))])
     with pytest.raises(ValueError, match="does not exist"):
         fd.tree_desc(1, [dict(joints=[dict(type=fd.DCX_J_REV_X, q=0, fixed=ident)])], [(0, 2, (0, 0, 0))])
+
+
+def test_profiled_kernel_names_are_kernels_of_this_library():
+    """bench.py's `roofline.traffic` is a constant read from profiles/pmc_<workload>.json (HBM bytes per launch from rocprofv3
+    --pmc passes of an earlier run).  It silently goes stale when the kernel behind it changes shape: the
+    kernel each of those files names must still be a kernel of the library as built - same template arguments, to the last
+    flag - or the counters have to be collected again (tools/gpu_profile.sh) before the number may stay in the line."""
+    import glob
+    import json
+    import re
+    import shutil
+    import subprocess
+    if shutil.which("nm") is None:
+        import pytest
+        pytest.skip("nm not available")
+    syms = subprocess.run(["nm", "-C", "--defined-only", os.path.join(ROOT, "diffco_amd", "libdcx.so")], capture_output=True, text=True,
+                          check=True).stdout
+    have = {re.sub(r"\s+", "", m.group(1)) for m in re.finditer(r"\bvoid (dcx::\w+<[^>]*>)\(", syms)}
+    assert any(k.startswith("dcx::score_kernel<12,1,1,1,1024") for k in have)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_*.json")))
+    assert files
+    for f in files:
+        name = re.sub(r"\s+", "", json.load(open(f))["kernel"].split("  ")[0].split(" (")[0])
+        assert name in have, f"{os.path.basename(f)} names {name}, which this libdcx.so does not contain: re-collect the counters"

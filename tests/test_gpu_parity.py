@@ -35,8 +35,26 @@ def fold_pipe(request, knob):
     gradient fold on the matrix cores (v_mfma_f32_16x16x4_f32, knob mfma = 1; shapes without an MFMA instantiation
     take the default form)"""
     knob("xf", 0 if request.param == "direct" else 1)
-    knob("mfma", 1 if request.param == "mfma" else 0)
+    if request.param == "mfma":
+        # (round 5: the shipped library no longer carries the matrix-core forms - measured slower, profiles/r03_mfma_ab.txt;
+        # this leg runs against `make EXTRA=-DDCX_WITH_MATRIX_FORMS`: profiles/r05_matrix_forms_tests.txt has that run)
+        from diffco_amd._lib import DcxUnsupported
+        try:
+            knob("mfma", 1)
+        except DcxUnsupported:
+            pytest.skip("this build of libdcx carries no matrix-core forms (make EXTRA=-DDCX_WITH_MATRIX_FORMS)")
+    else:
+        knob("mfma", 0)
     yield request.param
+
+
+def _need_xm(knob):
+    """knob xm = 1, or skip: the shipped library carries no matrix-core forms (see fold_pipe)"""
+    from diffco_amd._lib import DcxUnsupported
+    try:
+        knob("xm", 1)
+    except DcxUnsupported:
+        pytest.skip("this build of libdcx carries no matrix-core forms (make EXTRA=-DDCX_WITH_MATRIX_FORMS)")
 
 
 @pytest.fixture(scope="module")
@@ -273,7 +291,7 @@ def test_distance_gemm_on_the_matrix_cores_around_the_near_threshold(ops, knob, 
                                   q.numpy().astype(np.float64), dtype=np.float64)
     knob("xf", 1)
     knob("mfma", 0)
-    knob("xm", 1)
+    _need_xm(knob)
     s, gr = m.score_grad_raw(q.cuda())
     assert torch.isfinite(s).all() and torch.isfinite(gr).all()
     assert relerr(_n(s), so) < TOL and relerr(_n(gr), go) < TOL, (relerr(_n(s), so), relerr(_n(gr), go))
@@ -306,7 +324,7 @@ def test_distance_gemm_on_the_matrix_cores_with_fk(ops, knob, name, B):
     knob("mfma", 0)
     knob("xm", 0)
     s0, g0 = m.score_grad_raw(q)
-    knob("xm", 1)
+    _need_xm(knob)
     s1, g1 = m.score_grad_raw(q)
     s1b, g1b = m.score_grad_raw(q)
     assert torch.equal(s1, s1b) and torch.equal(g1, g1b)
@@ -547,7 +565,8 @@ def test_full_size_properties(ops, B, S, C, kspec, knob, fold_pipe):
     """headline / config #2 / config #3 sizes: linearity in the weights, additivity over a support
     split, invariance to batch order, and an fp64 spot check of 64 random rows."""
     from oracle import oracle
-    knob("nw", 4)
+    # (round 5, VERDICT r4 item 8: everything but the last block runs at the DEFAULT launch geometry - the 16-wave blocks the
+    # bench's headline actually runs, the 8-wave blocks of a five-class model, the split launch of the 4096 batch)
     rob, desc, sup, W, g = _rand_setup(ops, "baxter_left", S, C, kspec)
     q = _rand_q(rob, B, g)
     m = ops.ScoreModel(desc, *kspec, sup, W)
@@ -575,6 +594,14 @@ def test_full_size_properties(ops, B, S, C, kspec, knob, fold_pipe):
     idx = torch.randint(0, B, (64,), generator=g)
     so, go, _ = oracle.score_grad(desc, *kspec, _n(sup).astype(np.float64), _n(W), _n(q[idx.cuda()]), dtype=np.float64)
     assert relerr(_n(s[idx.cuda()]), so) < TOL and relerr(_n(gr[idx.cuda()]), go) < TOL
+    # another block size (4 waves: other support slices, another fold tree): the same properties, and the same numbers up to
+    # the reassociation of the sums
+    knob("nw", 4)
+    s4w, g4w = m.score_grad_raw(q)
+    assert float((s4w - s).abs().max()) < 3e-6 * scale_s and float((g4w - gr).abs().max()) < 3e-6 * scale_g
+    sp, gp = m.score_grad_raw(q[perm].contiguous())
+    assert torch.equal(sp, s4w[perm]) and torch.equal(gp, g4w[perm])
+    assert relerr(_n(s4w[idx.cuda()]), so) < TOL and relerr(_n(g4w[idx.cuda()]), go) < TOL
 
 
 def test_config4_se3_streaming(ops):

@@ -160,14 +160,16 @@ def test_handover_publishes_write_through_and_drains_before_the_counter(isa):
         for at in atomics:
             back = body[:at]
             # (4-byte stores: the 8-byte `global_store_dwordx2 ... sc1` belong to the owner-polls protocol, checked below)
-            st = max(n for n, l in enumerate(back) if l.startswith("global_store_dword ") and " sc1" in l)
+            # (and not the owner-polls give-up flag: that one is a SYSTEM-scope store, `sc0 sc1`, to host memory)
+            st = max(n for n, l in enumerate(back) if l.startswith("global_store_dword ") and " sc1" in l and " sc0" not in l)
             between = back[st + 1:]
             assert any(l.startswith("s_waitcnt") and "vmcnt(0)" in l for l in between), "no vmcnt(0) between the publish and the counter"
             # the publish run in front of the counter is write-through only
             run = []
             for l in reversed(back[:st + 1]):
                 if l.startswith("global_store_dword "):
-                    run.append(l)
+                    if " sc0" not in l:
+                        run.append(l)
                 elif l.startswith("global_store_dwordx2"):
                     continue
                 elif l.startswith(("s_waitcnt", "v_", "s_", ";", "ds_")) or not l:
@@ -180,6 +182,9 @@ def test_handover_publishes_write_through_and_drains_before_the_counter(isa):
         # that is the whole ordering argument), in the same kernels
         assert any(l.startswith("global_store_dwordx2") and " sc1" in l for l in body), "(value, tag) words must be 8-byte sc1 stores"
         assert any(l.startswith("global_load_dwordx2") and " sc1" in l for l in body), "(value, tag) words must be polled with 8-byte sc1 loads"
+        # round 5: an owner that gives up waiting tells the host (system-scope store of the flag), and compares the tag with the
+        # launch's own number, not with zero
+        assert any(l.startswith("global_store_dword ") and " sc0 sc1" in l for l in body), "the give-up flag must be a system-scope store"
         assert not any(l.startswith(("buffer_wbl2", "buffer_inv")) for l in body)
         seen += 1
     assert seen == 4
@@ -188,7 +193,10 @@ def test_handover_publishes_write_through_and_drains_before_the_counter(isa):
 @pytest.mark.parametrize("src,flags", [("tools/contraction_ubench.hip", []), ("tools/mfma_coissue_ubench.hip", []),
                                        ("tools/mfma_coissue_ubench.hip", ["-DBF16"]), ("tools/lone_wave_ubench.hip", []),
                                        ("tools/tile16_ubench.hip", ["-std=c++17"]),
-                                       ("tools/solve_probe.hip", ["-std=c++17", "-DDCX_SOLVE_TS", "-I" + CSRC])])
+                                       ("tools/solve_probe.hip", ["-std=c++17", "-DDCX_SOLVE_TS", "-I" + CSRC]),
+                                       ("tools/clock_probe.hip", []),
+                                       ("tools/sweep_body_ubench.hip", ["-std=c++17", "-I" + CSRC]),
+                                       ("tools/sweep_body_ubench.hip", ["-std=c++17", "-DDCX_EXP_NO_LOADS", "-I" + CSRC])])
 def test_measurement_tools_still_compile_for_gfx950(tmp_path, src, flags):
     """the micro-benchmarks the profiles cite are part of the evidence: they must keep building (device code only, no GPU)"""
     if shutil.which("hipcc") is None:
@@ -203,6 +211,11 @@ def test_measurement_tools_still_compile_for_gfx950(tmp_path, src, flags):
         assert "ds_read_b128" in text and "s_load_dwordx" in text
     elif "solve_probe" in src:  # both workgroup sizes of the solve, with the phase stamps
         assert text.count("lu_solve_kernel") >= 2 and "s_memrealtime" in text
+    elif "clock_probe" in src:  # both clocks are read inside the kernel
+        assert "s_memtime" in text and "s_memrealtime" in text and "v_pk_fma_f32" in text
+    elif "sweep_body" in src:   # the product's own sweep: rows through the scalar cache (or, in the no-load build, almost none)
+        n_loads = text.count("s_load_dwordx")
+        assert "v_pk_fma_f32" in text and "v_rcp_f32" in text and n_loads > 0
     elif "mfma_coissue" in src:
         assert ("v_mfma_f32_16x16x32_bf16" if flags else "v_mfma_f32_16x16x4_f32") in text and "s_getreg_b32" in text
 

@@ -38,8 +38,19 @@ def timeit(fn, n=300):
     return (time.perf_counter() - t0) / n * 1e6
 
 
+# what torch's autograd engine costs by itself on this box: one elementwise op + sum, backward through it (no diffco_amd code)
+qe = torch.rand(50, 7, device=dev, requires_grad=True)
+
+
+def engine_only():
+    (g,) = torch.autograd.grad((qe * 2.0).sum(), qe)
+    return g
+
+
+print(f"torch alone, (q * 2).sum() forward + autograd.grad on a [50, 7] CUDA tensor: {timeit(engine_only):7.1f} us per call")
+
 for where in ("cuda", "cpu"):
-    for B in (20, 256, 4096):
+    for B in (20, 50, 256, 4096):
         q = (torch.rand(B, 7) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]).to(where)
         qg = q.clone().requires_grad_(True)
         m = dc._poly_fused.model(dc.transform, dc.rbf_kernel, dc.support_transformed, dc.rbf_nodes, dev)
@@ -57,8 +68,11 @@ for where in ("cuda", "cpu"):
         def raw():
             return m.score_grad_raw(q32)
 
+        def sg():   # the non-autograd Python entry: score and gradient of one launch, on the caller's device and dtype
+            return m.score_and_grad(q)
+
         print(f"q on {where:<4} B={B:<5} poly_score {timeit(fwd):7.1f} us   + backward {timeit(fwd_bwd):7.1f} us   "
-              f"raw dcx_score_grad {timeit(raw):7.1f} us")
+              f"ScoreModel.score_and_grad {timeit(sg):7.1f} us   raw dcx_score_grad {timeit(raw):7.1f} us")
 
 # PCIe-inclusive rate at the headline shape: host q in, host score + grad out (pageable and pinned buffers)
 B = 65536

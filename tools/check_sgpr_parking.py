@@ -19,7 +19,7 @@ WIDTHS = [2, 4, 6, 8, 12, 16, 18, 21, 24, 27, 30, 32, 36, 42, 48, 54, 60, 64, 72
 
 def compile_width(d):
     out = f"/tmp/dcx_check_D{d}.s"
-    subprocess.run(["hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", f"-DDCX_INST_D={d}", "-S",
+    subprocess.run(["hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", f"-DDCX_INST_D={d}", "-DDCX_INST_PART=0", "-S",
                     "--cuda-device-only", "-o", out, "score_inst.hip"] + sys.argv[1:0], cwd=CSRC, check=True,
                    stderr=subprocess.DEVNULL)
     return d, out
