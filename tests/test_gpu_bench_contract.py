@@ -103,8 +103,8 @@ def test_headline_line_carries_every_baseline_config():
     ps = d["callers"]["poly_score_us"]
     assert "error" not in ps, ps
     for B in ("B20", "B50", "B256", "B4096"):
-        assert 0 < ps[B]["raw"] and ps[B]["fwd"] < ps[B]["raw"] + 15.0, ps
-        assert ps[B]["score_and_grad"] < ps[B]["raw"] + 15.0, ps
+        assert 0 < ps[B]["raw"] and ps[B]["fwd"] < ps[B]["raw"] + 25.0, ps          # (measured: + 0 ... 3 us)
+        assert ps[B]["score_and_grad"] < ps[B]["raw"] + 25.0, ps                     # (measured: + 0 ... 3 us)
         # (through torch's autograd engine: 70 - 170 us on the pool's hosts where torch alone needs 60 - 80; bounded loosely)
         assert ps[B]["fwd_bwd"] < 4.0 * ps["torch_autograd_floor"] + 50.0, ps
     rf = d["roofline"]
