@@ -508,52 +508,22 @@ class TrajLoop:
         return None
 
 
-class ClockSampler:
-    """The GPU's shader clock and socket power from sysfs (amdgpu hwmon: freq1_input, power1_input / power1_average) sampled
-    every 2 ms by a thread while a measurement runs.  Why the line carries it: under the sweep's fp32-VALU load the part does
-    NOT hold the 2.4 GHz its peak figure assumes - the settle phase + timed region of the headline run at ~1.4 GHz on the
-    boxes of this pool (profiles/r05_clock_under_load.txt: tools/clock_probe.hip, tools/sweep_body_ubench.hip) - so the
-    roofline fraction against the nominal peak is bounded by that clock, whatever the kernel does."""
+def hwmon_read(dev_index=0):
+    """(sclk MHz, socket power W) from amdgpu's hwmon files, None where sysfs has nothing.  What freq1_input means differs between
+    the leases of this pool (a DPM level on some, an average on others: 2400, 2010 and 1410 MHz have all been read during the
+    same 85 - 87 us launches), so the line's clock is the in-kernel probe's; these two numbers ride along as `hwmon`."""
+    import glob
+    pick = lambda pat: (sorted(glob.glob(pat)) or [None])[0]
+    base = f"/sys/class/drm/card{dev_index}/device/hwmon/hwmon*/"
 
-    def __init__(self, dev_index=0):
-        import glob
-        import threading
-        pick = lambda pat: (sorted(glob.glob(pat)) or [None])[0]
-        base = f"/sys/class/drm/card{dev_index}/device/hwmon/hwmon*/"
-        self.f_clk = pick(base + "freq1_input")
-        self.f_pow = pick(base + "power1_input") or pick(base + "power1_average")
-        self.rows, self.stop_flag = [], False
-        self.thread = threading.Thread(target=self._run, daemon=True) if self.f_clk else None
-        if self.thread:
-            self.thread.start()
-
-    @staticmethod
-    def _read(path, scale):
+    def rd(path, scale):
         try:
             with open(path) as f:
                 return float(f.read().strip()) / scale
         except Exception:   # noqa: BLE001
             return None
-
-    def _run(self):
-        while not self.stop_flag:
-            self.rows.append((time.perf_counter(), self._read(self.f_clk, 1e6), self._read(self.f_pow, 1e6) if self.f_pow else None))
-            time.sleep(0.002)
-
-    def summary(self, t0=None):
-        """clock / power over the samples taken since t0 (perf_counter), None where sysfs has nothing"""
-        self.stop_flag = True
-        if self.thread:
-            self.thread.join(timeout=1.0)
-        r = [x for x in self.rows if x[1] is not None and (t0 is None or x[0] >= t0)]
-        if not r:
-            return None
-        clk = [x[1] for x in r]
-        pw = [x[2] for x in r if x[2] is not None]
-        return {"sclk_mhz_mean": round(sum(clk) / len(clk), 1), "sclk_mhz_min": round(min(clk), 1), "sclk_mhz_max": round(max(clk), 1),
-                "power_w_mean": round(sum(pw) / len(pw), 1) if pw else None, "samples": len(r),
-                "source": "amdgpu hwmon freq1_input / power1 (2 ms samples over the second half of the settle phase, the warm-up and the timed steps); "
-                          "what freq1_input means differs between boxes of the pool: see roofline.clock.shader_ghz_under_this_load"}
+    f_clk, f_pow = pick(base + "freq1_input"), pick(base + "power1_input") or pick(base + "power1_average")
+    return (rd(f_clk, 1e6) if f_clk else None), (rd(f_pow, 1e6) if f_pow else None)
 
 
 def clock_under_load(loop, dev, ms=6.0):
@@ -584,15 +554,27 @@ def clock_under_load(loop, dev, ms=6.0):
             per = max(e0.elapsed_time(e1) / SETTLE_STEPS, 1e-3)
             n = int(min(max(1.3 * ms / per, 1), 20000))
             loop.run(n)
+            # (the launches are queued: the GPU works them off while the host looks at the driver's sensors)
+            for _ in range(3):
+                c, p = hwmon_read(dev.index)
+                if c is not None:
+                    hw.append((c, p))
+                time.sleep(0.001)
             loop.drain()
         torch.cuda.synchronize(dev)
         t0, t1, r0, r1 = (int(v) for v in out.tolist())
         return (t1 - t0) / max(r1 - r0, 1) * khz.value * 1e-6, n + 2 * SETTLE_STEPS if busy else 0
 
+    hw = []
     idle, _ = probe(False)
     busy, n = probe(True)
-    return {"shader_ghz_under_this_load": round(busy, 3), "shader_ghz_idle": round(idle, 3), "probe_ms": ms, "launches_beside_the_probe": n,
-            "how": "dcx_debug_clock_probe on a side stream: (s_memtime ticks) / (s_memrealtime ticks) x its rate, one wave, beside the loop's launches"}
+    res = {"shader_ghz_under_this_load": round(busy, 3), "shader_ghz_idle": round(idle, 3), "probe_ms": ms, "launches_beside_the_probe": n,
+           "how": "dcx_debug_clock_probe on a side stream: (s_memtime ticks) / (s_memrealtime ticks) x its rate, one wave, beside the loop's launches"}
+    if hw:
+        pw = [p for _, p in hw if p is not None]
+        res["hwmon"] = {"sclk_mhz": round(sum(c for c, _ in hw) / len(hw), 1), "power_w": round(sum(pw) / len(pw), 1) if pw else None,
+                        "note": "amdgpu hwmon freq1_input / power1 read while the same launches ran; what freq1_input reports differs between leases"}
+    return res
 
 
 def measure(loop, steps, warmup, dev, multi):
@@ -925,12 +907,7 @@ def main():
         return strong_global
 
     w, loop = build(args.scaling, args.gather)
-    sampler = ClockSampler(local_rank) if rank == 0 else None
-    t_meas = time.perf_counter()
     wall, kern_ms, n_settle = measure(loop, args.steps, args.warmup, dev, multi)
-    clocks = None
-    if sampler is not None:
-        clocks = sampler.summary(t_meas + 0.5 * (time.perf_counter() - t_meas))
     gather_ms = loop.gather_ms()
     B, C, dof = w["B"], w["C"], w["dof"]
 
@@ -938,17 +915,14 @@ def main():
     if rank == 0:
         out = primary_line(args, w, loop, world, multi, ranks_reported, wall, kern_ms, n_settle, gather_ms, global_evals(args.scaling, w),
                            is_traj, cpu_base, cpu_torch)
-        # the clock the SIMDs really had under this loop's load (measured in the kernel, right after the timed region), the
-        # fraction against the peak AT THAT CLOCK, and what the driver's hwmon says beside it (a DPM level on some boxes, an
-        # average on others: 2400 and 1410 MHz have both been read during the same 85 us launches)
+        # the clock the SIMDs really had under this loop's load (measured in the kernel, right AFTER the timed region: nothing
+        # samples anything while the K steps are timed), the fraction against the peak at that clock, the driver's sensors beside it
         try:
             # (N = 1 only: the probe's busy loop would issue this rank's collectives without its peers)
             ck = clock_under_load(loop, dev) if not (SAME_GPU or multi) else None
         except Exception as exc:  # noqa: BLE001  (a side measurement)
             ck = {"error": f"{type(exc).__name__}: {exc}"[:160]}
         if ck is not None:
-            if clocks is not None:
-                ck["hwmon"] = clocks
             out["roofline"]["clock"] = ck
             if ck.get("shader_ghz_under_this_load"):
                 out["roofline"]["frac_at_measured_clock"] = round(out["roofline"]["frac"] * 2.4 / ck["shader_ghz_under_this_load"], 4)
