@@ -296,3 +296,19 @@ class DiffCo(Perceptron):
                                           point)
         feats = transformed_point.reshape(len(transformed_point), -1)
         return self._polyx_fused.score(None, self.rbf_kernel, self.support_transformed, self.rbf_nodes, feats)
+
+    def poly_score_and_grad(self, point):
+        """(poly_score(point) [N, 1], d poly_score / d point [N, dof]) from ONE fused launch, without an autograd graph.
+        Not in the reference (its callers write `s = poly_score(p); s.sum().backward()`, optim.py:88-101): an extension for loops
+        that want the gradient at the cost of the raw call - 11 us per call where the route through torch's autograd engine costs
+        60 - 140 (profiles/r05_api_latency.txt).  Needs a fusable transform (a diffco_amd robot's `fkine`, or none)."""
+        if point.ndim == 1:
+            point = point.unsqueeze(0)
+        point = point.to(device=self.rbf_nodes.device, dtype=self.rbf_nodes.dtype)
+        dev = point.device if point.device.type == "cuda" else (
+            self.support_transformed.device if self.support_transformed.device.type == "cuda" else None)
+        m = self._poly_fused.model(self.transform, self.rbf_kernel, self.support_transformed, self.rbf_nodes, dev)
+        if m.desc.kind == 0 and self.transform is not None:
+            raise TypeError("poly_score_and_grad needs a fusable transform (a diffco_amd robot's fkine): a foreign transform's "
+                            "Jacobian is only available through its own autograd - use poly_score")
+        return m.score_and_grad(point.reshape(-1, m.dof))

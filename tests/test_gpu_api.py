@@ -533,6 +533,37 @@ def test_checker_refills_its_model_in_place():
     assert a.shape == b.shape == (64, 1) and raw._poly_fused._model.D == 14
 
 
+def test_poly_score_and_grad_equals_the_autograd_route():
+    """the one-launch (score, gradient) entry of the new-API checker = poly_score + torch.autograd.grad, bit for bit (C = 1: the
+    backward of the autograd route multiplies the same Jacobian row by an upstream of ones), on GPU and on CPU inputs"""
+    from diffco_amd import kernel
+    from diffco_amd.kernel_perceptrons import DiffCo
+    rob = make_robot("baxter_left")
+    lim = rob.limits
+    g = torch.Generator().manual_seed(21)
+    S = 300
+    sq = (torch.rand((S, 7), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]).cuda()
+    dc = DiffCo(transform=rob.fkine)
+    dc.support_points, dc.support_transformed = sq, rob.fkine(sq)
+    dc.rbf_kernel, dc.rbf_nodes = kernel.Polyharmonic(1, 1.0), torch.randn(S, generator=g).cuda()
+    for dev in ("cuda", "cpu"):
+        q = (torch.rand((77, 7), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]).to(dev)
+        s, gr = dc.poly_score_and_grad(q)
+        qg = q.clone().requires_grad_(True)
+        s2 = dc.poly_score(qg)
+        (g2,) = torch.autograd.grad(s2.sum(), qg)
+        # (like poly_score, the point goes where the nodes live - kernel_perceptrons.py:313 - and the results come back there)
+        assert s.shape == (77, 1) and gr.shape == (77, 7) and s.device == s2.device and gr.dtype == q.dtype
+        assert torch.equal(s, s2.detach()) and torch.equal(gr, g2.to(gr.device))
+    one = dc.poly_score_and_grad(q[0])
+    assert one[0].shape == (1, 1) and one[1].shape == (1, 7)
+    foreign = DiffCo(transform=lambda x: rob.fkine(x))
+    foreign.support_points, foreign.support_transformed = sq, rob.fkine(sq)
+    foreign.rbf_kernel, foreign.rbf_nodes = dc.rbf_kernel, dc.rbf_nodes
+    with pytest.raises(TypeError, match="fusable transform"):
+        foreign.poly_score_and_grad(q)
+
+
 def test_refill_waits_for_launches_on_other_streams():
     """dcx_model_update runs on the current stream; a sweep of the same model still running on ANOTHER torch stream
     must have read its rows before they are repacked.  Many long sweeps on a side stream, then the refill on the default
