@@ -150,13 +150,16 @@ def _solve_device(a32: torch.Tensor, b32: torch.Tensor) -> torch.Tensor:
 
 def solve(kmat: torch.Tensor, rhs: torch.Tensor) -> torch.Tensor:
     """x with kmat @ x = rhs, solved on the GPU: the S x S system of fit_poly (reference kernel_perceptrons.py:283,
-    deprecated/MultiDiffCo.py:149).  Up to 3072 unknowns: dcx_solve, one launch (LU with partial pivoting in fp64,
-    csrc/solve_kernels.hip); beyond, or for more than 64 right-hand sides, torch's hipSOLVER binding - a plain library
-    factorisation.  Result on kmat's device and dtype.  Like every other op here it needs the GPU."""
+    deprecated/MultiDiffCo.py:149).  float32 systems of up to 3072 unknowns: dcx_solve, one launch (LU with partial pivoting,
+    fp64 inside, fp32 in and out: csrc/solve_kernels.hip); beyond, for more than 64 right-hand sides, and for FLOAT64 systems
+    (dcx_solve reads fp32: a float64 `kmat + reg * eye` with a small `reg` would lose it on the way in - ADVICE r4) torch's
+    hipSOLVER binding, a plain library factorisation in the caller's precision.  Result on kmat's device and dtype.  An exactly
+    zero (or NaN) pivot raises torch.linalg.LinAlgError from dcx_solve, as LAPACK's info does; the library route returns what
+    hipSOLVER returns.  Like every other op here it needs the GPU."""
     _lib.require_gpu()
     dev = _device(kmat.device)
     n = kmat.shape[-1]
-    if kmat.dim() == 2 and rhs.dim() in (1, 2) and 1 <= n <= SOLVE_MAX_N and rhs.shape[0] == n \
+    if kmat.dtype != torch.float64 and kmat.dim() == 2 and rhs.dim() in (1, 2) and 1 <= n <= SOLVE_MAX_N and rhs.shape[0] == n \
             and 1 <= rhs.numel() // n <= SOLVE_MAX_RHS:
         x = _solve_device(_f32(kmat, dev), _f32(rhs.reshape(n, -1), dev))
         return x.reshape(rhs.shape).to(device=kmat.device, dtype=kmat.dtype)

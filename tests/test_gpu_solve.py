@@ -157,6 +157,11 @@ def test_ops_solve_and_fit_nodes_keep_device_dtype_and_shape():
     x = _ops.solve(torch.from_numpy(a).double(), torch.from_numpy(t))       # CPU fp64 in -> CPU fp64 out, 1-d stays 1-d
     assert x.device.type == "cpu" and x.dtype == torch.float64 and x.shape == (n,)
     assert relerr(x.numpy(), ref) < 2e-7
+    # a float64 system keeps its precision (it used to be cast to fp32 on the way in - a `reg` of 1e-9 on the diagonal of a
+    # float64 matrix vanished): the library's LU in float64
+    a64 = a.astype(np.float64) + 1e-9 * np.eye(n)
+    x64 = _ops.solve(torch.from_numpy(a64), torch.from_numpy(t.astype(np.float64)))
+    assert x64.dtype == torch.float64 and relerr(x64.numpy(), oracle.solve(a64, t.astype(np.float64))) < 1e-9
     nodes = _ops.fit_nodes(KIND["poly"], 1, 1.0, torch.from_numpy(pts), torch.from_numpy(t)[:, None])
     assert nodes.shape == (n, 1) and nodes.device.type == "cpu" and relerr(nodes.numpy()[:, 0], ref) < 5e-5
     # reg goes on the diagonal (deprecated/MultiDiffCo.py:151)
