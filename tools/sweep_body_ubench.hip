@@ -20,6 +20,9 @@ __global__ __launch_bounds__(256, WPS) void body_kernel(const ScoreArgs a, int r
     for (int k = 0; k < D; ++k) { x[k] = 0.01f * (float)(lane + k) - 0.3f; gx[k] = 0.f; }
 #pragma unroll
     for (int c = 0; c < CC; ++c) { up[c] = 1.f; sc[c] = 0.f; }
+#ifdef UBENCH_SKEW   // do waves that do NOT run in lockstep get a different clock?  every wave starts up to 15 x UBENCH_SKEW x 64 cycles late
+    for (int i = 0; i < (int)((blockIdx.x * 7u + (threadIdx.x >> 6) * 3u) & 15u); ++i) __builtin_amdgcn_s_sleep(UBENCH_SKEW);
+#endif
     const unsigned long long t0 = clock64();
     for (int r = 0; r < reps; ++r) sweep_rows<D, KF, CC, MODE, true>(a, x, up, 0, rows_n, sc, gx);
     const unsigned long long t1 = clock64();
