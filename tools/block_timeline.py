@@ -41,6 +41,11 @@ for b in range(4096):
     rows.append((b, t0, t1, t2, xcc, se, sh, cu))
 if not rows:
     sys.exit("no stamps")
+# the tick counters of different XCDs have different bases: every block's stamps are taken relative to the first start ON ITS XCD
+xbase = {}
+for r in rows:
+    xbase[r[4]] = min(xbase.get(r[4], r[1]), r[1])
+rows = [(b, t0 - xbase[x], t1 - xbase[x], t2 - xbase[x], x, se, sh, cu) for (b, t0, t1, t2, x, se, sh, cu) in rows]
 base = min(r[1] for r in rows)
 end = max(r[3] for r in rows)
 print(f"{args.workload} B={w['B']}: {len(rows)} blocks stamped, first start -> last end {end - base} ticks")
@@ -62,3 +67,16 @@ late = [len([x for x in v if x[1] - base > 20000]) for v in per_cu.values()]
 print(f"CUs that started a block more than 20k ticks after the launch began: {sum(1 for x in late if x)}")
 worst = max(per_cu.items(), key=lambda kv: max(x[3] for x in kv[1]))
 print("the CU that finished last:", worst[0], [(x[0], x[1] - base, x[3] - base) for x in sorted(worst[1], key=lambda x: x[1])])
+
+# the launch in four numbers (ticks relative to the first block start of the same XCD)
+sw0 = sorted(r[2] for r in rows)
+print("first sweep starts                   : p0 %d  p10 %d  p50 %d" % (sw0[0], pct(sw0, .1), pct(sw0, .5)))
+second = sorted(r[1] for r in rows if r[1] > 20000)
+if second:
+    print("blocks of the later rounds start     : p0 %d  p50 %d  p100 %d  (%d blocks)" % (second[0], pct(second, .5), second[-1], len(second)))
+last_end_per_cu = sorted(max(x[3] for x in v) for v in per_cu.values())
+print("a CU's last block ends               : p0 %d  p50 %d  p100 %d" % (last_end_per_cu[0], pct(last_end_per_cu, .5), last_end_per_cu[-1]))
+last_sweep_start_per_cu = sorted(max(x[2] for x in v) for v in per_cu.values())
+print("a CU's last block starts sweeping    : p0 %d  p50 %d  p100 %d" % (last_sweep_start_per_cu[0], pct(last_sweep_start_per_cu, .5), last_sweep_start_per_cu[-1]))
+busy = [sum(x[3] - x[1] for x in v) for v in per_cu.values()]
+print("sum of block lifetimes per CU        : min %d  p50 %d  max %d   (2 resident at a time: / 2 = %d)" % (min(busy), pct(sorted(busy), .5), max(busy), pct(sorted(busy), .5) // 2))
