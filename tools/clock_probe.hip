@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <vector>
 #include <algorithm>
+#include <time.h>
 
 typedef float float2_ __attribute__((ext_vector_type(2)));
 
@@ -34,6 +35,44 @@ __global__ __launch_bounds__(256) void k(unsigned long long* ts, int iters, floa
         ts[blockIdx.x * 4 + 0] = t0; ts[blockIdx.x * 4 + 1] = t1; ts[blockIdx.x * 4 + 2] = r0; ts[blockIdx.x * 4 + 3] = r1;
     }
     if (s == 123.456f) ts[0] = (unsigned long long)s;
+}
+
+// the clock as a function of the time since the launch began: block 0's first wave stamps both counters every `chunk` instructions
+__global__ __launch_bounds__(256) void k_ramp(unsigned long long* ts, int chunks, int chunk, float seed) {
+    float2_ p[8];
+    for (int i = 0; i < 8; ++i) p[i] = float2_{seed + i + threadIdx.x, seed + i + 1.f};
+    const float2_ m2 = {1.0000001f, 1.0000001f}, c2 = {1e-9f, 1e-9f};
+    for (int c = 0; c < chunks; ++c) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) { ts[2 * c] = clock64(); ts[2 * c + 1] = wall_clock64(); }
+        for (int it = 0; it < chunk; ++it) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(m2), "v"(c2));
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ts[2 * chunks] = clock64(); ts[2 * chunks + 1] = wall_clock64(); }
+    float s = 0.f;
+    for (int i = 0; i < 8; ++i) s += p[i].x + p[i].y;
+    if (s == 123.456f) ts[0] = (unsigned long long)s;
+}
+void run_ramp(int blocks, const char* what, int gap_us) {
+    const int chunks = 40, chunk = 150;   // 8 x 150 = 1200 pk_fma per chunk and wave: ~2.5 us per chunk at 8 waves per SIMD
+    unsigned long long* ts;
+    hipMalloc(&ts, sizeof(unsigned long long) * 2 * (chunks + 1));
+    std::vector<unsigned long long> h(2 * (chunks + 1));
+    for (int l = 0; l < 4; ++l) {   // back to back (gap_us = 0) or with an idle gap in front of each launch
+        if (gap_us) { hipDeviceSynchronize(); timespec t{0, gap_us * 1000}; nanosleep(&t, nullptr); }
+        k_ramp<<<blocks, 256>>>(ts, chunks, chunk, 1.f);
+    }
+    hipDeviceSynchronize();
+    hipMemcpy(h.data(), ts, sizeof(unsigned long long) * 2 * (chunks + 1), hipMemcpyDeviceToHost);
+    printf("%s: GHz in consecutive ~%d-instruction windows of the LAST of four launches (time since its start in us : GHz)\n   ", what, 8 * chunk);
+    for (int c = 0; c < chunks; ++c) {
+        const double dt = (double)(h[2 * c + 3] - h[2 * c + 1]) * 0.01, ghz = (double)(h[2 * c + 2] - h[2 * c]) / ((double)(h[2 * c + 3] - h[2 * c + 1]) * 10.0);
+        printf(" %.0f:%.2f", (double)(h[2 * c + 3] - h[1]) * 0.01, ghz);
+        (void)dt;
+    }
+    printf("\n");
+    hipFree(ts);
 }
 
 template <int OP>
@@ -80,5 +119,8 @@ int main() {
     run<1>("pk_fma full", cus * 8, 20000, 6);      // ~10 ms per launch, 8 waves per SIMD
     run<0>("fma full", cus * 8, 20000, 6);
     run<1>("pk_fma 1/SIMD", cus, 20000, 3);
+    run_ramp(cus * 8, "v_pk_fma_f32 on every SIMD, 8 waves each, launches back to back", 0);
+    run_ramp(cus * 8, "the same with 200 us of idle GPU before each launch", 200);
+    run_ramp(cus * 8, "the same with 20 ms of idle GPU before each launch", 20000);
     return 0;
 }
