@@ -74,6 +74,33 @@ for where in ("cuda", "cpu"):
         print(f"q on {where:<4} B={B:<5} poly_score {timeit(fwd):7.1f} us   + backward {timeit(fwd_bwd):7.1f} us   "
               f"ScoreModel.score_and_grad {timeit(sg):7.1f} us   raw dcx_score_grad {timeit(raw):7.1f} us")
 
+# a HIP-graph replay of the same call (VERDICT r4 item 4 asked for the offer): one captured dcx_score_grad on static buffers, replayed
+# after copying the new q into the graph's input - against simply calling the library again
+for B in (50, 4096):
+    m = dc._poly_fused.model(dc.transform, dc.rbf_kernel, dc.support_transformed, dc.rbf_nodes, dev)
+    q_new = (torch.rand(B, 7) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]).to(dev)
+    q_static = q_new.clone()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):          # the split-launch scratch of this stream must exist before the capture
+        m.score_grad_raw(q_static)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        out_static = m.score_grad_raw(q_static)
+    torch.cuda.synchronize()
+
+    def replay():
+        q_static.copy_(q_new)
+        graph.replay()
+        return out_static
+
+    def replay_only():
+        graph.replay()
+        return out_static
+
+    print(f"B={B:<5} raw dcx_score_grad {timeit(lambda: m.score_grad_raw(q_new)):7.1f} us   graph: copy q in + replay {timeit(replay):7.1f} us   "
+          f"replay alone {timeit(replay_only):7.1f} us   (one kernel per call either way: a one-node graph has nothing to amortise)")
+
 # PCIe-inclusive rate at the headline shape: host q in, host score + grad out (pageable and pinned buffers)
 B = 65536
 m = dc._poly_fused.model(dc.transform, dc.rbf_kernel, dc.support_transformed, dc.rbf_nodes, dev)
