@@ -659,7 +659,8 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
     // Measured (profiles/r04_owner_poll.txt): config #2 11.57 -> 11.06 us, config #3's shard 20.6 -> 20.1, Polyharmonic nodes
     // 22.35 -> 21.8; Panda (22 accumulators on 8 waves: three dependent polls per wave) 15.4 -> 15.6, hence acc <= 2 nw.
     if (counters != nullptr && g.red_slots == g.nw && g.nw > 1 && knobs().owner_poll != 0 && (acc <= 2 * g.nw || knobs().owner_poll > 0) &&
-        nblk * nz * g.ys <= (int64_t)m->n_cu && 2 * nblk * nz <= (int64_t)m->n_cu && m->giveup_dev != nullptr && opoll_stream_ok(m->device, st)) {
+        nblk * nz * g.ys <= (int64_t)m->n_cu && 2 * nblk * nz <= (int64_t)m->n_cu && m->giveup_dev != nullptr &&
+        (knobs().owner_poll > 0 || opoll_stream_ok(m->device, st))) {   // (knob owner_poll = 1: the caller vouches for the stream - tests)
         a.pwords = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(part) + (size_t)2 * m->n_cu * (m->Dt + m->Cc) * 64 * sizeof(float));
         a.ptag = ptag;           // this launch's tag: words of any other launch never match (score_kernel.h)
         a.giveup = m->giveup_dev;

@@ -216,6 +216,31 @@ def test_owner_polls_handover_equals_the_counter_protocol_bitwise(ops, name, kno
     knob("owner_poll", -1)
 
 
+def test_owner_polls_on_one_stream_counters_on_the_others(ops, knob):
+    """round 5: owners of concurrent launches on several streams could together fill every workgroup slot before
+    any publisher is dispatched, so the rule gives the owner-polls hand-over to ONE stream per device (the first that asked)
+    and the arrival counters to every other; both produce the same bits, launches interleaved over three streams, and the
+    words of a launch carry that launch's own tag (a second model on the same streams: its own scratch, its own tags)"""
+    d = load("cfg2_baxter_poly1")
+    kind, p0, p1 = case_kernel(d)
+    sup, w = _t(d["sup_x32"].reshape(len(d["sup_x32"]), -1)), _t(d["weights"])
+    m1 = ops.ScoreModel(desc_for("baxter_left"), kind, p0, p1, sup, w)
+    m2 = ops.ScoreModel(desc_for("baxter_left"), kind, p0, p1, sup, 2.0 * w)
+    q = _t(d["q"][:700])
+    knob("qt", 0)   # the split launch, not the 16-configuration tile
+    s0, g0 = m1.score_grad_raw(q)
+    s0, g0 = s0.clone(), g0.clone()
+    streams = [torch.cuda.current_stream(), torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = []
+    for it in range(60):
+        with torch.cuda.stream(streams[it % 3]):
+            outs.append((1.0, m1.score_grad_raw(q)))
+            outs.append((2.0, m2.score_grad_raw(q)))
+    torch.cuda.synchronize()
+    for f, (s, g) in outs:
+        assert torch.equal(s, f * s0) and torch.equal(g, f * g0)
+
+
 @pytest.mark.parametrize("name", ["cfg2_baxter_poly1", "cfg3_baxter_rq_c5"])
 def test_split_launch_finish_modes_agree_bitwise(ops, name, knob):
     """small batches split the supports across blocks; the rows are added either by the last block to arrive
