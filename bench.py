@@ -7,8 +7,9 @@ A "step" = one pass of the hot path (ONE `dcx_score_grad` launch; config #5: one
 of synthetic configurations already resident in HBM.
 
     python bench.py                      # 1 GPU, headline workload
+    python bench.py --gpus N --steps K --warmup W    # N > 1 without a launcher: becomes its own (self_launch) ...
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W [--scaling weak|strong] [--gather per-call|overlapped|bucketed|none]
+        bench.py --gpus N --steps K --warmup W [--scaling weak|strong] [--gather per-call|overlapped|bucketed|none]   # ... or under one
 
 N > 1: one process per GPU, the model replicated, the configuration batch sharded, no data-path collective; the scores
 of EVERY call are all-gathered over RCCL/xGMI (`--gather per-call`, the default: in order on the launch stream, what a
@@ -16,7 +17,10 @@ consumer that needs the scores before its next call sees; `overlapped`: the gath
 sweep of call i+1 on the process group's stream; `graph`: the same inside a captured HIP graph).  `--scaling weak` (default) keeps the per-GPU batch fixed as N grows,
 `--scaling strong` divides the workload's fixed global batch (65536 for headline / config #3, 256 restarts for
 config #5) by N.  With N > 1 the line also carries short measurements of the other variants (`variants`): the
-other scaling mode, the overlapped gather, the gather bucketed every 4 calls, and no gather.
+other scaling mode, the overlapped gather, the gather bucketed every 4 calls, and no gather.  The per-call form is measured and
+parked first (`multi.primary`); of the forms that deliver every call's scores (per-call, overlapped, graph), each timed over
+exactly K steps, the fastest that completed is the line's `value` (`multi.gather`).  Side measurements that hang end after
+DCX_BENCH_SIDE_BUDGET_S (240 s) with the line measured so far.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` and `cpu_baseline`.  The line cannot
 be lost to a side measurement: rank 0 hands the PRIMARY line (timed region + CPU baseline) to a keeper process as soon as
