@@ -263,7 +263,7 @@ int fk_device_copy(int device, const dcx_fk_desc& fk, FkProg** out) {
 struct Knobs {
     std::atomic<int64_t> ys{-1}, nw{-1}, min_rows{-1}, split_finish_kernel{-1}, inlaunch_tiles{-1}, jac_per_class{-1},
         mfma{-1}, traj_fused{-1}, xf{-1}, jac_one_sweep{-1}, train_grid{-1}, fkk{-1}, jt_waves{-1}, hess_ys{-1}, xm{-1},
-        traj_ys{-1}, traj_across{-1}, owner_poll{-1}, solve_threads{-1}, qt{-1};
+        traj_ys{-1}, traj_across{-1}, owner_poll{-1}, solve_threads{-1}, qt{-1}, giveup_inject{-1};
     Knobs() {
         auto rd = [](const char* name, std::atomic<int64_t>& dst, bool flag) {
             if (const char* e = std::getenv(name)) dst = flag ? 1 : std::atoll(e);
@@ -551,6 +551,10 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
     if (!qt) g = pick_geometry(m, B * nz, acc, true);
     float* part = nullptr;
     uint32_t ptag = 0;
+    if (knobs().giveup_inject > 0 && m->giveup_host) {   // fault injection (tests): as if an owner of the previous launch had given up
+        knobs().giveup_inject = -1;
+        *m->giveup_host = 1;
+    }
     if (m->giveup_host && *m->giveup_host)
         return fail(DCX_ERR_HIP, "an earlier split launch of this model gave up waiting for its peer workgroups (owner-polls hand-over: "
                                  "they were never scheduled - the GPU is shared with another process?); its results were NaN. "
@@ -715,7 +719,7 @@ int dcx_debug_set(const char* name, int64_t value) {
     const std::string n(name);
     std::atomic<int64_t>* dst = n == "ys" ? &k.ys : n == "nw" ? &k.nw : n == "min_rows" ? &k.min_rows
         : n == "split_finish_kernel" ? &k.split_finish_kernel : n == "inlaunch_tiles" ? &k.inlaunch_tiles
-        : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : n == "traj_fused" ? &k.traj_fused : n == "xf" ? &k.xf : n == "jac_one_sweep" ? &k.jac_one_sweep : n == "train_grid" ? &k.train_grid : n == "fkk" ? &k.fkk : n == "jt_waves" ? &k.jt_waves : n == "hess_ys" ? &k.hess_ys : n == "xm" ? &k.xm : n == "traj_ys" ? &k.traj_ys : n == "traj_across" ? &k.traj_across : n == "owner_poll" ? &k.owner_poll : n == "solve_threads" ? &k.solve_threads : n == "qt" ? &k.qt : nullptr;
+        : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : n == "traj_fused" ? &k.traj_fused : n == "xf" ? &k.xf : n == "jac_one_sweep" ? &k.jac_one_sweep : n == "train_grid" ? &k.train_grid : n == "fkk" ? &k.fkk : n == "jt_waves" ? &k.jt_waves : n == "hess_ys" ? &k.hess_ys : n == "xm" ? &k.xm : n == "traj_ys" ? &k.traj_ys : n == "traj_across" ? &k.traj_across : n == "owner_poll" ? &k.owner_poll : n == "solve_threads" ? &k.solve_threads : n == "qt" ? &k.qt : n == "giveup_inject" ? &k.giveup_inject : nullptr;
     if (!dst) return fail(DCX_ERR_INVALID, "unknown knob: " + n);
 #ifndef DCX_WITH_MATRIX_FORMS
     if ((dst == &k.mfma || dst == &k.xm) && value > 0)

@@ -216,6 +216,27 @@ def test_owner_polls_handover_equals_the_counter_protocol_bitwise(ops, name, kno
     knob("owner_poll", -1)
 
 
+def test_a_launch_that_gave_up_is_reported_by_the_next_one(ops, knob):
+    """round 5: an owner block whose peers never publish gives up after seconds, turns its tile into NaN and sets a
+    host-visible flag on the model; the model's NEXT launch must fail loudly instead of computing on (knob giveup_inject sets the
+    flag the way the kernel would).  Other models are not affected."""
+    from diffco_amd._lib import DcxError
+    d = load("cfg2_baxter_poly1")
+    kind, p0, p1 = case_kernel(d)
+    sup, w = _t(d["sup_x32"].reshape(len(d["sup_x32"]), -1)), _t(d["weights"])
+    m1 = ops.ScoreModel(desc_for("baxter_left"), kind, p0, p1, sup, w)
+    m2 = ops.ScoreModel(desc_for("baxter_left"), kind, p0, p1, sup, w)
+    q = _t(d["q"][:300])
+    s0, _ = m1.score_grad_raw(q)
+    knob("giveup_inject", 1)
+    with pytest.raises(DcxError, match="gave up waiting"):
+        m1.score_grad_raw(q)
+    with pytest.raises(DcxError, match="gave up waiting"):      # sticky: this model's results can no longer be trusted
+        m1.score_raw(q)
+    s2, _ = m2.score_grad_raw(q)                                  # another model of the same shape is fine
+    assert torch.equal(s2, s0)
+
+
 def test_owner_polls_on_one_stream_counters_on_the_others(ops, knob):
     """round 5: owners of concurrent launches on several streams could together fill every workgroup slot before
     any publisher is dispatched, so the rule gives the owner-polls hand-over to ONE stream per device (the first that asked)
