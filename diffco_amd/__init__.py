@@ -13,10 +13,11 @@ from . import deprecated  # noqa: F401
 from . import optim  # noqa: F401
 from . import sharded  # noqa: F401
 from . import traj  # noqa: F401
+from . import escape  # noqa: F401
 from . import urdf  # noqa: F401
 from .urdf import URDFRobotFK, MultiURDFRobotFK  # noqa: F401
 from . import collision_checkers  # noqa: F401
 from .collision_checkers import RBFDiffCo, ForwardKinematicsDiffCo  # noqa: F401
 from .traj import fused_adam_traj_optimize  # noqa: F401
 
-__all__ = ["kernel", "model", "utils", "optim", "sharded", "traj", "fused_adam_traj_optimize", "urdf", "URDFRobotFK", "MultiURDFRobotFK", "collision_checkers", "RBFDiffCo", "ForwardKinematicsDiffCo", "deprecated", "DiffCo", "MultiDiffCo", "DiffCoBeta"]
+__all__ = ["kernel", "model", "utils", "optim", "sharded", "traj", "escape", "fused_adam_traj_optimize", "urdf", "URDFRobotFK", "MultiURDFRobotFK", "collision_checkers", "RBFDiffCo", "ForwardKinematicsDiffCo", "deprecated", "DiffCo", "MultiDiffCo", "DiffCoBeta"]

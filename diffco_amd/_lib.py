@@ -39,6 +39,9 @@ SYMBOLS = {
     "dcx_score_hinge_grad": (C.c_int, [C.c_void_p, _c_fp, C.c_int64, C.c_float, C.c_float, _c_fp, _c_fp, C.c_void_p]),
     "dcx_traj_adam_step": (C.c_int, [C.c_int, C.POINTER(FkDesc), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "dcx_traj_adam_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "dcx_escape_work_bytes": (C.c_size_t, [C.c_void_p, C.c_int64]),
+    "dcx_escape_adam": (C.c_int, [C.c_void_p, _c_fp, C.c_int64, _c_fp, C.c_void_p, C.c_void_p, C.c_size_t, _c_fp, C.c_void_p,
+                                  C.c_void_p]),
     "dcx_train_perceptron": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_float), C.c_float, _c_fp, C.c_int64, C.c_int32, _c_fp,
                                        C.c_int32, _c_fp, _c_fp, _c_fp, C.c_int32, _c_fp, C.c_void_p]),
     "dcx_train_perceptron_ex": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_float), C.c_float, _c_fp, C.c_int64, C.c_int32, _c_fp,
@@ -65,6 +68,12 @@ class TrajOpts(C.Structure):
     """ctypes mirror of dcx_traj_opts (include/dcx.h)"""
     _fields_ = [(n, C.c_float) for n in ("lr", "beta1", "beta2", "eps", "w_diff", "w_collision", "w_max_move",
                                          "w_joint_limit", "safety_margin", "max_speed", "valid_tol", "grad_tol")]
+
+
+class EscapeOpts(C.Structure):
+    """ctypes mirror of dcx_escape_opts (include/dcx.h)"""
+    _fields_ = [(n, C.c_float) for n in ("lr", "beta1", "beta2", "eps")] + [
+        (n, C.c_int32) for n in ("n_steps", "record_freq", "joint", "reserved")] + [("wrap_mask", C.c_uint64)]
 
 
 _lib = None

@@ -1384,6 +1384,80 @@ int dcx_traj_adam_run(const dcx_model* m, const dcx_traj_state* st, const dcx_tr
     return DCX_OK;
 }
 
+// ---- escape from collision (scripts/escape.py:19-38 as launches on the caller's stream) ----------------------------------------
+namespace {
+struct EscapeWork {
+    size_t m_off, v_off, score_off, grad_off, total;
+};
+EscapeWork escape_work(int dof, int C, int64_t B) {
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    EscapeWork w;
+    const size_t qd = up((size_t)B * dof * sizeof(float));
+    w.m_off = 0;
+    w.v_off = qd;
+    w.score_off = 2 * qd;
+    w.grad_off = w.score_off + up((size_t)B * C * sizeof(float));
+    w.total = w.grad_off + qd;
+    return w;
+}
+}  // namespace
+
+size_t dcx_escape_work_bytes(const dcx_model* m, int64_t B) {
+    if (!m || B <= 0) return 0;
+    return escape_work(m->fk.dof, m->C, B).total;
+}
+
+int dcx_escape_adam(const dcx_model* m, float* q, int64_t B, const float* margin, const dcx_escape_opts* opt, void* work,
+                    size_t work_bytes, float* history, int32_t* steps, void* stream) {
+    if (!m) return fail(DCX_ERR_INVALID, "model is NULL");
+    if (!opt) return fail(DCX_ERR_INVALID, "escape options are NULL");
+    if (B < 0 || (B > 0 && (!q || !steps || !work))) return fail(DCX_ERR_INVALID, "q / steps / work is NULL or B < 0");
+    if (opt->n_steps < 1 || opt->record_freq < 0) return fail(DCX_ERR_INVALID, "escape needs n_steps >= 1 and record_freq >= 0");
+    if (!(opt->lr > 0.f) || !(opt->beta1 >= 0.f && opt->beta1 < 1.f) || !(opt->beta2 >= 0.f && opt->beta2 < 1.f))
+        return fail(DCX_ERR_INVALID, "Adam options out of range");
+    if (B == 0) return DCX_OK;
+    const EscapeWork w = escape_work(m->fk.dof, m->C, B);
+    if (work_bytes < w.total) return fail(DCX_ERR_INVALID, "escape workspace is smaller than dcx_escape_work_bytes");
+    if (int rc = set_device(m->device)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    char* base = (char*)work;
+    hipError_t e = hipMemsetAsync(base, 0, w.score_off, st);  // both moments
+    if (e == hipSuccess) e = hipMemsetAsync(steps, 0, 2 * sizeof(int32_t) * (opt->joint ? 1 : (size_t)B), st);
+    if (e != hipSuccess) return fail_hip(e, "escape workspace initialisation");
+    EscapeArgs a{};
+    a.q = q;
+    a.score = (const float*)(base + w.score_off);
+    a.grad = (const float*)(base + w.grad_off);
+    a.margin = margin;
+    a.adam_m = (float*)(base + w.m_off);
+    a.adam_v = (float*)(base + w.v_off);
+    a.history = history;
+    a.steps = steps;
+    a.B = B;
+    a.dof = m->fk.dof;
+    a.C = m->C;
+    a.record_freq = opt->record_freq;
+    a.joint = opt->joint ? 1 : 0;
+    a.wrap_mask = opt->wrap_mask;
+    a.lr = opt->lr;
+    a.beta1 = opt->beta1;
+    a.beta2 = opt->beta2;
+    a.eps = opt->eps;
+    for (int s = 0; s < opt->n_steps; ++s) {
+        // upstream = nullptr: the gradient of the row's sum over the classes (the folded weight column)
+        if (int rc = run_score(m, q, B, nullptr, const_cast<float*>(a.score), const_cast<float*>(a.grad), MODE_GRAD_ROW, -1,
+                               m->fk.dof, st))
+            return rc;
+        e = launch_escape_step(a, s, st);
+        if (e != hipSuccess) return fail_hip(e, "escape step launch");
+    }
+    if (history) {
+        e = launch_escape_finish(a, st);
+        if (e != hipSuccess) return fail_hip(e, "escape finish launch");
+    }
+    return DCX_OK;
+}
+
 int dcx_train_perceptron(int device, int kernel_kind, const float* kparams, float beta, const float* feats, int64_t N,
                          int32_t D, const float* y, int32_t C, float* gains, float* hypothesis, float* kernel_matrix,
                          int32_t max_iteration, int32_t* info, void* stream) {

@@ -102,5 +102,21 @@ constexpr int kTrainGridMaxN = 128 * 1024;  // 128 workgroups x 1024 samples (tr
 // traj_kernels.hip
 hipError_t launch_traj_adam_step(const FkProg* fk_dev, const dcx_fk_desc& fk, const dcx_traj_state& st,
                                  const dcx_traj_opts& opt, int step, hipStream_t stream);
+// the update half of dcx_escape_adam: pointers into the caller's workspace, one configuration per lane
+struct EscapeArgs {
+    float* q;             // [B, dof] in/out
+    const float* score;   // [B, C]   this step's dist_est(q)
+    const float* grad;    // [B, dof] this step's d sum_c score_c / d q
+    const float* margin;  // [C] or nullptr
+    float *adam_m, *adam_v;
+    float* history;       // [n_slots, B, dof] or nullptr
+    int32_t* steps;       // [n_loops, 2]: evaluations, Adam steps (traj_kernels.hip)
+    int64_t B;
+    int32_t dof, C, step, record_freq, joint;
+    uint64_t wrap_mask;
+    float lr, beta1, beta2, eps, bias1, bias2_sqrt;
+};
+hipError_t launch_escape_step(EscapeArgs a, int step, hipStream_t stream);   // step is 0-based
+hipError_t launch_escape_finish(const EscapeArgs& a, hipStream_t stream);
 
 }  // namespace dcx

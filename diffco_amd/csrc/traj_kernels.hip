@@ -202,4 +202,136 @@ hipError_t launch_traj_adam_step(const FkProg* fk_dev, const dcx_fk_desc& fk, co
     return hipGetLastError();
 }
 
+// ---- escape from collision: the update half of dcx_escape_adam (include/dcx.h) ------------------------------------------------
+// The loop of OptimSampler.optim_escape (scripts/escape.py:19-38) with its decisions kept on the device: the fused sweep has
+// written score [B, C] and grad [B, dof] of THIS step (gradient of sum_c score_c); one lane = one configuration decides
+// whether its loop goes on, records, takes the Adam step (the arithmetic of traj_adam_step_kernel above) and wraps.
+//   steps[loop][0]   evaluations of dist_est so far      steps[loop][1]   Adam steps taken so far
+// A loop that goes on takes one step per evaluation, a loop that stops has evaluated once more than it stepped: "stopped" is
+// steps[loop][0] != steps[loop][1], and no other flag is kept (joint form: one loop, index 0).
+namespace {
+
+__device__ __forceinline__ float escape_wrap2pi(float q) {  // utils.py:51-52 on fp32 tensors: (pi + q) % (2 pi) - pi, Python's %
+    const float pi = 3.14159265358979323846f, two_pi = 6.28318530717958647692f;
+    float r = fmodf(pi + q, two_pi);
+    if (r != 0.f && r < 0.f) r += two_pi;
+    return r - pi;
+}
+
+// joint form, before the update: ONE workgroup sums score - margin over the whole batch (escape.py:26) and takes the loop's
+// decision, so that the update launch only reads it
+// the whole batch's excess (escape.py:26), summed in double by one workgroup of 1024 lanes; every lane returns the sum
+__device__ __forceinline__ double escape_total_excess(const EscapeArgs& a, double* part) {
+    double acc = 0.0;
+    const int64_t n = a.B * a.C;
+    for (int64_t e = threadIdx.x; e < n; e += blockDim.x) {
+        const float mg = a.margin ? a.margin[e % a.C] : 0.f;
+        acc += (double)(a.score[e] - mg);
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+        __syncthreads();
+    }
+    return part[0];
+}
+
+// configuration b of a loop that goes on: record, Adam step (the arithmetic of traj_adam_step_kernel), wrap
+__device__ __forceinline__ void escape_row_step(const EscapeArgs& a, int64_t b) {
+    const int dof = a.dof;
+    float* q = a.q + b * dof;
+    if (a.history && a.record_freq > 0 && a.step % a.record_freq == 0) {
+        float* h = a.history + ((int64_t)(a.step / a.record_freq) * a.B + b) * dof;
+        for (int i = 0; i < dof; ++i) h[i] = q[i];
+    }
+    for (int i = 0; i < dof; ++i) {
+        const float g = a.grad[b * dof + i];
+        float m = a.adam_m[b * dof + i], v = a.adam_v[b * dof + i];
+        m = fmaf(a.beta1, m, (1.f - a.beta1) * g);
+        v = fmaf(a.beta2, v, (1.f - a.beta2) * g * g);
+        const float denom = sqrtf(v) / a.bias2_sqrt + a.eps;
+        float qn = traj_adam_q(q[i], a.lr, a.bias1, m, denom);
+        if ((a.wrap_mask >> i) & 1ull) qn = escape_wrap2pi(qn);
+        a.adam_m[b * dof + i] = m;
+        a.adam_v[b * dof + i] = v;
+        q[i] = qn;
+    }
+}
+
+// joint form, before the update: ONE workgroup sums score - margin over the whole batch and takes the loop's decision, so that
+// the update launch only reads it
+__global__ __launch_bounds__(1024) void escape_decide_kernel(const EscapeArgs a) {
+    __shared__ double part[1024];
+    if (a.steps[0] != a.steps[1]) return;  // workgroup-uniform: stopped in an earlier step
+    const double excess = escape_total_excess(a, part);
+    if (threadIdx.x == 0) {
+        a.steps[0] += 1;
+        if (excess > 0.0) a.steps[1] += 1;  // the update launch behind this one takes the step
+    }
+}
+
+// joint form, B <= 1024: decision and update in the same workgroup (same sums, same steps as the two launches)
+__global__ __launch_bounds__(1024) void escape_joint_small_kernel(const EscapeArgs a) {
+    __shared__ double part[1024];
+    if (a.steps[0] != a.steps[1]) return;
+    const double excess = escape_total_excess(a, part);
+    __syncthreads();                       // everybody has read steps[] and part[0]
+    if (threadIdx.x == 0) {
+        a.steps[0] += 1;
+        if (excess > 0.0) a.steps[1] += 1;
+    }
+    if (excess > 0.0 && (int64_t)threadIdx.x < a.B) escape_row_step(a, threadIdx.x);
+}
+
+__global__ __launch_bounds__(256) void escape_update_kernel(const EscapeArgs a) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    if (a.joint) {
+        // escape_decide_kernel ran in front of this launch: it counted this step's Adam step iff the loop goes on
+        if (a.steps[1] != a.step + 1) return;
+    } else {
+        if (a.steps[2 * b] != a.steps[2 * b + 1]) return;
+        float excess = 0.f;
+        for (int c = 0; c < a.C; ++c) excess += a.score[b * a.C + c] - (a.margin ? a.margin[c] : 0.f);
+        a.steps[2 * b] += 1;
+        if (excess <= 0.f) return;
+        a.steps[2 * b + 1] += 1;
+    }
+    escape_row_step(a, b);
+}
+
+// after the last step: every loop's final configuration into the slot behind its last record (escape.py:37)
+__global__ __launch_bounds__(256) void escape_finish_kernel(const EscapeArgs a) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    const int updates = a.steps[a.joint ? 1 : 2 * b + 1];
+    const int slot = a.record_freq > 0 ? (updates + a.record_freq - 1) / a.record_freq : 0;
+    float* h = a.history + ((int64_t)slot * a.B + b) * a.dof;
+    for (int i = 0; i < a.dof; ++i) h[i] = a.q[b * a.dof + i];
+}
+
+}  // namespace
+
+hipError_t launch_escape_step(EscapeArgs a, int step, hipStream_t stream) {
+    a.step = step;
+    a.bias1 = (float)(1.0 - pow((double)a.beta1, (double)(step + 1)));
+    a.bias2_sqrt = (float)sqrt(1.0 - pow((double)a.beta2, (double)(step + 1)));
+    if (a.joint && a.B <= 1024) {   // the usual call (one configuration): decision and update in one workgroup, one launch
+        escape_joint_small_kernel<<<1, 1024, 0, stream>>>(a);
+        return hipGetLastError();
+    }
+    if (a.joint) {
+        escape_decide_kernel<<<1, 1024, 0, stream>>>(a);
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    }
+    escape_update_kernel<<<dim3((unsigned)((a.B + 255) / 256)), 256, 0, stream>>>(a);
+    return hipGetLastError();
+}
+
+hipError_t launch_escape_finish(const EscapeArgs& a, hipStream_t stream) {
+    escape_finish_kernel<<<dim3((unsigned)((a.B + 255) / 256)), 256, 0, stream>>>(a);
+    return hipGetLastError();
+}
+
 }  // namespace dcx

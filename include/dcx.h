@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DCX_VERSION 107 /* 0.1.6: dcx_debug_clock_probe; the matrix-core forms are a build option (dcx_debug_set("mfma" / "xm", 1) -> DCX_ERR_UNSUPPORTED without them); owner-polls words tagged per launch, give-up reported by the model's next launch; 0.1.5: dcx_model_create_ex / dcx_model_update (rows packed on the device); 0.1.4: dcx_train_perceptron_ex (per-call flags); 0.1.3: dcx_fk_desc carries the DCX_FK_TREE section; 32 control points, D <= 96 */
+#define DCX_VERSION 108 /* 0.1.7: dcx_escape_adam (the escape loop of scripts/escape.py on the stream); 0.1.6: dcx_debug_clock_probe; the matrix-core forms are a build option (dcx_debug_set("mfma" / "xm", 1) -> DCX_ERR_UNSUPPORTED without them); owner-polls words tagged per launch, give-up reported by the model's next launch; 0.1.5: dcx_model_create_ex / dcx_model_update (rows packed on the device); 0.1.4: dcx_train_perceptron_ex (per-call flags); 0.1.3: dcx_fk_desc carries the DCX_FK_TREE section; 32 control points, D <= 96 */
 
 /* ---- status codes ---------------------------------------------------------------- */
 #define DCX_OK 0
@@ -288,6 +288,40 @@ int dcx_traj_adam_step(int device, const dcx_fk_desc* fk, const dcx_traj_state* 
  * robot's FK.  st->col_score / st->col_grad are used as scratch ([R*W], [R*W, dof], non-const here).      */
 int dcx_traj_adam_run(const dcx_model* model, const dcx_traj_state* st, const dcx_traj_opts* opt,
                       int32_t first_step, int32_t n_iters, void* stream);
+
+/* ---- escape from collision (caller of the path; SURVEY.md §8f-2 names it beside the trajectory step) -- */
+/* Batched restatement of OptimSampler.optim_escape (scripts/escape.py:19-38): Adam on the configurations themselves,
+ *   for step in range(n_steps):
+ *       excess = sum(dist_est(q) - safety_margin)          # escape.py:26 (no clamp: the loop stops instead)
+ *       if excess <= 0: break                              # :27-28
+ *       [record q]; q <- Adam(q, d excess / d q); q <- post_transform(q)       # :29-36
+ * entirely on the caller's stream: per step one fused score + gradient sweep (the gradient of sum_c score_c: the
+ * margin is a constant) and one update launch; nothing is read back, the loop's decisions stay on the device.
+ *   joint != 0: ONE loop for the whole batch, as the reference runs it - `excess` is the sum over all B configurations
+ *               and all classes, and everybody stops together;  steps [1, 2]
+ *   joint == 0: B independent loops advanced together - a configuration stops (and is left where it is) as soon as its
+ *               own sum over the classes is <= 0;  steps [B, 2]
+ * steps (int32, device, out): per loop (evaluations of dist_est = the reference's second return value, escape.py:38;
+ *   Adam steps taken - one fewer when the loop stopped on its last evaluation).
+ * history (device, out, may be NULL): [n_slots, B, dof] with n_slots = (record_freq > 0 ? ceil(n_steps / record_freq) : 0)
+ *   + 1: slot s / record_freq holds q BEFORE the update of step s when record_freq divides s (escape.py:29-30), and the
+ *   slot behind a loop's last record its final configuration (:37); later slots are not written.  q [B, dof] is advanced
+ *   in place and holds the final configurations either way.
+ * margin [C] device (NULL = 0).  wrap_mask bit i: coordinate i is wrapped to [-pi, pi) after every step - all ones below
+ *   dof for post_transform = utils.wrap2pi (utils.py:51-52), bit 2 for utils.se2_wrap2pi (:54-55), 0 for None.
+ * work: dcx_escape_work_bytes(model, B) bytes of device memory, the caller's (Adam moments, score and gradient of the
+ *   current step); initialised here.  No allocation, no synchronisation.                          */
+typedef struct dcx_escape_opts {
+    float lr, beta1, beta2, eps;       /* torch.optim.Adam: lr 5e-2 (escape.py:12), betas 0.9 / 0.999, eps 1e-8        */
+    int32_t n_steps;                   /* N_WAYPOINTS (escape.py:10): the most checks a loop makes                      */
+    int32_t record_freq;               /* escape.py:13; 0 or None = final configuration only                            */
+    int32_t joint;
+    int32_t reserved;                  /* 0                                                                             */
+    uint64_t wrap_mask;
+} dcx_escape_opts;
+size_t dcx_escape_work_bytes(const dcx_model* m, int64_t B);
+int dcx_escape_adam(const dcx_model* m, float* q, int64_t B, const float* margin, const dcx_escape_opts* opt, void* work,
+                    size_t work_bytes, float* history, int32_t* steps, void* stream);
 
 /* ---- kernel-perceptron trainer (producer of the path's state) ----------------------- */
 /* DiffCo.train_perceptron kernel_perceptrons.py:98-137 and MultiDiffCo.train_perceptron

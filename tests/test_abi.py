@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"libdcx.so does not export {n}"
     assert set(names) == set(_lib.SYMBOLS), "ctypes table and header disagree"
-    assert lib.dcx_version() == 107
+    assert lib.dcx_version() == 108
     assert isinstance(lib.dcx_device_count(), int)
 
 
@@ -61,6 +61,19 @@ def test_traj_struct_layouts_match_c(tmp_path):
     out = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
     assert out == [ctypes.sizeof(TrajState), TrajState.path.offset, TrajState.col_score.offset, TrajState.steps.offset,
                    ctypes.sizeof(TrajOpts), TrajOpts.valid_tol.offset]
+
+
+def test_escape_opts_layout_matches_c(tmp_path):
+    from diffco_amd._lib import EscapeOpts
+    prog = tmp_path / "sz3.c"
+    prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "dcx.h"\n'
+                    'int main(){printf("%zu %zu %zu %zu %zu", sizeof(dcx_escape_opts), offsetof(dcx_escape_opts, eps),'
+                    ' offsetof(dcx_escape_opts, n_steps), offsetof(dcx_escape_opts, joint), offsetof(dcx_escape_opts, wrap_mask));}')
+    exe = tmp_path / "sz3"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)], check=True)
+    out = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    assert out == [ctypes.sizeof(EscapeOpts), EscapeOpts.eps.offset, EscapeOpts.n_steps.offset, EscapeOpts.joint.offset,
+                   EscapeOpts.wrap_mask.offset]
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")

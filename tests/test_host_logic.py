@@ -418,3 +418,48 @@ def test_fused_constraint_jacobian_chain_rule_on_the_oracle():
     x = prob.init_path[1:-1].reshape(-1).numpy()
     J = terms._jac_collision_fused(x, OracleModel())
     assert relerr(J, d["jac0_f64"]) < 2e-6   # (the dense points travel as fp32 to the launch)
+
+
+def test_escape_host_loop_against_the_reference_record():
+    """OptimSampler's host loop (the route a foreign dist_est takes) on a torch-only spline score reproduces the records the
+    REFERENCE's OptimSampler made (tests/golden/escape.npz: scripts/escape.py:19-38 run on reference checkers), evaluation
+    and record counts exactly; and the rules that decide whether a loop can run as dcx_escape_adam"""
+    from diffco_amd import utils
+    from diffco_amd.escape import OptimSampler, resampling_escape
+    d = load("escape")
+    rob = TorchDHRobot(make_robot("baxter_left"))
+    sup = rob.fkine(torch.from_numpy(d["bx_sup_q"]).double()).reshape(len(d["bx_sup_q"]), -1)
+    w = torch.from_numpy(d["bx_w"]).double()
+    kern = TorchKernel("poly1", 1, 1.0)
+
+    def dist_est(p):
+        s = kern(rob.fkine(p.double()).reshape(-1, sup.shape[1]), sup) @ w
+        return s.to(p.dtype)
+    starts = torch.from_numpy(d["bx_starts"])
+    assert relerr(dist_est(starts).numpy(), d["bx_score0"].reshape(-1)) < 1e-5
+    m1, m3 = float(d["bx_margin1"]), float(d["bx_margin3"])
+    for tag, start, args in (
+            ("bx_single", starts[:1], {"N_WAYPOINTS": 20, "safety_margin": m1, "lr": 5e-2, "record_freq": 1}),
+            ("bx_flat", starts[0], {"N_WAYPOINTS": 20, "safety_margin": m1, "lr": 5e-2, "record_freq": 3}),
+            ("bx_three", starts[:3], {"N_WAYPOINTS": 12, "safety_margin": m3, "lr": 2e-2, "record_freq": 2,
+                                      "opt_args": {"lr": 2e-2, "betas": (0.8, 0.99), "eps": 1e-6}})):
+        sampler = OptimSampler(rob, dist_est, args)
+        hist, checks = sampler.optim_escape(start)
+        assert sampler.last_route == "host" and checks == int(d[tag + "_checks"])
+        assert tuple(hist.shape) == d[tag + "_hist"].shape and relerr(hist.numpy(), d[tag + "_hist"]) < 1e-4
+        assert torch.equal(hist[0], start)          # the first record is the start itself (escape.py:29-30)
+    # the batch entry point has no host form
+    with pytest.raises(TypeError):
+        OptimSampler(rob, dist_est, {}).optim_escape_batch(starts)
+    # what the fused form accepts
+    s = OptimSampler(rob, dist_est, {"lr": 0.2})
+    assert s._adam() == (0.2, 0.9, 0.999, 1e-8) and s._wrap_mask(7) == 0
+    assert OptimSampler(rob, dist_est, {"opt_args": {"lr": 0.1, "betas": (0.5, 0.9), "eps": 1e-6}})._adam() == (0.1, 0.5, 0.9, 1e-6)
+    assert OptimSampler(rob, dist_est, {"opt_args": {"lr": 0.1, "weight_decay": 0.1}})._adam() is None
+    assert OptimSampler(rob, dist_est, {"opt_args": {"lr": 0.1, "amsgrad": True}})._adam() is None
+    assert OptimSampler(rob, dist_est, {"optimizer": torch.optim.SGD})._adam() is None
+    assert OptimSampler(rob, dist_est, {"post_transform": utils.wrap2pi})._wrap_mask(7) == 127
+    assert OptimSampler(rob, dist_est, {"post_transform": utils.se2_wrap2pi})._wrap_mask(3) == 4
+    assert OptimSampler(rob, dist_est, {"post_transform": lambda x: x})._wrap_mask(3) is None
+    cfg = resampling_escape(rob)
+    assert cfg.shape == (1, 7) and bool(((cfg >= rob.limits[:, 0]) & (cfg <= rob.limits[:, 1])).all())

@@ -714,6 +714,89 @@ def gen_optim_scipy(out, robots):
          tc_maxiter=np.array(6))
 
 
+def gen_escape(out, robots):
+    """Row f2's escape variant: the reference's OptimSampler.optim_escape (scripts/escape.py:19-38), imported
+    from where it lies and run unmodified on reference checkers, in the three call patterns the reference's scripts use:
+    scripts/2d_escape.py:98-110 (record every step, per-class margins), scripts/compare_sampling.py:177-195 (three Adam steps
+    with wrap2pi on one random configuration at a time, last configuration only) and a batch that is ONE loop."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_escape", f"{REF}/scripts/escape.py")
+    esc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(esc)
+    gen = torch.Generator().manual_seed(1700)
+    arrs = {}
+
+    def run(tag, rob, dist_est, starts, args, one_loop):
+        """one_loop: `starts` is one start_cfg; otherwise every row is its own call with a [1, dof] start"""
+        sampler = esc.OptimSampler(rob, dist_est, dict(args))
+        if one_loop:
+            h, n = sampler.optim_escape(starts.clone())
+            arrs[tag + "_hist"], arrs[tag + "_checks"] = h.detach(), np.array(n)
+            print(f"  {tag}: {n} checks, {len(h)} records")
+            return
+        finals, checks, hists = [], [], []
+        for b in range(len(starts)):
+            h, n = sampler.optim_escape(starts[b:b + 1].clone())
+            finals.append(h[-1, 0].detach()); checks.append(n); hists.append(h[:, 0].detach())
+        width = max(len(h) for h in hists)
+        arrs[tag + "_final"], arrs[tag + "_checks"] = torch.stack(finals), np.array(checks)
+        arrs[tag + "_nrec"] = np.array([len(h) for h in hists])
+        arrs[tag + "_hist"] = torch.stack([torch.cat([h, h[-1:].expand(width - len(h), -1)]) for h in hists], dim=1)
+        print(f"  {tag}: checks {checks}")
+
+    # ---- Baxter, Polyharmonic(1, 1) spline score (new API poly_score), C = 1 ---------------------------------------
+    rob = robots["baxter_left"]
+    sup_q = rand_cfgs(rob, 200, gen)
+    w = torch.randn(200, generator=gen) * 0.05 + 0.004
+    dc = new_diffco(rob, "poly", (1, 1.0), sup_q, w, "poly")
+    starts = rand_cfgs(rob, 12, gen)
+    s0 = dc.poly_score(starts).detach()
+    arrs.update(bx_sup_q=sup_q, bx_w=w, bx_starts=starts, bx_score0=s0)
+    m1 = float(s0[0]) - 0.12            # a margin the first start reaches after some steps
+    arrs["bx_margin1"] = np.array(m1, dtype=np.float32)
+    run("bx_single", rob, dc.poly_score, starts[:1], {"N_WAYPOINTS": 20, "safety_margin": m1, "lr": 5e-2, "record_freq": 1}, True)
+    run("bx_flat", rob, dc.poly_score, starts[0], {"N_WAYPOINTS": 20, "safety_margin": m1, "lr": 5e-2, "record_freq": 3}, True)
+    m3 = float(s0[:3].mean()) - 1e3      # never reached: the loop runs out of steps
+    arrs["bx_margin3"] = np.array(m3, dtype=np.float32)
+    run("bx_three", rob, dc.poly_score, starts[:3], {"N_WAYPOINTS": 12, "safety_margin": m3, "lr": 2e-2, "record_freq": 2,
+                                                      "opt_args": {"lr": 2e-2, "betas": (0.8, 0.99), "eps": 1e-6}}, True)
+    mb = float(s0.median())
+    arrs["bx_marginb"] = np.array(mb, dtype=np.float32)
+    run("bx_batch", rob, dc.poly_score, starts, {"N_WAYPOINTS": 15, "safety_margin": mb - 0.05, "lr": 5e-2, "record_freq": 4}, False)
+
+    # ---- planar 3-link arm, three classes (old MultiDiffCo.rbf_score), per-class margins, wrap2pi: compare_sampling's options
+    rob = robots["planar3"]
+    S, C = 150, 3
+    sup_q = rand_cfgs(rob, S, gen)
+    W = torch.randn((S, C), generator=gen) * 0.1 + 0.01
+    md = R.old_MultiDiffCo.MultiDiffCo.__new__(R.old_MultiDiffCo.MultiDiffCo)
+    md.fkine, md.support_points, md.support_fkine = rob.fkine, sup_q, fk32(rob, sup_q).reshape(S, -1)
+    md.rbf_kernel, md.rbf_nodes, md.num_class = make_kernel("poly", (1, 1.0)), W, C
+    starts = rand_cfgs(rob, 16, gen) * 1.5          # some start outside [-pi, pi): the wrap matters
+    s0 = md.rbf_score(starts).detach()
+    margin = s0.median(dim=0).values - 0.3
+    arrs.update(pl_sup_q=sup_q, pl_w=W, pl_starts=starts, pl_score0=s0, pl_margin=margin)
+    opts = {"N_WAYPOINTS": 3, "safety_margin": margin, "lr": 0.2, "record_freq": None, "post_transform": R.utils.wrap2pi,
+            "optimizer": torch.optim.Adam}
+    run("pl_batch", rob, md.rbf_score, starts, opts, False)
+    run("pl_long", rob, md.rbf_score, starts[:6], dict(opts, N_WAYPOINTS=20, record_freq=1, lr=0.1), False)
+
+    # ---- SE(2) body, RQ perceptron score (new API score), se2_wrap2pi ------------------------------------------
+    rob = robots["se2"]
+    sup_q = rand_cfgs(rob, 120, gen)
+    g = torch.randn(120, generator=gen) * 0.5 + 0.2
+    dc2 = new_diffco(rob, "rq", (0.02, 2), sup_q, g, "score")   # a kernel as wide as the workspace (limits +-10)
+    starts = rand_cfgs(rob, 8, gen)
+    starts[:, 2] *= 1.8
+    s0 = dc2.score(starts).detach()
+    arrs.update(se2_sup_q=sup_q, se2_w=g, se2_starts=starts, se2_score0=s0, se2_kparams=np.array([0.02, 2.0]))
+    print("  se2 scores at the starts:", [round(float(v), 3) for v in s0])
+    run("se2_batch", rob, dc2.score, starts, {"N_WAYPOINTS": 10, "safety_margin": float(s0.median()) - 0.5, "lr": 0.1,
+                                              "record_freq": 3, "post_transform": R.utils.se2_wrap2pi}, False)
+    arrs["se2_margin"] = np.array(float(s0.median()) - 0.5, dtype=np.float32)
+    save(out, "escape", **arrs)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
@@ -737,6 +820,8 @@ def main():
         print("second derivatives"); gen_hess(out, robots)
     if args.only in (None, "all", "optim_scipy"):
         print("SLSQP / trust-constr drivers and their collision constraint"); gen_optim_scipy(out, robots)
+    if args.only in (None, "all", "escape"):
+        print("escape loops (scripts/escape.py)"); gen_escape(out, robots)
     with open(os.path.join(out, "MANIFEST.json"), "w") as f:
         json.dump({"generator": "tools/make_golden.py", "torch": torch.__version__, "numpy": np.__version__,
                    "reference": "ucsdarclab/diffco @ /root/reference (2025-03-21)",
