@@ -73,7 +73,7 @@ class TrajOpts(C.Structure):
 class EscapeOpts(C.Structure):
     """ctypes mirror of dcx_escape_opts (include/dcx.h)"""
     _fields_ = [(n, C.c_float) for n in ("lr", "beta1", "beta2", "eps")] + [
-        (n, C.c_int32) for n in ("n_steps", "record_freq", "joint", "reserved")] + [("wrap_mask", C.c_uint64)]
+        (n, C.c_int32) for n in ("n_steps", "record_freq", "joint", "compact_every")] + [("wrap_mask", C.c_uint64)]
 
 
 _lib = None

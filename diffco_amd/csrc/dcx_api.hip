@@ -1387,17 +1387,22 @@ int dcx_traj_adam_run(const dcx_model* m, const dcx_traj_state* st, const dcx_tr
 // ---- escape from collision (scripts/escape.py:19-38 as launches on the caller's stream) ----------------------------------------
 namespace {
 struct EscapeWork {
-    size_t m_off, v_off, score_off, grad_off, total;
+    size_t m_off, v_off, score_off, grad_off, qa_off[2], idx_off[2], count_off, total;
 };
 EscapeWork escape_work(int dof, int C, int64_t B) {
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
     EscapeWork w;
-    const size_t qd = up((size_t)B * dof * sizeof(float));
+    const size_t qd = up((size_t)B * dof * sizeof(float)), ib = up((size_t)B * sizeof(int32_t));
     w.m_off = 0;
     w.v_off = qd;
     w.score_off = 2 * qd;
     w.grad_off = w.score_off + up((size_t)B * C * sizeof(float));
-    w.total = w.grad_off + qd;
+    w.qa_off[0] = w.grad_off + qd;      // compaction (compact_every > 0): the running loops' configurations, dense, ping-pong
+    w.qa_off[1] = w.qa_off[0] + qd;
+    w.idx_off[0] = w.qa_off[1] + qd;    // ... and which configurations of the caller's they are
+    w.idx_off[1] = w.idx_off[0] + ib;
+    w.count_off = w.idx_off[1] + ib;
+    w.total = w.count_off + 256;
     return w;
 }
 }  // namespace
@@ -1412,14 +1417,24 @@ int dcx_escape_adam(const dcx_model* m, float* q, int64_t B, const float* margin
     if (!m) return fail(DCX_ERR_INVALID, "model is NULL");
     if (!opt) return fail(DCX_ERR_INVALID, "escape options are NULL");
     if (B < 0 || (B > 0 && (!q || !steps || !work))) return fail(DCX_ERR_INVALID, "q / steps / work is NULL or B < 0");
-    if (opt->n_steps < 1 || opt->record_freq < 0) return fail(DCX_ERR_INVALID, "escape needs n_steps >= 1 and record_freq >= 0");
+    if (opt->n_steps < 1 || opt->record_freq < 0 || opt->compact_every < 0)
+        return fail(DCX_ERR_INVALID, "escape needs n_steps >= 1, record_freq >= 0 and compact_every >= 0");
     if (!(opt->lr > 0.f) || !(opt->beta1 >= 0.f && opt->beta1 < 1.f) || !(opt->beta2 >= 0.f && opt->beta2 < 1.f))
         return fail(DCX_ERR_INVALID, "Adam options out of range");
+    if (B > INT32_MAX) return fail(DCX_ERR_UNSUPPORTED, "escape: more than 2^31 - 1 configurations");
     if (B == 0) return DCX_OK;
     const EscapeWork w = escape_work(m->fk.dof, m->C, B);
     if (work_bytes < w.total) return fail(DCX_ERR_INVALID, "escape workspace is smaller than dcx_escape_work_bytes");
     if (int rc = set_device(m->device)) return rc;
     hipStream_t st = (hipStream_t)stream;
+    const int compact = opt->joint ? 0 : opt->compact_every;   // one loop: nothing to take out
+    if (compact > 0) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+            (void)hipGetLastError();
+            return fail(DCX_ERR_UNSUPPORTED, "dcx_escape_adam with compact_every > 0 reads a count back: not on a stream that is being captured");
+        }
+    }
     char* base = (char*)work;
     hipError_t e = hipMemsetAsync(base, 0, w.score_off, st);  // both moments
     if (e == hipSuccess) e = hipMemsetAsync(steps, 0, 2 * sizeof(int32_t) * (opt->joint ? 1 : (size_t)B), st);
@@ -1443,13 +1458,33 @@ int dcx_escape_adam(const dcx_model* m, float* q, int64_t B, const float* margin
     a.beta1 = opt->beta1;
     a.beta2 = opt->beta2;
     a.eps = opt->eps;
+    a.idx = nullptr;
+    a.qa = nullptr;
+    a.n_act = B;
+    int32_t* count = (int32_t*)(base + w.count_off);
+    int side = 0;   // which half of the ping-pong the NEXT compaction writes
     for (int s = 0; s < opt->n_steps; ++s) {
         // upstream = nullptr: the gradient of the row's sum over the classes (the folded weight column)
-        if (int rc = run_score(m, q, B, nullptr, const_cast<float*>(a.score), const_cast<float*>(a.grad), MODE_GRAD_ROW, -1,
-                               m->fk.dof, st))
+        if (int rc = run_score(m, a.qa ? a.qa : q, a.n_act, nullptr, const_cast<float*>(a.score), const_cast<float*>(a.grad),
+                               MODE_GRAD_ROW, -1, m->fk.dof, st))
             return rc;
         e = launch_escape_step(a, s, st);
         if (e != hipSuccess) return fail_hip(e, "escape step launch");
+        if (compact > 0 && (s + 1) % compact == 0 && s + 1 < opt->n_steps) {
+            int32_t* idx_out = (int32_t*)(base + w.idx_off[side]);
+            float* qa_out = (float*)(base + w.qa_off[side]);
+            int32_t left = 0;
+            e = hipMemsetAsync(count, 0, sizeof(int32_t), st);
+            if (e == hipSuccess) e = launch_escape_compact(a, a.idx, a.n_act, idx_out, qa_out, count, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(&left, count, sizeof(int32_t), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) return fail_hip(e, "escape compaction");
+            if (left == 0) break;       // every loop has stopped
+            a.idx = idx_out;
+            a.qa = qa_out;
+            a.n_act = left;
+            side ^= 1;
+        }
     }
     if (history) {
         e = launch_escape_finish(a, st);

@@ -115,8 +115,15 @@ struct EscapeArgs {
     int32_t dof, C, step, record_freq, joint;
     uint64_t wrap_mask;
     float lr, beta1, beta2, eps, bias1, bias2_sqrt;
+    // after a compaction the sweep's batch is the n_act loops still running: score / grad rows i, configuration idx[i] of q,
+    // its current value also in qa[i] (what the sweep reads).  Before the first one: idx = qa = nullptr, n_act = B.
+    const int32_t* idx;
+    float* qa;
+    int64_t n_act;
 };
 hipError_t launch_escape_step(EscapeArgs a, int step, hipStream_t stream);   // step is 0-based
 hipError_t launch_escape_finish(const EscapeArgs& a, hipStream_t stream);
+hipError_t launch_escape_compact(const EscapeArgs& a, const int32_t* idx_in, int64_t n_in, int32_t* idx_out, float* qa_out,
+                                 int32_t* count, hipStream_t stream);
 
 }  // namespace dcx

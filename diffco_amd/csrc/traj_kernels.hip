@@ -237,25 +237,27 @@ __device__ __forceinline__ double escape_total_excess(const EscapeArgs& a, doubl
     return part[0];
 }
 
-// configuration b of a loop that goes on: record, Adam step (the arithmetic of traj_adam_step_kernel), wrap
-__device__ __forceinline__ void escape_row_step(const EscapeArgs& a, int64_t b) {
+// configuration b (row i of the sweep's batch) of a loop that goes on: record, Adam step (the arithmetic of
+// traj_adam_step_kernel), wrap
+__device__ __forceinline__ void escape_row_step(const EscapeArgs& a, int64_t b, int64_t i) {
     const int dof = a.dof;
     float* q = a.q + b * dof;
     if (a.history && a.record_freq > 0 && a.step % a.record_freq == 0) {
         float* h = a.history + ((int64_t)(a.step / a.record_freq) * a.B + b) * dof;
-        for (int i = 0; i < dof; ++i) h[i] = q[i];
+        for (int k = 0; k < dof; ++k) h[k] = q[k];
     }
-    for (int i = 0; i < dof; ++i) {
-        const float g = a.grad[b * dof + i];
-        float m = a.adam_m[b * dof + i], v = a.adam_v[b * dof + i];
+    for (int k = 0; k < dof; ++k) {
+        const float g = a.grad[i * dof + k];
+        float m = a.adam_m[b * dof + k], v = a.adam_v[b * dof + k];
         m = fmaf(a.beta1, m, (1.f - a.beta1) * g);
         v = fmaf(a.beta2, v, (1.f - a.beta2) * g * g);
         const float denom = sqrtf(v) / a.bias2_sqrt + a.eps;
-        float qn = traj_adam_q(q[i], a.lr, a.bias1, m, denom);
-        if ((a.wrap_mask >> i) & 1ull) qn = escape_wrap2pi(qn);
-        a.adam_m[b * dof + i] = m;
-        a.adam_v[b * dof + i] = v;
-        q[i] = qn;
+        float qn = traj_adam_q(q[k], a.lr, a.bias1, m, denom);
+        if ((a.wrap_mask >> k) & 1ull) qn = escape_wrap2pi(qn);
+        a.adam_m[b * dof + k] = m;
+        a.adam_v[b * dof + k] = v;
+        q[k] = qn;
+        if (a.qa) a.qa[i * dof + k] = qn;   // the dense copy the next sweep reads
     }
 }
 
@@ -281,24 +283,49 @@ __global__ __launch_bounds__(1024) void escape_joint_small_kernel(const EscapeAr
         a.steps[0] += 1;
         if (excess > 0.0) a.steps[1] += 1;
     }
-    if (excess > 0.0 && (int64_t)threadIdx.x < a.B) escape_row_step(a, threadIdx.x);
+    if (excess > 0.0 && (int64_t)threadIdx.x < a.B) escape_row_step(a, threadIdx.x, threadIdx.x);
 }
 
+// lane i of the sweep's batch is configuration `row` of the caller's (a.idx: the loops still running after a compaction)
 __global__ __launch_bounds__(256) void escape_update_kernel(const EscapeArgs a) {
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= a.B) return;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_act) return;
+    const int64_t b = a.idx ? a.idx[i] : i;
     if (a.joint) {
         // escape_decide_kernel ran in front of this launch: it counted this step's Adam step iff the loop goes on
         if (a.steps[1] != a.step + 1) return;
     } else {
         if (a.steps[2 * b] != a.steps[2 * b + 1]) return;
         float excess = 0.f;
-        for (int c = 0; c < a.C; ++c) excess += a.score[b * a.C + c] - (a.margin ? a.margin[c] : 0.f);
+        for (int c = 0; c < a.C; ++c) excess += a.score[i * a.C + c] - (a.margin ? a.margin[c] : 0.f);
         a.steps[2 * b] += 1;
         if (excess <= 0.f) return;
         a.steps[2 * b + 1] += 1;
     }
-    escape_row_step(a, b);
+    escape_row_step(a, b, i);
+}
+
+// the loops still running, taken out of [0, n_in) into a dense list (order as the waves arrive: a configuration's arithmetic
+// does not depend on its place in the batch) with their current configurations side by side for the next sweeps
+__global__ __launch_bounds__(256) void escape_compact_kernel(const EscapeArgs a, const int32_t* idx_in, int64_t n_in, int32_t* idx_out,
+                                                             float* qa_out, int32_t* count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    int64_t b = 0;
+    bool alive = false;
+    if (i < n_in) {
+        b = idx_in ? idx_in[i] : i;
+        alive = a.steps[2 * b] == a.steps[2 * b + 1];
+    }
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(alive);
+    int base = 0;
+    if (lane == 0 && mask) base = atomicAdd(count, __builtin_popcountll(mask));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (alive) {
+        const int j = base + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+        idx_out[j] = (int32_t)b;
+        for (int k = 0; k < a.dof; ++k) qa_out[(int64_t)j * a.dof + k] = a.q[b * a.dof + k];
+    }
 }
 
 // after the last step: every loop's final configuration into the slot behind its last record (escape.py:37)
@@ -325,7 +352,13 @@ hipError_t launch_escape_step(EscapeArgs a, int step, hipStream_t stream) {
         escape_decide_kernel<<<1, 1024, 0, stream>>>(a);
         if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     }
-    escape_update_kernel<<<dim3((unsigned)((a.B + 255) / 256)), 256, 0, stream>>>(a);
+    escape_update_kernel<<<dim3((unsigned)((a.n_act + 255) / 256)), 256, 0, stream>>>(a);
+    return hipGetLastError();
+}
+
+hipError_t launch_escape_compact(const EscapeArgs& a, const int32_t* idx_in, int64_t n_in, int32_t* idx_out, float* qa_out,
+                                 int32_t* count, hipStream_t stream) {
+    escape_compact_kernel<<<dim3((unsigned)((n_in + 255) / 256)), 256, 0, stream>>>(a, idx_in, n_in, idx_out, qa_out, count);
     return hipGetLastError();
 }
 

@@ -92,7 +92,7 @@ class OptimSampler:
         return self._margin_dev
 
     # ---- the fused loop ---------------------------------------------------------------------------------------------
-    def _fused(self, plan, q0, joint, want_history):
+    def _fused(self, plan, q0, joint, want_history, compact_every=0):
         """q0 [B, dof] -> (final [B, dof], steps [n_loops, 2] int32 (evaluations, Adam steps), history or None), on the GPU"""
         model, (lr, b1, b2, eps), mask = plan
         lib, dev = _lib.require_gpu(), model.dev
@@ -100,18 +100,16 @@ class OptimSampler:
         B, dof = q.shape
         margin = self._margin_on(dev, model.C)
         n, rf = int(self.N_WAYPOINTS), int(self.record_freq or 0)
-        opts = _lib.EscapeOpts(lr, b1, b2, eps, n, rf, 1 if joint else 0, 0, mask)
+        opts = _lib.EscapeOpts(lr, b1, b2, eps, n, rf, 1 if joint else 0, 0 if joint else int(compact_every), mask)
         steps = torch.empty((1 if joint else B, 2), device=dev, dtype=torch.int32)
         # slots behind a loop's last record are never returned as they are (optim_escape cuts, optim_escape_batch overwrites)
         hist = torch.empty((((n + rf - 1) // rf if rf else 0) + 1, B, dof), device=dev) if want_history else None
-        model.acquire()   # the checker must not refill these rows under the enqueued loop
-        try:
-            with _ops._on_device(dev):
-                work = torch.empty(int(lib.dcx_escape_work_bytes(model._h, B)), device=dev, dtype=torch.uint8)
-                _lib.check(lib.dcx_escape_adam(model._h, _ops._ptr(q), B, _ops._ptr(margin), C.byref(opts), _ops._ptr(work),
-                                               work.numel(), _ops._ptr(hist), _ops._ptr(steps), model._st()))
-        finally:
-            model.release()
+        # (no lease on the model: a refill of its rows - ScoreModel.update - is enqueued behind this loop on the same stream, and
+        # waits for the streams recorded by _st() otherwise)
+        with _ops._on_device(dev):
+            work = torch.empty(int(lib.dcx_escape_work_bytes(model._h, B)), device=dev, dtype=torch.uint8)
+            _lib.check(lib.dcx_escape_adam(model._h, _ops._ptr(q), B, _ops._ptr(margin), C.byref(opts), _ops._ptr(work),
+                                           work.numel(), _ops._ptr(hist), _ops._ptr(steps), model._st()))
         return q, steps, hist
 
     # ---- the host loop (foreign dist_est / optimiser / transform) ---------------------------------------------------
@@ -152,11 +150,17 @@ class OptimSampler:
         out = hist[:n_rec].reshape(n_rec, *start_cfg.shape)
         return out.to(device=start_cfg.device, dtype=start_cfg.dtype), evaluations
 
-    def optim_escape_batch(self, start_cfgs, history=False):
+    COMPACT_FROM = 16384   # batches from this size on take stopped loops out of the sweep every COMPACT_EVERY steps
+    COMPACT_EVERY = 4
+
+    def optim_escape_batch(self, start_cfgs, history=False, compact_every=None):
         """B independent escape loops advanced together: `start_cfgs` [B, dof] -> (final configurations [B, dof], evaluations
         [B] int64); with history=True also (records [n_slots, B, dof], n_records [B]) - row b's records are
         records[:n_records[b], b], as `optim_escape(start_cfgs[b:b+1])` would return them; later slots repeat its final
-        configuration.  A fused plan is required (there is nothing batched about the host loop)."""
+        configuration.  A fused plan is required (there is nothing batched about the host loop).
+        compact_every: 0 = every step sweeps all B configurations and nothing synchronises; k > 0 = after every k-th step the
+        loops that stopped are taken out of the sweep (one stream synchronisation each time; the call returns as soon as every
+        loop has stopped); None = COMPACT_EVERY for B >= COMPACT_FROM (profiles/r05_escape.txt), else 0."""
         start_cfgs = torch.as_tensor(start_cfgs)
         if start_cfgs.ndim != 2:
             raise ValueError("optim_escape_batch takes [B, dof]")
@@ -168,7 +172,9 @@ class OptimSampler:
         if len(start_cfgs) == 0:
             e = torch.zeros(0, dtype=torch.int64)
             return (start_cfgs.clone(), e) if not history else (start_cfgs.clone(), e, start_cfgs.new_zeros((1, 0, start_cfgs.shape[1])), e)
-        q, steps, hist = self._fused(plan, start_cfgs, False, history)
+        if compact_every is None:
+            compact_every = self.COMPACT_EVERY if len(start_cfgs) >= self.COMPACT_FROM else 0
+        q, steps, hist = self._fused(plan, start_cfgs, False, history, compact_every)
         back = dict(device=start_cfgs.device, dtype=start_cfgs.dtype)
         final, evaluations = q.to(**back), steps[:, 0].to(device=start_cfgs.device, dtype=torch.int64)
         if not history:

@@ -310,13 +310,19 @@ int dcx_traj_adam_run(const dcx_model* model, const dcx_traj_state* st, const dc
  * margin [C] device (NULL = 0).  wrap_mask bit i: coordinate i is wrapped to [-pi, pi) after every step - all ones below
  *   dof for post_transform = utils.wrap2pi (utils.py:51-52), bit 2 for utils.se2_wrap2pi (:54-55), 0 for None.
  * work: dcx_escape_work_bytes(model, B) bytes of device memory, the caller's (Adam moments, score and gradient of the
- *   current step); initialised here.  No allocation, no synchronisation.                          */
+ *   current step, the list of the loops still running); initialised here.  No allocation.
+ * compact_every = 0: no synchronisation either - every step sweeps all B configurations, stopped loops included (they are
+ *   left alone by the update), and the call can be captured in a HIP graph.
+ * compact_every = k > 0 (joint == 0): after every k-th step the loops that stopped are taken out of the sweep's batch.  The
+ *   call then SYNCHRONISES the stream there (it reads how many loops are left to size the next launches) and returns as
+ *   soon as none is; not capturable.  A configuration's arithmetic does not depend on its place in the batch; the launch
+ *   geometry follows the batch size, so results agree with compact_every = 0 to fp32 rounding of the sums, not bit for bit. */
 typedef struct dcx_escape_opts {
     float lr, beta1, beta2, eps;       /* torch.optim.Adam: lr 5e-2 (escape.py:12), betas 0.9 / 0.999, eps 1e-8        */
     int32_t n_steps;                   /* N_WAYPOINTS (escape.py:10): the most checks a loop makes                      */
     int32_t record_freq;               /* escape.py:13; 0 or None = final configuration only                            */
     int32_t joint;
-    int32_t reserved;                  /* 0                                                                             */
+    int32_t compact_every;             /* 0 = never; k > 0 (independent loops only): see above                          */
     uint64_t wrap_mask;
 } dcx_escape_opts;
 size_t dcx_escape_work_bytes(const dcx_model* m, int64_t B);

@@ -198,6 +198,70 @@ def test_float64_restatement_on_the_oracle_score():
     assert (evals > 1).sum() > 50 and (evals < n).sum() > 50
 
 
+@pytest.mark.parametrize("k", [1, 3, 7])
+def test_stopped_loops_taken_out_of_the_sweep(k):
+    """compact_every = k: the loops that stopped leave the sweep's batch after every k-th step (dcx_escape_adam reads the count
+    back and sizes the next launches by it).  Same evaluation counts, configurations and records as the un-compacted call up to
+    the rounding of sums taken in another launch geometry; the golden batch as well; and the early return when nothing is left"""
+    from diffco_amd import utils
+    from diffco_amd.escape import OptimSampler
+    d = load("escape")
+    rob, dc = _baxter(d)
+    g = torch.Generator().manual_seed(11 + k)
+    lim = rob.limits
+    starts = torch.rand((5000, 7), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]
+    s0 = dc.poly_score(starts)
+    sampler = OptimSampler(rob, dc.poly_score, {"N_WAYPOINTS": 14, "safety_margin": float(s0.median()) - 0.03, "lr": 4e-2,
+                                                "record_freq": 3, "post_transform": utils.wrap2pi})
+    f0, c0, h0, n0 = sampler.optim_escape_batch(starts, history=True, compact_every=0)
+    f1, c1, h1, n1 = sampler.optim_escape_batch(starts, history=True, compact_every=k)
+    assert 0.2 < float((c0 == 1).float().mean()) < 0.8 and int(c0.max()) == 14      # a mix: free at once ... never free
+    same = c0 == c1            # a loop whose excess passes within rounding of zero may stop a step apart
+    assert float(same.float().mean()) > 0.995
+    assert torch.equal(n0[same], n1[same])
+    assert relerr(_np(f1[same]), _np(f0[same])) < 1e-5 and relerr(_np(h1[:, same]), _np(h0[:, same])) < 1e-5
+    # the golden batch (12 loops, records every 4 steps)
+    sampler = OptimSampler(rob, dc.poly_score, {"N_WAYPOINTS": 15, "safety_margin": float(d["bx_marginb"]) - 0.05, "lr": 5e-2,
+                                                "record_freq": 4})
+    final, checks, hist, n_rec = sampler.optim_escape_batch(torch.from_numpy(d["bx_starts"]), history=True, compact_every=k)
+    np.testing.assert_array_equal(_np(checks), d["bx_batch_checks"])
+    np.testing.assert_array_equal(_np(n_rec), d["bx_batch_nrec"])
+    assert relerr(_np(final), d["bx_batch_final"]) < TOL and relerr(_np(hist[:4]), d["bx_batch_hist"]) < TOL
+    # everything free at the first evaluation: one sweep, then the call returns
+    free = OptimSampler(rob, dc.poly_score, {"N_WAYPOINTS": 50, "safety_margin": 1e3})
+    f, c = free.optim_escape_batch(starts, compact_every=1)
+    assert torch.equal(f, starts) and int(c.min()) == int(c.max()) == 1
+
+
+def test_compaction_is_refused_under_stream_capture():
+    """compact_every > 0 reads a count back: on a capturing stream the call returns DCX_ERR_UNSUPPORTED before touching anything
+    (the capture stays valid); compact_every = 0 is captured (test_the_loop_is_captured_in_a_hip_graph)"""
+    import ctypes as C
+
+    from diffco_amd import _lib, _ops, traj
+    d = load("escape")
+    rob, dc = _baxter(d)
+    model = traj._resolve_model(dc.poly_score)
+    lib = _lib.require_gpu()
+    q = torch.from_numpy(d["bx_starts"]).cuda()
+    steps = torch.zeros((len(q), 2), device="cuda", dtype=torch.int32)
+    work = torch.empty(int(lib.dcx_escape_work_bytes(model._h, len(q))), device="cuda", dtype=torch.uint8)
+    opts = _lib.EscapeOpts(5e-2, 0.9, 0.999, 1e-8, 6, 0, 0, 2, 0)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        s0 = model.score_raw(q)              # (this stream's scratch exists before the capture)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+        rc = lib.dcx_escape_adam(model._h, _ops._ptr(q), len(q), None, C.byref(opts), _ops._ptr(work), work.numel(), None,
+                                 _ops._ptr(steps), C.c_void_p(side.cuda_stream))
+        msg = lib.dcx_last_error()
+        s1 = model.score_raw(q)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert rc == 2 and b"captured" in msg and torch.equal(s1, s0)
+
+
 def test_one_loop_over_a_large_batch():
     """more than 1024 configurations in ONE loop: the decision is its own launch there (traj_kernels.hip); against the host loop
     on the same score"""

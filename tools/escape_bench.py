@@ -81,14 +81,17 @@ def main():
     # ---- B independent loops together ----------------------------------------------------------------------------------
     batch = OptimSampler(rob, dc.poly_score, {"N_WAYPOINTS": 20, "safety_margin": margin, "lr": 5e-2, "record_freq": None,
                                               "post_transform": utils.wrap2pi})
-    print("B independent loops, N_WAYPOINTS 20, lr 0.05 (every step sweeps all B rows; stopped rows are left alone):")
-    for B in (64, 1024, 4096, 16384, 65536):
-        q = starts[:B]
-        final, checks = batch.optim_escape_batch(q)
-        t = timed(lambda: batch.optim_escape_batch(q), 20 if B <= 4096 else 5)
+    print("B independent loops, N_WAYPOINTS 20, lr 0.05; compact_every = 0: every step sweeps all B rows (stopped loops are left alone),")
+    print("k > 0: the loops that stopped are taken out of the sweep after every k-th step (one stream synchronisation each):")
+    for B in (64, 1024, 4096, 16384, 65536, 262144):
+        q = (starts[:B] if B <= len(starts) else starts.repeat((B + len(starts) - 1) // len(starts), 1)[:B] + 1e-3 * torch.randn(B, 7, device="cuda")).contiguous()
+        line = f"    B = {B:6d}"
+        for k in (0, 1, 2, 4):
+            final, checks = batch.optim_escape_batch(q, compact_every=k)
+            t = timed(lambda: batch.optim_escape_batch(q, compact_every=k), 20 if B <= 4096 else 5)
+            line += f"   k={k}: {t * 1e3:7.3f} ms {B / t / 1e6:7.2f} M/s"
         free = float((checks < 20).float().mean())
-        print(f"    B = {B:6d}   {t * 1e3:8.3f} ms per batch   {B / t / 1e6:8.3f} M escapes/s   {float(checks.float().mean()):5.1f} "
-              f"evaluations per loop on average, {free * 100:4.1f} % free before step 20")
+        print(line + f"   ({float(checks.float().mean()):4.1f} evaluations per loop, {free * 100:4.1f} % free before step 20)")
 
 
 if __name__ == "__main__":
