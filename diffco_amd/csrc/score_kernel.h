@@ -181,6 +181,13 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define DCX_D2_MULTI 1
 #endif
 #define DCX_D2_ACCS(D) (!DCX_D2_MULTI ? 1 : (D) >= 32 ? 4 : (D) >= 16 ? 2 : 1)
+// narrow one-class rows in the direct form: the two rows of a pipeline stage share every packed instruction (see pair2)
+#ifndef DCX_PAIR2
+#define DCX_PAIR2 1
+#endif
+#ifndef DCX_PAIR2_MAX_D
+#define DCX_PAIR2_MAX_D 8
+#endif
 // rows fetched in whole groups of four floats by the four-row pipeline (see load_row)
 #ifndef DCX_LOAD_GROUPS
 #define DCX_LOAD_GROUPS 1
@@ -648,6 +655,52 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
             if constexpr (D & 1) gx[D - 1] = fmaf(coef, dl[D - 1], gx[D - 1]);
         }
     };
+    // ---- two rows per packed instruction (round 5) -------------------------------------------------------------------------
+    // `pair` packs a row's features two by two: D/2 differences, D/2 squared-distance terms, one add of the two halves, then a
+    // scalar chain (kernel function, score, coefficient) and D/2 gradient terms.  For NARROW rows the chain is a third of the
+    // body (config #4, D = 6: 15 VALU instructions per pair, 6 of them the chain + the add of the halves).  Here the two rows
+    // of a pipeline stage ride in the two halves of every packed register instead: feature k of both rows is one operand pair
+    // (x_k broadcast by op_sel, (r0_k, r1_k) an SGPR pair), the squared distances of the two rows come out of D packed
+    // fmas with no add of halves, the chain runs once for both rows in packed multiplies (the reciprocal / rsqrt stay one per
+    // row: no packed form exists), and the gradient accumulators hold the even and the odd rows' sums side by side (2 D
+    // registers instead of D: why this is for D <= 8 only).  24 instead of 30 VALU instructions per two rows at D = 6.
+    constexpr bool P2 = DCX_PAIR2 && !XF && CC == 1 && (D % 2) == 0 && D <= DCX_PAIR2_MAX_D && PARTS == 0 &&
+                        (KF == KF_RQ2 || KF == KF_POLY1);
+    v2f gp[P2 ? D : 1];     // gradient, rows of even / odd position in the stage
+    v2f scp = {0.0f, 0.0f};
+    if constexpr (P2) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) gp[k] = v2f{0.0f, 0.0f};
+    }
+    auto pair2 = [&](const float (&r0)[L::RS], const float (&r1)[L::RS]) __attribute__((always_inline)) {
+        v2f dk[D];
+        v2f acc = {d2_seed<KF>(a), d2_seed<KF>(a)};
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const v2f xv = {x[k], x[k]};
+            const v2f rv = {r0[k], r1[k]};
+            dk[k] = xv - rv;
+            acc = __builtin_elementwise_fma(dk[k], dk[k], acc);
+        }
+        v2f val, g;
+        if constexpr (KF == KF_RQ2) {   // sweep_eval<KF_RQ2> on both halves
+            const v2f u = {__builtin_amdgcn_rcpf(acc.x), __builtin_amdgcn_rcpf(acc.y)};
+            val = u * u;
+            g = val * u;
+        } else {                        // kernel_eval<KF_POLY1>
+            const v2f d2c = {fmaxf(acc.x, 1e-30f), fmaxf(acc.y, 1e-30f)};
+            g = v2f{__builtin_amdgcn_rsqf(d2c.x), __builtin_amdgcn_rsqf(d2c.y)};
+            val = d2c * g;
+        }
+        const v2f w2 = {r0[L::W_OFF], r1[L::W_OFF]};
+        scp = __builtin_elementwise_fma(w2, val, scp);
+        if constexpr (GRAD) {
+            v2f coef = g * w2;
+            if constexpr (MODE != MODE_GRAD_ROW) coef = coef * v2f{up[0], up[0]};
+#pragma unroll
+            for (int k = 0; k < D; ++k) gp[k] = __builtin_elementwise_fma(coef, dk[k], gp[k]);
+        }
+    };
     // (whole groups of four floats: the padding of the row stride is readable, and 7 floats fetched as 8 are ONE s_load_dwordx8
     // instead of x4 + x2 + x1, 14 as 16 one x16 instead of x8 + x4 + x2)
     constexpr int USED4 = (USED + 3) / 4 * 4;
@@ -829,6 +882,8 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (XFA) {
                 stage_x(rowA, rowB);
+            } else if constexpr (P2) {
+                pair2(rowA, rowB);
             } else {
                 pair(rowA);
                 pair(rowB);
@@ -841,6 +896,8 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (XFA) {
                 stage_x(rowC, rowD);
+            } else if constexpr (P2) {
+                pair2(rowC, rowD);
             } else {
                 pair(rowC);
                 pair(rowD);
@@ -1058,6 +1115,13 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
         for (int k = 0; k + 1 < D; k += 2) {
             gx[k] += gx2[k / 2].x;
             gx[k + 1] += gx2[k / 2].y;
+        }
+        if constexpr (P2) {   // the stages' even and odd rows, then the rows the tail took one by one (above)
+            sc[0] += scp.x + scp.y;
+            if constexpr (GRAD) {
+#pragma unroll
+                for (int k = 0; k < D; ++k) gx[k] += gp[k].x + gp[k].y;
+            }
         }
     }
     if constexpr (SC2) {

@@ -98,7 +98,7 @@ template __global__ void score_kernel<6, KF_RQ2, 1, MODE_GRAD_ROW, 1024, false, 
 def test_round4_sweeps_rq_folded_expanded_and_the_two_buffer_pipeline(tmp_path):
     """Round 4 (score_kernel.h, "the two-buffer pipeline", sweep_eval): what the counter passes of config #3 / #4 led to,
     held in the generated code.  (a) RQKernel(p = 2) with its constants folded: 15 VALU instructions per pair at D = 6
-    (config #4; 17 before), no multiply by gamma left in the loop; (b) config #3's loop (D = 12, C = 5) in the expanded
+    (config #4; 17 before; 12 since round 5's pair2), no multiply by gamma left in the loop; (b) config #3's loop (D = 12, C = 5) in the expanded
     form: 22 per pair (28 in round 3's direct form) and in the direct form 26; (c) its pipeline intact: each row's scalar
     loads stand BEFORE the other row's body (two v_rcp per iteration, each preceded by the loads of the row after it), and
     no s_mov copies of row registers, no lane parking"""
@@ -129,8 +129,12 @@ def test_round4_sweeps_rq_folded_expanded_and_the_two_buffer_pipeline(tmp_path):
         rows = sum("v_rcp_f32" in x for x in seg)
         return sum(x.startswith("v_") for x in seg) / rows, sum(x.startswith("s_mov") for x in seg), rows
 
-    v, movs, rows = per_row(loop((6, 1, 0)))
-    assert rows == 4 and v <= 15.0 and movs <= 2, (v, movs)
+    # round 5: the two rows of a stage share every packed instruction (pair2): 12 per pair, no add of halves; the s_mov are the
+    # SGPR pairs (r0_k, r1_k) it is fed with (7 per two rows + the loop's own)
+    seg6 = loop((6, 1, 0))
+    v, movs, rows = per_row(seg6)
+    assert rows == 4 and v <= 12.0 and movs <= 30, (v, movs)
+    assert not any(x.startswith(("v_add_f32", "v_mov_b32", "v_readlane", "v_writelane")) for x in seg6)
     v, movs, rows = per_row(loop((12, 1, 1)))
     assert rows == 4 and v <= 19.0, v                     # incl. the flush block's share (direct form: 24)
     for key, vmax in (((12, 5, 1), 25.0), ((12, 5, 0), 26.0)):   # the expanded loop range holds the flush block (7 VALU / 2 rows)
