@@ -188,6 +188,10 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #ifndef DCX_PAIR2_MAX_D
 #define DCX_PAIR2_MAX_D 8
 #endif
+// ... and are fetched together: two adjacent rows = ONE scalar load, one address per stage (see the P2 pipeline)
+#ifndef DCX_PAIR2_LOADS
+#define DCX_PAIR2_LOADS 1
+#endif
 // rows fetched in whole groups of four floats by the four-row pipeline (see load_row)
 #ifndef DCX_LOAD_GROUPS
 #define DCX_LOAD_GROUPS 1
@@ -862,6 +866,56 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
             load_row(rowA, j);
             __builtin_amdgcn_s_waitcnt(0xC07F);
             single_x(rowA);
+        }
+    }
+    } else if constexpr (P2 && DCX_PAIR2_LOADS) {
+    // pair2's own pipeline: the two rows of a stage are adjacent in memory, so they arrive by ONE scalar load of 2 RS floats
+    // (one address computation per stage instead of one per row: with 12 VALU instructions per pair the scalar unit, which the
+    // four SIMDs of a CU share, had become nearly as busy as the vector one).  The model's rows have a readable tail
+    // (rows_tail_floats), so the look-ahead load at the end of a slice may run one row past it.
+    //   wait -> issue {C,D} -> body(A,B) -> wait -> issue {A,B} -> body(C,D)
+    if (j0 < j1) {
+        constexpr int R2 = 2 * L::RS;
+        float ab[R2], cd[R2];
+        auto load2 = [&](float (&dst)[R2], int j) __attribute__((always_inline)) {
+            cfloat_ptr r = rows + (size_t)j * RSTRIDE;
+#pragma unroll
+            for (int e = 0; e < R2; ++e) dst[e] = r[e];
+        };
+        auto body2 = [&](const float (&b)[R2]) __attribute__((always_inline)) {
+            // (the stride's padding counts as used where the rows are consumed: the compiler narrows a load whose tail is dead
+            // into x4 + x2 + x1 pieces otherwise)
+#pragma unroll
+            for (int e = USED; e < L::RS; ++e) asm volatile("" ::"s"(b[e]), "s"(b[L::RS + e]));
+            pair2(*reinterpret_cast<const float(*)[L::RS]>(&b[0]), *reinterpret_cast<const float(*)[L::RS]>(&b[L::RS]));
+        };
+        const int jl = j1 - 1;
+        load2(ab, j0);
+        int j = j0;
+        for (; j + 3 < j1; j += 4) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_sched_barrier(0);
+            load2(cd, j + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            body2(ab);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_sched_barrier(0);
+            load2(ab, (j + 4 < j1) ? j + 4 : jl);
+            __builtin_amdgcn_sched_barrier(0);
+            body2(cd);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // up to three rows left; ab holds rows j and j + 1 whenever j < j1
+        if (j + 1 < j1) {
+            body2(ab);
+            if (j + 2 < j1) {
+                float rowC[L::RS];
+                load_row(rowC, j + 2);
+                pair(rowC);
+            }
+        } else if (j < j1) {
+            pair(*reinterpret_cast<const float(*)[L::RS]>(&ab[0]));
         }
     }
     } else if constexpr (PARTS == 0) {
