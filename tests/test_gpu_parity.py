@@ -537,6 +537,42 @@ def test_ragged_empty_and_padding(ops, knob):
     assert he.shape == (70, 7, 7) and float(he.abs().max()) == 0.0 and float(gh.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("D", [2, 4, 6, 8])
+@pytest.mark.parametrize("kspec", [(0, 10.0, 2.0), (1, 1.0, 1.0)])
+def test_two_rows_per_packed_instruction_every_tail(ops, knob, D, kspec):
+    """round 5 (score_kernel.h pair2): narrow one-class rows in the direct form take the two rows of a pipeline stage in the two
+    halves of every packed register, fetched by one load.  Raw D-dimensional inputs (no transform), both compiled kernel
+    functions, support counts and block sizes that leave every tail of a slice (0 .. 3 rows behind the last whole stage, slices
+    of a single row, a slice ending on the model's last row): score, gradient with the row weight and with an explicit upstream
+    against the float64 oracle, and the score-only launch; 2 D = 3, 5, 7 features run padded to the compiled width"""
+    from diffco_amd import _fkdesc
+    from oracle import oracle
+    knob("xf", 0)      # the direct form whatever the data would allow
+    g = torch.Generator().manual_seed(100 * D + kspec[0])
+    for Du in ((D,) if D == 2 else (D - 1, D)):
+        desc = _fkdesc.none_desc(Du)
+        for S in (1, 2, 3, 5, 7, 31, 64, 257, 1001):
+            sup = torch.randn((S, Du), generator=g) * 2.0
+            W = torch.randn((S, 1), generator=g)
+            q = (torch.randn((200, Du), generator=g) * 2.0).cuda()
+            q[3] = sup[S // 2].cuda()                      # r = 0 on one pair
+            m = ops.ScoreModel(desc, *kspec, sup.cuda(), W.cuda())
+            so, go, _ = oracle.score_grad(desc, *kspec, sup.numpy().astype(np.float64), W.numpy().astype(np.float64),
+                                          _n(q).astype(np.float64), dtype=np.float64)
+            up = torch.randn((200, 1), generator=g).cuda()
+            for nw in (1, 4, 16):
+                knob("nw", nw)
+                s, gr = m.score_grad_raw(q)
+                s0 = m.score_raw(q)
+                su, gu = m.score_grad_raw(q, up)
+                tag = (Du, S, nw)
+                assert relerr(_n(s), so) < TOL and relerr(_n(gr), go) < TOL, tag
+                assert relerr(_n(s0), so) < TOL and torch.equal(su, s), tag
+                assert relerr(_n(gu), go * _n(up).astype(np.float64)) < TOL, tag
+    knob("nw", -1)
+    knob("xf", -1)
+
+
 @pytest.mark.parametrize("C", [1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("rob_name,kspec", [("baxter_left", (0, 10.0, 2.0)), ("baxter_left", (1, 1.0, 1.0)), ("planar3", (2, 0.8, 0.0))])
 def test_every_class_count(ops, C, rob_name, kspec, knob):
