@@ -795,6 +795,52 @@ def api_latency(dev, n=200):
     return out
 
 
+def escape_latency(dev, n=100):
+    """The escape loop next to the path (SURVEY 8f-2's variant, reference scripts/escape.py:19-38) with the options of
+    scripts/compare_sampling.py:177-195 - one configuration, at most three Adam steps at lr 0.2, wrap2pi, last configuration only -
+    on a Baxter checker with 2000 supports: microseconds of wall time per escape for the fused form (`dcx_escape_adam`: one
+    library call, one read-back) and for the reference's Python loop on the same HIP score (autograd + torch.optim.Adam +
+    a host decision per step), on a start that takes all three steps; and 65536 independent loops of 20 steps
+    (`optim_escape_batch`, stopped loops compacted out of the sweep every 4 steps).  tools/escape_bench.py is the long form."""
+    from diffco_amd import kernel, model, utils
+    from diffco_amd.escape import OptimSampler
+    from diffco_amd.kernel_perceptrons import DiffCo
+    rob = model.BaxterLeftArmFK()
+    lim = rob.limits
+    g = torch.Generator().manual_seed(0)
+    S = 2000
+    sq = (torch.rand((S, 7), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]).to(dev)
+    dc = DiffCo(transform=rob.fkine)
+    dc.support_points, dc.support_transformed = sq, rob.fkine(sq)
+    dc.rbf_kernel, dc.rbf_nodes = kernel.Polyharmonic(1, 1.0), (torch.randn(S, generator=g) * 0.02 + 0.001).to(dev)
+    starts = (torch.rand((65536, 7), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]).to(dev)
+    s0 = dc.poly_score(starts[:4096]).reshape(-1)
+    margin = float(s0.median()) - 0.2
+    one = starts[int(torch.argmax(s0))][None].clone()
+    # (a margin no step reaches: the loop always takes its three steps, whatever the lease's rounding)
+    opts = {"N_WAYPOINTS": 3, "safety_margin": -1e3, "lr": 0.2, "record_freq": None, "post_transform": utils.wrap2pi}
+    fused = OptimSampler(rob, dc.poly_score, opts)
+    host = OptimSampler(rob, dc.poly_score, dict(opts, post_transform=lambda x: utils.wrap2pi(x)))
+
+    def timeit(fn, reps):
+        fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / reps
+    out = {"unit": "us per escape", "what": "OptimSampler.optim_escape, Baxter checker with 2000 supports, one configuration, 3 Adam steps, wrap2pi",
+           "evaluations": fused.optim_escape(one)[1], "routes": None}
+    out["fused"] = round(timeit(lambda: fused.optim_escape(one), n) * 1e6, 1)
+    out["host_loop"] = round(timeit(lambda: host.optim_escape(one), max(10, n // 5)) * 1e6, 1)
+    out["routes"] = [fused.last_route, host.last_route]
+    batch = OptimSampler(rob, dc.poly_score, dict(opts, N_WAYPOINTS=20, lr=5e-2, safety_margin=margin))
+    tb = timeit(lambda: batch.optim_escape_batch(starts), 5)
+    out["batch_65536x20"] = {"ms": round(tb * 1e3, 3), "M_escapes_per_s": round(65536 / tb / 1e6, 2)}
+    return out
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher around it: this process BECOMES `python -m torch.distributed.run
     --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port> bench.py <the same arguments>` (exec: same
@@ -1031,6 +1077,10 @@ def main():
             callers["poly_score_us"] = api_latency(dev)
         except Exception as exc:  # noqa: BLE001
             callers["poly_score_us"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+        try:   # the escape loop (round 5 widening)
+            callers["escape_us"] = escape_latency(dev)
+        except Exception as exc:  # noqa: BLE001
+            callers["escape_us"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
 
     if rank == 0:
         if multi:

@@ -112,6 +112,11 @@ def test_headline_line_carries_every_baseline_config():
         assert ps[B]["score_and_grad"] < ps[B]["raw"] + 25.0, ps                     # (measured: + 0 ... 3 us)
         # (through torch's autograd engine: 70 - 170 us on the pool's hosts where torch alone needs 60 - 80; bounded loosely)
         assert ps[B]["fwd_bwd"] < 4.0 * ps["torch_autograd_floor"] + 50.0, ps
+    # the escape loop as one library call: both routes ran, all three steps were taken, and the fused form is the faster one
+    es = d["callers"]["escape_us"]
+    assert "error" not in es, es
+    assert es["routes"] == ["fused", "host"] and es["evaluations"] == 3 and 0 < es["fused"] < es["host_loop"], es
+    assert es["batch_65536x20"]["M_escapes_per_s"] > 5.0, es
     rf = d["roofline"]
     ck = rf["clock"]   # measured inside the kernel beside the loop's launches: the part does not hold 2.4 GHz under this load
     assert "error" not in ck, ck
