@@ -1436,9 +1436,7 @@ int dcx_escape_adam(const dcx_model* m, float* q, int64_t B, const float* margin
         }
     }
     char* base = (char*)work;
-    hipError_t e = hipMemsetAsync(base, 0, w.score_off, st);  // both moments
-    if (e == hipSuccess) e = hipMemsetAsync(steps, 0, 2 * sizeof(int32_t) * (opt->joint ? 1 : (size_t)B), st);
-    if (e != hipSuccess) return fail_hip(e, "escape workspace initialisation");
+    hipError_t e = hipSuccess;   // (no memset: step 0's update launch initialises the moments and the counters, traj_kernels.hip)
     EscapeArgs a{};
     a.q = q;
     a.score = (const float*)(base + w.score_off);

@@ -209,6 +209,8 @@ hipError_t launch_traj_adam_step(const FkProg* fk_dev, const dcx_fk_desc& fk, co
 //   steps[loop][0]   evaluations of dist_est so far      steps[loop][1]   Adam steps taken so far
 // A loop that goes on takes one step per evaluation, a loop that stops has evaluated once more than it stepped: "stopped" is
 // steps[loop][0] != steps[loop][1], and no other flag is kept (joint form: one loop, index 0).
+// Step 0 INITIALISES: every loop is alive there, its counters and Adam moments are taken as zero without being read, so the
+// caller's buffers need no memset (two launches fewer per call: a three-step escape is seven launches).
 namespace {
 
 __device__ __forceinline__ float escape_wrap2pi(float q) {  // utils.py:51-52 on fp32 tensors: (pi + q) % (2 pi) - pi, Python's %
@@ -248,7 +250,8 @@ __device__ __forceinline__ void escape_row_step(const EscapeArgs& a, int64_t b, 
     }
     for (int k = 0; k < dof; ++k) {
         const float g = a.grad[i * dof + k];
-        float m = a.adam_m[b * dof + k], v = a.adam_v[b * dof + k];
+        float m = 0.f, v = 0.f;
+        if (a.step > 0) { m = a.adam_m[b * dof + k]; v = a.adam_v[b * dof + k]; }
         m = fmaf(a.beta1, m, (1.f - a.beta1) * g);
         v = fmaf(a.beta2, v, (1.f - a.beta2) * g * g);
         const float denom = sqrtf(v) / a.bias2_sqrt + a.eps;
@@ -265,23 +268,26 @@ __device__ __forceinline__ void escape_row_step(const EscapeArgs& a, int64_t b, 
 // the update launch only reads it
 __global__ __launch_bounds__(1024) void escape_decide_kernel(const EscapeArgs a) {
     __shared__ double part[1024];
-    if (a.steps[0] != a.steps[1]) return;  // workgroup-uniform: stopped in an earlier step
+    const int ev = a.step > 0 ? a.steps[0] : 0, up = a.step > 0 ? a.steps[1] : 0;
+    if (ev != up) return;  // workgroup-uniform: stopped in an earlier step
     const double excess = escape_total_excess(a, part);
     if (threadIdx.x == 0) {
-        a.steps[0] += 1;
-        if (excess > 0.0) a.steps[1] += 1;  // the update launch behind this one takes the step
+        a.steps[0] = ev + 1;
+        a.steps[1] = up + (excess > 0.0 ? 1 : 0);  // the update launch behind this one takes the step
     }
 }
 
-// joint form, B <= 1024: decision and update in the same workgroup (same sums, same steps as the two launches)
+// joint form, B <= 1024: decision and update in the same workgroup (same sums, same steps as the two launches); the launch
+// sizes the workgroup by the batch (one wave for the usual single configuration)
 __global__ __launch_bounds__(1024) void escape_joint_small_kernel(const EscapeArgs a) {
     __shared__ double part[1024];
-    if (a.steps[0] != a.steps[1]) return;
+    const int ev = a.step > 0 ? a.steps[0] : 0, up = a.step > 0 ? a.steps[1] : 0;
+    if (ev != up) return;
     const double excess = escape_total_excess(a, part);
     __syncthreads();                       // everybody has read steps[] and part[0]
     if (threadIdx.x == 0) {
-        a.steps[0] += 1;
-        if (excess > 0.0) a.steps[1] += 1;
+        a.steps[0] = ev + 1;
+        a.steps[1] = up + (excess > 0.0 ? 1 : 0);
     }
     if (excess > 0.0 && (int64_t)threadIdx.x < a.B) escape_row_step(a, threadIdx.x, threadIdx.x);
 }
@@ -295,12 +301,13 @@ __global__ __launch_bounds__(256) void escape_update_kernel(const EscapeArgs a) 
         // escape_decide_kernel ran in front of this launch: it counted this step's Adam step iff the loop goes on
         if (a.steps[1] != a.step + 1) return;
     } else {
-        if (a.steps[2 * b] != a.steps[2 * b + 1]) return;
+        const int ev = a.step > 0 ? a.steps[2 * b] : 0, up = a.step > 0 ? a.steps[2 * b + 1] : 0;
+        if (ev != up) return;
         float excess = 0.f;
         for (int c = 0; c < a.C; ++c) excess += a.score[i * a.C + c] - (a.margin ? a.margin[c] : 0.f);
-        a.steps[2 * b] += 1;
+        a.steps[2 * b] = ev + 1;
+        a.steps[2 * b + 1] = up + (excess > 0.f ? 1 : 0);
         if (excess <= 0.f) return;
-        a.steps[2 * b + 1] += 1;
     }
     escape_row_step(a, b, i);
 }
@@ -345,7 +352,8 @@ hipError_t launch_escape_step(EscapeArgs a, int step, hipStream_t stream) {
     a.bias1 = (float)(1.0 - pow((double)a.beta1, (double)(step + 1)));
     a.bias2_sqrt = (float)sqrt(1.0 - pow((double)a.beta2, (double)(step + 1)));
     if (a.joint && a.B <= 1024) {   // the usual call (one configuration): decision and update in one workgroup, one launch
-        escape_joint_small_kernel<<<1, 1024, 0, stream>>>(a);
+        const int64_t n = a.B * a.C > a.B ? a.B * a.C : a.B;
+        escape_joint_small_kernel<<<1, n <= 64 ? 64 : n <= 256 ? 256 : 1024, 0, stream>>>(a);
         return hipGetLastError();
     }
     if (a.joint) {
