@@ -1466,7 +1466,7 @@ int dcx_escape_adam(const dcx_model* m, float* q, int64_t B, const float* margin
         if (int rc = run_score(m, a.qa ? a.qa : q, a.n_act, nullptr, const_cast<float*>(a.score), const_cast<float*>(a.grad),
                                MODE_GRAD_ROW, -1, m->fk.dof, st))
             return rc;
-        e = launch_escape_step(a, s, st);
+        e = launch_escape_step(a, s, s + 1 == opt->n_steps, st);
         if (e != hipSuccess) return fail_hip(e, "escape step launch");
         if (compact > 0 && (s + 1) % compact == 0 && s + 1 < opt->n_steps) {
             int32_t* idx_out = (int32_t*)(base + w.idx_off[side]);
@@ -1484,11 +1484,7 @@ int dcx_escape_adam(const dcx_model* m, float* q, int64_t B, const float* margin
             side ^= 1;
         }
     }
-    if (history) {
-        e = launch_escape_finish(a, st);
-        if (e != hipSuccess) return fail_hip(e, "escape finish launch");
-    }
-    return DCX_OK;
+    return DCX_OK;   // (every loop wrote its final record where it stopped, or behind the last step)
 }
 
 int dcx_train_perceptron(int device, int kernel_kind, const float* kparams, float beta, const float* feats, int64_t N,

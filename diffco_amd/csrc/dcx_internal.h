@@ -113,6 +113,7 @@ struct EscapeArgs {
     int32_t* steps;       // [n_loops, 2]: evaluations, Adam steps (traj_kernels.hip)
     int64_t B;
     int32_t dof, C, step, record_freq, joint;
+    int32_t last;         // this is the call's last step (the loops still running leave their final configuration behind it)
     uint64_t wrap_mask;
     float lr, beta1, beta2, eps, bias1, bias2_sqrt;
     // after a compaction the sweep's batch is the n_act loops still running: score / grad rows i, configuration idx[i] of q,
@@ -121,8 +122,7 @@ struct EscapeArgs {
     float* qa;
     int64_t n_act;
 };
-hipError_t launch_escape_step(EscapeArgs a, int step, hipStream_t stream);   // step is 0-based
-hipError_t launch_escape_finish(const EscapeArgs& a, hipStream_t stream);
+hipError_t launch_escape_step(EscapeArgs a, int step, bool last, hipStream_t stream);   // step is 0-based
 hipError_t launch_escape_compact(const EscapeArgs& a, const int32_t* idx_in, int64_t n_in, int32_t* idx_out, float* qa_out,
                                  int32_t* count, hipStream_t stream);
 

@@ -664,7 +664,8 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
     // scalar chain (kernel function, score, coefficient) and D/2 gradient terms.  For NARROW rows the chain is a third of the
     // body (config #4, D = 6: 15 VALU instructions per pair, 6 of them the chain + the add of the halves).  Here the two rows
     // of a pipeline stage ride in the two halves of every packed register instead: feature k of both rows is one operand pair
-    // (x_k broadcast by op_sel, (r0_k, r1_k) an SGPR pair), the squared distances of the two rows come out of D packed
+    // (x_k in both halves - D register pairs made once per sweep -, (r0_k, r1_k) an SGPR pair built by two s_mov), the squared
+    // distances of the two rows come out of D packed
     // fmas with no add of halves, the chain runs once for both rows in packed multiplies (the reciprocal / rsqrt stay one per
     // row: no packed form exists), and the gradient accumulators hold the even and the odd rows' sums side by side (2 D
     // registers instead of D: why this is for D <= 8 only).  24 instead of 30 VALU instructions per two rows at D = 6.

@@ -210,7 +210,8 @@ hipError_t launch_traj_adam_step(const FkProg* fk_dev, const dcx_fk_desc& fk, co
 // A loop that goes on takes one step per evaluation, a loop that stops has evaluated once more than it stepped: "stopped" is
 // steps[loop][0] != steps[loop][1], and no other flag is kept (joint form: one loop, index 0).
 // Step 0 INITIALISES: every loop is alive there, its counters and Adam moments are taken as zero without being read, so the
-// caller's buffers need no memset (two launches fewer per call: a three-step escape is seven launches).
+// caller's buffers need no memset, and a loop's final record is written where the loop stops or takes the call's last step
+// (no pass afterwards): a three-step escape is six launches.
 namespace {
 
 __device__ __forceinline__ float escape_wrap2pi(float q) {  // utils.py:51-52 on fp32 tensors: (pi + q) % (2 pi) - pi, Python's %
@@ -239,9 +240,18 @@ __device__ __forceinline__ double escape_total_excess(const EscapeArgs& a, doubl
     return part[0];
 }
 
+// a loop's final configuration into the slot behind its last record (escape.py:37): written by the lane that sees the loop
+// stop, or take the call's last step - no pass over the batch afterwards
+__device__ __forceinline__ void escape_final_record(const EscapeArgs& a, int64_t b, int updates) {
+    if (!a.history) return;
+    const int slot = a.record_freq > 0 ? (updates + a.record_freq - 1) / a.record_freq : 0;
+    float* h = a.history + ((int64_t)slot * a.B + b) * a.dof;
+    for (int k = 0; k < a.dof; ++k) h[k] = a.q[b * a.dof + k];
+}
+
 // configuration b (row i of the sweep's batch) of a loop that goes on: record, Adam step (the arithmetic of
 // traj_adam_step_kernel), wrap
-__device__ __forceinline__ void escape_row_step(const EscapeArgs& a, int64_t b, int64_t i) {
+__device__ __forceinline__ void escape_row_step(const EscapeArgs& a, int64_t b, int64_t i, int updates) {
     const int dof = a.dof;
     float* q = a.q + b * dof;
     if (a.history && a.record_freq > 0 && a.step % a.record_freq == 0) {
@@ -262,6 +272,7 @@ __device__ __forceinline__ void escape_row_step(const EscapeArgs& a, int64_t b, 
         q[k] = qn;
         if (a.qa) a.qa[i * dof + k] = qn;   // the dense copy the next sweep reads
     }
+    if (a.last) escape_final_record(a, b, updates);
 }
 
 // joint form, before the update: ONE workgroup sums score - margin over the whole batch and takes the loop's decision, so that
@@ -289,7 +300,10 @@ __global__ __launch_bounds__(1024) void escape_joint_small_kernel(const EscapeAr
         a.steps[0] = ev + 1;
         a.steps[1] = up + (excess > 0.0 ? 1 : 0);
     }
-    if (excess > 0.0 && (int64_t)threadIdx.x < a.B) escape_row_step(a, threadIdx.x, threadIdx.x);
+    if ((int64_t)threadIdx.x < a.B) {
+        if (excess > 0.0) escape_row_step(a, threadIdx.x, threadIdx.x, up + 1);
+        else escape_final_record(a, threadIdx.x, up);     // the loop stops here
+    }
 }
 
 // lane i of the sweep's batch is configuration `row` of the caller's (a.idx: the loops still running after a compaction)
@@ -297,19 +311,32 @@ __global__ __launch_bounds__(256) void escape_update_kernel(const EscapeArgs a) 
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n_act) return;
     const int64_t b = a.idx ? a.idx[i] : i;
+    int up;
     if (a.joint) {
-        // escape_decide_kernel ran in front of this launch: it counted this step's Adam step iff the loop goes on
-        if (a.steps[1] != a.step + 1) return;
+        // escape_decide_kernel ran in front of this launch: it counted this evaluation, and this step's Adam step iff the loop
+        // goes on (the loop is a step behind its evaluations from the moment it stops)
+        const int ev = a.steps[0];
+        up = a.steps[1];
+        if (ev != a.step + 1) return;                 // stopped in an earlier step
+        if (up != a.step + 1) {                       // stops here
+            escape_final_record(a, b, up);
+            return;
+        }
     } else {
-        const int ev = a.step > 0 ? a.steps[2 * b] : 0, up = a.step > 0 ? a.steps[2 * b + 1] : 0;
+        const int ev = a.step > 0 ? a.steps[2 * b] : 0;
+        up = a.step > 0 ? a.steps[2 * b + 1] : 0;
         if (ev != up) return;
         float excess = 0.f;
         for (int c = 0; c < a.C; ++c) excess += a.score[i * a.C + c] - (a.margin ? a.margin[c] : 0.f);
         a.steps[2 * b] = ev + 1;
         a.steps[2 * b + 1] = up + (excess > 0.f ? 1 : 0);
-        if (excess <= 0.f) return;
+        if (excess <= 0.f) {
+            escape_final_record(a, b, up);            // stops here
+            return;
+        }
+        up += 1;
     }
-    escape_row_step(a, b, i);
+    escape_row_step(a, b, i, up);
 }
 
 // the loops still running, taken out of [0, n_in) into a dense list (order as the waves arrive: a configuration's arithmetic
@@ -335,20 +362,11 @@ __global__ __launch_bounds__(256) void escape_compact_kernel(const EscapeArgs a,
     }
 }
 
-// after the last step: every loop's final configuration into the slot behind its last record (escape.py:37)
-__global__ __launch_bounds__(256) void escape_finish_kernel(const EscapeArgs a) {
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= a.B) return;
-    const int updates = a.steps[a.joint ? 1 : 2 * b + 1];
-    const int slot = a.record_freq > 0 ? (updates + a.record_freq - 1) / a.record_freq : 0;
-    float* h = a.history + ((int64_t)slot * a.B + b) * a.dof;
-    for (int i = 0; i < a.dof; ++i) h[i] = a.q[b * a.dof + i];
-}
-
 }  // namespace
 
-hipError_t launch_escape_step(EscapeArgs a, int step, hipStream_t stream) {
+hipError_t launch_escape_step(EscapeArgs a, int step, bool last, hipStream_t stream) {
     a.step = step;
+    a.last = last ? 1 : 0;
     a.bias1 = (float)(1.0 - pow((double)a.beta1, (double)(step + 1)));
     a.bias2_sqrt = (float)sqrt(1.0 - pow((double)a.beta2, (double)(step + 1)));
     if (a.joint && a.B <= 1024) {   // the usual call (one configuration): decision and update in one workgroup, one launch
@@ -370,9 +388,5 @@ hipError_t launch_escape_compact(const EscapeArgs& a, const int32_t* idx_in, int
     return hipGetLastError();
 }
 
-hipError_t launch_escape_finish(const EscapeArgs& a, hipStream_t stream) {
-    escape_finish_kernel<<<dim3((unsigned)((a.B + 255) / 256)), 256, 0, stream>>>(a);
-    return hipGetLastError();
-}
 
 }  // namespace dcx
