@@ -306,6 +306,50 @@ __global__ __launch_bounds__(1024) void escape_joint_small_kernel(const EscapeAr
     }
 }
 
+// joint form of a handful of configurations (B * dof and B * C <= 64: the usual single configuration): ONE wave, lane = one
+// coordinate.  Everything the step may need is requested up front (one round trip instead of counters -> scores -> moments in
+// turn: a lone wave pays ~1 us per dependent global load), the excess is a wave reduction, no LDS, no barrier.  Same decision
+// and the same Adam arithmetic per coordinate as the kernels above.
+__global__ __launch_bounds__(64) void escape_joint_wave_kernel(const EscapeArgs a) {
+    const int l = threadIdx.x;
+    const int nE = (int)a.B * a.dof, nS = (int)a.B * a.C;
+    int ev = 0, up = 0;
+    if (a.step > 0) { ev = a.steps[0]; up = a.steps[1]; }
+    const float sc = l < nS ? a.score[l] - (a.margin ? a.margin[l % a.C] : 0.f) : 0.f;
+    float g = 0.f, m = 0.f, v = 0.f, q = 0.f;
+    if (l < nE) {
+        g = a.grad[l];
+        q = a.q[l];
+        if (a.step > 0) { m = a.adam_m[l]; v = a.adam_v[l]; }
+    }
+    if (ev != up) return;                  // stopped in an earlier step
+    double ex = (double)sc;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ex += __shfl_xor(ex, o, 64);
+    const bool go = ex > 0.0;
+    if (l == 0) {
+        a.steps[0] = ev + 1;
+        a.steps[1] = up + (go ? 1 : 0);
+    }
+    if (l >= nE) return;
+    const int rf = a.record_freq;
+    auto slot_of = [&](int updates) { return rf > 0 ? (updates + rf - 1) / rf : 0; };
+    if (!go) {                             // the loop stops here: its final record (escape.py:37)
+        if (a.history) a.history[(int64_t)slot_of(up) * nE + l] = q;
+        return;
+    }
+    if (a.history && rf > 0 && a.step % rf == 0) a.history[(int64_t)(a.step / rf) * nE + l] = q;
+    m = fmaf(a.beta1, m, (1.f - a.beta1) * g);
+    v = fmaf(a.beta2, v, (1.f - a.beta2) * g * g);
+    const float denom = sqrtf(v) / a.bias2_sqrt + a.eps;
+    float qn = traj_adam_q(q, a.lr, a.bias1, m, denom);
+    if ((a.wrap_mask >> (l % a.dof)) & 1ull) qn = escape_wrap2pi(qn);
+    a.adam_m[l] = m;
+    a.adam_v[l] = v;
+    a.q[l] = qn;
+    if (a.last && a.history) a.history[(int64_t)slot_of(up + 1) * nE + l] = qn;
+}
+
 // lane i of the sweep's batch is configuration `row` of the caller's (a.idx: the loops still running after a compaction)
 __global__ __launch_bounds__(256) void escape_update_kernel(const EscapeArgs a) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -369,7 +413,11 @@ hipError_t launch_escape_step(EscapeArgs a, int step, bool last, hipStream_t str
     a.last = last ? 1 : 0;
     a.bias1 = (float)(1.0 - pow((double)a.beta1, (double)(step + 1)));
     a.bias2_sqrt = (float)sqrt(1.0 - pow((double)a.beta2, (double)(step + 1)));
-    if (a.joint && a.B <= 1024) {   // the usual call (one configuration): decision and update in one workgroup, one launch
+    if (a.joint && a.B * a.dof <= 64 && a.B * a.C <= 64) {   // the usual call (one configuration): one wave, one round trip
+        escape_joint_wave_kernel<<<1, 64, 0, stream>>>(a);
+        return hipGetLastError();
+    }
+    if (a.joint && a.B <= 1024) {   // decision and update in one workgroup, one launch
         const int64_t n = a.B * a.C > a.B ? a.B * a.C : a.B;
         escape_joint_small_kernel<<<1, n <= 64 ? 64 : n <= 256 ? 256 : 1024, 0, stream>>>(a);
         return hipGetLastError();
