@@ -23,6 +23,11 @@ class CollisionChecker:
     def predict(self, point):
         return self.score(point) > 0
 
+    def line_collision(self, start, target, res=50):
+        """any of the `res` points from start towards target in collision (deprecated/DiffCo.py:20-22), as ONE batch"""
+        from .kernel_perceptrons import _line_query
+        return _line_query(self, start, target, res)
+
     def __call__(self, *args, **kwargs):
         return self.predict(*args, **kwargs)
 

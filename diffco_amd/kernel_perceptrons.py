@@ -32,8 +32,21 @@ class Perceptron:
     def predict(self, point):
         return self.score(point) > 0
 
+    def line_predict(self, start, target, res=50):
+        """is any of the `res` points start + (target - start) i / res, i = 0 .. res - 1, in collision?  (reference
+        kernel_perceptrons.py:22-24 asks `is_collision` once per point; here the points are ONE batch: one launch)"""
+        return _line_query(self, start, target, res)
+
     def __call__(self, *args, **kwargs):
         return self.predict(*args, **kwargs)
+
+
+def _line_query(checker, start, target, res):
+    import torch
+    start, target = torch.as_tensor(start), torch.as_tensor(target)
+    frac = torch.arange(res, dtype=start.dtype if start.is_floating_point() else torch.float32, device=start.device) / res
+    points = start[None, :] + (target - start)[None, :] * frac[:, None]
+    return bool(torch.as_tensor(checker.is_collision(points)).any())
 
 
 class DiffCo(Perceptron):

@@ -68,6 +68,29 @@ def test_score_rq_and_is_collision():
     assert torch.equal(dc(q.detach()), dc.score(q.detach()) > 0)
 
 
+def test_line_queries_are_one_batch():
+    """Perceptron.line_predict (kernel_perceptrons.py:22-24) and the old API's line_collision (deprecated/DiffCo.py:20-22):
+    `any(is_collision(start + (target - start) i / res))`, asked as one batch - equal to the per-point loop the reference runs"""
+    from diffco_amd import deprecated, kernel
+    d = load("cfg2_baxter_rq")
+    rob = make_robot("baxter_left")
+    dc = _new_diffco(rob, d, "score", "cuda")
+    q = torch.from_numpy(d["q"])
+    s = dc.score(q)
+    free, hit = q[int(torch.argmin(s))], q[int(torch.argmax(s))]
+    for a, b, res in ((free, hit, 50), (hit, free, 7), (free, free, 3), (q[0], q[1], 50), (q[2], q[3], 50)):
+        want = any(bool(dc.is_collision(a + (b - a) / res * i)) for i in range(res))
+        assert dc.line_predict(a, b, res=res) is want
+        assert dc.line_predict(a.cuda(), b.cuda(), res=res) is want
+    assert dc.line_predict(hit, free, 7) is True
+    old = deprecated.DiffCo(None, kernel_func=kernel.FKKernel(rob.fkine, kernel.RQKernel(10.0)), beta=1.0)
+    old.train_method = "original"
+    old.support_points, old.gains = torch.from_numpy(d["sup_q"]), torch.from_numpy(d["weights"]).reshape(-1)
+    for a, b in ((free, hit), (q[0], q[1])):
+        want = any(bool(old.is_collision(a + (b - a) / 50 * i)) for i in range(50))
+        assert old.line_collision(a, b) is want
+
+
 def test_planar_config1_on_cpu_tensors():
     """BASELINE config #1: 2-DoF planar arm, RQ(10), 200 supports, batch 256 — CPU tensors in and out,
     computed by the HIP path (the reference runs this case on PyTorch CPU)."""
