@@ -141,6 +141,27 @@ def test_independent_loops_three_classes_wrap2pi():
     _check_batch(OptimSampler(rob, md.rbf_score, dict(opts, N_WAYPOINTS=20, record_freq=1, lr=0.1)), starts[:6], d, "pl_long")
 
 
+def test_five_classes_on_baxter():
+    """config #3's shape - old MultiDiffCo.rbf_score, five classes with zeroed weights, per-class margins - on the DH arm, wrap2pi,
+    records every second step: B independent loops and one loop over four configurations, against the reference's records"""
+    from diffco_amd import MultiDiffCo, kernel, utils
+    from diffco_amd.escape import OptimSampler
+    d = load("escape")
+    rob = make_robot("baxter_left")
+    md = MultiDiffCo(None, kernel_func=kernel.FKKernel(rob.fkine, kernel.RQKernel(10.0)))
+    md.fkine, md.support_points = rob.fkine, torch.from_numpy(d["b5_sup_q"])
+    md.support_fkine = rob.fkine(md.support_points).reshape(len(md.support_points), -1)
+    md.rbf_kernel, md.rbf_nodes, md.num_class = kernel.Polyharmonic(1, 1.0), torch.from_numpy(d["b5_w"]), 5
+    starts, margin = torch.from_numpy(d["b5_starts"]), torch.from_numpy(d["b5_margin"])
+    assert relerr(_np(md.rbf_score(starts)), d["b5_score0"]) < 1e-5
+    opts = {"N_WAYPOINTS": 10, "safety_margin": margin, "lr": 5e-2, "record_freq": 2, "post_transform": utils.wrap2pi}
+    _check_batch(OptimSampler(rob, md.rbf_score, opts), starts, d, "b5_batch")
+    joint = OptimSampler(rob, md.rbf_score, dict(opts, N_WAYPOINTS=6, record_freq=1))
+    hist, checks = joint.optim_escape(starts[:4])
+    assert joint.last_route == "fused" and checks == int(d["b5_joint_checks"])
+    assert tuple(hist.shape) == d["b5_joint_hist"].shape and relerr(_np(hist), d["b5_joint_hist"]) < TOL
+
+
 def test_independent_loops_se2_wrap():
     from diffco_amd import utils
     from diffco_amd.escape import OptimSampler

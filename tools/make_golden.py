@@ -781,6 +781,22 @@ def gen_escape(out, robots):
     run("pl_batch", rob, md.rbf_score, starts, opts, False)
     run("pl_long", rob, md.rbf_score, starts[:6], dict(opts, N_WAYPOINTS=20, record_freq=1, lr=0.1), False)
 
+    # ---- Baxter, five classes (config #3's shape: old MultiDiffCo.rbf_score, Polyharmonic nodes), per-class margins, wrap2pi
+    rob = robots["baxter_left"]
+    S, C = 400, 5
+    sup_q = rand_cfgs(rob, S, gen)
+    W = (torch.randn((S, C), generator=gen) * 0.05 + 0.002) * (torch.rand((S, C), generator=gen) >= 0.4)
+    md5 = R.old_MultiDiffCo.MultiDiffCo.__new__(R.old_MultiDiffCo.MultiDiffCo)
+    md5.fkine, md5.support_points, md5.support_fkine = rob.fkine, sup_q, fk32(rob, sup_q).reshape(S, -1)
+    md5.rbf_kernel, md5.rbf_nodes, md5.num_class = make_kernel("poly", (1, 1.0)), W, C
+    starts = rand_cfgs(rob, 10, gen)
+    s0 = md5.rbf_score(starts).detach()
+    margin = s0.median(dim=0).values - 0.05
+    arrs.update(b5_sup_q=sup_q, b5_w=W, b5_starts=starts, b5_score0=s0, b5_margin=margin)
+    o5 = {"N_WAYPOINTS": 10, "safety_margin": margin, "lr": 5e-2, "record_freq": 2, "post_transform": R.utils.wrap2pi}
+    run("b5_batch", rob, md5.rbf_score, starts, o5, False)
+    run("b5_joint", rob, md5.rbf_score, starts[:4], dict(o5, N_WAYPOINTS=6, record_freq=1), True)
+
     # ---- SE(2) body, RQ perceptron score (new API score), se2_wrap2pi ------------------------------------------
     rob = robots["se2"]
     sup_q = rand_cfgs(rob, 120, gen)
