@@ -37,6 +37,10 @@ SYMBOLS = {
     "dcx_score_jac": (C.c_int, [C.c_void_p, _c_fp, C.c_int64, _c_fp, _c_fp, C.c_void_p]),
     "dcx_score_hess": (C.c_int, [C.c_void_p, _c_fp, C.c_int64, _c_fp, _c_fp, _c_fp, C.c_void_p]),
     "dcx_score_hinge_grad": (C.c_int, [C.c_void_p, _c_fp, C.c_int64, C.c_float, C.c_float, _c_fp, _c_fp, C.c_void_p]),
+    "dcx_score_hinge_grad_mc": (C.c_int, [C.c_void_p, _c_fp, C.c_int64, C.POINTER(C.c_float), C.c_float, _c_fp, _c_fp, C.c_void_p]),
+    "dcx_traj_adam_run_mc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.c_int32, C.c_void_p]),
+    "dcx_traj_adam_step_mc": (C.c_int, [C.c_int, C.POINTER(FkDesc), C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.c_int32,
+                                        C.c_void_p]),
     "dcx_traj_adam_step": (C.c_int, [C.c_int, C.POINTER(FkDesc), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "dcx_traj_adam_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "dcx_escape_work_bytes": (C.c_size_t, [C.c_void_p, C.c_int64]),
@@ -48,6 +52,10 @@ SYMBOLS = {
                                           C.c_int32, _c_fp, _c_fp, _c_fp, C.c_int32, _c_fp, C.c_int32, C.c_void_p]),
     "dcx_fkine": (C.c_int, [C.c_int, C.POINTER(FkDesc), _c_fp, C.c_int64, _c_fp, C.c_void_p]),
     "dcx_fkine_vjp": (C.c_int, [C.c_int, C.POINTER(FkDesc), _c_fp, _c_fp, C.c_int64, _c_fp, C.c_void_p]),
+    "dcx_dh_frames": (C.c_int, [C.c_int, _c_fp, C.c_int64, C.c_int32, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, C.c_void_p]),
+    "dcx_dh_frames_vjp": (C.c_int, [C.c_int, _c_fp, C.c_int64, C.c_int32, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, C.c_void_p]),
+    "dcx_euler_frames": (C.c_int, [C.c_int, _c_fp, C.c_int64, _c_fp, C.c_void_p]),
+    "dcx_euler_frames_vjp": (C.c_int, [C.c_int, _c_fp, _c_fp, C.c_int64, _c_fp, C.c_void_p]),
     "dcx_kernel_matrix": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_float), _c_fp, C.c_int64, _c_fp, C.c_int64,
                                     C.c_int32, _c_fp, C.c_void_p]),
     "dcx_solve_work_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),

@@ -342,14 +342,32 @@ class ScoreModel:
                                                 self._st()))
         return grad, hess
 
+    def margins(self, margin):
+        """a safety margin as the C ABI wants it: C host floats (a scalar serves every class, like the reference's broadcast in
+        `dist_est(p) - safety_margin`, optim.py:88-89)"""
+        if torch.is_tensor(margin):
+            margin = margin.detach().reshape(-1).tolist()
+        elif not isinstance(margin, (list, tuple)):
+            try:
+                margin = [float(v) for v in margin.reshape(-1)]      # numpy
+            except AttributeError:
+                margin = [float(margin)]
+        if len(margin) == 1:
+            margin = list(margin) * self.C
+        if len(margin) != self.C:
+            raise ValueError(f"{len(margin)} safety margins for a score with {self.C} outputs")
+        return (C.c_float * self.C)(*(float(v) for v in margin))
+
     def score_hinge_grad_raw(self, q32, margin, weight):
-        """(score [B,1], weight * 1[score > margin] * dscore/dq [B,dof]) — the optimisers' collision term, one launch"""
+        """(score [B, C], d/dq of weight * sum_c clamp(score_c - margin_c, 0) [B, dof]) - the optimisers' collision term
+        (optim.py:88-89); `margin`: a number or one per class.  One launch for one class, two (class scores, then the sweep
+        whose upstream is the hinge's indicator) for several."""
         B = q32.shape[0]
         out = torch.empty((B, self.C), device=self.dev, dtype=torch.float32)
         grad = torch.empty((B, self.dof), device=self.dev, dtype=torch.float32)
         with _on_device(self.dev):
-            _lib.check(self._lib.dcx_score_hinge_grad(self._h, _ptr(q32), B, float(margin), float(weight), _ptr(out),
-                                                      _ptr(grad), self._st()))
+            _lib.check(self._lib.dcx_score_hinge_grad_mc(self._h, _ptr(q32), B, self.margins(margin), float(weight), _ptr(out),
+                                                         _ptr(grad), self._st()))
         return out, grad
 
     # autograd-aware ------------------------------------------------------------------------

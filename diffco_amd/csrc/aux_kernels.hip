@@ -182,6 +182,106 @@ size_t fk_lds_bytes(const dcx_fk_desc& fk, bool with_g) {
     return sizeof(float) * (fk_prog_floats(fk) + ((64 * fk.dof + 3) & ~3) + 64 * d_fk * (with_g ? 2 : 1) + 64 * fk_frame_floats(fk));
 }
 
+// ---- utils.DH2mat / utils.euler2mat as callables of their own (reference utils.py:66-75, 15-38; round 6) ---------------------
+// User-written robot classes build their FK from these (model.py:230, 437 do: DH2mat -> a chain of bmm); the fused kernels
+// never materialise link frames, so these exist for that API only.  HBM-bound by construction: 4 B in, 64 B out per joint.
+// One lane = one (configuration, joint) entry; the frames leave through LDS as whole 16-byte pieces, coalesced.
+typedef float v4f_aux __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void dh_frames_kernel(const float* q, int64_t n, int dof, const float* a, const float* d,
+                                                        const float* sa, const float* ca, float* T) {
+    __shared__ v4f_aux sT[256 * 4];
+    const int tid = threadIdx.x;
+    const int64_t e0 = (int64_t)blockIdx.x * 256, e = e0 + tid;
+    if (e < n) {
+        const int j = (int)(e % dof);
+        float s, c;
+        sincos_f32(q[e], &s, &c);
+        const float aj = a[j], saj = sa[j], caj = ca[j];
+        // T = Rz(theta) Tz(d) Tx(a) Rx(alpha)  (utils.py:69-74, row by row)
+        sT[tid * 4 + 0] = v4f_aux{c, -s * caj, s * saj, aj * c};
+        sT[tid * 4 + 1] = v4f_aux{s, c * caj, -c * saj, aj * s};
+        sT[tid * 4 + 2] = v4f_aux{0.0f, saj, caj, d[j]};
+        sT[tid * 4 + 3] = v4f_aux{0.0f, 0.0f, 0.0f, 1.0f};
+    }
+    __syncthreads();
+    const int64_t left = n - e0;
+    const int rows = (int)(left < 256 ? left : 256) * 4;
+    v4f_aux* dst = reinterpret_cast<v4f_aux*>(T + e0 * 16);
+    for (int i = tid; i < rows; i += 256) dst[i] = sT[i];
+}
+// autograd of the above w.r.t. the joint angles: only rows 0 and 1 of a frame depend on theta
+__global__ __launch_bounds__(256) void dh_frames_vjp_kernel(const float* q, int64_t n, int dof, const float* a, const float* sa,
+                                                            const float* ca, const float* gT, float* gq) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const int j = (int)(e % dof);
+    float s, c;
+    sincos_f32(q[e], &s, &c);
+    const v4f_aux g0 = reinterpret_cast<const v4f_aux*>(gT + e * 16)[0], g1 = reinterpret_cast<const v4f_aux*>(gT + e * 16)[1];
+    const float aj = a[j], saj = sa[j], caj = ca[j];
+    float r = g0.x * -s;
+    r = fmaf(g0.y, -c * caj, r);
+    r = fmaf(g0.z, c * saj, r);
+    r = fmaf(g0.w, -aj * s, r);
+    r = fmaf(g1.x, c, r);
+    r = fmaf(g1.y, -s * caj, r);
+    r = fmaf(g1.z, s * saj, r);
+    r = fmaf(g1.w, aj * c, r);
+    gq[e] = r;
+}
+// R = Rz(yaw) Ry(pitch) Rx(roll) for phi = (roll, pitch, yaw)  (utils.py:15-38: `rz @ ry @ rx`, left to right)
+__device__ __forceinline__ void euler_parts(const float* phi, float (&M)[3][3], float& sx, float& cx, float& sy, float& cy, float& sz, float& cz) {
+    sincos_f32(phi[0], &sx, &cx);
+    sincos_f32(phi[1], &sy, &cy);
+    sincos_f32(phi[2], &sz, &cz);
+    // M = Rz Ry
+    M[0][0] = cz * cy; M[0][1] = -sz; M[0][2] = cz * sy;
+    M[1][0] = sz * cy; M[1][1] = cz;  M[1][2] = sz * sy;
+    M[2][0] = -sy;     M[2][1] = 0.f; M[2][2] = cy;
+}
+__global__ __launch_bounds__(256) void euler_frames_kernel(const float* phi, int64_t B, float* R) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    float M[3][3], sx, cx, sy, cy, sz, cz;
+    euler_parts(phi + b * 3, M, sx, cx, sy, cy, sz, cz);
+    float* o = R + b * 9;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {     // (M Rx)[i] = (M_i0, M_i1 cx + M_i2 sx, -M_i1 sx + M_i2 cx)
+        o[3 * i] = M[i][0];
+        o[3 * i + 1] = fmaf(M[i][2], sx, M[i][1] * cx);
+        o[3 * i + 2] = fmaf(M[i][2], cx, -(M[i][1] * sx));
+    }
+}
+__global__ __launch_bounds__(256) void euler_frames_vjp_kernel(const float* phi, const float* gR, int64_t B, float* gphi) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    float M[3][3], sx, cx, sy, cy, sz, cz;
+    euler_parts(phi + b * 3, M, sx, cx, sy, cy, sz, cz);
+    const float* g = gR + b * 9;
+    // roll: R = M Rx, dRx/droll = [[0,0,0],[0,-sx,-cx],[0,cx,-sx]]
+    float gr = 0.f, gp = 0.f, gy = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        gr = fmaf(g[3 * i + 1], fmaf(M[i][2], cx, -(M[i][1] * sx)), gr);
+        gr = fmaf(g[3 * i + 2], -fmaf(M[i][2], sx, M[i][1] * cx), gr);
+    }
+    // pitch: dM/dpitch = Rz dRy: [[-cz sy, 0, cz cy], [-sz sy, 0, sz cy], [-cy, 0, -sy]];  yaw: dM/dyaw = dRz Ry: [[-sz cy, -cz, -sz sy], [cz cy, -sz, cz sy], [0, 0, 0]]
+    const float P[3][3] = {{-cz * sy, 0.f, cz * cy}, {-sz * sy, 0.f, sz * cy}, {-cy, 0.f, -sy}};
+    const float Y[3][3] = {{-sz * cy, -cz, -sz * sy}, {cz * cy, -sz, cz * sy}, {0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        gp = fmaf(g[3 * i], P[i][0], gp);
+        gp = fmaf(g[3 * i + 1], fmaf(P[i][2], sx, P[i][1] * cx), gp);
+        gp = fmaf(g[3 * i + 2], fmaf(P[i][2], cx, -(P[i][1] * sx)), gp);
+        gy = fmaf(g[3 * i], Y[i][0], gy);
+        gy = fmaf(g[3 * i + 1], fmaf(Y[i][2], sx, Y[i][1] * cx), gy);
+        gy = fmaf(g[3 * i + 2], fmaf(Y[i][2], cx, -(Y[i][1] * sx)), gy);
+    }
+    gphi[b * 3] = gr;
+    gphi[b * 3 + 1] = gp;
+    gphi[b * 3 + 2] = gy;
+}
+
 }  // namespace
 
 hipError_t launch_fkine(const FkProg* fk_dev, const dcx_fk_desc& fk, const float* q, int64_t B, float* X,
@@ -239,6 +339,31 @@ __global__ void clock_probe_kernel(unsigned long long* out, unsigned long long w
         out[3] = r1;
     }
 }
+hipError_t launch_dh_frames(const float* q, int64_t B, int dof, const float* a, const float* d, const float* sa, const float* ca,
+                            float* T, hipStream_t st) {
+    const int64_t n = B * dof;
+    if (n == 0) return hipSuccess;
+    dh_frames_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>(q, n, dof, a, d, sa, ca, T);
+    return hipGetLastError();
+}
+hipError_t launch_dh_frames_vjp(const float* q, int64_t B, int dof, const float* a, const float* sa, const float* ca, const float* gT,
+                                float* gq, hipStream_t st) {
+    const int64_t n = B * dof;
+    if (n == 0) return hipSuccess;
+    dh_frames_vjp_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>(q, n, dof, a, sa, ca, gT, gq);
+    return hipGetLastError();
+}
+hipError_t launch_euler_frames(const float* phi, int64_t B, float* R, hipStream_t st) {
+    if (B == 0) return hipSuccess;
+    euler_frames_kernel<<<dim3((unsigned)((B + 255) / 256)), 256, 0, st>>>(phi, B, R);
+    return hipGetLastError();
+}
+hipError_t launch_euler_frames_vjp(const float* phi, const float* gR, int64_t B, float* gphi, hipStream_t st) {
+    if (B == 0) return hipSuccess;
+    euler_frames_vjp_kernel<<<dim3((unsigned)((B + 255) / 256)), 256, 0, st>>>(phi, gR, B, gphi);
+    return hipGetLastError();
+}
+
 hipError_t launch_clock_probe(unsigned long long* out, unsigned long long wall_ticks, hipStream_t st) {
     clock_probe_kernel<<<1, 64, 0, st>>>(out, wall_ticks);
     return hipGetLastError();

@@ -456,7 +456,7 @@ unsigned long long* traj_exchange_rows(const dcx_model* m, hipStream_t st, size_
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
     if (!hit) {
-        const size_t fixed = (size_t)2 * m->n_cu * (m->Dt + 1) * 64 * sizeof(unsigned long long);
+        const size_t fixed = (size_t)2 * m->n_cu * (m->Dt + m->Cc) * 64 * sizeof(unsigned long long);
         if (bytes > fixed) return nullptr;
         unsigned long long* p = nullptr;
         if (hipMalloc((void**)&p, fixed) != hipSuccess) {
@@ -497,8 +497,9 @@ void set_fk_walk(const dcx_model* m, ScoreArgs& a) {
 }
 
 struct Hinge {
-    int on = 0;
+    int on = 0;                 // 1: one class, applied to the gradient row;  2: several classes, `upstream` holds the scores (score_kernel.h)
     float margin = 0.f, weight = 0.f;
+    float margin_c[DCX_MAX_C] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 };
 
 // nz > 1 (MODE_GRAD_UP): the nz classes' one-hot sweeps in ONE launch (gridDim.z), rows to grad + z * dof.  Returns
@@ -602,6 +603,7 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
     a.hinge = hinge.on;
     a.hinge_margin = hinge.margin;
     a.hinge_weight = hinge.weight;
+    for (int c = 0; c < DCX_MAX_C; ++c) a.hinge_margin_c[c] = hinge.margin_c[c];
     // Expanded form of the sweep (score_kernel.h XF) wherever it is compiled (Polyharmonic(1), rows <= 37 floats): 13-17 %
     // faster for chip-filling batches, 1-3 % for split launches (profiles/r02_xf_probe.txt).  Knob xf = 0: direct form.
     a.xf = xf_able ? 1 : 0;
@@ -1120,17 +1122,40 @@ int dcx_score_grad(const dcx_model* m, const float* q, int64_t B, const float* u
     return run_score(m, q, B, upstream, score, grad, mode, -1, m->fk.dof, (hipStream_t)stream);
 }
 
+// the collision term of the optimisers for any class count: one launch for one class; for several, the class scores first and
+// then the sweep whose upstream is weight * 1[score_c > margin_c] (score_kernel.h, ScoreArgs::hinge == 2)
+static int run_hinge(const dcx_model* m, const float* q, int64_t B, const float* margin /* host [C] */, float weight, float* score,
+                     float* grad, hipStream_t st) {
+    Hinge h;
+    h.weight = weight;
+    if (m->C == 1) {
+        h.on = 1;
+        h.margin = margin[0];
+        return run_score(m, q, B, nullptr, score, grad, MODE_GRAD_ROW, -1, m->fk.dof, st, h);
+    }
+    h.on = 2;
+    for (int c = 0; c < m->C; ++c) h.margin_c[c] = margin[c];
+    if (int rc = run_score(m, q, B, nullptr, score, nullptr, MODE_SCORE, -1, m->fk.dof, st)) return rc;
+    return run_score(m, q, B, score, nullptr, grad, MODE_GRAD_UP, -1, m->fk.dof, st, h);
+}
+
 int dcx_score_hinge_grad(const dcx_model* m, const float* q, int64_t B, float margin, float weight, float* score,
                          float* grad, void* stream) {
     if (!m) return fail(DCX_ERR_INVALID, "model is NULL");
-    if (m->C != 1) return fail(DCX_ERR_UNSUPPORTED, "dcx_score_hinge_grad needs a C == 1 model");
+    if (m->C != 1) return fail(DCX_ERR_UNSUPPORTED, "dcx_score_hinge_grad needs a C == 1 model (several classes: dcx_score_hinge_grad_mc)");
     if (B < 0 || (B > 0 && (!q || !grad))) return fail(DCX_ERR_INVALID, "q / grad is NULL or B < 0");
     if (int rc = set_device(m->device)) return rc;
-    Hinge h;
-    h.on = 1;
-    h.margin = margin;
-    h.weight = weight;
-    return run_score(m, q, B, nullptr, score, grad, MODE_GRAD_ROW, -1, m->fk.dof, (hipStream_t)stream, h);
+    return run_hinge(m, q, B, &margin, weight, score, grad, (hipStream_t)stream);
+}
+
+int dcx_score_hinge_grad_mc(const dcx_model* m, const float* q, int64_t B, const float* margin, float weight, float* score,
+                            float* grad, void* stream) {
+    if (!m) return fail(DCX_ERR_INVALID, "model is NULL");
+    if (!margin) return fail(DCX_ERR_INVALID, "margin is NULL (C host floats)");
+    if (B < 0 || (B > 0 && (!q || !grad))) return fail(DCX_ERR_INVALID, "q / grad is NULL or B < 0");
+    if (m->C > 1 && B > 0 && !score) return fail(DCX_ERR_INVALID, "several classes: score must not be NULL (it carries the first sweep's result to the second)");
+    if (int rc = set_device(m->device)) return rc;
+    return run_hinge(m, q, B, margin, weight, score, grad, (hipStream_t)stream);
 }
 
 int dcx_score_hess(const dcx_model* m, const float* q, int64_t B, const float* upstream, float* grad, float* hess,
@@ -1254,24 +1279,56 @@ static int check_traj(const dcx_traj_state* st, const dcx_traj_opts* opt, int do
     return DCX_OK;
 }
 
-int dcx_traj_adam_step(int device, const dcx_fk_desc* fk, const dcx_traj_state* st, const dcx_traj_opts* opt,
-                       int32_t step, void* stream) {
+static int traj_step(int device, const dcx_fk_desc* fk, const dcx_traj_state* st, const dcx_traj_opts* opt, const float* margin,
+                     int32_t C, int32_t step, void* stream) {
     if (!fk) return fail(DCX_ERR_INVALID, "fk is NULL");
+    if (C < 1 || C > DCX_MAX_C) return fail(DCX_ERR_UNSUPPORTED, "trajectory step: 1 <= C <= DCX_MAX_C");
     if (step < 1) return fail(DCX_ERR_INVALID, "step is 1-based");
     if (int rc = check_fk(*fk)) return rc;
     if (int rc = check_traj(st, opt, fk->dof)) return rc;
     if (int rc = set_device(device)) return rc;
     FkProg* dev = nullptr;
     if (int rc = fk_device_copy(device, *fk, &dev)) return rc;
-    hipError_t e = launch_traj_adam_step(dev, *fk, *st, *opt, step, (hipStream_t)stream);
+    hipError_t e = launch_traj_adam_step(dev, *fk, *st, *opt, step, (hipStream_t)stream, C, margin);
     if (e != hipSuccess) return fail_hip(e, "trajectory step launch");
     return DCX_OK;
 }
 
+int dcx_traj_adam_step(int device, const dcx_fk_desc* fk, const dcx_traj_state* st, const dcx_traj_opts* opt,
+                       int32_t step, void* stream) {
+    return traj_step(device, fk, st, opt, nullptr, 1, step, stream);
+}
+
+int dcx_traj_adam_step_mc(int device, const dcx_fk_desc* fk, const dcx_traj_state* st, const dcx_traj_opts* opt,
+                          const float* margin, int32_t C, int32_t step, void* stream) {
+    return traj_step(device, fk, st, opt, margin, C, step, stream);
+}
+
+static int traj_run(const dcx_model* m, const dcx_traj_state* st, const dcx_traj_opts* opt, const float* margin_in, int32_t first_step,
+                    int32_t n_iters, void* stream);
+
 int dcx_traj_adam_run(const dcx_model* m, const dcx_traj_state* st, const dcx_traj_opts* opt, int32_t first_step,
                       int32_t n_iters, void* stream) {
     if (!m) return fail(DCX_ERR_INVALID, "model is NULL");
-    if (m->C != 1) return fail(DCX_ERR_UNSUPPORTED, "dcx_traj_adam_run needs a C == 1 model");
+    if (m->C != 1) return fail(DCX_ERR_UNSUPPORTED, "dcx_traj_adam_run needs a C == 1 model (several classes: dcx_traj_adam_run_mc)");
+    return traj_run(m, st, opt, nullptr, first_step, n_iters, stream);
+}
+
+int dcx_traj_adam_run_mc(const dcx_model* m, const dcx_traj_state* st, const dcx_traj_opts* opt, const float* margin,
+                         int32_t first_step, int32_t n_iters, void* stream) {
+    if (!m) return fail(DCX_ERR_INVALID, "model is NULL");
+    return traj_run(m, st, opt, margin, first_step, n_iters, stream);
+}
+
+static int traj_run(const dcx_model* m, const dcx_traj_state* st, const dcx_traj_opts* opt, const float* margin_in, int32_t first_step,
+                    int32_t n_iters, void* stream) {
+    if (!opt) return fail(DCX_ERR_INVALID, "traj state / opts is NULL");
+    // the per-class margins (several classes: optim.py:88-89 with safety_margin [C]); NULL = opt->safety_margin for every class
+    float margin[DCX_MAX_C];
+    for (int c = 0; c < DCX_MAX_C; ++c) margin[c] = (margin_in && c < m->C) ? margin_in[c] : opt->safety_margin;
+    dcx_traj_opts opt1 = *opt;
+    if (m->C == 1) opt1.safety_margin = margin[0];
+    opt = &opt1;
     if (first_step < 1 || n_iters < 0) return fail(DCX_ERR_INVALID, "first_step is 1-based, n_iters >= 0");
     if (int rc = check_traj(st, opt, m->fk.dof)) return rc;
     if (int rc = set_device(m->device)) return rc;
@@ -1303,12 +1360,14 @@ int dcx_traj_adam_run(const dcx_model* m, const dcx_traj_state* st, const dcx_tr
         const bool dh_ok = m->fk.kind == DCX_FK_DH && m->dh_dev && knobs().fkk != 0 && knobs().fkk != 1 && knobs().jt_waves != 0 &&
                            m->dh.n_chains <= 2 && m->dh.end0 <= kDhUnroll && m->dh.n_steps - m->dh.end0 <= kDhUnroll;
         auto lds_of = [&](int w) {
-            return sizeof(float) * (size_t)(traj_fused_plan(m->fk.dof, d_fk, m->frame_floats, w, m->Dt, (dh_ok && w >= 4) ? m->dh.n_pt : 0).total + m->prog_floats);
+            return sizeof(float) * (size_t)(traj_fused_plan(m->fk.dof, d_fk, m->frame_floats, w, m->Dt, (dh_ok && w >= 4) ? m->dh.n_pt : 0, m->Cc).total + m->prog_floats);
         };
         while (nw > 1 && lds_of(nw) > 150 * 1024) nw /= 2;
         traj_fused_fn fn = traj_fused_for(m->Dt);
-        if (fn && lds_of(nw) <= 150 * 1024) {
+        bool fused_ok = fn && lds_of(nw) <= 150 * 1024;
+        if (fused_ok) {
             TrajFusedArgs a{};
+            for (int c = 0; c < DCX_MAX_C; ++c) a.margin_c[c] = margin[c];
             a.sc.rows = m->rows_dev;
             set_fk_walk(m, a.sc);
             a.sc.jt_rows = a.sc.jt_waves = (dh_ok && nw >= 4 && a.sc.fkk == 2) ? 1 : 0;
@@ -1324,10 +1383,10 @@ int dcx_traj_adam_run(const dcx_model* m, const dcx_traj_state* st, const dcx_tr
             a.sc.d_fk = d_fk;
             a.sc.frame_floats = m->frame_floats;
             a.sc.kind = m->kind;
-            a.sc.c_out = 1;
+            a.sc.c_out = m->C;
             a.sc.kp0 = m->kp0_sweep;
             a.sc.kp1 = m->kp1;
-            a.sc.xf = (knobs().xf != 0 && m->kf == KF_POLY1 && xf_applies(m->Dt, 1, KF_POLY1) && m->rows_xf_dev) ? 1 : 0;
+            a.sc.xf = (knobs().xf != 0 && m->kf == KF_POLY1 && xf_applies(m->Dt, m->Cc, KF_POLY1) && m->rows_xf_dev) ? 1 : 0;
             if (a.sc.xf) {
                 a.sc.rows = m->rows_xf_dev;
                 a.sc.centre = m->centre_dev;
@@ -1346,7 +1405,7 @@ int dcx_traj_adam_run(const dcx_model* m, const dcx_traj_state* st, const dcx_tr
                 }
                 a.ys = 1;
                 if (ys > 1) {
-                    a.exch = traj_exchange_rows(m, (hipStream_t)stream, (size_t)st->n_paths * 2 * ys * (m->Dt + 1) * 64 * sizeof(unsigned long long),
+                    a.exch = traj_exchange_rows(m, (hipStream_t)stream, (size_t)st->n_paths * 2 * ys * (m->Dt + m->Cc) * 64 * sizeof(unsigned long long),
                                                 &a.tag_base);
                     if (a.exch) a.ys = ys;
                     a.cl_across = knobs().traj_across > 0 ? 1 : 0;
@@ -1356,29 +1415,32 @@ int dcx_traj_adam_run(const dcx_model* m, const dcx_traj_state* st, const dcx_tr
                     a.s_super = m->S_active;
                     a.sc.s_chunk = (m->S_active + nw - 1) / nw;
                 }
-                hipError_t e = fn(m->kf, nw, lds_of(nw), st->n_paths, a, (hipStream_t)stream);
+                hipError_t e = fn(m->kf, m->Cc, nw, lds_of(nw), st->n_paths, a, (hipStream_t)stream);
+                if (e == hipErrorNotSupported && done == 0) {   // this width / kernel function has no multi-class instantiation
+                    (void)hipGetLastError();
+                    fused_ok = false;
+                    break;
+                }
                 if (e != hipSuccess && a.ys > 1) {
                     // the cooperative launch was refused (the grid does not fit beside what else is resident): nothing ran
                     (void)hipGetLastError();
                     ys = a.ys = 1;
                     a.s_super = m->S_active;
                     a.sc.s_chunk = (m->S_active + nw - 1) / nw;
-                    e = fn(m->kf, nw, lds_of(nw), st->n_paths, a, (hipStream_t)stream);
+                    e = fn(m->kf, m->Cc, nw, lds_of(nw), st->n_paths, a, (hipStream_t)stream);
                 }
                 if (e != hipSuccess) return fail_hip(e, "fused trajectory launch");
             }
-            return DCX_OK;
+            if (fused_ok) return DCX_OK;
         }
     }
-    Hinge h;
-    h.on = 1;
-    h.margin = opt->safety_margin;
-    h.weight = opt->w_collision;
+    // the loop as launches per iteration: the collision term (one sweep; several classes: scores, then the hinge-gradient sweep)
+    // and the fused step (traj_kernels.hip)
     for (int it = 0; it < n_iters; ++it) {
-        int rc = run_score(m, st->path, B, nullptr, const_cast<float*>(st->col_score), const_cast<float*>(st->col_grad),
-                           MODE_GRAD_ROW, -1, m->fk.dof, (hipStream_t)stream, h);
+        int rc = run_hinge(m, st->path, B, margin, opt->w_collision, const_cast<float*>(st->col_score), const_cast<float*>(st->col_grad),
+                           (hipStream_t)stream);
         if (rc) return rc;
-        hipError_t e = launch_traj_adam_step(m->fk_dev, m->fk, *st, *opt, first_step + it, (hipStream_t)stream);
+        hipError_t e = launch_traj_adam_step(m->fk_dev, m->fk, *st, *opt, first_step + it, (hipStream_t)stream, m->C, margin);
         if (e != hipSuccess) return fail_hip(e, "trajectory step launch");
     }
     return DCX_OK;
@@ -1528,6 +1590,42 @@ int dcx_fkine(int device, const dcx_fk_desc* fk, const float* q, int64_t B, floa
     if (int rc = fk_device_copy(device, *fk, &dev)) return rc;
     hipError_t e = launch_fkine(dev, *fk, q, B, X, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "fkine launch");
+    return DCX_OK;
+}
+
+int dcx_dh_frames(int device, const float* q, int64_t B, int32_t dof, const float* a, const float* d, const float* sin_alpha,
+                  const float* cos_alpha, float* T, void* stream) {
+    if (B < 0 || dof < 1 || (B > 0 && (!q || !a || !d || !sin_alpha || !cos_alpha || !T)))
+        return fail(DCX_ERR_INVALID, "dcx_dh_frames: a pointer is NULL, B < 0 or dof < 1");
+    if (int rc = set_device(device)) return rc;
+    hipError_t e = launch_dh_frames(q, B, dof, a, d, sin_alpha, cos_alpha, T, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "dh_frames launch");
+    return DCX_OK;
+}
+
+int dcx_dh_frames_vjp(int device, const float* q, int64_t B, int32_t dof, const float* a, const float* sin_alpha,
+                      const float* cos_alpha, const float* gT, float* gq, void* stream) {
+    if (B < 0 || dof < 1 || (B > 0 && (!q || !a || !sin_alpha || !cos_alpha || !gT || !gq)))
+        return fail(DCX_ERR_INVALID, "dcx_dh_frames_vjp: a pointer is NULL, B < 0 or dof < 1");
+    if (int rc = set_device(device)) return rc;
+    hipError_t e = launch_dh_frames_vjp(q, B, dof, a, sin_alpha, cos_alpha, gT, gq, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "dh_frames_vjp launch");
+    return DCX_OK;
+}
+
+int dcx_euler_frames(int device, const float* phi, int64_t B, float* R, void* stream) {
+    if (B < 0 || (B > 0 && (!phi || !R))) return fail(DCX_ERR_INVALID, "dcx_euler_frames: phi / R is NULL or B < 0");
+    if (int rc = set_device(device)) return rc;
+    hipError_t e = launch_euler_frames(phi, B, R, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "euler_frames launch");
+    return DCX_OK;
+}
+
+int dcx_euler_frames_vjp(int device, const float* phi, const float* gR, int64_t B, float* gphi, void* stream) {
+    if (B < 0 || (B > 0 && (!phi || !gR || !gphi))) return fail(DCX_ERR_INVALID, "dcx_euler_frames_vjp: a pointer is NULL or B < 0");
+    if (int rc = set_device(device)) return rc;
+    hipError_t e = launch_euler_frames_vjp(phi, gR, B, gphi, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "euler_frames_vjp launch");
     return DCX_OK;
 }
 

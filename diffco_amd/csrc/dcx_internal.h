@@ -55,8 +55,9 @@ DCX_DECLARE_JAC(60) DCX_DECLARE_JAC(64) DCX_DECLARE_JAC(72) DCX_DECLARE_JAC(84)
 DCX_DECLARE_JAC(96)
 #undef DCX_DECLARE_JAC
 // config #5 as one persistent launch (traj_fused.h), one entry point per compiled D as well
-typedef hipError_t (*traj_fused_fn)(int kf, int nw, size_t lds_bytes, int n_paths, const TrajFusedArgs& args, hipStream_t stream);
-#define DCX_DECLARE_TRAJ(D) hipError_t launch_traj_fused_D##D(int, int, size_t, int, const TrajFusedArgs&, hipStream_t);
+// (cc > 1: the two-sweep form for several classes, compiled up to D = 24 for RQKernel(p = 2) / Polyharmonic(1); hipErrorNotSupported elsewhere)
+typedef hipError_t (*traj_fused_fn)(int kf, int cc, int nw, size_t lds_bytes, int n_paths, const TrajFusedArgs& args, hipStream_t stream);
+#define DCX_DECLARE_TRAJ(D) hipError_t launch_traj_fused_D##D(int, int, int, size_t, int, const TrajFusedArgs&, hipStream_t);
 DCX_DECLARE_TRAJ(2)  DCX_DECLARE_TRAJ(4)  DCX_DECLARE_TRAJ(6)  DCX_DECLARE_TRAJ(8)
 DCX_DECLARE_TRAJ(12) DCX_DECLARE_TRAJ(16) DCX_DECLARE_TRAJ(18) DCX_DECLARE_TRAJ(21)
 DCX_DECLARE_TRAJ(24) DCX_DECLARE_TRAJ(27) DCX_DECLARE_TRAJ(30) DCX_DECLARE_TRAJ(32)
@@ -72,6 +73,13 @@ hipError_t launch_fkine(const FkProg* fk_dev, const dcx_fk_desc& fk_host, const 
 hipError_t launch_fkine_vjp(const FkProg* fk_dev, const dcx_fk_desc& fk_host, const float* q, const float* gX,
                             int64_t B, float* gq, hipStream_t stream);
 hipError_t launch_clock_probe(unsigned long long* out, unsigned long long wall_ticks, hipStream_t stream);
+// utils.DH2mat / utils.euler2mat (utils.py:66-75, 15-38) and their autograd with respect to the angles
+hipError_t launch_dh_frames(const float* q, int64_t B, int dof, const float* a, const float* d, const float* sa, const float* ca,
+                            float* T, hipStream_t stream);
+hipError_t launch_dh_frames_vjp(const float* q, int64_t B, int dof, const float* a, const float* sa, const float* ca, const float* gT,
+                                float* gq, hipStream_t stream);
+hipError_t launch_euler_frames(const float* phi, int64_t B, float* R, hipStream_t stream);
+hipError_t launch_euler_frames_vjp(const float* phi, const float* gR, int64_t B, float* gphi, hipStream_t stream);
 hipError_t launch_kernel_matrix(int kind, float kp0, float kp1, const float* x, int64_t B, const float* s, int64_t S,
                                 int D, float* K, hipStream_t stream);
 
@@ -100,8 +108,9 @@ hipError_t launch_perceptron(int kind, float kp0, float kp1, float beta, const f
 constexpr int kTrainGridMaxN = 128 * 1024;  // 128 workgroups x 1024 samples (train_kernels.hip perceptron_grid_kernel)
 
 // traj_kernels.hip
+// (n_class, margin_c: col_score is [R*W, n_class] under per-class margins; margin_c == nullptr: opt.safety_margin for every class)
 hipError_t launch_traj_adam_step(const FkProg* fk_dev, const dcx_fk_desc& fk, const dcx_traj_state& st,
-                                 const dcx_traj_opts& opt, int step, hipStream_t stream);
+                                 const dcx_traj_opts& opt, int step, hipStream_t stream, int n_class = 1, const float* margin_c = nullptr);
 // the update half of dcx_escape_adam: pointers into the caller's workspace, one configuration per lane
 struct EscapeArgs {
     float* q;             // [B, dof] in/out

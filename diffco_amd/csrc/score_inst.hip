@@ -9,15 +9,15 @@
 #error "compile with -DDCX_INST_D=<feature width>"
 #endif
 
-#if defined(DCX_STUB) && DCX_INST_PART != 0
-// (the stubs of this width live in its part-0 object)
+#if (defined(DCX_STUB) && DCX_INST_PART != 0) || (DCX_INST_PART == 2 && DCX_INST_D > 24)
+// (the stubs of this width live in its part-0 object; part 2 - the multi-class trajectory kernels - exists up to D = 24)
 #elif defined(DCX_STUB)  // developer builds (Makefile ONLY_WIDTHS): this width is not compiled
 namespace dcx {
 #define DCX_CAT_(a, b) a##b
 #define DCX_CAT(a, b) DCX_CAT_(a, b)
 hipError_t DCX_CAT(launch_score_D, DCX_INST_D)(int, int, int, int, size_t, int64_t, const ScoreArgs&, hipStream_t) { return hipErrorNotSupported; }
 hipError_t DCX_CAT(launch_jac_D, DCX_INST_D)(int, int, int, size_t, int64_t, const ScoreArgs&, hipStream_t) { return hipErrorNotSupported; }
-hipError_t DCX_CAT(launch_traj_fused_D, DCX_INST_D)(int, int, size_t, int, const TrajFusedArgs&, hipStream_t) { return hipErrorNotSupported; }
+hipError_t DCX_CAT(launch_traj_fused_D, DCX_INST_D)(int, int, int, size_t, int, const TrajFusedArgs&, hipStream_t) { return hipErrorNotSupported; }
 }  // namespace dcx
 #else
 namespace dcx {
@@ -106,11 +106,33 @@ hipError_t by_cc(int cc, int mode, int nw, size_t lds, int64_t nblk, const Score
 #define DCX_CAT(a, b) DCX_CAT_(a, b)
 // Every width is built as TWO objects (Makefile, -DDCX_INST_PART=0 / 1; round 5: 21 objects of up to 155 s each left a
 // 16-core build two rounds of the longest ones): part 0 = the sweep with the two specialised kernel functions, part 1 = the
-// generic kernel function, the one-sweep Jacobian and the persistent trajectory kernel.
+// generic kernel function, the one-sweep Jacobian and the persistent trajectory kernel; round 6: part 2 (widths up to 24) = the
+// persistent trajectory kernel for several classes.
 #ifndef DCX_INST_PART
-#error "compile with -DDCX_INST_PART=0 and -DDCX_INST_PART=1"
+#error "compile with -DDCX_INST_PART=0, 1 and (D <= 24) 2"
 #endif
 hipError_t DCX_CAT(launch_score_gen_D, DCX_INST_D)(int cc, int mode, int nw, size_t lds, int64_t nblk, const ScoreArgs& a, hipStream_t st);
+namespace {
+// the persistent trajectory kernel's launch: plain, or cooperative for the cluster form
+template <class K>
+hipError_t traj_go(K kern, int nw, size_t lds, int n_paths, const TrajFusedArgs& a, hipStream_t st) {
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    if (a.ys > 1) {
+        // the cluster form: the ys workgroups of a path wait for each other once per iteration, so the whole grid must be
+        // resident at once - a cooperative launch checks that and keeps other cooperative grids off the device meanwhile
+        TrajFusedArgs copy = a;
+        void* params[] = {&copy};
+        const dim3 grid = a.cl_across ? dim3((unsigned)a.ys, (unsigned)n_paths) : dim3((unsigned)n_paths, (unsigned)a.ys);
+        return hipLaunchCooperativeKernel((const void*)kern, grid, dim3(64 * nw), params, (unsigned int)lds, st);
+    }
+    kern<<<dim3((unsigned)n_paths), dim3(64 * nw), lds, st>>>(a);
+    return hipGetLastError();
+}
+
+}  // namespace
 #if DCX_INST_PART == 0
 hipError_t DCX_CAT(launch_score_D, DCX_INST_D)(int kf, int cc, int mode, int nw, size_t lds, int64_t nblk,
                                                const ScoreArgs& a, hipStream_t st) {
@@ -121,7 +143,7 @@ hipError_t DCX_CAT(launch_score_D, DCX_INST_D)(int kf, int cc, int mode, int nw,
     default: return hipErrorInvalidValue;
     }
 }
-#else
+#elif DCX_INST_PART == 1
 hipError_t DCX_CAT(launch_score_gen_D, DCX_INST_D)(int cc, int mode, int nw, size_t lds, int64_t nblk, const ScoreArgs& a, hipStream_t st) {
     return by_cc<KF_GEN>(cc, mode, nw, lds, nblk, a, st);
 }
@@ -166,24 +188,21 @@ hipError_t DCX_CAT(launch_jac_D, DCX_INST_D)(int kf, int cc, int nw, size_t lds,
     }
 }
 
-hipError_t DCX_CAT(launch_traj_fused_D, DCX_INST_D)(int kf, int nw, size_t lds, int n_paths, const TrajFusedArgs& a,
+#if DCX_INST_PART == 1
+// several classes (part 2 of this width, D <= 24): two sweeps per iteration, see traj_fused.h
+#if DCX_INST_D <= 24
+hipError_t DCX_CAT(launch_traj_fused_mc_D, DCX_INST_D)(int kf, int cc, int nw, size_t lds, int n_paths, const TrajFusedArgs& a, hipStream_t st);
+#endif
+hipError_t DCX_CAT(launch_traj_fused_D, DCX_INST_D)(int kf, int cc, int nw, size_t lds, int n_paths, const TrajFusedArgs& a,
                                                     hipStream_t st) {
-    auto go_t = [&](auto kern) {
-        if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-        }
-        if (a.ys > 1) {
-            // the cluster form: the ys workgroups of a path wait for each other once per iteration, so the whole grid must be
-            // resident at once - a cooperative launch checks that and keeps other cooperative grids off the device meanwhile
-            TrajFusedArgs copy = a;
-            void* params[] = {&copy};
-            const dim3 grid = a.cl_across ? dim3((unsigned)a.ys, (unsigned)n_paths) : dim3((unsigned)n_paths, (unsigned)a.ys);
-            return hipLaunchCooperativeKernel((const void*)kern, grid, dim3(64 * nw), params, (unsigned int)lds, st);
-        }
-        kern<<<dim3((unsigned)n_paths), dim3(64 * nw), lds, st>>>(a);
-        return hipGetLastError();
-    };
+    if (cc > 1) {
+#if DCX_INST_D <= 24
+        return DCX_CAT(launch_traj_fused_mc_D, DCX_INST_D)(kf, cc, nw, lds, n_paths, a, st);
+#else
+        return hipErrorNotSupported;   // (the caller runs the three-launch loop)
+#endif
+    }
+    auto go_t = [&](auto kern) { return traj_go(kern, nw, lds, n_paths, a, st); };
     if (a.ys > 1) {
         if constexpr (xf_applies(kD, 1, KF_POLY1)) {
             if (kf == KF_POLY1 && a.sc.xf) return go_t(traj_fused_kernel<kD, KF_POLY1, kMaxT, true, true>);
@@ -205,7 +224,44 @@ hipError_t DCX_CAT(launch_traj_fused_D, DCX_INST_D)(int kf, int nw, size_t lds, 
     default: return hipErrorInvalidValue;
     }
 }
+#endif  // part 1
 
+#else   // ---- part 2: the persistent trajectory kernel for several classes (D <= 24; RQKernel(p = 2) and Polyharmonic(1)) ----
+namespace {
+template <int CC>
+hipError_t traj_mc(int kf, int nw, size_t lds, int n_paths, const TrajFusedArgs& a, hipStream_t st) {
+    auto go_t = [&](auto kern) { return traj_go(kern, nw, lds, n_paths, a, st); };
+    if (a.ys > 1) {
+        if constexpr (xf_applies(kD, CC, KF_POLY1)) {
+            if (kf == KF_POLY1 && a.sc.xf) return go_t(traj_fused_kernel<kD, KF_POLY1, kMaxT, true, true, CC>);
+        }
+        switch (kf) {
+        case KF_RQ2: return go_t(traj_fused_kernel<kD, KF_RQ2, kMaxT, false, true, CC>);
+        case KF_POLY1: return go_t(traj_fused_kernel<kD, KF_POLY1, kMaxT, false, true, CC>);
+        default: return hipErrorNotSupported;   // (any other kernel function: the three-launch loop)
+        }
+    }
+    if constexpr (xf_applies(kD, CC, KF_POLY1)) {
+        if (kf == KF_POLY1 && a.sc.xf) return go_t(traj_fused_kernel<kD, KF_POLY1, kMaxT, true, false, CC>);
+    }
+    switch (kf) {
+    case KF_RQ2: return go_t(traj_fused_kernel<kD, KF_RQ2, kMaxT, false, false, CC>);
+    case KF_POLY1: return go_t(traj_fused_kernel<kD, KF_POLY1, kMaxT, false, false, CC>);
+    default: return hipErrorNotSupported;
+    }
+}
+}  // namespace
+hipError_t DCX_CAT(launch_traj_fused_mc_D, DCX_INST_D)(int kf, int cc, int nw, size_t lds, int n_paths, const TrajFusedArgs& a, hipStream_t st) {
+    switch (cc) {
+    case 5: return traj_mc<5>(kf, nw, lds, n_paths, a, st);
+#ifndef DCX_DEV_FAST
+    case 2: return traj_mc<2>(kf, nw, lds, n_paths, a, st);
+    case 4: return traj_mc<4>(kf, nw, lds, n_paths, a, st);
+    case 8: return traj_mc<8>(kf, nw, lds, n_paths, a, st);
+#endif
+    default: return hipErrorNotSupported;
+    }
+}
 #endif  // DCX_INST_PART
 }  // namespace dcx
 #endif  // DCX_STUB

@@ -98,8 +98,12 @@ struct ScoreArgs {
     int32_t jt_rows;          // fkk == 2, chains of <= kDhUnroll steps, >= 2 waves per chain: the chain runs row-split
     int32_t jt_waves;         // jt_rows and the block folds in parallel with room in its scratch rows for 12 columns per
                               // point step (+ 1): J^T runs on several waves (fk_device.h dh2_vjp_r1_sel / r1b / r2_sel)
-    int32_t hinge;            // C == 1: gradient of weight * clamp(score - margin, 0) instead of the score's
+    int32_t hinge;            // 1 (C == 1): gradient of weight * clamp(score - margin, 0) instead of the score's;  2 (MODE_GRAD_UP,
+                              // C > 1): `upstream` holds this batch's SCORES (an earlier score-only launch) and the sweep's upstream
+                              // is hinge_weight * 1[score_c - hinge_margin_c[c] > 0]: the gradient of
+                              // weight * sum_c clamp(score_c - margin_c, 0) (optim.py:88-89 on a MultiDiffCo, scripts/active.py:65)
     float hinge_margin, hinge_weight;
+    float hinge_margin_c[8];  // hinge == 2: the per-class margins (DCX_MAX_C)
     int32_t qt;               // 1: the quarter-tile form (score_kernel<..., QT>): 16 configurations per block, rows from LDS
     int32_t qt_off;           // ... float offset of the rows' copy inside the block's LDS
     int32_t qt_per;           // ... rows per slice (kQtSlices * nw slices; a slice starts four banks behind the one before)
@@ -1500,11 +1504,11 @@ __device__ __forceinline__ void sweep_rows_mfma(const ScoreArgs& a, const float 
 // so the sums do not depend on nw's parallelism - into row 0.  The block sizes the launch rules pick are compiled in: all nw
 // reads of an accumulator are in flight before the first add (a run-time trip count left one dependent LDS round trip per
 // row).  Caller synchronises before and after.
-template <int ACC>
+template <int ACC, int E0 = 0, int E1 = ACC>   // accumulators [E0, E1) of rows with stride ACC (the persistent trajectory kernel folds class scores and gradient apart)
 __device__ __forceinline__ void fold_partial_rows(float* sRed, int wave, int lane, int nw) {
     auto fold_rows = [&](auto nwc) __attribute__((always_inline)) {
         constexpr int NWC = decltype(nwc)::value;
-        for (int e = wave; e < ACC; e += NWC) {
+        for (int e = E0 + wave; e < E1; e += NWC) {
             float r[NWC];
 #pragma unroll
             for (int w = 0; w < NWC; ++w) r[w] = sRed[((size_t)w * ACC + e) * 64 + lane];
@@ -1519,7 +1523,7 @@ __device__ __forceinline__ void fold_partial_rows(float* sRed, int wave, int lan
     else if (nw == 4) fold_rows(std::integral_constant<int, 4>{});
     else if (nw == 2) fold_rows(std::integral_constant<int, 2>{});
     else {
-        for (int e = wave; e < ACC; e += nw) {
+        for (int e = E0 + wave; e < E1; e += nw) {
             float v = sRed[e * 64 + lane];
             for (int w = 1; w < nw; ++w) v += sRed[((size_t)w * ACC + e) * 64 + lane];
             sRed[e * 64 + lane] = v;
@@ -1639,6 +1643,10 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF, MF, XM, QT)) void 
         const int hot = (a.nz > 1) ? (int)blockIdx.z : a.one_hot;
 #pragma unroll
         for (int c = 0; c < CC; ++c) up[c] = (hot >= 0) ? (c == hot ? 1.0f : 0.0f) : (c < a.c_out ? a.upstream[bl * a.c_out + c] : 0.0f);
+        if (a.hinge == 2) {   // the multi-class hinge: what was read are the scores of an earlier launch (wave-uniform branch)
+#pragma unroll
+            for (int c = 0; c < CC; ++c) up[c] = (c < a.c_out && up[c] - a.hinge_margin_c[c < 8 ? c : 7] > 0.0f) ? a.hinge_weight : 0.0f;
+        }
     }
 
     // ---- the sweep: this wave's slice of the supports ----------------------------------------

@@ -74,6 +74,7 @@ struct TrajFusedArgs {
     int32_t cl_across;              // 1: grid (ys, n_paths) - consecutive workgroup ids = the ys members of a path, which the
                                     // dispatcher deals out to DIFFERENT XCDs; 0: grid (n_paths, ys) - with n_paths a multiple of
                                     // 8 the members of a path land on ONE XCD and exchange through its L2 (see traj_exchange)
+    float margin_c[8];              // CC > 1 (traj_fused_kernel<..., CC>): the per-class safety margins (opt.safety_margin is the one of CC == 1)
     float bias1[kTrajFusedMaxIters];       // 1 - beta1^t          (host double arithmetic, like launch_traj_adam_step)
     float bias2_sqrt[kTrajFusedMaxIters];  // sqrt(1 - beta2^t)
 };
@@ -84,7 +85,7 @@ struct TrajFusedPlan {
 };
 // d_acc = the compiled feature width D of the sweep (>= d_fk): a fold row holds D + 1 floats per lane;  n_pt > 0: the
 // several-wave J^T's scratch, 15 columns per point step (9 rotation, 3 + 3 for the collision and the path gradient)
-__host__ __device__ inline TrajFusedPlan traj_fused_plan(int dof, int d_fk, int frame_floats, int nw, int d_acc, int n_pt = 0) {
+__host__ __device__ inline TrajFusedPlan traj_fused_plan(int dof, int d_fk, int frame_floats, int nw, int d_acc, int n_pt = 0, int cc = 1) {
     TrajFusedPlan p;
     const int rows = (64 * dof + 3) & ~3;
     p.x = 0;
@@ -97,7 +98,7 @@ __host__ __device__ inline TrajFusedPlan traj_fused_plan(int dof, int d_fk, int 
     p.gc = p.f + 64 * frame_floats;
     p.gp = p.gc + 64 * d_fk;
     p.red = p.gp + 64 * d_fk;
-    p.r = p.red + nw * (d_acc + 1) * 64;
+    p.r = p.red + nw * (d_acc + cc) * 64;   // cc: class scores in front of the feature gradient
     p.jl = p.r + 128;                 // [2 dof][64]: per-joint limit excess and gradient entry (Adam on several waves)
     p.jt = p.jl + 2 * dof * 64;
     p.fk = p.jt + 15 * n_pt * 64;
@@ -124,10 +125,10 @@ __device__ __forceinline__ float traj_wave_sum(float v) {
 struct TrajLds {
     float *sQ, *sM, *sV, *sGQc, *sGQp, *sF, *sX, *sGc, *sGp, *sRed, *sR, *sJl, *sJ, *sFk;
 };
-template <int D, class A>
+template <int D, int CC = 1, class A>
 __device__ __forceinline__ TrajLds traj_lds(float* smem, const A& b, int nw) {
     const bool jt = b.sc.jt_waves != 0;
-    const TrajFusedPlan lp = traj_fused_plan(b.sc.dof, b.sc.d_fk, b.sc.frame_floats, nw, D, jt ? b.sc.dh.n_pt : 0);
+    const TrajFusedPlan lp = traj_fused_plan(b.sc.dof, b.sc.d_fk, b.sc.frame_floats, nw, D, jt ? b.sc.dh.n_pt : 0, CC);
     TrajLds l;
     l.sQ = smem + lp.q; l.sM = smem + lp.m; l.sV = smem + lp.v; l.sGQc = smem + lp.gqc; l.sGQp = smem + lp.gqp;
     l.sF = smem + lp.f; l.sX = smem + lp.x; l.sGc = smem + lp.gc; l.sGp = smem + lp.gp; l.sRed = smem + lp.red;
@@ -171,13 +172,15 @@ __device__ __forceinline__ unsigned long long traj_pack(float v, uint32_t tag) {
     return ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
 }
 // first half: fold this wave's accumulators over the block's rows and publish them
-template <int ACC>
+// (E0, E1: the accumulators of this exchange - all of them with one class; with several the class scores [0, CC) travel after the
+// first sweep and the feature gradient [CC, CC + D) after the second, through disjoint words of the same slot)
+template <int ACC, int E0 = 0, int E1 = ACC>
 __device__ __forceinline__ void traj_exchange_publish(const float* sRed, unsigned long long* slot /* this path's rows of this parity, + lane */,
                                                       uint32_t tag, int y, int wave, int lane, int nw) {
     auto fold_pub = [&](auto nwc) __attribute__((always_inline)) {
         constexpr int NWC = decltype(nwc)::value;
         const int nwr = NWC > 0 ? NWC : nw;
-        for (int e = wave; e < ACC; e += nwr) {
+        for (int e = E0 + wave; e < E1; e += nwr) {
             float v;
             if constexpr (NWC > 0) {
                 float r[NWC];
@@ -200,11 +203,11 @@ __device__ __forceinline__ void traj_exchange_publish(const float* sRed, unsigne
 }
 // second half: poll the ys copies of each of this wave's accumulators; totals to row 0 of the scratch (only this wave touches
 // accumulator e's slots)
-template <int ACC>
+template <int ACC, int E0 = 0, int E1 = ACC>
 __device__ __forceinline__ bool traj_exchange_collect(float* sRed, const unsigned long long* slot, uint32_t tag, int ys, int wave, int lane,
                                                       int nw) {
     bool ok = true;
-    for (int e = wave; e < ACC; e += nw) {
+    for (int e = E0 + wave; e < E1; e += nw) {
         float tot = 0.0f;
         int spins = 0;
         for (;;) {
@@ -284,10 +287,19 @@ __device__ __forceinline__ void traj_path_terms(const A& b, const TrajLds& L, in
         if (lane == 0) { L.sR[0] = so; L.sR[16] = sm; }
 }
 
-template <int D, int KF, int MAXT, bool XF = false, bool CL = false>
+// CC > 1 (round 6): a multi-class checker (MultiDiffCo.rbf_score -> [W, C]) under the reference's per-class margins,
+//   collision = sum_w sum_c clamp(score_wc - margin_c, 0)          (optim.py:88-89 with safety_margin [C]: scripts/2d_trajopt.py:94-102,
+//                                                                   scripts/active.py:35, 65)
+// The gradient's upstream w_collision * 1[score_wc > margin_c] is only known once ALL supports have been seen, so an iteration
+// sweeps twice: class scores first (MODE_SCORE; fold / exchange of the CC score accumulators), then the feature gradient with that
+// upstream per lane (MODE_GRAD_UP; fold / exchange of the D gradient accumulators) - the arithmetic, slicing and fold order of
+// dcx_score followed by dcx_score_hinge_grad_mc's second launch, which is what the three-launch loop of dcx_traj_adam_run_mc runs
+// where this kernel is not compiled (bit-identical for equal slicing, tests/test_gpu_traj.py).  Fold rows: [c][64] scores, then
+// [k][64] gradient (the sweep kernel's layout).
+template <int D, int KF, int MAXT, bool XF = false, bool CL = false, int CC = 1>
 __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_fused_kernel(const TrajFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int ACC = D + 1;
+    constexpr int ACC = D + CC;
     const int r = (CL && a.cl_across) ? blockIdx.y : blockIdx.x;
     const int ycl = CL ? (a.cl_across ? (int)blockIdx.x : (int)blockIdx.y) : 0;   // this workgroup's place among the path's ys
     if (a.st.done[r]) return;  // frozen path (cluster form: the ys workgroups of a path all see the same flag - it is only
@@ -297,7 +309,7 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
     const int nw = blockDim.x >> 6;
     {
         const int W = a.st.n_waypoints, dof = a.sc.dof;
-        const TrajLds L = traj_lds<D>(smem, a, nw);
+        const TrajLds L = traj_lds<D, CC>(smem, a, nw);
         (void)fk_stage_sel(a.sc.fkk, a.sc.fk, a.sc.fk_dwords, a.sc.dh, L.sFk, tid, blockDim.x);
         // waypoint rows (lanes past the path replicate its last row, like a ragged tile of the sweep) and Adam moments
         const size_t base = (size_t)r * W * dof;
@@ -333,7 +345,7 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
         {
             // ---- forward kinematics of the current waypoints (once per iteration) -----------------------------------
             const auto& b = reload_kernargs<TrajFusedArgs>();
-            const TrajLds L = traj_lds<D>(smem, b, nw);
+            const TrajLds L = traj_lds<D, CC>(smem, b, nw);
             const int dof = b.sc.dof, d_fk = b.sc.d_fk;
             DhArgs dh;
             DCX_COPY_DH(dh, b.sc.dh);
@@ -384,16 +396,52 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
             sa.kp1 = b.sc.kp1;
         }
         // ---- collision sweep: score and feature gradient against this wave's supports -------------------------------
-        float sc[1] = {0.0f};
+        float sc[CC];
         float gx[D];
-        const float up[1] = {1.0f};
 #pragma unroll
         for (int k = 0; k < D; ++k) gx[k] = 0.0f;
-        sweep_rows<D, KF, 1, MODE_GRAD_ROW, XF, DCX_TRAJ_NACC>(sa, x, up, j0, j1, sc, gx);
+#pragma unroll
+        for (int c = 0; c < CC; ++c) sc[c] = 0.0f;
+        if constexpr (CC == 1) {
+            const float up[1] = {1.0f};
+            sweep_rows<D, KF, 1, MODE_GRAD_ROW, XF, DCX_TRAJ_NACC>(sa, x, up, j0, j1, sc, gx);
+        } else {
+            // several classes: the class scores first ...
+            float up[CC];
+#pragma unroll
+            for (int c = 0; c < CC; ++c) up[c] = 0.0f;
+            sweep_rows<D, KF, CC, MODE_SCORE, XF, DCX_TRAJ_NACC>(sa, x, up, j0, j1, sc, gx);
+            {
+                const auto& b = reload_kernargs<TrajFusedArgs>();
+                const TrajLds L = traj_lds<D, CC>(smem, b, nw);
+                float* mine = L.sRed + (size_t)wave * ACC * 64 + lane;
+#pragma unroll
+                for (int c = 0; c < CC; ++c) mine[c * 64] = sc[c];
+                __syncthreads();
+                if constexpr (CL) {
+                    unsigned long long* slot = b.exch + ((size_t)(r * 2 + (it & 1)) * b.ys) * ACC * 64 + lane;
+                    const uint32_t tag = b.tag_base + (uint32_t)it + 1u;
+                    traj_exchange_publish<ACC, 0, CC>(L.sRed, slot, tag, ycl, wave, lane, nw);
+                    if (!traj_exchange_collect<ACC, 0, CC>(L.sRed, slot, tag, b.ys, wave, lane, nw)) L.sR[kTrajAbort] = 1.0f;
+                } else {
+                    fold_partial_rows<ACC, 0, CC>(L.sRed, wave, lane, nw);
+                }
+                __syncthreads();
+                // ... then the gradient of w_collision * sum_c clamp(score_c - margin_c, 0): upstream per lane and class (the totals
+                // stay in row 0 of the scratch: the second sweep's partial rows only use the gradient columns)
+#pragma unroll
+                for (int c = 0; c < CC; ++c) {
+                    const float t = L.sRed[c * 64 + lane];
+                    up[c] = (c < b.sc.c_out && t - b.margin_c[c < 8 ? c : 7] > 0.0f) ? b.opt.w_collision : 0.0f;
+                    sc[c] = 0.0f;
+                }
+            }
+            sweep_rows<D, KF, CC, MODE_GRAD_UP, XF, DCX_TRAJ_NACC>(sa, x, up, j0, j1, sc, gx);
+        }
         DCX_TTS(3);
         {
             const auto& b = reload_kernargs<TrajFusedArgs>();
-            const TrajLds L = traj_lds<D>(smem, b, nw);
+            const TrajLds L = traj_lds<D, CC>(smem, b, nw);
             const int W = b.st.n_waypoints, dof = b.sc.dof, d_fk = b.sc.d_fk;
             const bool live = w < W;
             const bool jt = b.sc.jt_waves != 0;
@@ -408,21 +456,22 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
             float col = 0.f;
             const int pwave = (nw > 1 && !tree) ? 1 : 0;
             auto path_terms = [&]() __attribute__((always_inline)) { traj_path_terms(b, L, lane); };
-            if (CL || nw > 1) {
+            constexpr int E0 = CC > 1 ? CC : 0;   // (several classes: the scores' totals already sit in row 0)
+            if (CL || nw > 1 || CC > 1) {
                 // the sweep's parallel cross-wave fold (score_kernel.h): row 0 first, then 1, 2, ...
                 float* mine = L.sRed + (size_t)wave * ACC * 64 + lane;
-                mine[0] = sc[0];
+                if constexpr (CC == 1) mine[0] = sc[0];
 #pragma unroll
-                for (int k = 0; k < D; ++k) mine[(1 + k) * 64] = gx[k];
+                for (int k = 0; k < D; ++k) mine[(CC + k) * 64] = gx[k];
                 __syncthreads();
                 DCX_TTS(4);
                 if constexpr (CL) {
                     unsigned long long* slot = b.exch + ((size_t)(r * 2 + (it & 1)) * b.ys) * ACC * 64 + lane;
                     const uint32_t tag = b.tag_base + (uint32_t)it + 1u;
-                    traj_exchange_publish<ACC>(L.sRed, slot, tag, ycl, wave, lane, nw);
-                    if (!traj_exchange_collect<ACC>(L.sRed, slot, tag, b.ys, wave, lane, nw)) L.sR[kTrajAbort] = 1.0f;
+                    traj_exchange_publish<ACC, E0, ACC>(L.sRed, slot, tag, ycl, wave, lane, nw);
+                    if (!traj_exchange_collect<ACC, E0, ACC>(L.sRed, slot, tag, b.ys, wave, lane, nw)) L.sR[kTrajAbort] = 1.0f;
                 } else {
-                fold_partial_rows<ACC>(L.sRed, wave, lane, nw);
+                fold_partial_rows<ACC, E0, ACC>(L.sRed, wave, lane, nw);
                 }
                 DCX_TTS(5);
                 DCX_TTS(6);  // (the path terms and phase R1 of J^T ran in front of the sweep)
@@ -433,11 +482,20 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
                 // ---- both J^T products on several waves (fk_device.h): l = R^T g per point step for the collision gradient
                 // (the folded totals x the hinge factor, read in place) and for the path gradient; then the two wrench
                 // recurrences side by side, chain by chain: collision on waves 0 (, 1), path on waves 2 (, 3) ----------
-                const float s0 = L.sRed[lane] - b.opt.safety_margin;
-                const float scale = (s0 > 0.0f) ? b.opt.w_collision : 0.0f;
-                if (wave == 0 && live && s0 > 0.f) col = s0;
+                float scale = 1.0f;   // (several classes: the hinge went into the second sweep's upstream)
+                if constexpr (CC == 1) {
+                    const float s0 = L.sRed[lane] - b.opt.safety_margin;
+                    scale = (s0 > 0.0f) ? b.opt.w_collision : 0.0f;
+                    if (wave == 0 && live && s0 > 0.f) col = s0;
+                } else if (wave == 0 && live) {
+#pragma unroll
+                    for (int c = 0; c < CC; ++c) {
+                        const float e = L.sRed[c * 64 + lane] - b.margin_c[c < 8 ? c : 7];
+                        if (c < b.sc.c_out && e > 0.f) col += e;
+                    }
+                }
                 const int half = nw >> 1;
-                if (wave < half) dh2_vjp_r1b(fw.dh, dh, L.sRed + 64 + lane, scale, L.sJ + lane, L.sGQc + lane * dof, dof, wave, half, 15, 9);
+                if (wave < half) dh2_vjp_r1b(fw.dh, dh, L.sRed + CC * 64 + lane, scale, L.sJ + lane, L.sGQc + lane * dof, dof, wave, half, 15, 9);
                 else dh2_vjp_r1b(fw.dh, dh, L.sGp + lane, 1.0f, L.sJ + lane, L.sGQp + lane * dof, dof, wave - half, nw - half, 15, 12);
                 __syncthreads();
                 DCX_TTS(8);
@@ -446,20 +504,29 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
             } else {
                 // ---- wave 0: hinge + J^T of the collision gradient;  wave 1: path terms + their J^T --------------------
                 if (wave == 0) {
-                    if (nw > 1) {
-                        sc[0] = L.sRed[lane];
+                    if (nw > 1 || CC > 1) {
 #pragma unroll
-                        for (int k = 0; k < D; ++k) gx[k] = L.sRed[(1 + k) * 64 + lane];
+                        for (int c = 0; c < CC; ++c) sc[c] = L.sRed[c * 64 + lane];
+#pragma unroll
+                        for (int k = 0; k < D; ++k) gx[k] = L.sRed[(CC + k) * 64 + lane];
                     }
-                    const float scale = (sc[0] - b.opt.safety_margin > 0.0f) ? b.opt.w_collision : 0.0f;
+                    const float scale = CC > 1 ? 1.0f : ((sc[0] - b.opt.safety_margin > 0.0f) ? b.opt.w_collision : 0.0f);
 #pragma unroll
                     for (int k = 0; k < D; ++k)
                         if (k < d_fk) L.sGc[k * 64 + lane] = gx[k] * scale;
                     // q row -> gq row in a separate buffer (the two-launch form overwrites the q row; same arithmetic)
                     for (int i = 0; i < dof; ++i) L.sGQc[lane * dof + i] = L.sQ[lane * dof + i];
                     fk_vjp_sel(fw, dh, L.sGQc + lane * dof, L.sF + lane, L.sGc + lane, L.sGQc + lane * dof, dof);
-                    const float s0 = sc[0] - b.opt.safety_margin;
-                    if (live && s0 > 0.f) col = s0;
+                    if constexpr (CC == 1) {
+                        const float s0 = sc[0] - b.opt.safety_margin;
+                        if (live && s0 > 0.f) col = s0;
+                    } else if (live) {
+#pragma unroll
+                        for (int c = 0; c < CC; ++c) {
+                            const float e = sc[c] - b.margin_c[c < 8 ? c : 7];
+                            if (c < b.sc.c_out && e > 0.f) col += e;
+                        }
+                    }
                 }
                 if (wave == pwave) {
                     path_terms();
@@ -480,7 +547,7 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
             // run over them - limit excess, |g|^2 - are put together afterwards in the order i = 0, 1, ... a single wave would
             // use, so the loss terms do not change by a bit) ----------------------------------------------------------------
             const auto& b = reload_kernargs<TrajFusedArgs>();
-            const TrajLds L = traj_lds<D>(smem, b, nw);
+            const TrajLds L = traj_lds<D, CC>(smem, b, nw);
             const int W = b.st.n_waypoints, dof = b.sc.dof;
             const bool live = w < W;
             const bool endpoint = (w == 0) || (w == W - 1);
@@ -512,7 +579,7 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
         __syncthreads();
         {
             const auto& b = reload_kernargs<TrajFusedArgs>();
-            const TrajLds L = traj_lds<D>(smem, b, nw);
+            const TrajLds L = traj_lds<D, CC>(smem, b, nw);
             const int dof = b.sc.dof;
             if (wave == 0) {
                 const float* sJl = L.sJl;
@@ -555,7 +622,7 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
         __syncthreads();
         {
             const auto& b = reload_kernargs<TrajFusedArgs>();
-            const TrajLds L = traj_lds<D>(smem, b, nw);
+            const TrajLds L = traj_lds<D, CC>(smem, b, nw);
             const int W = b.st.n_waypoints, dof = b.sc.dof;
             flags = __float_as_int(L.sR[kTrajFlags]);
             if constexpr (CL) {
@@ -594,7 +661,7 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
     // ---- state back to HBM ------------------------------------------------------------------------------------------
     {
         const auto& b = reload_kernargs<TrajFusedArgs>();
-        const TrajLds L = traj_lds<D>(smem, b, nw);
+        const TrajLds L = traj_lds<D, CC>(smem, b, nw);
         const int W = b.st.n_waypoints, dof = b.sc.dof;
         const size_t base = (size_t)r * W * dof;
         for (int i = tid; i < W * dof; i += blockDim.x) {

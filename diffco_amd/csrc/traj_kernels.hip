@@ -23,6 +23,8 @@ struct TrajArgs {
     int32_t dof, d_fk, n_points, point_dim, frame_floats;
     int32_t coord_major;  // features laid out [point_dim][n_points] (DCX_FK_TREE, t_coord_major) instead of [n_points][point_dim]
     float bias1, bias2_sqrt;  // 1 - beta1^t, sqrt(1 - beta2^t)
+    int32_t n_class;          // columns of col_score: [R*W, n_class] (several classes: a MultiDiffCo score under per-class margins)
+    float margin_c[8];        // ... and their margins (n_class == 1: opt.safety_margin)
 };
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -96,8 +98,11 @@ __global__ __launch_bounds__(1024) void traj_adam_step_kernel(const TrajArgs a) 
     if (live) {
         const size_t base = ((size_t)r * W + w) * dof;
         const bool endpoint = (w == 0) || (w == W - 1);
-        const float sc = a.st.col_score[(size_t)r * W + w] - a.opt.safety_margin;
-        if (sc > 0.f) col = sc;
+        // collision term of this waypoint: sum_c clamp(score_c - margin_c, 0) (optim.py:88-89; one class: one term)
+        for (int c = 0; c < a.n_class; ++c) {
+            const float sc = a.st.col_score[((size_t)r * W + w) * a.n_class + c] - a.margin_c[c];
+            if (sc > 0.f) col += sc;
+        }
         for (int i = 0; i < dof; ++i) {
             const float q = myQ[i];
             const float lo = a.st.limits[2 * i], hi = a.st.limits[2 * i + 1];
@@ -177,9 +182,11 @@ size_t traj_lds_bytes(const dcx_fk_desc& fk, int nw) {
 }
 
 hipError_t launch_traj_adam_step(const FkProg* fk_dev, const dcx_fk_desc& fk, const dcx_traj_state& st,
-                                 const dcx_traj_opts& opt, int step, hipStream_t stream) {
+                                 const dcx_traj_opts& opt, int step, hipStream_t stream, int n_class, const float* margin_c) {
     if (st.n_paths == 0) return hipSuccess;
     TrajArgs a;
+    a.n_class = n_class;
+    for (int c = 0; c < 8; ++c) a.margin_c[c] = (margin_c && c < n_class) ? margin_c[c] : opt.safety_margin;
     a.fk = fk_dev;
     a.st = st;
     a.opt = opt;

@@ -199,13 +199,13 @@ class _ScipyTerms:
             return self.prob.segment_collision(self.prob.full(x).detach(), self.dist_est, self.dense_cap).numpy()
 
     def _fused_model(self):
-        """the ScoreModel behind dist_est when it is a diffco_amd checker method with one output, else None"""
+        """the ScoreModel behind dist_est when it is a diffco_amd checker method of this robot (any class count), else None"""
         if not hasattr(self, "_model"):
             self._model = None
             try:
                 from .traj import _resolve_model
                 m = _resolve_model(self.dist_est)
-                if m.C == 1 and m.desc.key() == self.prob.robot.fk_desc().key():
+                if m.desc.key() == self.prob.robot.fk_desc().key():
                     self._model = m.acquire()   # a lease for the lifetime of these terms (released in __del__)
             except Exception:
                 self._model = None
@@ -249,19 +249,40 @@ class _ScipyTerms:
             # the chain rule stays on the device (round 4): one launch, a handful of fp64 tensor ops, ONE copy back - the
             # [n_seg, (W-2) dof] array scipy asked for
             q32 = pts.to(device=dev, dtype=torch.float32).contiguous()
-            _, h = model.score_hinge_grad_raw(q32, prob.safety_margin, -1.0)  # h_n = d c_n / d dense_n
-            h = h.double()
             pd, segd, stepd = p.to(dev), seg.to(dev), step.to(dev)
+            if model.C == 1:
+                _, h = model.score_hinge_grad_raw(q32, prob.safety_margin, -1.0)  # h_n = d c_n / d dense_n
+                h = h.double()
+            else:
+                # several classes (round 6): the reference flattens the [n_pt, C] costs and cuts the flat vector into n_seg
+                # rows (optim.py:199-207), so entry (n, c) belongs to row (n C + c) // (entries per row) and every entry needs
+                # its own gradient: the full Jacobian [n_pt, C, dof] in one launch (dcx_score_jac), masked by the hinge
+                sc, jac = model.score_jac_raw(q32)
+                mg = torch.tensor(list(model.margins(prob.safety_margin)), device=dev, dtype=torch.float32)
+                h = (-((sc - mg) > 0).double()[:, :, None] * jac.double()).reshape(n_pt * model.C, dof)
+                per = self._flat_per(n_pt, n_seg, model.C)
+                segd, stepd = segd.repeat_interleave(model.C), stepd.repeat_interleave(model.C)
             delta = pd[1:] - pd[:-1]
             length = delta.norm(dim=1)
             unit = delta / length[:, None]
-            u = unit[segd]                                                  # [n_pt, dof]
+            u = unit[segd]                                                  # [n_pt (C), dof]
             scale = (stepd * ms / length[segd])[:, None]
             a = scale * (h - u * (u * h).sum(dim=1, keepdim=True))          # part carried by p_{i+1}
-            row = torch.arange(n_pt, device=dev) // per
+            row = torch.arange(len(h), device=dev) // per
             J.index_put_((row, segd), h - a, accumulate=True)
             J.index_put_((row, segd + 1), a, accumulate=True)
         return J[:, 1:-1].cpu().numpy().reshape(n_seg, -1)
+
+    @staticmethod
+    def _flat_per(n_pt, n_seg, C):
+        """entries per constraint row when the reference reshapes its flat [n_pt * C (+ padding)] cost vector into
+        [n_seg, -1] (optim.py:199-207; the padding is sized for ONE class there, so with several classes the reshape only
+        exists when the total happens to divide - the same RuntimeError otherwise)"""
+        mult = n_pt // n_seg + (1 if n_pt % n_seg else 0)
+        total = n_pt * C + (n_seg * mult - n_pt if n_pt % n_seg else 0)
+        if total % n_seg:
+            raise RuntimeError(f"shape '[{n_seg}, -1]' is invalid for input of size {total}")
+        return total // n_seg
 
     HESS_FD_STEP = 4e-3  # rad (or m); only where dcx_score_hess reports DCX_ERR_UNSUPPORTED
 
@@ -298,6 +319,8 @@ class _ScipyTerms:
         per = -(-n_pt // n_seg)
         q32 = pts.to(device=model.dev, dtype=torch.float32).contiguous()
         dev = model.dev
+        if model.C > 1:
+            return self._hess_collision_fused_mc(p, v, model, q32, pts, seg, step, n_seg, n_pt)
         s, g = model.score_grad_raw(q32)
         try:
             _, S = model.score_hess_raw(q32)
@@ -319,6 +342,31 @@ class _ScipyTerms:
         active = -((s - prob.safety_margin) > 0).double() * vd[torch.arange(n_pt, device=dev) // per]  # d(v.c)/d score_n
         S = 0.5 * (S + S.transpose(1, 2)) * active[:, None, None]
         h = g * active[:, None]
+
+        def taylor(z):
+            delta = z[1:] - z[:-1]
+            unit = delta / delta.norm(dim=1, keepdim=True)
+            d = z[segd] + (stepd * ms)[:, None] * unit[segd] - ptsd
+            return (h * d).sum() + 0.5 * torch.einsum('ni,nij,nj->', d, S, d)
+        H = torch.autograd.functional.hessian(taylor, p.to(dev), vectorize=True)
+        return H[1:-1, :, 1:-1, :].cpu().numpy().reshape((W - 2) * dof, -1)
+
+    def _hess_collision_fused_mc(self, p, v, model, q32, pts, seg, step, n_seg, n_pt):
+        """several classes: d(v . c) / d score_nc = -1[score_nc > margin_c] v[row(n, c)] is the per-point upstream of ONE
+        dcx_score_hess launch (gradient and Hessian of sum_c upstream_nc score_nc); the dense-path geometry is chained as
+        for one class"""
+        prob, dev, ms = self.prob, model.dev, self.prob.max_speed
+        W, dof = p.shape
+        C = model.C
+        per = self._flat_per(n_pt, n_seg, C)
+        sc = model.score_raw(q32)
+        mg = torch.tensor(list(model.margins(prob.safety_margin)), device=dev, dtype=torch.float32)
+        vrow = v.to(dev)[torch.arange(n_pt * C, device=dev) // per].reshape(n_pt, C)
+        up = (-((sc - mg) > 0).double() * vrow).float().contiguous()
+        h, S = model.score_hess_raw(q32, up)
+        h, S = h.double(), S.double()
+        S = 0.5 * (S + S.transpose(1, 2))
+        segd, stepd, ptsd = seg.to(dev), step.to(dev), pts.to(dev)
 
         def taylor(z):
             delta = z[1:] - z[:-1]
@@ -388,7 +436,7 @@ def trustconstr_traj_optimize(robot, dist_est, start_cfg, target_cfg, options):
     def run(terms, x0):
         fused = terms._fused_model() is not None and terms.dense_cap is None
         if mode == 'fused' and not fused:
-            raise ValueError("constraint_hessian='fused' needs dist_est to be a single-output diffco_amd score of this robot")
+            raise ValueError("constraint_hessian='fused' needs dist_est to be a diffco_amd score of this robot")
         if mode == 'autograd':
             terms._model = None
         hess = BFGS() if mode == 'bfgs' or (mode == 'auto' and not fused) else terms.hess_collision

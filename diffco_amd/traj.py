@@ -1,10 +1,13 @@
 """Fused, batched-restart Adam trajectory optimiser (BASELINE config #5).
 
 Same inputs, option keys and result record as `optim.adam_traj_optimize` (reference diffco/optim.py:13-163), but
-all NUM_RE_TRIALS restarts advance together on the GPU and each iteration is two launches enqueued from native
-code (`dcx_traj_adam_run`): the fused score + hinge-gradient sweep over every waypoint of every restart, and
-the fused Adam step (FK-coupled path terms, J^T, Adam update, best-so-far bookkeeping).  No host
-synchronisation inside the loop (the reference syncs every iteration, optim.py:107-118).
+all NUM_RE_TRIALS restarts advance together on the GPU inside native code (`dcx_traj_adam_run_mc`): one persistent
+launch per <= 192 iterations when a path is one tile of the sweep, else per iteration the fused score + hinge-gradient
+sweep over every waypoint of every restart and the fused Adam step (FK-coupled path terms, J^T, Adam update,
+best-so-far bookkeeping).  No host synchronisation inside the loop (the reference syncs every iteration,
+optim.py:107-118).  `dist_est` may have several outputs (a MultiDiffCo's rbf_score) with options['safety_margin'] one
+number or one per class - the reference's `clamp(dist_est(p) - safety_margin, min=0).sum()` (optim.py:88-89 as
+scripts/2d_trajopt.py:94-102 and scripts/active.py:28-121 call it).
 
 The restarts are initialised exactly like the reference's sequential trials (trial 0: init_solution or the
 straight line, later trials: torch.rand in joint limits, same seed, same order), and the returned record follows
@@ -86,8 +89,9 @@ class ShardedAdamRun:
         self.W, self.dof = W, dof
         path = init_paths[lo:hi].to(**f32).contiguous().clone() if self.R else torch.empty((0, W, dof), **f32)
         R, inf = self.R, float('inf')
+        self.margin = model.margins(safety_margin)    # one per class (a number serves all of them)
         self.t = dict(path=path, adam_m=torch.zeros_like(path), adam_v=torch.zeros_like(path),
-                      limits=limits.to(**f32).contiguous(), col_score=torch.empty((R * W,), **f32),
+                      limits=limits.to(**f32).contiguous(), col_score=torch.empty((R * W * model.C,), **f32),
                       col_grad=torch.empty((R * W, dof), **f32), stats=torch.zeros((R, 8), **f32),
                       lowest_loss=torch.full((R,), inf, **f32), lowest_obj=torch.full((R,), inf, **f32),
                       lowest_path=path.clone(), best_valid_obj=torch.full((R,), inf, **f32),
@@ -95,7 +99,7 @@ class ShardedAdamRun:
                       steps=torch.zeros((R,), device=dev, dtype=torch.int32))
         self.st = _lib.TrajState(R, W, *(C.c_void_p(v.data_ptr() if v.numel() else 0) for v in self.t.values()))
         self.opt = _lib.TrajOpts(lr, 0.9, 0.999, 1e-8, DIF_WEIGHT, COLLISION_WEIGHT, MAX_MOVE_WEIGHT, JOINT_LIMIT_WEIGHT,
-                                 float(safety_margin), float(max_speed),
+                                 float(self.margin[0]), float(max_speed),
                                  VALID_CONSTRAINT_LOSS if valid_tol is None else float(valid_tol),
                                  STATIONARY_GRAD_NORM if grad_tol is None else float(grad_tol))
         self.it = 0
@@ -119,8 +123,8 @@ class ShardedAdamRun:
             dev = self.model.dev
             with torch.cuda.device(dev):
                 stream = self.model._st()
-                _lib.check(self.lib.dcx_traj_adam_run(self.model._h, C.byref(self.st), C.byref(self.opt), self.it + 1,
-                                                      int(n_iters), stream))
+                _lib.check(self.lib.dcx_traj_adam_run_mc(self.model._h, C.byref(self.st), C.byref(self.opt), self.margin,
+                                                         self.it + 1, int(n_iters), stream))
         self.it += n_iters
 
     def all_done(self):
@@ -154,9 +158,7 @@ def fused_adam_traj_optimize(robot, dist_est, start_cfg, target_cfg, options, gr
     torch.manual_seed(seed)
     prob = _PathProblem(robot, start_cfg, target_cfg, options)
     t0 = time.time()
-    model = _resolve_model(dist_est)
-    if model.C != 1:
-        raise ValueError("the fused optimiser needs a single-output collision score (C == 1)")
+    model = _resolve_model(dist_est)   # any class count: a MultiDiffCo score under options['safety_margin'] = a number or [C]
     desc = robot.fk_desc()
     if desc.key() != model.desc.key():
         raise ValueError("the checker's transform is not this robot's fkine: the fused step shares one FK")

@@ -1,10 +1,92 @@
 """Host-side helpers the reference keeps in diffco/utils.py (behaviour restated, torch on the
 caller's device; none of this is on the score/grad hot path).  Reference: utils.py:4-13 (rotz),
 40-48 (rot_2d), 51-52 (wrap2pi), 54-55 (se2_wrap2pi), 60-64 (anglin), 79-85 (make_continue),
-87-101 (dense_path).  DH2mat / euler2mat live on the device (csrc/fk_device.h)."""
+87-101 (dense_path).  DH2mat (utils.py:66-75) and euler2mat (15-38) - the two link-transform helpers robot classes written
+against the reference build their FK from (model.py:230, 437) - are HIP kernels behind the same call signatures
+(`dcx_dh_frames`, `dcx_euler_frames`), differentiable with respect to the angles; like every op of this package they need the
+GPU (CPU tensors go there and come back)."""
+import ctypes as C
 import math
 
 import torch
+from torch.autograd.function import once_differentiable
+
+
+class _DHFrames(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, a, d, s_alpha, c_alpha):
+        from . import _lib, _ops
+        lib = _lib.require_gpu()
+        dev = _ops._device(q.device)
+        B, dof = q.shape
+        q32 = _ops._f32(q, dev)
+        par = [_ops._f32(torch.as_tensor(t).reshape(-1).expand(dof), dev) for t in (a, d, s_alpha, c_alpha)]
+        T = torch.empty((B, dof, 4, 4), device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.check(lib.dcx_dh_frames(dev.index, _ops._ptr(q32), B, dof, *(_ops._ptr(t) for t in par), _ops._ptr(T),
+                                         _ops._stream(dev)))
+        ctx.dev, ctx.in_dtype, ctx.in_device = dev, q.dtype, q.device
+        ctx.save_for_backward(q32, par[0], par[2], par[3])
+        return T.to(device=q.device, dtype=q.dtype)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gT):
+        from . import _lib, _ops
+        lib = _lib.require_gpu()
+        q32, a, sa, ca = ctx.saved_tensors
+        dev = ctx.dev
+        B, dof = q32.shape
+        g32 = _ops._f32(gT, dev)
+        gq = torch.empty((B, dof), device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.check(lib.dcx_dh_frames_vjp(dev.index, _ops._ptr(q32), B, dof, _ops._ptr(a), _ops._ptr(sa), _ops._ptr(ca),
+                                             _ops._ptr(g32), _ops._ptr(gq), _ops._stream(dev)))
+        return gq.to(device=ctx.in_device, dtype=ctx.in_dtype), None, None, None, None
+
+
+def DH2mat(q, a, d, s_alpha, c_alpha):
+    """standard DH link transforms T[b, i] = Rz(q[b, i]) Tz(d_i) Tx(a_i) Rx(alpha_i) -> [B, dof, 4, 4] (reference utils.py:66-75),
+    computed by `dcx_dh_frames`; differentiable with respect to q (the DH parameters are constants, as in the reference's models)"""
+    if q.ndim != 2:
+        raise ValueError("DH2mat: q is [B, dof]")
+    return _DHFrames.apply(q, a, d, s_alpha, c_alpha)
+
+
+class _EulerFrames(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, phi):
+        from . import _lib, _ops
+        lib = _lib.require_gpu()
+        dev = _ops._device(phi.device)
+        p32 = _ops._f32(phi, dev)
+        B = p32.shape[0]
+        R = torch.empty((B, 3, 3), device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.check(lib.dcx_euler_frames(dev.index, _ops._ptr(p32), B, _ops._ptr(R), _ops._stream(dev)))
+        ctx.dev, ctx.in_dtype, ctx.in_device = dev, phi.dtype, phi.device
+        ctx.save_for_backward(p32)
+        return R.to(device=phi.device, dtype=phi.dtype)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gR):
+        from . import _lib, _ops
+        lib = _lib.require_gpu()
+        (p32,) = ctx.saved_tensors
+        dev = ctx.dev
+        B = p32.shape[0]
+        g32 = _ops._f32(gR, dev)
+        gp = torch.empty((B, 3), device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.check(lib.dcx_euler_frames_vjp(dev.index, _ops._ptr(p32), _ops._ptr(g32), B, _ops._ptr(gp), _ops._stream(dev)))
+        return gp.to(device=ctx.in_device, dtype=ctx.in_dtype)
+
+
+def euler2mat(phi):
+    """rotation matrices Rz(yaw) Ry(pitch) Rx(roll) of (roll, pitch, yaw) rows -> [N, 3, 3] (reference utils.py:15-38), computed
+    by `dcx_euler_frames`; differentiable with respect to phi"""
+    return _EulerFrames.apply(phi.reshape((-1, 3)))
 
 
 def wrap2pi(theta):

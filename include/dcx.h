@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DCX_VERSION 108 /* 0.1.7: dcx_escape_adam (the escape loop of scripts/escape.py on the stream); 0.1.6: dcx_debug_clock_probe; the matrix-core forms are a build option (dcx_debug_set("mfma" / "xm", 1) -> DCX_ERR_UNSUPPORTED without them); owner-polls words tagged per launch, give-up reported by the model's next launch; 0.1.5: dcx_model_create_ex / dcx_model_update (rows packed on the device); 0.1.4: dcx_train_perceptron_ex (per-call flags); 0.1.3: dcx_fk_desc carries the DCX_FK_TREE section; 32 control points, D <= 96 */
+#define DCX_VERSION 109 /* 0.1.8: the optimisers' collision term for several classes under per-class margins (dcx_score_hinge_grad_mc, dcx_traj_adam_run_mc, dcx_traj_adam_step_mc), dcx_dh_frames / dcx_euler_frames (utils.DH2mat / euler2mat); 0.1.7: dcx_escape_adam (the escape loop of scripts/escape.py on the stream); 0.1.6: dcx_debug_clock_probe; the matrix-core forms are a build option (dcx_debug_set("mfma" / "xm", 1) -> DCX_ERR_UNSUPPORTED without them); owner-polls words tagged per launch, give-up reported by the model's next launch; 0.1.5: dcx_model_create_ex / dcx_model_update (rows packed on the device); 0.1.4: dcx_train_perceptron_ex (per-call flags); 0.1.3: dcx_fk_desc carries the DCX_FK_TREE section; 32 control points, D <= 96 */
 
 /* ---- status codes ---------------------------------------------------------------- */
 #define DCX_OK 0
@@ -244,6 +244,16 @@ int dcx_score_hess(const dcx_model* m, const float* q, int64_t B, const float* u
  * same pass that produces the score.  score may be NULL.                                                */
 int dcx_score_hinge_grad(const dcx_model* m, const float* q, int64_t B, float margin, float weight,
                          float* score, float* grad, void* stream);
+/* The same for ANY class count under per-class margins - the collision term the reference's Adam loops build on a
+ * MultiDiffCo score (optim.py:88-89 with options['safety_margin'] a [C] tensor: scripts/2d_trajopt.py:94-102,
+ * scripts/active.py:35, 65):
+ *   grad[b, :] = d/dq_b of  weight * sum_c clamp(score[b, c] - margin[c], min=0)
+ *              = weight * sum_c 1[score[b, c] - margin[c] > 0] * d score[b, c] / d q_b
+ * margin: C HOST floats (they travel as kernel arguments).  score [B, C] dev out; with C > 1 it must not be NULL: the
+ * class scores are swept first (the hinge's upstream is only known once every support has been seen), then the gradient
+ * with that upstream - two launches, no synchronisation.  C == 1 is dcx_score_hinge_grad's single launch.          */
+int dcx_score_hinge_grad_mc(const dcx_model* m, const float* q, int64_t B, const float* margin, float weight,
+                            float* score, float* grad, void* stream);
 
 /* ---- fused Adam trajectory step (caller of the path) ------------------------------- */
 /* Batched restatement of the loop body of adam_traj_optimize (optim.py:86-127): R independent paths of W
@@ -260,7 +270,7 @@ typedef struct dcx_traj_state {
     float* adam_m;                     /* [R, W, dof]  first moment  (zero before step 1)                */
     float* adam_v;                     /* [R, W, dof]  second moment (zero before step 1)                */
     const float* limits;               /* [dof, 2]     joint limits (lo, hi)                             */
-    const float* col_score;            /* [R*W]        dist_est(path) of THIS step (dcx_score*)          */
+    const float* col_score;            /* [R*W] ([R*W, C] for the _mc entry points) dist_est(path) of THIS step */
     const float* col_grad;             /* [R*W, dof]   hinge gradient of this step (dcx_score_hinge_grad)*/
     float* stats;                      /* [R, 8] out: loss, objective, constraint, |grad|, collision, max_move, joint_limit, 0 */
     float* lowest_loss;                /* [R] in/out (+inf before step 1)                                */
@@ -288,6 +298,17 @@ int dcx_traj_adam_step(int device, const dcx_fk_desc* fk, const dcx_traj_state* 
  * robot's FK.  st->col_score / st->col_grad are used as scratch ([R*W], [R*W, dof], non-const here).      */
 int dcx_traj_adam_run(const dcx_model* model, const dcx_traj_state* st, const dcx_traj_opts* opt,
                       int32_t first_step, int32_t n_iters, void* stream);
+/* The same loop on a model with ANY class count C (a MultiDiffCo score) under per-class margins:
+ *   collision term = sum over waypoints and classes of clamp(score[w, c] - margin[c], 0)    (optim.py:88-89 with a [C] margin)
+ * margin: C HOST floats, or NULL = opt->safety_margin for every class.  st->col_score is [R*W, C] here (scratch).
+ * One persistent launch per <= 192 iterations where the two-sweep form of the trajectory kernel is compiled (D <= 24,
+ * RQKernel(p = 2) / Polyharmonic(1), W <= 64), else three launches per iteration (class scores, hinge-gradient sweep,
+ * step); the same arithmetic either way.  dcx_traj_adam_step_mc is the step half on its own: col_score [R*W, C] and
+ * col_grad [R*W, dof] must hold dcx_score_hinge_grad_mc's outputs for the current path.                            */
+int dcx_traj_adam_run_mc(const dcx_model* model, const dcx_traj_state* st, const dcx_traj_opts* opt, const float* margin,
+                         int32_t first_step, int32_t n_iters, void* stream);
+int dcx_traj_adam_step_mc(int device, const dcx_fk_desc* fk, const dcx_traj_state* st, const dcx_traj_opts* opt,
+                          const float* margin, int32_t C, int32_t step, void* stream);
 
 /* ---- escape from collision (caller of the path; SURVEY.md §8f-2 names it beside the trajectory step) -- */
 /* Batched restatement of OptimSampler.optim_escape (scripts/escape.py:19-38): Adam on the configurations themselves,
@@ -366,6 +387,20 @@ int dcx_fkine(int device, const dcx_fk_desc* fk, const float* q, int64_t B, floa
 /* gq[b] = J_T(q_b)^T gX[b]  (autograd of fkine).  gX [B, D] dev -> gq [B, dof] dev          */
 int dcx_fkine_vjp(int device, const dcx_fk_desc* fk, const float* q, const float* gX, int64_t B,
                   float* gq, void* stream);
+/* Link transforms on their own - the two helpers user-written robot classes build their FK from (model.py:230, 437):
+ *   dcx_dh_frames     utils.DH2mat utils.py:66-75: T[b, i] = Rz(theta) Tz(d_i) Tx(a_i) Rx(alpha_i), theta = q[b, i]
+ *                     rows (c, -s ca, s sa, a c), (s, c ca, -c sa, a s), (0, sa, ca, d), (0, 0, 0, 1)
+ *                     q [B, dof] dev; a, d, sin_alpha, cos_alpha [dof] dev -> T [B, dof, 4, 4] dev
+ *   dcx_euler_frames  utils.euler2mat utils.py:15-38: R[b] = Rz(yaw) Ry(pitch) Rx(roll), phi[b] = (roll, pitch, yaw)
+ *                     phi [B, 3] dev -> R [B, 3, 3] dev
+ * and their autograd with respect to the angles: gq[b, i] = sum_rc gT[b, i, r, c] dT[b, i, r, c] / d q[b, i];
+ * gphi[b, k] = sum_rc gR[b, r, c] dR[b, r, c] / d phi[b, k].  HBM-bound (64 B / 36 B written per frame).           */
+int dcx_dh_frames(int device, const float* q, int64_t B, int32_t dof, const float* a, const float* d, const float* sin_alpha,
+                  const float* cos_alpha, float* T, void* stream);
+int dcx_dh_frames_vjp(int device, const float* q, int64_t B, int32_t dof, const float* a, const float* sin_alpha,
+                      const float* cos_alpha, const float* gT, float* gq, void* stream);
+int dcx_euler_frames(int device, const float* phi, int64_t B, float* R, void* stream);
+int dcx_euler_frames_vjp(int device, const float* phi, const float* gR, int64_t B, float* gphi, void* stream);
 /* K[b, j] = K(x_b, s_j): KernelFunc.__call__ kernel.py:17-29, 49-57, 73-79 (used by the trainer's
  * row fill kernel_perceptrons.py:117-119 and fit_poly :271-287).  x [B, D], s [S, D] dev -> K [B, S] dev */
 int dcx_kernel_matrix(int device, int kernel_kind, const float* kparams, const float* x, int64_t B,

@@ -714,6 +714,125 @@ def gen_optim_scipy(out, robots):
          tc_maxiter=np.array(6))
 
 
+def gen_frames(out, robots):
+    """utils.DH2mat (utils.py:66-75) and utils.euler2mat (utils.py:15-38) called as the reference's robot classes call them
+    (model.py:230 with Baxter's DH table, model.py:437 with Panda's; RigidBody.fkine's euler2mat, model.py:156-159): fp32 outputs,
+    an fp64 evaluation of the same functions, and vector-Jacobian products from autograd in fp64"""
+    gen = torch.Generator().manual_seed(1900)
+    arrs = {}
+    for name in ("baxter_left", "panda"):
+        rob = robots[name]
+        q = rand_cfgs(rob, 48, gen)
+        q[0] = 0.0
+        ang = q + rob.dhparams.theta                                       # model.py:229
+        a, dd, sa, ca = rob.dhparams.a, rob.dhparams.d, rob.s_alpha, rob.c_alpha
+        T32 = R.utils.DH2mat(ang, a, dd, sa, ca)
+        qd = ang.double().requires_grad_(True)
+        T64 = R.utils.DH2mat(qd, a.double(), dd.double(), sa.double(), ca.double())
+        gT = torch.randn(T64.shape, generator=gen, dtype=torch.float32).double()
+        (gq,) = torch.autograd.grad((T64 * gT).sum(), qd)
+        arrs.update({f"{name}_q": ang, f"{name}_a": a, f"{name}_d": dd, f"{name}_sa": sa, f"{name}_ca": ca, f"{name}_T32": T32,
+                     f"{name}_T64": T64.detach(), f"{name}_gT": gT.float(), f"{name}_gq64": gq})
+    phi = (torch.rand((64, 3), generator=gen) * 2 - 1) * math.pi
+    phi[0] = 0.0
+    pd = phi.double().requires_grad_(True)
+    R64 = R.utils.euler2mat(pd)
+    gR = torch.randn(R64.shape, generator=gen, dtype=torch.float32).double()
+    (gp,) = torch.autograd.grad((R64 * gR).sum(), pd)
+    arrs.update(euler_phi=phi, euler_R32=R.utils.euler2mat(phi), euler_R64=R64.detach(), euler_gR=gR.float(), euler_gphi64=gp)
+    save(out, "frames", **arrs)
+
+
+def gen_optim_multi(out, robots):
+    """Rows f2 / f4 for a MULTI-CLASS checker (round 6): the reference's adam_traj_optimize (optim.py:13-163) run unmodified on an
+    old-API MultiDiffCo's rbf_score ([W, C] scores, deprecated/MultiDiffCo.py:156-169) with options['safety_margin'] a [C] tensor -
+    the call of scripts/2d_trajopt.py:94-102 / scripts/active.py:28-121, on BASELINE config #3's shape (Baxter, five classes,
+    Polyharmonic nodes with 40 % of the entries zero) - and the collision constraint of the scipy drivers (optim.py:190-218,
+    380-391) on the same checker at a path whose dense point count divides by the segment count (the reference's flat reshape
+    only exists then for C > 1).  The checker's state is held in float64 (rbf_score does not cast: the optimisers' float64
+    waypoints need float64 supports)."""
+    gen = torch.Generator().manual_seed(1800)
+    rob = robots["baxter_left"]
+    S, C = 300, 5
+    sup_q = rand_cfgs(rob, S, gen)
+    Wn = (torch.randn((S, C), generator=gen) * 0.05 + 0.002) * (torch.rand((S, C), generator=gen) >= 0.4)
+    md = R.old_MultiDiffCo.MultiDiffCo.__new__(R.old_MultiDiffCo.MultiDiffCo)
+    md.fkine, md.support_points = rob.fkine, sup_q.double()
+    md.support_fkine = rob.fkine(sup_q.double()).reshape(S, -1)
+    md.rbf_kernel, md.rbf_nodes, md.num_class = make_kernel("poly", (1, 1.0)), Wn.double(), C
+    start, target = rand_cfgs(rob, 1, gen)[0], rand_cfgs(rob, 1, gen)[0]
+    n_wp = 20
+    t = torch.linspace(0, 1, n_wp)[:, None].double()
+    init = start.double() * (1 - t) + target.double() * t
+    init[1:-1] += 0.05 * torch.randn((n_wp - 2, 7), generator=gen).double()
+    with torch.no_grad():
+        s_init = md.rbf_score(init)
+    # per-class margins that leave the hinge active on part of the path in every class (the 60 % quantile per class)
+    margin = s_init.quantile(0.6, dim=0).float()
+    options = {"N_WAYPOINTS": n_wp, "NUM_RE_TRIALS": 1, "MAXITER": 50, "safety_margin": margin.double(), "max_speed": 0.3,
+               "seed": 1234, "history": False, "extra_optimizer_options": {"lr": 0.05}, "init_solution": init.clone()}
+    p = init.clone().requires_grad_(True)
+    col = torch.clamp(md.rbf_score(p) - margin.double(), min=0).sum()
+    cp = rob.fkine(p)
+    mm = torch.clamp((cp[1:] - cp[:-1]).square().sum(dim=2) - 0.3 ** 2, min=0).sum()
+    jl = (torch.clamp(rob.limits[:, 0] - p, min=0) + torch.clamp(p - rob.limits[:, 1], min=0)).sum()
+    diff = (cp[1:] - cp[:-1]).square().sum()
+    loss = diff + 10 * col + 10 * mm + 10 * jl
+    (gl,) = torch.autograd.grad(loss, p)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        rec = R.optim.adam_traj_optimize(rob, md.rbf_score, start.double(), target.double(), dict(options))
+    print(f"  multi-class adam record: success={rec['success']} cost={rec['cost']:.6f} cnt_check={rec['cnt_check']} "
+          f"active at the initial path: {int(((s_init - margin.double()) > 0).sum())} of {s_init.numel()}")
+
+    # ---- the scipy drivers' constraint on the same checker ----------------------------------------------------------------
+    n_wp2 = 12
+    t2 = torch.linspace(0, 1, n_wp2)[:, None].double()
+    init2 = start.double() * (1 - t2) + target.double() * t2
+    init2[1:-1] += 0.05 * torch.randn((n_wp2 - 2, 7), generator=gen).double()
+    n_seg = n_wp2 - 1
+    max_speed = None
+    for ms in np.arange(0.30, 0.02, -0.0005):      # the first speed whose dense path has a multiple of n_seg inner points
+        n_pt = len(R.utils.dense_path(init2, float(ms))) - 2
+        if n_pt % n_seg == 0 and n_pt >= 2 * n_seg:
+            max_speed = float(ms)
+            break
+    assert max_speed is not None
+    dense = R.utils.dense_path(init2, max_speed)
+    with torch.no_grad():
+        s_dense = md.rbf_score(dense[1:-1])
+    margin2 = s_dense.quantile(0.5, dim=0).float()
+
+    def con(pp):  # optim.py:190-207 with return_tensor=True
+        dense_p = R.utils.dense_path(pp, max_speed)
+        cost = -(md.rbf_score(dense_p[1:-1]) - margin2.double())
+        cost = torch.clamp(cost, max=0).reshape(-1)
+        n_segment, n_point = len(pp) - 1, len(dense_p) - 2
+        mult = n_point // n_segment
+        if n_point % n_segment != 0:
+            mult += 1
+            cost = torch.cat([cost, torch.zeros(n_segment * mult - n_point, dtype=cost.dtype)])
+        return cost.reshape(n_segment, -1).sum(dim=1)
+
+    vvec = torch.rand(n_seg, generator=gen).double()
+    p2 = init2.clone().requires_grad_(True)
+    c0 = con(p2).detach()
+    jac = torch.autograd.functional.jacobian(con, p2, create_graph=False, strict=False, vectorize=True, strategy="reverse-mode")
+    jac = jac[:, 1:-1].reshape(jac.shape[0], -1)
+    hess = torch.autograd.functional.hessian(lambda x: torch.dot(con(x), vvec), p2, create_graph=False, strict=False,
+                                             vectorize=True, outer_jacobian_strategy="reverse-mode")
+    hess = hess[1:-1, :, 1:-1, :].reshape((n_wp2 - 2) * 7, -1)
+    print(f"  multi-class constraint: {len(dense) - 2} dense points over {n_seg} segments at max_speed {max_speed:.4f}, "
+          f"{int((c0 < 0).sum())} rows active")
+    save(out, "optim_multi_baxter", sup_q=sup_q, weights=Wn, start=start, target=target, init=init, margin=margin,
+         score_init=s_init, loss0=loss.detach(), loss0_terms=torch.stack([diff, col, mm, jl]).detach(), grad0=gl,
+         solution=np.array(rec["solution"]), cost=np.array(rec["cost"]), cnt_check=np.array(rec["cnt_check"]),
+         success=np.array(rec["success"]), lr=np.array(0.05), maxiter=np.array(50), max_speed=np.array(0.3), seed=np.array(1234),
+         init2=init2, margin2=margin2, max_speed2=np.array(max_speed), n_dense2=np.array(len(dense)), v2=vvec,
+         con0=c0, jac0=jac, hess0=hess)
+
+
 def gen_escape(out, robots):
     """Row f2's escape variant: the reference's OptimSampler.optim_escape (scripts/escape.py:19-38), imported
     from where it lies and run unmodified on reference checkers, in the three call patterns the reference's scripts use:
@@ -836,6 +955,10 @@ def main():
         print("second derivatives"); gen_hess(out, robots)
     if args.only in (None, "all", "optim_scipy"):
         print("SLSQP / trust-constr drivers and their collision constraint"); gen_optim_scipy(out, robots)
+    if args.only in (None, "all", "frames"):
+        print("DH2mat / euler2mat"); gen_frames(out, robots)
+    if args.only in (None, "all", "optim_multi"):
+        print("Adam loop and scipy constraint on a multi-class checker"); gen_optim_multi(out, robots)
     if args.only in (None, "all", "escape"):
         print("escape loops (scripts/escape.py)"); gen_escape(out, robots)
     with open(os.path.join(out, "MANIFEST.json"), "w") as f:
