@@ -263,6 +263,7 @@ class ScoreModel:
         self._h = handle
         self._lib = lib
         self.leases = 0          # holders that need the rows to stay as they are (acquire / release)
+        self.revision = 0        # bumped by update(): a backward pass that re-sweeps checks it still sees its forward's rows
         self._streams = set()    # raw handles of the streams that have launched this model since the last update()
 
     def acquire(self):
@@ -290,6 +291,7 @@ class ScoreModel:
             _lib.check(self._lib.dcx_model_update(self._h, _ptr(sf), _ptr(w), len(sf), _stream(self.dev)))
         self.S = len(sf)
         self.capacity = max(self.capacity, self.S)
+        self.revision += 1
         return self
 
     def _st(self):
@@ -417,6 +419,7 @@ class _ScoreFn(torch.autograd.Function):
         else:
             s = model.score_raw(q32)
             ctx.save_for_backward(q32)
+            ctx.revision = model.revision   # (C > 1: backward sweeps again - against the rows this forward saw, or not at all)
         return s.to(device=q.device, dtype=q.dtype)
 
     @staticmethod
@@ -427,6 +430,11 @@ class _ScoreFn(torch.autograd.Function):
         if model.C == 1:  # saved = d score / d q  [B, dof]; gs [B, 1]: ONE elementwise launch
             return (gs * saved).reshape(ctx.in_shape), None
         q32 = saved
+        if model.revision != ctx.revision:
+            # train / fit_poly / update refilled the model's rows in place between this forward and its backward:
+            # the gradient would be the NEW model's
+            raise RuntimeError("the checker's supports / weights changed between the forward pass of a multi-class score and its "
+                               "backward pass: run backward before retraining (or score again)")
         if _is_batched(gs):
             _, jac = model.score_jac_raw(q32)  # [B, C, dof]
             jac = jac.to(device=ctx.in_device, dtype=ctx.in_dtype)

@@ -183,7 +183,13 @@ class FusedScorer:
     (`ScoreModel.update`: same storage, FK tables, per-stream scratch) - unless somebody holds a lease on it
     (`ScoreModel.acquire()` / `release()`: a ShardedAdamRun while it iterates, an optimiser's constraint terms), in which
     case the holder keeps the rows it started with and the cache builds a new model.  `model()` hands out the cache's own
-    model: a caller that keeps it across a later train / fit_poly and needs it unchanged takes a lease."""
+    model: a caller that keeps it across a later train / fit_poly and needs it unchanged takes a lease.  (A multi-class score's
+    backward pass re-sweeps the model: it checks `ScoreModel.revision` and raises if the rows were refilled after its forward.)
+
+    The per-call check compares the transform by IDENTITY (a robot's bound `fkine`): a robot whose FK parameters (link lengths,
+    DH table, URDF tree) are edited in place after the checker has scored keeps the same bound method, so such an edit must
+    be followed by `invalidate()` - like the `.data` edits above.  The robots of diffco_amd.model / urdf do not change after
+    construction."""
 
     def __init__(self):
         self._key, self._model, self._sup, self._w = None, None, None, None

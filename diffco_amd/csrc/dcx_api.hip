@@ -25,6 +25,8 @@ struct dcx_model {
     DhArgs dh{};                   // its control part, copied into every launch's arguments
     int32_t fk_dwords = 0;         // dwords of FkProg the transform uses
     float* rows_dev = nullptr;     // [S_active][RS]
+    float* rows_p2_dev = nullptr;  // the PAIR-INTERLEAVED copy of rows_dev the two-rows-per-instruction sweeps read (score_kernel.h pair2,
+                                   // p2_applies models only; padded to an even row count with a zero-weight row)
     float* rows_xf_dev = nullptr;  // what the expanded-form sweeps read (score_kernel.h): the rows shifted by `centre`,
                                    // |s - c|^2 in their last column
     unsigned short* aplanes_dev = nullptr;  // XM sweep (score_kernel.h): the centred supports as bf16 planes, MFMA A-operand layout
@@ -589,6 +591,14 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
     a.ys = g.ys;
     a.s_super = (m->S_active + g.ys - 1) / g.ys;
     a.s_chunk = (a.s_super + g.nw - 1) / g.nw;
+    // two rows per packed instruction (score_kernel.h pair2: the direct form of a narrow one-class model): the pair-interleaved
+    // rows, every slice starting on an even row
+    const bool p2 = !qt && !xf_able && m->rows_p2_dev != nullptr && p2_applies(m->Dt, m->Cc, m->kf);
+    if (p2) {
+        a.rows = m->rows_p2_dev;
+        a.s_super = (a.s_super + 1) & ~1;
+        a.s_chunk = ((a.s_super + g.nw - 1) / g.nw + 1) & ~1;
+    }
     a.red_slots = g.red_slots;
     a.dof = m->fk.dof;
     a.d_fk = d_fk;
@@ -748,8 +758,9 @@ static size_t aplane_shorts(int64_t rows) { return ((size_t)(rows + 15) / 16 + 2
 static void model_free_rows(dcx_model* m) {
     if (m->rows_dev) (void)hipFree(m->rows_dev);
     if (m->rows_xf_dev) (void)hipFree(m->rows_xf_dev);
+    if (m->rows_p2_dev) (void)hipFree(m->rows_p2_dev);
     if (m->aplanes_dev) (void)hipFree(m->aplanes_dev);
-    m->rows_dev = m->rows_xf_dev = nullptr;
+    m->rows_dev = m->rows_xf_dev = m->rows_p2_dev = nullptr;
     m->aplanes_dev = nullptr;
     m->cap = 0;
 }
@@ -761,9 +772,10 @@ static int model_alloc_rows(dcx_model* m, int64_t cap) {
     // the new buffers first, the old ones freed only when both exist: a failed growth leaves the model as it was (ADVICE r4:
     // freeing first left rows_dev null beside the old S_active, and the next launch read through it)
     const size_t floats = (size_t)cap * m->RS + rows_tail_floats(m);
-    float *rows = nullptr, *rows_xf = nullptr;
+    float *rows = nullptr, *rows_xf = nullptr, *rows_p2 = nullptr;
     hipError_t e = hipMalloc((void**)&rows, floats * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&rows_xf, floats * sizeof(float));
+    if (e == hipSuccess && p2_applies(m->Dt, m->Cc, m->kf)) e = hipMalloc((void**)&rows_p2, (floats + m->RS) * sizeof(float));
     if (e == hipSuccess && !m->centre_dev) e = hipMalloc((void**)&m->centre_dev, (size_t)m->Dt * sizeof(float));
     if (e == hipSuccess && !m->info_dev) e = hipMalloc((void**)&m->info_dev, 16);
     if (e == hipSuccess && !m->info_host) e = hipHostMalloc((void**)&m->info_host, 16, hipHostMallocDefault);
@@ -777,11 +789,13 @@ static int model_alloc_rows(dcx_model* m, int64_t cap) {
     if (e != hipSuccess) {
         if (rows) (void)hipFree(rows);
         if (rows_xf) (void)hipFree(rows_xf);
+        if (rows_p2) (void)hipFree(rows_p2);
         return fail_hip(e, "device allocation of the model");
     }
     model_free_rows(m);
     m->rows_dev = rows;
     m->rows_xf_dev = rows_xf;
+    m->rows_p2_dev = rows_p2;
     m->cap = cap;
     return DCX_OK;
 }
@@ -963,8 +977,12 @@ static int model_fill(dcx_model* m, const float* support_feat, const float* weig
     // the XM planes (knob xm > 0: measurements only) are split on the host
     const bool on_device = S > 0 && is_device_ptr(support_feat) && is_device_ptr(weights) &&
                            !(knobs().xm > 0 && xm_applies(m->Dt, m->Cc, m->kf));
-    if (on_device) return model_fill_device(m, support_feat, weights, S, stream);
-    return model_fill_host(m, support_feat, weights, S, stream);
+    int rc = on_device ? model_fill_device(m, support_feat, weights, S, stream) : model_fill_host(m, support_feat, weights, S, stream);
+    if (rc == DCX_OK && m->rows_p2_dev) {   // the pair-interleaved copy (stream-ordered behind the rows it reads)
+        hipError_t e = launch_interleave_rows(m->rows_dev, m->rows_p2_dev, (int32_t)m->S_active, m->RS, (int32_t)rows_tail_floats(m), stream);
+        if (e != hipSuccess) return fail_hip(e, "interleaving of the support rows");
+    }
+    return rc;
 }
 
 int dcx_model_create(dcx_model** out, int device, const dcx_fk_desc* fk, int kernel_kind, const float* kparams,
@@ -1084,6 +1102,7 @@ void dcx_model_destroy(dcx_model* m) {
     if (m->dh_dev) (void)hipFree(m->dh_dev);
     if (m->rows_dev) (void)hipFree(m->rows_dev);
     if (m->rows_xf_dev) (void)hipFree(m->rows_xf_dev);
+    if (m->rows_p2_dev) (void)hipFree(m->rows_p2_dev);
     if (m->centre_dev) (void)hipFree(m->centre_dev);
     if (m->aplanes_dev) (void)hipFree(m->aplanes_dev);
     if (m->info_dev) (void)hipFree(m->info_dev);
@@ -1377,8 +1396,17 @@ static int traj_run(const dcx_model* m, const dcx_traj_state* st, const dcx_traj
             a.sc.ts = g_ts_dev;
 #endif
             a.sc.S = m->S_active;
-            a.s_super = (m->S_active + ys - 1) / ys;
-            a.sc.s_chunk = (a.s_super + nw - 1) / nw;
+            // this launch's slices: ys super-chunks, nw wave slices each; a model whose direct-form sweep takes two rows per
+            // instruction (score_kernel.h pair2) reads the pair-interleaved rows on even-aligned slices, like run_score
+            bool traj_p2 = false;
+            auto slice = [&](int ys_) {
+                a.s_super = (m->S_active + ys_ - 1) / ys_;
+                a.sc.s_chunk = (a.s_super + nw - 1) / nw;
+                if (traj_p2) {
+                    a.s_super = (a.s_super + 1) & ~1;
+                    a.sc.s_chunk = ((a.s_super + nw - 1) / nw + 1) & ~1;
+                }
+            };
             a.sc.dof = m->fk.dof;
             a.sc.d_fk = d_fk;
             a.sc.frame_floats = m->frame_floats;
@@ -1390,7 +1418,11 @@ static int traj_run(const dcx_model* m, const dcx_traj_state* st, const dcx_traj
             if (a.sc.xf) {
                 a.sc.rows = m->rows_xf_dev;
                 a.sc.centre = m->centre_dev;
+            } else if (m->rows_p2_dev && p2_applies(m->Dt, m->Cc, m->kf)) {
+                a.sc.rows = m->rows_p2_dev;
+                traj_p2 = true;
             }
+            slice(ys);
             a.st = *st;
             a.opt = *opt;
             a.n_points = m->fk.n_points;
@@ -1412,8 +1444,7 @@ static int traj_run(const dcx_model* m, const dcx_traj_state* st, const dcx_traj
                 }
                 if (a.ys != ys) {  // no exchange rows right now: one workgroup per path, the whole support set each
                     ys = 1;
-                    a.s_super = m->S_active;
-                    a.sc.s_chunk = (m->S_active + nw - 1) / nw;
+                    slice(1);
                 }
                 hipError_t e = fn(m->kf, m->Cc, nw, lds_of(nw), st->n_paths, a, (hipStream_t)stream);
                 if (e == hipErrorNotSupported && done == 0) {   // this width / kernel function has no multi-class instantiation
@@ -1425,8 +1456,7 @@ static int traj_run(const dcx_model* m, const dcx_traj_state* st, const dcx_traj
                     // the cooperative launch was refused (the grid does not fit beside what else is resident): nothing ran
                     (void)hipGetLastError();
                     ys = a.ys = 1;
-                    a.s_super = m->S_active;
-                    a.sc.s_chunk = (m->S_active + nw - 1) / nw;
+                    slice(1);
                     e = fn(m->kf, m->Cc, nw, lds_of(nw), st->n_paths, a, (hipStream_t)stream);
                 }
                 if (e != hipSuccess) return fail_hip(e, "fused trajectory launch");

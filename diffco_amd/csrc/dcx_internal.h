@@ -22,10 +22,11 @@ inline int template_d_for(int D) {
 // the ~3*D live registers of the sweep
 inline int max_threads_for(int Dt) { return Dt <= 16 ? 1024 : (Dt <= 48 ? 512 : 256); }
 
-// class counts the sweeps are compiled for: 3 runs as 4, 6 and 7 as 8 - the extra classes are zero weight columns in the
+// class counts the sweeps are compiled for: 2 and 3 run as 4, 6 and 7 as 8 - the extra classes are zero weight columns in the
 // rows, never read from `upstream` and never written to `score` (ScoreArgs::c_out).  Five is BASELINE config #3's count.
-// (Round 4: eight compiled class counts x 21 widths x 3 kernel functions x modes x forms had grown to 115 MB and 10 minutes.)
-inline int compiled_classes(int C) { return C <= 2 ? C : C <= 4 ? 4 : C == 5 ? 5 : 8; }
+// (Round 4: eight compiled class counts x 21 widths x 3 kernel functions x modes x forms had grown to 115 MB and 10 minutes;
+// round 6: two classes through the four-class bodies as well - one instantiation in five less to build, two idle fma per pair.)
+inline int compiled_classes(int C) { return C <= 1 ? C : C <= 4 ? 4 : C == 5 ? 5 : 8; }
 
 inline int row_stride(int Dt, int C) {   // RowLayout<Dt, C>::RS
     const int al = C > 1 ? DCX_ROW_ALIGN_MULTI : 4;

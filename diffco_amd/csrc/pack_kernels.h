@@ -21,5 +21,8 @@ struct PackArgs {
     float fold, seed;    // weight factor (1/eps, (2/gamma)^2 or 1); 2/gamma
 };
 hipError_t launch_pack_rows(const PackArgs& a, hipStream_t stream);
+// the pair-interleaved copy of `kept` rows for the two-rows-per-instruction sweeps (score_kernel.h pair2): row j's element e at
+// rows_il[(j >> 1) * 2 RS + 2 e + (j & 1)]; an odd count is padded with a zero row; `tail` zeroed floats behind
+hipError_t launch_interleave_rows(const float* rows, float* rows_il, int32_t kept, int32_t RS, int32_t tail, hipStream_t stream);
 
 }  // namespace dcx

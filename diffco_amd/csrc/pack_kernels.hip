@@ -16,6 +16,8 @@
 // The host reads back 16 bytes (kept rows, max |s - c|^2) - the launch geometry depends on the row count - and nothing else.
 // One workgroup: a model is a few thousand rows; the packing is latency, not bandwidth
 // (dcx_model_update at S = 2000: ~0.1 ms including the read-back; profiles/r04_model_latency.txt).
+#include <algorithm>
+
 #include "pack_kernels.h"
 
 namespace dcx {
@@ -128,7 +130,27 @@ __global__ __launch_bounds__(kPackThreads) void pack_rows_kernel(const PackArgs 
     }
 }
 
+__global__ __launch_bounds__(256) void interleave_rows_kernel(const float* rows, float* il, int32_t kept, int32_t RS, int32_t tail) {
+    const int32_t even = (kept + 1) & ~1;
+    const int64_t n = (int64_t)even * RS + tail;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i >= (int64_t)even * RS) {
+            il[i] = 0.0f;
+            continue;
+        }
+        const int32_t j = (int32_t)(i / RS), e = (int32_t)(i % RS);
+        il[(size_t)(j >> 1) * 2 * RS + 2 * e + (j & 1)] = j < kept ? rows[i] : 0.0f;
+    }
+}
+
 }  // namespace
+
+hipError_t launch_interleave_rows(const float* rows, float* rows_il, int32_t kept, int32_t RS, int32_t tail, hipStream_t stream) {
+    const int64_t n = (int64_t)((kept + 1) & ~1) * RS + tail;
+    const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 1024);
+    interleave_rows_kernel<<<dim3(blocks ? blocks : 1), 256, 0, stream>>>(rows, rows_il, kept, RS, tail);
+    return hipGetLastError();
+}
 
 hipError_t launch_pack_rows(const PackArgs& a, hipStream_t stream) {
     pack_rows_kernel<<<dim3(1), dim3(kPackThreads), 0, stream>>>(a);

@@ -92,8 +92,7 @@ hipError_t by_cc(int cc, int mode, int nw, size_t lds, int64_t nblk, const Score
     case 1: return by_mode<KF, 1>(mode, nw, lds, nblk, a, st);
     case 5: return by_mode<KF, 5>(mode, nw, lds, nblk, a, st);
 #ifndef DCX_DEV_FAST  // developer builds (EXTRA=-DDCX_DEV_FAST): one and five classes only
-    case 2: return by_mode<KF, 2>(mode, nw, lds, nblk, a, st);   // (3 runs as 4, 6 and 7 as 8: dcx_internal.h compiled_classes)
-    case 4: return by_mode<KF, 4>(mode, nw, lds, nblk, a, st);
+    case 4: return by_mode<KF, 4>(mode, nw, lds, nblk, a, st);   // (2 and 3 run as 4, 6 and 7 as 8: dcx_internal.h compiled_classes)
     case 8: return by_mode<KF, 8>(mode, nw, lds, nblk, a, st);
 #endif
     default: return hipErrorInvalidValue;
@@ -169,7 +168,6 @@ hipError_t jac_by_cc(int cc, int nw, size_t lds, int64_t nblk, const ScoreArgs& 
     switch (cc) {
     case 5: return jac_go<KF, 5>(nw, lds, nblk, a, st);
 #ifndef DCX_DEV_FAST
-    case 2: return jac_go<KF, 2>(nw, lds, nblk, a, st);
     case 4: return jac_go<KF, 4>(nw, lds, nblk, a, st);
     case 8: return jac_go<KF, 8>(nw, lds, nblk, a, st);
 #endif
@@ -255,7 +253,6 @@ hipError_t DCX_CAT(launch_traj_fused_mc_D, DCX_INST_D)(int kf, int cc, int nw, s
     switch (cc) {
     case 5: return traj_mc<5>(kf, nw, lds, n_paths, a, st);
 #ifndef DCX_DEV_FAST
-    case 2: return traj_mc<2>(kf, nw, lds, n_paths, a, st);
     case 4: return traj_mc<4>(kf, nw, lds, n_paths, a, st);
     case 8: return traj_mc<8>(kf, nw, lds, n_paths, a, st);
 #endif

@@ -193,6 +193,11 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define DCX_PAIR2_MAX_D 8
 #endif
 // ... and are fetched together: two adjacent rows = ONE scalar load, one address per stage (see the P2 pipeline)
+// Round 6: the rows such a sweep reads are stored PAIR-INTERLEAVED (dcx_api.hip rows_p2: rows 2i and 2i + 1 as (r0_0, r1_0, r0_1, r1_1,
+// ..., w0, w1, ...), an odd count padded with a zero-weight row), so the operand pair (r0_k, r1_k) of every packed instruction IS
+// an aligned SGPR pair of the stage's one scalar load: the two s_mov per feature that used to build it (6 of the 8.9 SALU
+// instructions per pair at config #4, profiles/pmc_cfg4.json - one scalar unit serves a CU's four SIMDs) are gone.  Slices start
+// on even rows (the host rounds s_chunk / s_super up), a slice that ends on the model's odd last row runs into the padding row.
 #ifndef DCX_PAIR2_LOADS
 #define DCX_PAIR2_LOADS 1
 #endif
@@ -418,6 +423,12 @@ constexpr bool xf_applies(int D, int CC, int KF) {
     const int used = D + CC + (CC > 1 ? 1 : 0);
     const int parts = (4 * used <= (CC > 1 ? DCX_P0_MAX_MULTI : DCX_P0_MAX_SINGLE)) ? 0 : (used + 37) / 38;
     return (KF == KF_POLY1 || KF == KF_RQ2) && used + 1 <= 38 && parts <= 1;
+}
+// Does a launch of this shape in the DIRECT form take two rows per packed instruction (sweep_rows, P2) - and therefore read the
+// pair-interleaved copy of the rows on even-aligned slices?  (the host's mirror of sweep_rows' own condition)
+constexpr bool p2_applies(int D, int CC, int KF) {
+    return DCX_PAIR2 && DCX_PAIR2_LOADS && CC == 1 && (D % 2) == 0 && D <= DCX_PAIR2_MAX_D && 4 * (D + 1) <= DCX_P0_MAX_SINGLE &&
+           (KF == KF_RQ2 || KF == KF_POLY1);
 }
 // Round 4: RQKernel(p = 2) takes the expanded form as well, on FK-CENTRED features only (the host's rule, dcx_api.hip
 // xf_rq_ok: gamma * max |s - c|^2 <= 32, a transform present).  The kernel is smooth at d2 = 0, so there is no near-pair
@@ -673,21 +684,22 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
     // fmas with no add of halves, the chain runs once for both rows in packed multiplies (the reciprocal / rsqrt stay one per
     // row: no packed form exists), and the gradient accumulators hold the even and the odd rows' sums side by side (2 D
     // registers instead of D: why this is for D <= 8 only).  24 instead of 30 VALU instructions per two rows at D = 6.
-    constexpr bool P2 = DCX_PAIR2 && !XF && CC == 1 && (D % 2) == 0 && D <= DCX_PAIR2_MAX_D && PARTS == 0 &&
-                        (KF == KF_RQ2 || KF == KF_POLY1);
+    constexpr bool P2 = !XF && p2_applies(D, CC, KF);
+    static_assert(!P2 || PARTS == 0, "pair2: whole rows in the four-row budget");
     v2f gp[P2 ? D : 1];     // gradient, rows of even / odd position in the stage
     v2f scp = {0.0f, 0.0f};
     if constexpr (P2) {
 #pragma unroll
         for (int k = 0; k < D; ++k) gp[k] = v2f{0.0f, 0.0f};
     }
-    auto pair2 = [&](const float (&r0)[L::RS], const float (&r1)[L::RS]) __attribute__((always_inline)) {
+    // b: the stage's 2 RS floats, pair-interleaved (element e of the even row at b[2 e], of the odd row at b[2 e + 1])
+    auto pair2 = [&](const float (&b)[2 * L::RS]) __attribute__((always_inline)) {
         v2f dk[D];
         v2f acc = {d2_seed<KF>(a), d2_seed<KF>(a)};
 #pragma unroll
         for (int k = 0; k < D; ++k) {
             const v2f xv = {x[k], x[k]};
-            const v2f rv = {r0[k], r1[k]};
+            const v2f rv = {b[2 * k], b[2 * k + 1]};
             dk[k] = xv - rv;
             acc = __builtin_elementwise_fma(dk[k], dk[k], acc);
         }
@@ -701,7 +713,7 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
             g = v2f{__builtin_amdgcn_rsqf(d2c.x), __builtin_amdgcn_rsqf(d2c.y)};
             val = d2c * g;
         }
-        const v2f w2 = {r0[L::W_OFF], r1[L::W_OFF]};
+        const v2f w2 = {b[2 * L::W_OFF], b[2 * L::W_OFF + 1]};
         scp = __builtin_elementwise_fma(w2, val, scp);
         if constexpr (GRAD) {
             v2f coef = g * w2;
@@ -874,10 +886,11 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
         }
     }
     } else if constexpr (P2 && DCX_PAIR2_LOADS) {
-    // pair2's own pipeline: the two rows of a stage are adjacent in memory, so they arrive by ONE scalar load of 2 RS floats
-    // (one address computation per stage instead of one per row: with 12 VALU instructions per pair the scalar unit, which the
-    // four SIMDs of a CU share, had become nearly as busy as the vector one).  The model's rows have a readable tail
-    // (rows_tail_floats), so the look-ahead load at the end of a slice may run one row past it.
+    // pair2's own pipeline: the two rows of a stage are ONE piece of memory (pair-interleaved, see above), so they arrive by one
+    // scalar load of 2 RS floats (one address computation per stage instead of one per row: with 12 VALU instructions per pair the
+    // scalar unit, which the four SIMDs of a CU share, had become nearly as busy as the vector one).  j0 is even (the host's
+    // slicing); a slice that ends on an odd row - the model's last - takes the zero-weight padding row with it.  The rows have a
+    // readable tail (rows_tail_floats), so the look-ahead load at the end of a slice may run one stage past it.
     //   wait -> issue {C,D} -> body(A,B) -> wait -> issue {A,B} -> body(C,D)
     if (j0 < j1) {
         constexpr int R2 = 2 * L::RS;
@@ -891,13 +904,14 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
             // (the stride's padding counts as used where the rows are consumed: the compiler narrows a load whose tail is dead
             // into x4 + x2 + x1 pieces otherwise)
 #pragma unroll
-            for (int e = USED; e < L::RS; ++e) asm volatile("" ::"s"(b[e]), "s"(b[L::RS + e]));
-            pair2(*reinterpret_cast<const float(*)[L::RS]>(&b[0]), *reinterpret_cast<const float(*)[L::RS]>(&b[L::RS]));
+            for (int e = 2 * USED; e < R2; ++e) asm volatile("" ::"s"(b[e]));
+            pair2(b);
         };
-        const int jl = j1 - 1;
+        const int j1e = (j1 + 1) & ~1;
+        const int jl = j1e - 2;
         load2(ab, j0);
         int j = j0;
-        for (; j + 3 < j1; j += 4) {
+        for (; j + 3 < j1e; j += 4) {
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_sched_barrier(0);
             load2(cd, j + 2);
@@ -906,22 +920,12 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_sched_barrier(0);
-            load2(ab, (j + 4 < j1) ? j + 4 : jl);
+            load2(ab, (j + 4 < j1e) ? j + 4 : jl);
             __builtin_amdgcn_sched_barrier(0);
             body2(cd);
             __builtin_amdgcn_sched_barrier(0);
         }
-        // up to three rows left; ab holds rows j and j + 1 whenever j < j1
-        if (j + 1 < j1) {
-            body2(ab);
-            if (j + 2 < j1) {
-                float rowC[L::RS];
-                load_row(rowC, j + 2);
-                pair(rowC);
-            }
-        } else if (j < j1) {
-            pair(*reinterpret_cast<const float(*)[L::RS]>(&ab[0]));
-        }
+        if (j < j1e) body2(ab);   // one stage left; ab holds it
     }
     } else if constexpr (PARTS == 0) {
     // Explicit software pipeline, two rows per stage (4 row buffers): the wait before a stage covers loads
@@ -941,8 +945,6 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (XFA) {
                 stage_x(rowA, rowB);
-            } else if constexpr (P2) {
-                pair2(rowA, rowB);
             } else {
                 pair(rowA);
                 pair(rowB);
@@ -955,8 +957,6 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (XFA) {
                 stage_x(rowC, rowD);
-            } else if constexpr (P2) {
-                pair2(rowC, rowD);
             } else {
                 pair(rowC);
                 pair(rowD);

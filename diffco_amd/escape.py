@@ -103,7 +103,7 @@ class OptimSampler:
         opts = _lib.EscapeOpts(lr, b1, b2, eps, n, rf, 1 if joint else 0, 0 if joint else int(compact_every), mask)
         steps = torch.empty((1 if joint else B, 2), device=dev, dtype=torch.int32)
         # slots behind a loop's last record are never returned as they are (optim_escape cuts, optim_escape_batch overwrites)
-        hist = torch.empty((((n + rf - 1) // rf if rf else 0) + 1, B, dof), device=dev) if want_history else None
+        hist = torch.empty((((n + rf - 1) // rf if rf else 0) + 1, B, dof), device=dev, dtype=torch.float32) if want_history else None
         # (no lease on the model: a refill of its rows - ScoreModel.update - is enqueued behind this loop on the same stream, and
         # waits for the streams recorded by _st() otherwise)
         with _ops._on_device(dev):

@@ -26,7 +26,10 @@ from .optim import (COLLISION_WEIGHT, DIF_WEIGHT, JOINT_LIMIT_WEIGHT, MAX_MOVE_W
 
 
 def _resolve_model(dist_est, device=None):
-    """ScoreModel behind `dist_est`: a ScoreModel, or a bound score method of a diffco_amd checker"""
+    """ScoreModel behind `dist_est`: a ScoreModel, or a bound score method of a diffco_amd checker.  A checker whose transform is
+    not a diffco_amd robot's `fkine` cannot be fused (its model scores FEATURES; only `FusedScorer.score` runs the foreign
+    transform in front of it): TypeError, and the callers keep their host route (the escape loop used to score the
+    raw configurations of such a checker)."""
     if isinstance(dist_est, _ops.ScoreModel):
         return dist_est
     owner, name = getattr(dist_est, "__self__", None), getattr(dist_est, "__name__", "")
@@ -35,19 +38,26 @@ def _resolve_model(dist_est, device=None):
                         "of a diffco_amd checker (an arbitrary callable cannot be fused)")
     from .deprecated import DiffCo as OldDiffCo
     from .kernel_perceptrons import DiffCo as NewDiffCo
+    tf, model = None, None
     if isinstance(owner, NewDiffCo):
+        tf = owner.transform
         if name == "poly_score":
-            return owner._poly_fused.model(owner.transform, owner.rbf_kernel, owner.support_transformed, owner.rbf_nodes, device)
-        if name in ("score", "score_original"):
-            return owner._score_fused.model(owner.transform, owner.kernel_func, owner.support_transformed, owner.gains, device)
-    if isinstance(owner, OldDiffCo):
+            model = owner._poly_fused.model(tf, owner.rbf_kernel, owner.support_transformed, owner.rbf_nodes, device)
+        elif name in ("score", "score_original"):
+            model = owner._score_fused.model(tf, owner.kernel_func, owner.support_transformed, owner.gains, device)
+    elif isinstance(owner, OldDiffCo):
         if name in ("rbf_score", "poly_score"):
-            feats = owner.support_fkine if owner.fkine is not None else owner.support_points
-            return owner._rbf_fused.model(owner.fkine, owner.rbf_kernel, feats, owner.rbf_nodes, device)
-        if name in ("score", "score_original"):
+            tf = owner.fkine
+            feats = owner.support_fkine if tf is not None else owner.support_points
+            model = owner._rbf_fused.model(tf, owner.rbf_kernel, feats, owner.rbf_nodes, device)
+        elif name in ("score", "score_original"):
             tf, pk, feats = owner._score_state()
-            return owner._score_fused.model(tf, pk, feats, owner.gains, device)
-    raise TypeError(f"cannot fuse {dist_est!r}")
+            model = owner._score_fused.model(tf, pk, feats, owner.gains, device)
+    if model is None:
+        raise TypeError(f"cannot fuse {dist_est!r}")
+    if tf is not None and model.desc.kind == 0:
+        raise TypeError(f"cannot fuse {dist_est!r}: its transform is not the fkine of a diffco_amd robot")
+    return model
 
 
 def select_trial(best_valid_obj, lowest_loss, lowest_obj, steps, n_waypoints):

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"libdcx.so does not export {n}"
     assert set(names) == set(_lib.SYMBOLS), "ctypes table and header disagree"
-    assert lib.dcx_version() == 108
+    assert lib.dcx_version() == 109
     assert isinstance(lib.dcx_device_count(), int)
 
 

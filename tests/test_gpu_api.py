@@ -879,3 +879,26 @@ def test_trainer_survives_a_diverging_run(knob):
         torch.cuda.synchronize()
         its.append(out[3])
     assert its[0] == its[1] == its[2]
+
+
+def test_multiclass_backward_refuses_rows_refilled_after_its_forward():
+    """a multi-class score's backward pass sweeps the model again; if train / fit_poly refilled the model's rows in
+    place between forward and backward the gradient would be the new model's - it raises instead (ScoreModel.revision)"""
+    from diffco_amd import _ops
+    rob = make_robot("baxter_left")
+    g = torch.Generator().manual_seed(4)
+    lim = rob.limits
+    S = 120
+    sq = torch.rand((S, 7), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]
+    sup = _ops.fkine(rob.fk_desc(), sq.cuda()).reshape(S, -1)
+    w = torch.randn((S, 3), generator=g).cuda()
+    m = _ops.ScoreModel(rob.fk_desc(), 1, 1.0, 1.0, sup, w, capacity=2 * S)
+    q = (torch.rand((40, 7), generator=g) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]).cuda().requires_grad_(True)
+    s = m.score(q)
+    (g1,) = torch.autograd.grad(s.sum(), q, retain_graph=True)       # fine: same rows
+    m.update(sup, 2 * w)
+    with pytest.raises(RuntimeError, match="changed between the forward"):
+        torch.autograd.grad(s.sum(), q)
+    s2 = m.score(q)
+    (g2,) = torch.autograd.grad(s2.sum(), q)
+    assert relerr(g2.cpu().numpy(), 2 * g1.cpu().numpy()) < 1e-6

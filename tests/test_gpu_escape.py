@@ -366,3 +366,49 @@ def test_the_loop_is_captured_in_a_hip_graph():
         graph.replay()
         side.synchronize()
     assert torch.equal(q, want_q) and torch.equal(steps, want_steps)
+
+
+def test_a_foreign_transform_keeps_the_host_route():
+    """a checker whose transform is not a diffco_amd fkine (here a width-preserving scaling) cannot run as
+    dcx_escape_adam - its model scores FEATURES, and the library would differentiate the raw configuration.  The sampler must take
+    the host loop, whose score runs the transform in torch first; and the history buffer is float32 whatever torch's default."""
+    from diffco_amd import kernel
+    from diffco_amd.escape import OptimSampler
+    from diffco_amd.kernel_perceptrons import DiffCo
+    g = torch.Generator().manual_seed(3)
+    sup = torch.randn((80, 4), generator=g)
+    dc = DiffCo(transform=lambda x: 2 * x)
+    dc.support_points = sup
+    dc.support_transformed = 2 * sup
+    dc.rbf_kernel, dc.rbf_nodes = kernel.Polyharmonic(1, 1.0), 0.1 * torch.randn(80, generator=g) + 0.05
+    start = torch.randn((1, 4), generator=g)
+    args = {"N_WAYPOINTS": 6, "lr": 5e-2, "record_freq": 1, "safety_margin": float(dc.poly_score(start)) - 0.05}
+    sampler = OptimSampler(None, dc.poly_score, args)
+    hist, checks = sampler.optim_escape(start)
+    assert sampler.last_route == "host"
+    # a float64 torch restatement of the loop with the transform inside the score
+    w, s2 = dc.rbf_nodes.double(), (2 * sup).double()
+    p = start.double().clone().requires_grad_(True)
+    opt = torch.optim.Adam([p], lr=5e-2)
+    kept, n = [], 0
+    for _ in range(6):
+        ex = (torch.cdist(2 * p, s2) @ w - args["safety_margin"]).sum()
+        n += 1
+        if ex <= 0:
+            break
+        kept.append(p.detach().clone())
+        opt.zero_grad(); ex.backward(); opt.step()
+    kept.append(p.detach().clone())
+    assert checks == n and relerr(_np(hist), torch.stack(kept).numpy()) < TOL
+    with pytest.raises(TypeError):
+        sampler.optim_escape_batch(start)
+    # the same checker WITHOUT a transform is fusable; float64 as torch's default dtype must not change the history's type
+    d = load("escape")
+    rob, bx = _baxter(d)
+    torch.set_default_dtype(torch.float64)
+    try:
+        smp = OptimSampler(rob, bx.poly_score, {"N_WAYPOINTS": 20, "lr": 5e-2, "record_freq": 1, "safety_margin": float(d["bx_margin1"])})
+        h, c = smp.optim_escape(torch.from_numpy(d["bx_starts"])[:1])
+    finally:
+        torch.set_default_dtype(torch.float32)
+    assert smp.last_route == "fused" and c == int(d["bx_single_checks"]) and relerr(_np(h), d["bx_single_hist"]) < TOL

@@ -7,6 +7,8 @@ output must be <= 1e-5 plus the reference's own distance from the referee (its t
 form is up to ~1e-4 off for large coordinates); HIP vs the fp32 oracle <= 1e-5.
 """
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -14,6 +16,17 @@ import torch
 from helpers import CASE_ROBOT, FK_NAMES, KIND, case_kernel, desc_for, load, make_robot, relerr
 
 pytestmark = pytest.mark.gpu
+
+# The matrix-core forms of the sweep (measured slower, profiles/r03_mfma_ab.txt) are not in the shipped library; they live in
+# diffco_amd/libdcx_matrix.so, which build() makes for the widths that have them (12 and 16).  A process loads ONE libdcx, so the
+# third leg of this file ("mfma") and the tests that need `xm` / `mfma` exist only in a process started with DCX_LIB pointing at that
+# library - tests/test_gpu_matrix_forms.py starts it (round 6: the leg used to skip under the driver).
+MATRIX_LIB = "matrix" in os.path.basename(os.environ.get("DCX_LIB", ""))
+
+
+def matrix_only(fn):
+    """collected only in the process that runs against the matrix-forms library"""
+    return fn if MATRIX_LIB else None
 
 TOL = 1e-5
 TOL_ORACLE = 1e-5  # the fp32 oracle sums S terms sequentially; it is itself ~5e-6 from the referee at S=10k
@@ -27,7 +40,7 @@ def _n(t):
     return t.detach().cpu().numpy()
 
 
-@pytest.fixture(autouse=True, params=["expanded", "direct", "mfma"])
+@pytest.fixture(autouse=True, params=["expanded", "direct"] + (["mfma"] if MATRIX_LIB else []))
 def fold_pipe(request, knob):
     """every test of this file runs three times: the sweep in its expanded form (score_kernel.h XF, the default; shapes
     without one — every kernel but Polyharmonic(1), rows wider than 37 floats — take the direct form), in its direct form
@@ -36,34 +49,20 @@ def fold_pipe(request, knob):
     take the default form)"""
     knob("xf", 0 if request.param == "direct" else 1)
     if request.param == "mfma":
-        # (round 5: the shipped library no longer carries the matrix-core forms - measured slower, profiles/r03_mfma_ab.txt;
-        # this leg runs against `make EXTRA=-DDCX_WITH_MATRIX_FORMS`: profiles/r05_matrix_forms_tests.txt has that run)
-        from diffco_amd._lib import DcxUnsupported
-        try:
-            knob("mfma", 1)
-        except DcxUnsupported:
-            pytest.skip("this build of libdcx carries no matrix-core forms (make EXTRA=-DDCX_WITH_MATRIX_FORMS)")
+        knob("mfma", 1)   # (only in the process that loaded libdcx_matrix.so: see MATRIX_LIB)
     else:
         knob("mfma", 0)
     yield request.param
 
 
 def _need_mfma(knob):
-    """knob mfma = 1, or skip: the shipped library carries no matrix-core forms (see fold_pipe)"""
-    from diffco_amd._lib import DcxUnsupported
-    try:
-        knob("mfma", 1)
-    except DcxUnsupported:
-        pytest.skip("this build of libdcx carries no matrix-core forms (make EXTRA=-DDCX_WITH_MATRIX_FORMS)")
+    """knob mfma = 1 (tests under @matrix_only)"""
+    knob("mfma", 1)
 
 
 def _need_xm(knob):
-    """knob xm = 1, or skip: the shipped library carries no matrix-core forms (see fold_pipe)"""
-    from diffco_amd._lib import DcxUnsupported
-    try:
-        knob("xm", 1)
-    except DcxUnsupported:
-        pytest.skip("this build of libdcx carries no matrix-core forms (make EXTRA=-DDCX_WITH_MATRIX_FORMS)")
+    """knob xm = 1 (tests under @matrix_only)"""
+    knob("xm", 1)
 
 
 @pytest.fixture(scope="module")
@@ -323,6 +322,7 @@ def test_expanded_form_around_the_near_threshold(ops, knob, D, C):
     assert relerr(_n(res[1][0]), _n(res[0][0])) < 6e-6 and relerr(_n(res[1][1]), _n(res[0][1])) < 6e-6
 
 
+@matrix_only
 @pytest.mark.parametrize("D", [4, 6, 8, 12, 16])
 def test_distance_gemm_on_the_matrix_cores_around_the_near_threshold(ops, knob, D):
     """XM (knob xm = 1): the expanded form's x . s^T as a bf16x3 split-operand GEMM on v_mfma_f32_16x16x32_bf16 - the
@@ -358,6 +358,7 @@ def test_distance_gemm_on_the_matrix_cores_around_the_near_threshold(ops, knob, 
     assert relerr(_n(s), _n(s0)) < 6e-6 and relerr(_n(gr), _n(g0)) < 6e-6
 
 
+@matrix_only
 @pytest.mark.parametrize("name", ["baxter_left", "panda", "baxter_dual"])
 @pytest.mark.parametrize("B", [1, 200, 4096, 30000])
 def test_distance_gemm_on_the_matrix_cores_with_fk(ops, knob, name, B):
@@ -390,6 +391,7 @@ def test_distance_gemm_on_the_matrix_cores_with_fk(ops, knob, name, B):
     assert relerr(_n(s1[:n64]), so) < TOL and relerr(_n(g1[:n64]), go) < TOL
 
 
+@matrix_only
 @pytest.mark.parametrize("C,kspec", [(5, (0, 10.0, 2.0)), (8, (0, 10.0, 2.0)), (8, (1, 1.0, 1.0)), (1, (1, 1.0, 1.0))])
 @pytest.mark.parametrize("B", [200, 4096, 20000])
 def test_matrix_core_form_of_the_weight_contraction(ops, knob, C, kspec, B):

@@ -463,3 +463,64 @@ def test_escape_host_loop_against_the_reference_record():
     assert OptimSampler(rob, dist_est, {"post_transform": lambda x: x})._wrap_mask(3) is None
     cfg = resampling_escape(rob)
     assert cfg.shape == (1, 7) and bool(((cfg >= rob.limits[:, 0]) & (cfg <= rob.limits[:, 1])).all())
+
+
+def test_multiclass_adam_plumbing_and_oracle_against_the_reference_record():
+    """tests/golden/optim_multi_baxter.npz (the reference's adam_traj_optimize on a reference MultiDiffCo with a [C] safety margin,
+    tools/make_golden.py gen_optim_multi) on the CPU: the fixture's class scores through the C oracle; the loss terms and gradient
+    through a float64 torch restatement of the multi-class collision term sum_c clamp(score_c - margin_c, 0) (optim.py:88-89); the
+    host optimiser with a vector margin reproducing the record; and the scipy terms' flat-reshape bookkeeping for several
+    classes (optim.py:199-207)"""
+    from diffco_amd import optim
+    d = load("optim_multi_baxter")
+    desc = desc_for("baxter_left")
+    rob = TorchDHRobot(make_robot("baxter_left"))
+    S, C = d["weights"].shape
+    sup = rob.fkine(torch.from_numpy(d["sup_q"]).double()).reshape(S, -1)
+    W = torch.from_numpy(d["weights"]).double()
+    margin = torch.from_numpy(d["margin"]).double()
+    kern = TorchKernel("poly1", 1, 1.0)
+
+    def dist_est(p):
+        return kern(rob.fkine(p).reshape(len(p), -1), sup) @ W
+    init = torch.from_numpy(d["init"])
+    # the oracle (fp64) on the same state agrees with the reference's scores at the initial path
+    so, _, _ = oracle.score_grad(desc, 1, 1.0, 1.0, sup.numpy(), W.numpy(), init.numpy(), dtype=np.float64)
+    assert relerr(so, d["score_init"]) < 1e-9
+    # and its gradient with the hinge's upstream is the collision part of the reference's gradient: check the whole loss
+    p = init.clone().requires_grad_(True)
+    col = torch.clamp(dist_est(p) - margin, min=0).sum()
+    cp = rob.fkine(p)
+    mm = torch.clamp((cp[1:] - cp[:-1]).square().sum(dim=2) - float(d["max_speed"]) ** 2, min=0).sum()
+    lim = rob.limits.double()
+    jl = (torch.clamp(lim[:, 0] - p, min=0) + torch.clamp(p - lim[:, 1], min=0)).sum()
+    diff = (cp[1:] - cp[:-1]).square().sum()
+    loss = diff + 10 * col + 10 * mm + 10 * jl
+    assert relerr(torch.stack([diff, col, mm, jl]).detach().numpy(), d["loss0_terms"]) < 1e-9
+    (g,) = torch.autograd.grad(loss, p, retain_graph=True)
+    assert relerr(g.numpy(), d["grad0"]) < 1e-8
+    up = ((torch.from_numpy(so) - margin) > 0).double().numpy() * 10.0
+    _, go, _ = oracle.score_grad(desc, 1, 1.0, 1.0, sup.numpy(), W.numpy(), init.numpy(), upstream=up, dtype=np.float64)
+    (g_path,) = torch.autograd.grad(diff + 10 * mm + 10 * jl, p, allow_unused=True)
+    assert relerr(go + g_path.numpy(), d["grad0"]) < 1e-7
+    options = {"N_WAYPOINTS": len(init), "NUM_RE_TRIALS": 1, "MAXITER": int(d["maxiter"]), "safety_margin": margin,
+               "max_speed": float(d["max_speed"]), "seed": int(d["seed"]), "history": False,
+               "extra_optimizer_options": {"lr": float(d["lr"])}, "init_solution": init.clone()}
+    rec = optim.adam_traj_optimize(rob, dist_est, torch.from_numpy(d["start"]), torch.from_numpy(d["target"]), options)
+    assert rec["success"] == bool(d["success"]) and rec["cnt_check"] == int(d["cnt_check"])
+    assert abs(rec["cost"] - float(d["cost"])) < 1e-6 * float(d["cost"])
+    assert relerr(np.array(rec["solution"]), d["solution"]) < 1e-6
+    # the scipy terms on the same checker (autograd route on the CPU): the reference's constraint, Jacobian and Hessian
+    start, target, init2 = (torch.from_numpy(d[k]).double() for k in ("start", "target", "init2"))
+    opts = {"N_WAYPOINTS": len(init2), "NUM_RE_TRIALS": 1, "MAXITER": 5, "safety_margin": torch.from_numpy(d["margin2"]).double(),
+            "max_speed": float(d["max_speed2"]), "seed": 1, "history": False, "init_solution": init2.clone()}
+    prob = optim._PathProblem(rob, start, target, opts)
+    prob.make_init(0)
+    terms = optim._ScipyTerms(prob, dist_est)
+    x = prob.init_path[1:-1].reshape(-1).numpy()
+    assert relerr(terms.collision(x), d["con0"]) < 1e-9 and prob.cnt_check == int(d["n_dense2"])
+    assert relerr(terms.jac_collision(x), d["jac0"]) < 1e-8
+    n_seg, n_pt = len(init2) - 1, int(d["n_dense2"]) - 2
+    assert optim._ScipyTerms._flat_per(n_pt, n_seg, C) == n_pt * C // n_seg
+    with pytest.raises(RuntimeError):
+        optim._ScipyTerms._flat_per(n_pt + 1, n_seg, C)     # 23 points, 5 classes, 11 rows: the reference's reshape fails too
