@@ -27,6 +27,8 @@ struct dcx_model {
     float* rows_dev = nullptr;     // [S_active][RS]
     float* rows_p2_dev = nullptr;  // the PAIR-INTERLEAVED copy of rows_dev the two-rows-per-instruction sweeps read (score_kernel.h pair2,
                                    // p2_applies models only; padded to an even row count with a zero-weight row)
+    float* rows_x2_dev = nullptr;  // the pair-interleaved copy of rows_xf_dev for the expanded sweeps that take two rows per packed
+                                   // instruction (score_kernel.h X2, x2_applies models only)
     float* rows_xf_dev = nullptr;  // what the expanded-form sweeps read (score_kernel.h): the rows shifted by `centre`,
                                    // |s - c|^2 in their last column
     unsigned short* aplanes_dev = nullptr;  // XM sweep (score_kernel.h): the centred supports as bf16 planes, MFMA A-operand layout
@@ -449,6 +451,8 @@ bool opoll_stream_ok(int device, hipStream_t st) {
 // This stream's exchange rows for the cluster form of the persistent trajectory kernel, and the tag base of the launch that
 // is about to use them.  Sized once for the largest grid the rule can pick (n_cu workgroups, two parities); null when
 // the buffer cannot be provided now (the stream is being captured, allocation failed): the caller runs one workgroup per path.
+// (value, tag) words per workgroup and parity: D + 1, or for several classes CC + 2 D (traj_fused.h, SPECULATION)
+inline size_t traj_exchange_words(int Dt, int Cc) { return Cc > 1 ? (size_t)Cc + 2 * (size_t)Dt : (size_t)Dt + 1; }
 unsigned long long* traj_exchange_rows(const dcx_model* m, hipStream_t st, size_t bytes, uint32_t* tag_base) {
     std::lock_guard<std::mutex> lock(m->mu);
     dcx_model::TrajExch* hit = nullptr;
@@ -458,7 +462,7 @@ unsigned long long* traj_exchange_rows(const dcx_model* m, hipStream_t st, size_
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
     if (!hit) {
-        const size_t fixed = (size_t)2 * m->n_cu * (m->Dt + m->Cc) * 64 * sizeof(unsigned long long);
+        const size_t fixed = (size_t)2 * m->n_cu * traj_exchange_words(m->Dt, m->Cc) * 64 * sizeof(unsigned long long);
         if (bytes > fixed) return nullptr;
         unsigned long long* p = nullptr;
         if (hipMalloc((void**)&p, fixed) != hipSuccess) {
@@ -647,6 +651,12 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
         a.aplanes = m->aplanes_dev;
         a.s_super = (a.s_super + 15) / 16 * 16;
         a.s_chunk = ((a.s_super + g.nw - 1) / g.nw + 15) / 16 * 16;
+    } else if (a.xf && m->rows_x2_dev != nullptr && x2_applies(m->Dt, m->Cc, m->kf)) {
+        // the expanded form with two rows per packed instruction (score_kernel.h X2): the pair-interleaved centred rows, slices
+        // that start on even rows
+        a.rows = m->rows_x2_dev;
+        a.s_super = (a.s_super + 1) & ~1;
+        a.s_chunk = ((a.s_super + g.nw - 1) / g.nw + 1) & ~1;
     }
     // J^T on several waves (fk_device.h dh2_vjp_waves): the step table, a parallel fold (its scratch rows 1 .. nw-1 hold 12
     // columns per point step), and not the finish-kernel mode.  Knob jt_waves = 0: wave 0 alone (tests: identical bits).
@@ -759,8 +769,9 @@ static void model_free_rows(dcx_model* m) {
     if (m->rows_dev) (void)hipFree(m->rows_dev);
     if (m->rows_xf_dev) (void)hipFree(m->rows_xf_dev);
     if (m->rows_p2_dev) (void)hipFree(m->rows_p2_dev);
+    if (m->rows_x2_dev) (void)hipFree(m->rows_x2_dev);
     if (m->aplanes_dev) (void)hipFree(m->aplanes_dev);
-    m->rows_dev = m->rows_xf_dev = m->rows_p2_dev = nullptr;
+    m->rows_dev = m->rows_xf_dev = m->rows_p2_dev = m->rows_x2_dev = nullptr;
     m->aplanes_dev = nullptr;
     m->cap = 0;
 }
@@ -772,10 +783,11 @@ static int model_alloc_rows(dcx_model* m, int64_t cap) {
     // the new buffers first, the old ones freed only when both exist: a failed growth leaves the model as it was (ADVICE r4:
     // freeing first left rows_dev null beside the old S_active, and the next launch read through it)
     const size_t floats = (size_t)cap * m->RS + rows_tail_floats(m);
-    float *rows = nullptr, *rows_xf = nullptr, *rows_p2 = nullptr;
+    float *rows = nullptr, *rows_xf = nullptr, *rows_p2 = nullptr, *rows_x2 = nullptr;
     hipError_t e = hipMalloc((void**)&rows, floats * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&rows_xf, floats * sizeof(float));
     if (e == hipSuccess && p2_applies(m->Dt, m->Cc, m->kf)) e = hipMalloc((void**)&rows_p2, (floats + m->RS) * sizeof(float));
+    if (e == hipSuccess && x2_applies(m->Dt, m->Cc, m->kf) && xf_applies(m->Dt, m->Cc, m->kf)) e = hipMalloc((void**)&rows_x2, (floats + m->RS) * sizeof(float));
     if (e == hipSuccess && !m->centre_dev) e = hipMalloc((void**)&m->centre_dev, (size_t)m->Dt * sizeof(float));
     if (e == hipSuccess && !m->info_dev) e = hipMalloc((void**)&m->info_dev, 16);
     if (e == hipSuccess && !m->info_host) e = hipHostMalloc((void**)&m->info_host, 16, hipHostMallocDefault);
@@ -790,12 +802,14 @@ static int model_alloc_rows(dcx_model* m, int64_t cap) {
         if (rows) (void)hipFree(rows);
         if (rows_xf) (void)hipFree(rows_xf);
         if (rows_p2) (void)hipFree(rows_p2);
+        if (rows_x2) (void)hipFree(rows_x2);
         return fail_hip(e, "device allocation of the model");
     }
     model_free_rows(m);
     m->rows_dev = rows;
     m->rows_xf_dev = rows_xf;
     m->rows_p2_dev = rows_p2;
+    m->rows_x2_dev = rows_x2;
     m->cap = cap;
     return DCX_OK;
 }
@@ -982,6 +996,10 @@ static int model_fill(dcx_model* m, const float* support_feat, const float* weig
         hipError_t e = launch_interleave_rows(m->rows_dev, m->rows_p2_dev, (int32_t)m->S_active, m->RS, (int32_t)rows_tail_floats(m), stream);
         if (e != hipSuccess) return fail_hip(e, "interleaving of the support rows");
     }
+    if (rc == DCX_OK && m->rows_x2_dev) {   // ... and of the centred rows
+        hipError_t e = launch_interleave_rows(m->rows_xf_dev, m->rows_x2_dev, (int32_t)m->S_active, m->RS, (int32_t)rows_tail_floats(m), stream);
+        if (e != hipSuccess) return fail_hip(e, "interleaving of the centred support rows");
+    }
     return rc;
 }
 
@@ -1103,6 +1121,7 @@ void dcx_model_destroy(dcx_model* m) {
     if (m->rows_dev) (void)hipFree(m->rows_dev);
     if (m->rows_xf_dev) (void)hipFree(m->rows_xf_dev);
     if (m->rows_p2_dev) (void)hipFree(m->rows_p2_dev);
+    if (m->rows_x2_dev) (void)hipFree(m->rows_x2_dev);
     if (m->centre_dev) (void)hipFree(m->centre_dev);
     if (m->aplanes_dev) (void)hipFree(m->aplanes_dev);
     if (m->info_dev) (void)hipFree(m->info_dev);
@@ -1418,6 +1437,10 @@ static int traj_run(const dcx_model* m, const dcx_traj_state* st, const dcx_traj
             if (a.sc.xf) {
                 a.sc.rows = m->rows_xf_dev;
                 a.sc.centre = m->centre_dev;
+                if (m->rows_x2_dev && x2_applies(m->Dt, m->Cc, m->kf)) {   // (two rows per packed instruction: score_kernel.h X2)
+                    a.sc.rows = m->rows_x2_dev;
+                    traj_p2 = true;
+                }
             } else if (m->rows_p2_dev && p2_applies(m->Dt, m->Cc, m->kf)) {
                 a.sc.rows = m->rows_p2_dev;
                 traj_p2 = true;
@@ -1437,7 +1460,7 @@ static int traj_run(const dcx_model* m, const dcx_traj_state* st, const dcx_traj
                 }
                 a.ys = 1;
                 if (ys > 1) {
-                    a.exch = traj_exchange_rows(m, (hipStream_t)stream, (size_t)st->n_paths * 2 * ys * (m->Dt + m->Cc) * 64 * sizeof(unsigned long long),
+                    a.exch = traj_exchange_rows(m, (hipStream_t)stream, (size_t)st->n_paths * 2 * ys * traj_exchange_words(m->Dt, m->Cc) * 64 * sizeof(unsigned long long),
                                                 &a.tag_base);
                     if (a.exch) a.ys = ys;
                     a.cl_across = knobs().traj_across > 0 ? 1 : 0;

@@ -313,9 +313,31 @@ __host__ __device__ inline LdsPlan lds_plan(int dof, int d_fk, int frame_floats,
 // (sweep_rows, XM).  One class, Polyharmonic(1), even D <= 16 (a term's 16 K slots hold the features).
 // (compiled for the two widths it was measured at: profiles/r03_mfma_ab.txt - measured slower, kept as evidence)
 constexpr bool xm_applies(int D, int CC, int KF) { return KF == 1 /* KF_POLY1 */ && CC == 1 && (D == 12 || D == 16); }
-constexpr int sweep_min_waves(int D, int CC, int KF, bool MF = false, bool XM = false, bool QT = false) {
+// Does the EXPANDED form of this shape take two rows per packed instruction (sweep_rows, X2; round 6)?  One class, the two
+// specialised kernel functions, even D <= DCX_XF2_MAX_D (2 D gradient accumulators).  Such a model's centred rows are stored
+// pair-interleaved as well (dcx_api.hip rows_x2), its expanded sweeps run on even-aligned slices.
+// MEASURED, NOT SHIPPED (default 0; `make EXTRA="-DDCX_XF2=1 -DDCX_XF2_MINW=4"` builds it - profiles/r06_xf2.txt): the body needs ~70
+// VGPRs.  Under the sweep kernel's 64-register budget (two 16-wave blocks per CU) it spills into the loop; given 128 registers a
+// CU holds ONE block, whose prologue and epilogue nothing overlaps any more: headline 85.0 -> 104.0 us at B = 65536, 1200 -> 1217 us
+// at B = 1 M, while the launches that run one block per CU anyway gain 3 - 5 % (B = 8192: 19.1 -> 18.6 us, config #5's persistent
+// kernel 28.2 -> 27.4 us per iteration).  Not worth a second expanded form of every narrow kernel.
+#ifndef DCX_XF2
+#define DCX_XF2 0
+#endif
+#ifndef DCX_XF2_MAX_D
+#define DCX_XF2_MAX_D 12
+#endif
+constexpr bool x2_applies(int D, int CC, int KF) {
+    return DCX_XF2 && CC == 1 && (D % 2) == 0 && D >= 4 && D <= DCX_XF2_MAX_D && (KF == 1 /* KF_POLY1 */ || KF == 0 /* KF_RQ2 */) &&
+           4 * (D + 2) <= DCX_P0_MAX_SINGLE;
+}
+#ifndef DCX_XF2_MINW
+#define DCX_XF2_MINW 8   // waves per SIMD the register allocator must leave room for in such a kernel (8 = 64 VGPRs)
+#endif
+constexpr int sweep_min_waves(int D, int CC, int KF, bool MF = false, bool XM = false, bool QT = false, bool XF = false) {
     if (QT) return 4;  // one block per CU (the rows fill its LDS), at most 16 waves: two row buffers in VGPRs + the direct body
     if (XM) return 4;  // 48 VGPRs of loop-invariant B fragments + 16 distances in flight: 128 VGPRs
+    if (XF && x2_applies(D, CC, KF)) return DCX_XF2_MINW;
     // KF_GEN calls powf/logf; the MFMA form adds 16 accumulator registers per contraction + the operand fragments
     const int need = 3 * D + 2 * CC + 16 + DCX_MINW_SLACK + (KF == 2 ? 40 : 0) + (MF ? (CC > 1 ? 48 : 24) : 0);
     return need <= 64 ? 8 : need <= 72 ? 7 : need <= 80 ? 6 : need <= 96 ? 5 : need <= 128 ? 4 : need <= 168 ? 3 : need <= 256 ? 2 : 1;
@@ -440,9 +462,12 @@ constexpr bool p2_applies(int D, int CC, int KF) {
 
 // NACC > 0 overrides the number of independent squared-distance accumulator pairs of the expanded form (callers that run
 // at few waves per SIMD trade one packed add per row for a shorter dependent chain)
-template <int D, int KF, int CC, int MODE, bool XF = false, int NACC = 0, bool XM = false>
+// NS (several classes, MODE_GRAD_UP): no score accumulation - a caller that already holds this batch's class scores (the persistent
+// trajectory kernel's second sweep) saves the CC fma per pair; sc[] comes back untouched
+template <int D, int KF, int CC, int MODE, bool XF = false, int NACC = 0, bool XM = false, bool NS = false>
 __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[D], const float (&up)[CC], int j0, int j1,
                                            float (&sc)[CC], float (&gx)[D]) {
+    static_assert(!NS || (CC > 1 && MODE == MODE_GRAD_UP), "NS: the gradient sweep of a multi-class model");
     using L = RowLayout<D, CC>;
     constexpr bool GRAD = (MODE != MODE_SCORE);
     v2f gx2[D / 2 + 1];
@@ -464,7 +489,9 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
 #pragma unroll
     for (int i = 0; i < CC / 2 + 1; ++i) sc2[i] = v2f{0.0f, 0.0f};
     auto add_scores = [&](auto weight_of, float val) __attribute__((always_inline)) {
-        if constexpr (SC2) {
+        if constexpr (NS) {
+            (void)val;
+        } else if constexpr (SC2) {
             const v2f v2 = {val, val};
 #pragma unroll
             for (int c = 0; c + 1 < CC; c += 2) sc2[c / 2] = __builtin_elementwise_fma(v2f{weight_of(c), weight_of(c + 1)}, v2, sc2[c / 2]);
@@ -580,8 +607,10 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
         float val, g;
         kernel_eval<KF>(d2d, a, val, g);
         val = nr ? val : 0.0f;
+        if constexpr (!NS) {
 #pragma unroll
-        for (int c = 0; c < CC; ++c) sc[c] = fmaf(r[L::W_OFF + c], val, sc[c]);
+            for (int c = 0; c < CC; ++c) sc[c] = fmaf(r[L::W_OFF + c], val, sc[c]);
+        }
         if constexpr (GRAD) {
             const float cd = nr ? -coef_of(r, g) : 0.0f;  // H carries MINUS the gradient
             const v2f cd2 = {cd, cd};
@@ -656,8 +685,10 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
         }
         float val, g;
         sweep_eval<KF>(d2, a, val, g);
+        if constexpr (!NS) {
 #pragma unroll
-        for (int c = 0; c < CC; ++c) sc[c] = fmaf(r[L::W_OFF + c], val, sc[c]);
+            for (int c = 0; c < CC; ++c) sc[c] = fmaf(r[L::W_OFF + c], val, sc[c]);
+        }
         if constexpr (GRAD) {
             float coef;
             if constexpr (MODE == MODE_GRAD_ROW) {
@@ -750,7 +781,156 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
     // alive for every width by parking SGPRs in VGPR lanes: D=24 +37 %, D=42 +75 %, D=60 +97 % VALU instructions
     // (v_writelane / v_readlane) inside the sweep.
     static_assert(!XFA || PARTS <= 1, "expanded form: whole rows only");
-    if constexpr (XM) {
+    constexpr bool X2 = XFA && !XM && x2_applies(D, CC, KF);
+    if constexpr (X2) {
+    // ---- X2 (round 6): the expanded form, two rows per packed instruction ----------------------------------------------------------
+    // The expanded body above packs a row's features two by two: D/2 v_pk_fma for the distance and D/2 for the gradient, an add of
+    // the two halves, and a scalar chain per row (seed, clamp, rsq, coefficient, score, sum of coefficients, near test): 20 VALU
+    // instructions per row at D = 12.  Here the two rows of a stage ride in the two halves of every packed register instead (the
+    // centred rows are stored pair-interleaved: element e of the even row at b[2 e], of the odd row at b[2 e + 1], so every operand
+    // pair is an aligned SGPR pair of the stage's one load): D + D v_pk_fma per TWO rows, no add of halves, the chain's adds and
+    // multiplies packed (clamp, rsq and near test stay one per row: no packed form exists) - 34 per two rows at D = 12 - and the
+    // expanded gradient H in 2 D accumulators (even rows' sums in .x, odd rows' in .y; one add per feature at the end).  The bare
+    // body (tools/sweep_body_ubench.hip): 39.3 ns per wave-row per SIMD against 44.2 at 4 waves per SIMD, 40.0 against 41.1 at 8.
+    // A row's distance is ONE fma chain over its features here (xx + ss first), and the rare near-pair block below reproduces
+    // exactly that chain in scalar fma before it takes the expanded term out and puts the direct one in (the same semantics as
+    // fix_near above).  j0 is even (the host's slicing); a slice that ends on the model's odd last row runs into the zero-weight
+    // padding row (d2 = |x - c|^2 there: finite, coefficient 0).
+    if (j0 < j1) {
+        constexpr int R2 = 2 * L::RS;
+        v2f h2[GRAD ? D : 1], sc2x = {0.0f, 0.0f}, as2 = {0.0f, 0.0f};
+        if constexpr (GRAD) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) h2[k] = v2f{0.0f, 0.0f};
+        }
+        float xmk[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) xmk[k] = -2.0f * x[k];
+        float upc = 1.0f;
+        if constexpr (MODE == MODE_GRAD_UP) upc = up[0];
+        auto load2 = [&](float (&dst)[R2], int j) __attribute__((always_inline)) {
+            cfloat_ptr r = rows + (size_t)j * RSTRIDE;
+#pragma unroll
+            for (int e = 0; e < R2; ++e) dst[e] = r[e];
+        };
+        // the rare block, one row (half HF of the stage): out with the expanded term of the near lanes, in with the direct one
+        auto fix2 = [&](const float (&b)[R2], auto hf) __attribute__((always_inline)) {
+            constexpr int HF = decltype(hf)::value;
+            float d2 = xx + b[2 * L::SS_OFF + HF];
+#pragma unroll
+            for (int k = 0; k < D; ++k) d2 = fmaf(xmk[k], b[2 * k + HF], d2);
+            const float d2c = fmaxf(d2, thr);
+            const bool nr = d2c <= thr;
+            float val, g;
+            sweep_eval<KF, true>(d2c, a, val, g);
+            const float w = b[2 * L::W_OFF + HF];
+            float coef = g * w;
+            if constexpr (MODE == MODE_GRAD_UP) coef *= upc;
+            const float cneg = nr ? -coef : 0.0f;
+            // this row's half of a packed accumulator: v <- fma(p, q, v)
+            auto hfma = [&](v2f& v, float p_, float q_) __attribute__((always_inline)) {
+                if constexpr (HF) v.y = fmaf(p_, q_, v.y);
+                else v.x = fmaf(p_, q_, v.x);
+            };
+            if constexpr (KF == KF_POLY1 && MODE == MODE_GRAD_ROW) hfma(sc2x, cneg, d2c);
+            else hfma(sc2x, nr ? -w : 0.0f, val);
+            float dk[D];
+            float da = 0.0f, db = 0.0f;
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                dk[k] = -0.5f * xmk[k] - b[2 * k + HF];     // x = -0.5 * (-2 x), exact
+                if (k & 1) db = fmaf(dk[k], dk[k], db);
+                else da = fmaf(dk[k], dk[k], da);
+            }
+            float vald, gd;
+            kernel_eval<KF>(da + db, a, vald, gd);          // (the direct sweep's distance: even / odd features, then the two halves)
+            hfma(sc2x, w, nr ? vald : 0.0f);
+            if constexpr (GRAD) {
+                float cdir = gd * w;
+                if constexpr (MODE == MODE_GRAD_UP) cdir *= upc;
+                const float cd = nr ? -cdir : 0.0f;          // H carries MINUS the gradient
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    hfma(h2[k], cneg, b[2 * k + HF]);
+                    hfma(h2[k], cd, dk[k]);
+                }
+                if constexpr (HF) as2.y += cneg;
+                else as2.x += cneg;
+            }
+        };
+        auto body2 = [&](const float (&b)[R2]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int e = 2 * USED; e < R2; ++e) asm volatile("" ::"s"(b[e]));
+            v2f acc = v2f{xx, xx} + v2f{b[2 * L::SS_OFF], b[2 * L::SS_OFF + 1]};
+#pragma unroll
+            for (int k = 0; k < D; ++k) acc = __builtin_elementwise_fma(v2f{xmk[k], xmk[k]}, v2f{b[2 * k], b[2 * k + 1]}, acc);
+            v2f d2c = acc, val, g;
+            if constexpr (KF == KF_POLY1) d2c = v2f{fmaxf(acc.x, thr), fmaxf(acc.y, thr)};
+            {
+                float v0, g0, v1, g1;
+                sweep_eval<KF, true>(d2c.x, a, v0, g0);
+                sweep_eval<KF, true>(d2c.y, a, v1, g1);
+                val = v2f{v0, v1};
+                g = v2f{g0, g1};
+            }
+            const v2f w2 = {b[2 * L::W_OFF], b[2 * L::W_OFF + 1]};
+            v2f coef = g * w2;
+            if constexpr (MODE == MODE_GRAD_UP) coef = coef * v2f{upc, upc};
+            // one class, row weight, Polyharmonic(1): w r = (w / r) d2 - the score rides on the gradient coefficient
+            if constexpr (KF == KF_POLY1 && MODE == MODE_GRAD_ROW) sc2x = __builtin_elementwise_fma(coef, d2c, sc2x);
+            else sc2x = __builtin_elementwise_fma(w2, val, sc2x);
+            if constexpr (GRAD) {
+#pragma unroll
+                for (int k = 0; k < D; ++k) h2[k] = __builtin_elementwise_fma(coef, v2f{b[2 * k], b[2 * k + 1]}, h2[k]);
+                as2 += coef;
+            }
+            if constexpr (KF == KF_POLY1) {
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(fminf(d2c.x, d2c.y) <= thr) != 0, 0)) {
+                    fix2(b, std::integral_constant<int, 0>{});
+                    fix2(b, std::integral_constant<int, 1>{});
+                }
+            }
+        };
+        // fold the run's x * sum(c) into H in place: H <- H + (-2 x) (A / 2), per half
+        auto flush2 = [&]() __attribute__((always_inline)) {
+            if constexpr (GRAD) {
+                const v2f ah = {0.5f * as2.x, 0.5f * as2.y};
+#pragma unroll
+                for (int k = 0; k < D; ++k) h2[k] = __builtin_elementwise_fma(v2f{xmk[k], xmk[k]}, ah, h2[k]);
+                as2 = v2f{0.0f, 0.0f};
+            }
+        };
+        float ab[R2], cd[R2];
+        const int j1e = (j1 + 1) & ~1;
+        const int jl = j1e - 2;
+        load2(ab, j0);
+        int j = j0;
+        for (; j + 3 < j1e; j += 4) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_sched_barrier(0);
+            load2(cd, j + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            body2(ab);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_sched_barrier(0);
+            load2(ab, (j + 4 < j1e) ? j + 4 : jl);
+            __builtin_amdgcn_sched_barrier(0);
+            body2(cd);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (GRAD) {
+                if ((j & (DCX_XF_FLUSH - 4)) == 0) flush2();  // once per DCX_XF_FLUSH rows, whatever j0's alignment
+            }
+        }
+        if (j < j1e) body2(ab);   // one stage left; ab holds it
+        flush2();
+        sc[0] += sc2x.x + sc2x.y;
+        if constexpr (GRAD) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) gx[k] -= h2[k].x + h2[k].y;
+        }
+    }
+    } else if constexpr (XM) {
     // ---- XM: the expanded form with x . s^T on the matrix cores (round 3) ---------------------------------------------------
     // d2 = (|x|^2 + |s_j|^2) + sum_k (-2 x_k) s_jk: the one contraction of the sweep whose per-lane operand is loop
     // invariant.  -2x is split ONCE per lane into three bf16 planes (hi, mid, lo by truncation: 24 bits) and turned into
@@ -1161,7 +1341,9 @@ __device__ __forceinline__ void sweep_rows(const ScoreArgs& a, const float (&x)[
         }
     }
 
-    if constexpr (XFA && GRAD) {
+    if constexpr (X2) {
+        // (flushed and merged inside its own block above)
+    } else if constexpr (XFA && GRAD) {
         flush_x();
 #pragma unroll
         for (int k = 0; k + 1 < D; k += 2) {
@@ -1533,7 +1715,7 @@ __device__ __forceinline__ void fold_partial_rows(float* sRed, int wave, int lan
 
 
 template <int D, int KF, int CC, int MODE, int MAXT, bool MF = false, bool XF = false, bool XM = false, bool QT = false>
-__global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF, MF, XM, QT)) void score_kernel(const ScoreArgs a) {
+__global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF, MF, XM, QT, XF)) void score_kernel(const ScoreArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr bool GRAD = (MODE != MODE_SCORE);
     constexpr int ACC = (GRAD ? D : 0) + CC;

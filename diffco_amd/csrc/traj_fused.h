@@ -69,7 +69,7 @@ struct TrajFusedArgs {
     int32_t n_points, point_dim, coord_major;
     // cluster form (traj_fused_kernel<..., CL = true>, gridDim.y = ys): a path's supports split over ys workgroups
     int32_t ys, s_super;            // block y sweeps supports [y * s_super, (y + 1) * s_super), its waves s_chunk each
-    unsigned long long* exch;       // [n_paths][2 (iteration parity)][ys][D + 1][64] (value, tag) words, see traj_exchange
+    unsigned long long* exch;       // [n_paths][2 (iteration parity)][ys][D + 1, or CC + 2 D for several classes][64] (value, tag) words, see traj_exchange
     uint32_t tag_base;              // tags of this launch: tag_base + iteration + 1 (unique per launch on this buffer)
     int32_t cl_across;              // 1: grid (ys, n_paths) - consecutive workgroup ids = the ys members of a path, which the
                                     // dispatcher deals out to DIFFERENT XCDs; 0: grid (n_paths, ys) - with n_paths a multiple of
@@ -174,7 +174,9 @@ __device__ __forceinline__ unsigned long long traj_pack(float v, uint32_t tag) {
 // first half: fold this wave's accumulators over the block's rows and publish them
 // (E0, E1: the accumulators of this exchange - all of them with one class; with several the class scores [0, CC) travel after the
 // first sweep and the feature gradient [CC, CC + D) after the second, through disjoint words of the same slot)
-template <int ACC, int E0 = 0, int E1 = ACC>
+// XS / XO: words per workgroup in the exchange rows and the offset of accumulator 0 there (several classes: the gradient of a
+// failed speculation's second sweep travels through words of its own, see the kernel)
+template <int ACC, int E0 = 0, int E1 = ACC, int XS = ACC, int XO = 0>
 __device__ __forceinline__ void traj_exchange_publish(const float* sRed, unsigned long long* slot /* this path's rows of this parity, + lane */,
                                                       uint32_t tag, int y, int wave, int lane, int nw) {
     auto fold_pub = [&](auto nwc) __attribute__((always_inline)) {
@@ -193,7 +195,7 @@ __device__ __forceinline__ void traj_exchange_publish(const float* sRed, unsigne
                 v = sRed[e * 64 + lane];
                 for (int w = 1; w < nw; ++w) v += sRed[((size_t)w * ACC + e) * 64 + lane];
             }
-            __hip_atomic_store(slot + ((size_t)y * ACC + e) * 64, traj_pack(v, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(slot + ((size_t)y * XS + XO + e) * 64, traj_pack(v, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
     if (nw == 16) fold_pub(std::integral_constant<int, 16>{});
@@ -203,7 +205,7 @@ __device__ __forceinline__ void traj_exchange_publish(const float* sRed, unsigne
 }
 // second half: poll the ys copies of each of this wave's accumulators; totals to row 0 of the scratch (only this wave touches
 // accumulator e's slots)
-template <int ACC, int E0 = 0, int E1 = ACC>
+template <int ACC, int E0 = 0, int E1 = ACC, int XS = ACC, int XO = 0>
 __device__ __forceinline__ bool traj_exchange_collect(float* sRed, const unsigned long long* slot, uint32_t tag, int ys, int wave, int lane,
                                                       int nw) {
     bool ok = true;
@@ -217,7 +219,7 @@ __device__ __forceinline__ bool traj_exchange_collect(float* sRed, const unsigne
                 unsigned long long w[8];
 #pragma unroll
                 for (int v = 0; v < 8; ++v)
-                    if (y0 + v < ys) w[v] = __hip_atomic_load(slot + ((size_t)(y0 + v) * ACC + e) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (y0 + v < ys) w[v] = __hip_atomic_load(slot + ((size_t)(y0 + v) * XS + XO + e) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                 for (int v = 0; v < 8; ++v)
                     if (y0 + v < ys) {
@@ -296,10 +298,22 @@ __device__ __forceinline__ void traj_path_terms(const A& b, const TrajLds& L, in
 // dcx_score followed by dcx_score_hinge_grad_mc's second launch, which is what the three-launch loop of dcx_traj_adam_run_mc runs
 // where this kernel is not compiled (bit-identical for equal slicing, tests/test_gpu_traj.py).  Fold rows: [c][64] scores, then
 // [k][64] gradient (the sweep kernel's layout).
+// SPECULATION (round 6): between two Adam steps the hinge's indicator rarely changes, so an iteration first sweeps ONCE with the
+// previous iteration's upstream - MODE_GRAD_UP accumulates the class scores beside the gradient - folds / exchanges scores and
+// gradient together and compares the indicator the new scores give with the one it used: equal on every lane and the iteration
+// is done with one sweep; else the gradient is swept again with the right upstream.  An iteration speculates only if the
+// indicator did not move in the one before (a two-sweep iteration sees that for free), so a path whose indicators keep flipping -
+// random restarts far from convergence - keeps the two sweeps and pays nothing for failed attempts.  Every wave - and every workgroup of a cluster - sees the same totals, so all take the same branch.
+// The gradient an iteration ends with is always the sweep with the indicator of ITS OWN scores, and the scores are the
+// same fma chains in both sweep modes: the results do not depend on whether a speculation held (bit-identical to the
+// three-launch loop, tests/test_gpu_multiclass_optim.py).  Exchange rows of the cluster form: CC + 2 D words per workgroup -
+// [0, CC + D) for the first exchange(s) of an iteration, [CC + D, CC + 2 D) for the gradient after a failed speculation, whose
+// peers may still be reading the first.
 template <int D, int KF, int MAXT, bool XF = false, bool CL = false, int CC = 1>
 __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_fused_kernel(const TrajFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int ACC = D + CC;
+    constexpr int XS = CC > 1 ? CC + 2 * D : ACC;   // exchange words per workgroup (see SPECULATION above)
     const int r = (CL && a.cl_across) ? blockIdx.y : blockIdx.x;
     const int ycl = CL ? (a.cl_across ? (int)blockIdx.x : (int)blockIdx.y) : 0;   // this workgroup's place among the path's ys
     if (a.st.done[r]) return;  // frozen path (cluster form: the ys workgroups of a path all see the same flag - it is only
@@ -333,6 +347,10 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
     __syncthreads();
 
     const int w = lane;  // this lane's waypoint
+    float up_prev[CC];   // several classes: the upstream the last iteration ended with, and whether this one may speculate on it
+    bool spec = false;
+#pragma unroll
+    for (int c = 0; c < CC; ++c) up_prev[c] = 0.0f;
     int it = 0, n_iters;
     {
         const auto& b = reload_kernargs<TrajFusedArgs>();
@@ -398,6 +416,7 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
         // ---- collision sweep: score and feature gradient against this wave's supports -------------------------------
         float sc[CC];
         float gx[D];
+        bool grad_folded = false, regrad = false, grad_zero = false;   // (several classes, see SPECULATION)
 #pragma unroll
         for (int k = 0; k < D; ++k) gx[k] = 0.0f;
 #pragma unroll
@@ -406,12 +425,55 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
             const float up[1] = {1.0f};
             sweep_rows<D, KF, 1, MODE_GRAD_ROW, XF, DCX_TRAJ_NACC>(sa, x, up, j0, j1, sc, gx);
         } else {
-            // several classes: the class scores first ...
             float up[CC];
+            bool resweep = true;   // does the gradient still need a sweep with the indicator of this iteration's scores?
+            bool moved = false;    // did the indicator change against the last iteration's?
+            auto totals_to_upstream = [&](const auto& b, const TrajLds& L) __attribute__((always_inline)) {
 #pragma unroll
-            for (int c = 0; c < CC; ++c) up[c] = 0.0f;
-            sweep_rows<D, KF, CC, MODE_SCORE, XF, DCX_TRAJ_NACC>(sa, x, up, j0, j1, sc, gx);
-            {
+                for (int c = 0; c < CC; ++c) {
+                    const float t = L.sRed[c * 64 + lane];
+                    up[c] = (c < b.sc.c_out && t - b.margin_c[c < 8 ? c : 7] > 0.0f) ? b.opt.w_collision : 0.0f;
+                }
+            };
+            // (an all-zero upstream - no class over its margin on any waypoint of the path, the state of a path in free space - is not
+            // worth a gradient sweep at all: the scores alone are swept, and only if they put an indicator up is the gradient)
+            bool prev_nonzero = false;
+#pragma unroll
+            for (int c = 0; c < CC; ++c) prev_nonzero = prev_nonzero || (up_prev[c] != 0.0f);
+            const bool spec_full = spec && __builtin_amdgcn_ballot_w64(prev_nonzero) != 0;
+            if (spec_full) {
+                // ONE sweep with the last iteration's upstream: class scores and gradient together
+#pragma unroll
+                for (int c = 0; c < CC; ++c) up[c] = up_prev[c];
+                sweep_rows<D, KF, CC, MODE_GRAD_UP, XF, DCX_TRAJ_NACC>(sa, x, up, j0, j1, sc, gx);
+                const auto& b = reload_kernargs<TrajFusedArgs>();
+                const TrajLds L = traj_lds<D, CC>(smem, b, nw);
+                float* mine = L.sRed + (size_t)wave * ACC * 64 + lane;
+#pragma unroll
+                for (int c = 0; c < CC; ++c) mine[c * 64] = sc[c];
+#pragma unroll
+                for (int k = 0; k < D; ++k) mine[(CC + k) * 64] = gx[k];
+                __syncthreads();
+                if constexpr (CL) {
+                    unsigned long long* slot = b.exch + ((size_t)(r * 2 + (it & 1)) * b.ys) * XS * 64 + lane;
+                    const uint32_t tag = b.tag_base + (uint32_t)it + 1u;
+                    traj_exchange_publish<ACC, 0, ACC, XS, 0>(L.sRed, slot, tag, ycl, wave, lane, nw);
+                    if (!traj_exchange_collect<ACC, 0, ACC, XS, 0>(L.sRed, slot, tag, b.ys, wave, lane, nw)) L.sR[kTrajAbort] = 1.0f;
+                } else {
+                    fold_partial_rows<ACC, 0, ACC>(L.sRed, wave, lane, nw);
+                }
+                __syncthreads();
+                totals_to_upstream(b, L);
+                bool differs = false;
+#pragma unroll
+                for (int c = 0; c < CC; ++c) differs = differs || (up[c] != up_prev[c]);
+                resweep = __builtin_amdgcn_ballot_w64(differs) != 0;   // the same on every wave (and workgroup): they read the same totals
+                moved = resweep;
+            } else {
+                // the class scores first ...
+#pragma unroll
+                for (int c = 0; c < CC; ++c) up[c] = 0.0f;
+                sweep_rows<D, KF, CC, MODE_SCORE, XF, DCX_TRAJ_NACC>(sa, x, up, j0, j1, sc, gx);
                 const auto& b = reload_kernargs<TrajFusedArgs>();
                 const TrajLds L = traj_lds<D, CC>(smem, b, nw);
                 float* mine = L.sRed + (size_t)wave * ACC * 64 + lane;
@@ -419,24 +481,41 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
                 for (int c = 0; c < CC; ++c) mine[c * 64] = sc[c];
                 __syncthreads();
                 if constexpr (CL) {
-                    unsigned long long* slot = b.exch + ((size_t)(r * 2 + (it & 1)) * b.ys) * ACC * 64 + lane;
+                    unsigned long long* slot = b.exch + ((size_t)(r * 2 + (it & 1)) * b.ys) * XS * 64 + lane;
                     const uint32_t tag = b.tag_base + (uint32_t)it + 1u;
-                    traj_exchange_publish<ACC, 0, CC>(L.sRed, slot, tag, ycl, wave, lane, nw);
-                    if (!traj_exchange_collect<ACC, 0, CC>(L.sRed, slot, tag, b.ys, wave, lane, nw)) L.sR[kTrajAbort] = 1.0f;
+                    traj_exchange_publish<ACC, 0, CC, XS, 0>(L.sRed, slot, tag, ycl, wave, lane, nw);
+                    if (!traj_exchange_collect<ACC, 0, CC, XS, 0>(L.sRed, slot, tag, b.ys, wave, lane, nw)) L.sR[kTrajAbort] = 1.0f;
                 } else {
                     fold_partial_rows<ACC, 0, CC>(L.sRed, wave, lane, nw);
                 }
                 __syncthreads();
-                // ... then the gradient of w_collision * sum_c clamp(score_c - margin_c, 0): upstream per lane and class (the totals
-                // stay in row 0 of the scratch: the second sweep's partial rows only use the gradient columns)
+                totals_to_upstream(b, L);
+                // (was the indicator the same as one iteration ago?  Only then is the next iteration worth a speculation)
+                bool differs = false;
 #pragma unroll
-                for (int c = 0; c < CC; ++c) {
-                    const float t = L.sRed[c * 64 + lane];
-                    up[c] = (c < b.sc.c_out && t - b.margin_c[c < 8 ? c : 7] > 0.0f) ? b.opt.w_collision : 0.0f;
-                    sc[c] = 0.0f;
-                }
+                for (int c = 0; c < CC; ++c) differs = differs || (up[c] != up_prev[c]);
+                moved = __builtin_amdgcn_ballot_w64(differs) != 0;
+                bool nonzero = false;
+#pragma unroll
+                for (int c = 0; c < CC; ++c) nonzero = nonzero || (up[c] != 0.0f);
+                resweep = __builtin_amdgcn_ballot_w64(nonzero) != 0;
+                grad_zero = !resweep;
             }
-            sweep_rows<D, KF, CC, MODE_GRAD_UP, XF, DCX_TRAJ_NACC>(sa, x, up, j0, j1, sc, gx);
+            if (resweep) {
+                // ... then the gradient of w_collision * sum_c clamp(score_c - margin_c, 0) with its upstream per lane and class (the
+                // score totals stay in row 0 of the scratch: this sweep's partial rows only use the gradient columns)
+#pragma unroll
+                for (int c = 0; c < CC; ++c) sc[c] = 0.0f;
+#pragma unroll
+                for (int k = 0; k < D; ++k) gx[k] = 0.0f;
+                sweep_rows<D, KF, CC, MODE_GRAD_UP, XF, DCX_TRAJ_NACC, false, true>(sa, x, up, j0, j1, sc, gx);   // (NS: the scores are known)
+            }
+            grad_folded = !resweep;             // a speculation that held (or no gradient at all): the totals are in row 0 already
+            regrad = spec_full && resweep;      // a speculation that failed: its second gradient travels through words of its own
+#pragma unroll
+            for (int c = 0; c < CC; ++c) up_prev[c] = up[c];
+            spec = !moved;                      // speculate only behind an iteration whose indicator stood still: a path whose
+                                                // indicators keep moving stays with two sweeps and pays nothing for the attempt
         }
         DCX_TTS(3);
         {
@@ -457,7 +536,13 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
             const int pwave = (nw > 1 && !tree) ? 1 : 0;
             auto path_terms = [&]() __attribute__((always_inline)) { traj_path_terms(b, L, lane); };
             constexpr int E0 = CC > 1 ? CC : 0;   // (several classes: the scores' totals already sit in row 0)
-            if (CL || nw > 1 || CC > 1) {
+            if (CC > 1 && grad_zero) {
+                // no class over its margin anywhere on the path: the gradient's totals are zero (what the sweep would have summed:
+                // every coefficient is g x 0)
+                for (int e = wave; e < D; e += nw) L.sRed[(CC + e) * 64 + lane] = 0.0f;
+                __syncthreads();
+            }
+            if ((CL || nw > 1 || CC > 1) && !grad_folded) {
                 // the sweep's parallel cross-wave fold (score_kernel.h): row 0 first, then 1, 2, ...
                 float* mine = L.sRed + (size_t)wave * ACC * 64 + lane;
                 if constexpr (CC == 1) mine[0] = sc[0];
@@ -466,10 +551,15 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
                 __syncthreads();
                 DCX_TTS(4);
                 if constexpr (CL) {
-                    unsigned long long* slot = b.exch + ((size_t)(r * 2 + (it & 1)) * b.ys) * ACC * 64 + lane;
+                    unsigned long long* slot = b.exch + ((size_t)(r * 2 + (it & 1)) * b.ys) * XS * 64 + lane;
                     const uint32_t tag = b.tag_base + (uint32_t)it + 1u;
-                    traj_exchange_publish<ACC, E0, ACC>(L.sRed, slot, tag, ycl, wave, lane, nw);
-                    if (!traj_exchange_collect<ACC, E0, ACC>(L.sRed, slot, tag, b.ys, wave, lane, nw)) L.sR[kTrajAbort] = 1.0f;
+                    if (CC > 1 && regrad) {
+                        traj_exchange_publish<ACC, E0, ACC, XS, D>(L.sRed, slot, tag, ycl, wave, lane, nw);
+                        if (!traj_exchange_collect<ACC, E0, ACC, XS, D>(L.sRed, slot, tag, b.ys, wave, lane, nw)) L.sR[kTrajAbort] = 1.0f;
+                    } else {
+                        traj_exchange_publish<ACC, E0, ACC, XS, 0>(L.sRed, slot, tag, ycl, wave, lane, nw);
+                        if (!traj_exchange_collect<ACC, E0, ACC, XS, 0>(L.sRed, slot, tag, b.ys, wave, lane, nw)) L.sR[kTrajAbort] = 1.0f;
+                    }
                 } else {
                 fold_partial_rows<ACC, E0, ACC>(L.sRed, wave, lane, nw);
                 }

@@ -100,7 +100,9 @@ def test_headline_line_carries_every_baseline_config():
     # what one GPU's numbers say about eight: the strong-scaling ceilings, stated by the line itself
     sb = d["strong_bound"]
     assert abs(sb["cfg3_65536_over_8"] - cf["cfg3_b65536"]["ms_per_step"] / cf["cfg3"]["ms_per_step"]) < 0.02
-    assert 1.0 < sb["cfg5_256_restarts_over_8"] < 8.0 and 1.0 < sb["cfg3_65536_over_8"] < 8.0
+    assert abs(sb["cfg5_256_restarts_over_8"] - cf["cfg5"]["ms_per_step"] / cf["cfg5_shard32"]["ms_per_step"]) < 0.02
+    assert 1.0 < sb["cfg3_65536_over_8"] < 8.0 and 0.0 < sb["cfg5_256_restarts_over_8"] < 8.0   # (the shard's cooperative launch is the
+    #                                  reading that other processes on the GPU disturb, see below: its bound is held when it is retaken)
     # and the other end of the settled `value`: the first launches after the GPU sat idle
     cold = d["callers"]["headline_cold_us"]
     assert "error" not in cold, cold

@@ -123,13 +123,18 @@ def test_multiclass_fused_and_dropin_optimisers_reproduce_the_reference_record()
     assert relerr(np.array(rec["solution"]), np.array(rec2["solution"])) < 2e-3
 
 
+@pytest.mark.parametrize("quantile", [0.6, 0.97, 0.999, 2.0])
 @pytest.mark.parametrize("kind,C_,R,W,iters,S,ys", [(1, 5, 7, 20, 40, 500, 1), (1, 5, 256, 50, 30, 2000, 1), (0, 5, 9, 33, 25, 800, 1),
                                                     (1, 3, 6, 50, 25, 600, 1), (1, 2, 5, 64, 20, 400, 1), (0, 8, 4, 30, 20, 640, 1),
                                                     (1, 5, 32, 50, 40, 2000, 8), (0, 5, 20, 40, 25, 1000, 4), (1, 3, 6, 50, 25, 600, 2)])
-def test_multiclass_persistent_launch_is_bit_identical_to_the_three_launch_loop(kind, C_, R, W, iters, S, ys, knob):
+def test_multiclass_persistent_launch_is_bit_identical_to_the_three_launch_loop(kind, C_, R, W, iters, S, ys, quantile, knob):
     """the two-sweep persistent kernel (traj_fused.h, CC > 1; cluster form for ys > 1) against the loop of {class scores,
     hinge-gradient sweep, step} launches sliced the same way: every output bit-identical - paths, moments, loss terms, records,
-    stop flags - for Polyharmonic(1) (expanded form) and RQKernel(p = 2) models of 2, 3 (run as 4), 5 and 8 classes"""
+    stop flags - for Polyharmonic(1) (expanded form) and RQKernel(p = 2) models of 2, 3 (both run as 4), 5 and 8 classes.  The margins
+    sit at a quantile of the initial scores: 0.6 (indicators flip every iteration: two sweeps), 0.97 / 0.999 (few entries over their
+    margin: the kernel's speculation on the last iteration's indicator mostly holds, sometimes fails; whole paths without an active
+    class skip the gradient sweep), 2.0 = above every score (free space: score sweeps only) - the results never depend on which
+    of those routes an iteration took"""
     from diffco_amd import _lib, _ops
     from test_gpu_traj import _random_paths, _traj_state
     rob = make_robot("baxter_left")
@@ -143,7 +148,7 @@ def test_multiclass_persistent_launch_is_bit_identical_to_the_three_launch_loop(
     model = _ops.ScoreModel(desc, kind, (1.0 if kind == 1 else 10.0), (1.0 if kind == 1 else 2.0), sup, Wn.cuda())
     paths = _random_paths(rob, R, W, seed=R * W + C_)
     s0 = model.score_raw(paths.reshape(-1, rob.dof).cuda())
-    margin = s0.quantile(0.6, dim=0)          # ~40 % of the (waypoint, class) entries over their margin
+    margin = s0.quantile(quantile, dim=0) if quantile <= 1.0 else s0.max(dim=0).values + 10.0
     opt = _lib.TrajOpts(0.02, 0.9, 0.999, 1e-8, 1, 10, 10, 10, 0.0, 0.3, 1e9, 0.35)
     outs = []
     # (equal slicing: eight classes = 20 accumulators per lane, whose 16 partial rows do not fit a sweep block's 64 KB - the sweep
@@ -170,7 +175,10 @@ def test_multiclass_persistent_launch_is_bit_identical_to_the_three_launch_loop(
     for k in a:
         assert torch.equal(a[k], b[k]), (k, float((a[k].float() - b[k].float()).abs().max()))
     assert float((a["path"].cpu() - paths).abs().max()) > 1e-3
-    assert float(a["stats"][:, 4].max()) > 0          # the collision term was active somewhere at the last step
+    if quantile <= 0.6:
+        assert float(a["stats"][:, 4].max()) > 0      # the collision term was active somewhere at the last step
+    if quantile > 1.0:
+        assert float(a["stats"][:, 4].max()) == 0.0
     assert torch.equal(a["path"][:, 0].cpu(), paths[:, 0]) and torch.equal(a["path"][:, -1].cpu(), paths[:, -1])
 
 
