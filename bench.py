@@ -615,6 +615,38 @@ def graph_replay_ms(loop, dev, G=16, reps=40):
     return ms
 
 
+def two_stream_us(loop, dev, n=200):
+    """microseconds per launch when INDEPENDENT launches of the loop's sweep alternate over two streams (launch i + 1's first blocks
+    start while launch i's last ones drain) against the same launches in order on one stream: what the ~10 us a B = 65536 launch
+    spends outside its steady-state sweep - first FK chains, last fold + J^T, clock ramp - cost a caller that has
+    independent batches, and gets back by overlapping them.  A side measurement: `value` is the one-stream loop (a kernel's own
+    duration is not defined while two of them share the chip; tools/two_stream_probe.py is the long form)."""
+    import ctypes as Ct
+    w = loop.w
+    B, C, dof = w["B"], w["C"], w["dof"]
+    outs = [(torch.empty((B, C), device=dev), torch.empty((B, dof), device=dev)) for _ in range(2)]
+    res = {}
+    for ns in (1, 2):
+        streams = [torch.cuda.Stream(dev) for _ in range(ns)]
+
+        def run(k):
+            for i in range(k):
+                o, g = outs[i % 2]
+                loop._lib.check(loop.lib.dcx_score_grad(w["model"]._h, loop.qp, B, None, Ct.c_void_p(o.data_ptr()), Ct.c_void_p(g.data_ptr()),
+                                                        Ct.c_void_p(streams[i % ns].cuda_stream)))
+        run(n)
+        torch.cuda.synchronize(dev)
+        run(int(SETTLE_MS * 1e-3 / 90e-6))
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        run(n)
+        torch.cuda.synchronize(dev)
+        res[ns] = (time.perf_counter() - t0) / n * 1e6
+    return {"unit": "us per launch (wall / launches)", "launches": n, "one_stream": round(res[1], 2), "two_streams": round(res[2], 2),
+            "gain": round(res[1] / res[2], 3),
+            "what": "independent headline launches alternating over two HIP streams against the same launches on one stream"}
+
+
 def cold_launch_us(loop, dev, n=20, idle_s=1.0, rounds=3):
     """microseconds per launch of the FIRST `n` launches after `idle_s` seconds of an idle GPU (HIP events on the launch stream),
     `rounds` times: the clocks have dropped, the first launches run below the settled rate (tools/clock_ramp.py,
@@ -1157,6 +1189,10 @@ def main():
             callers["headline_cold_us"] = cold_launch_us(loop, dev)
         except Exception as exc:  # noqa: BLE001
             callers["headline_cold_us"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+        try:   # ... and what overlapping independent launches gives back (round 6)
+            callers["headline_two_streams_us"] = two_stream_us(loop, dev)
+        except Exception as exc:  # noqa: BLE001
+            callers["headline_two_streams_us"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
         try:
             callers["fit_poly_solve"] = solve_times(dev)
         except Exception as exc:  # noqa: BLE001

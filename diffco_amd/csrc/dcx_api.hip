@@ -267,7 +267,7 @@ int fk_device_copy(int device, const dcx_fk_desc& fk, FkProg** out) {
 struct Knobs {
     std::atomic<int64_t> ys{-1}, nw{-1}, min_rows{-1}, split_finish_kernel{-1}, inlaunch_tiles{-1}, jac_per_class{-1},
         mfma{-1}, traj_fused{-1}, xf{-1}, jac_one_sweep{-1}, train_grid{-1}, fkk{-1}, jt_waves{-1}, hess_ys{-1}, xm{-1},
-        traj_ys{-1}, traj_across{-1}, owner_poll{-1}, solve_threads{-1}, qt{-1}, giveup_inject{-1};
+        traj_ys{-1}, traj_across{-1}, owner_poll{-1}, solve_threads{-1}, qt{-1}, giveup_inject{-1}, skew{-1};
     Knobs() {
         auto rd = [](const char* name, std::atomic<int64_t>& dst, bool flag) {
             if (const char* e = std::getenv(name)) dst = flag ? 1 : std::atoll(e);
@@ -292,6 +292,7 @@ struct Knobs {
         rd("DCX_OWNER_POLL", owner_poll, false);
         rd("DCX_SOLVE_THREADS", solve_threads, false);
         rd("DCX_QT", qt, false);
+        rd("DCX_SKEW", skew, false);
 #ifndef DCX_WITH_MATRIX_FORMS
         if (mfma > 0) mfma = -1;   // (forms this build does not carry)
         if (xm > 0) xm = -1;
@@ -489,6 +490,17 @@ unsigned long long* traj_exchange_rows(const dcx_model* m, hipStream_t st, size_
     return hit->ptr;
 }
 
+// The shares of a 16-wave block's rows its four wave groups (waves 0-3, 4-7, 8-11, 12-15: one wave per SIMD each) sweep, packed
+// for score_kernel.h wave_slice.  A SIMD issues oldest-first, so with equal slices a block's first waves leave the sweep after
+// 22 k cycles and its last after 51 k, running nearly alone at the end (profiles/r06_wave_skew.txt): 48 / 32 / 15 / 5 % instead of
+// 25 % each - headline 85.4 -> 83.0 us, B = 16384 29.3 -> 25.8, config #3's shard 20.9 -> 19.7, config #5 29.3 -> 26.6 us per
+// iteration; chip-filling batches of many rounds and the five-class sweeps at B = 65536 are unchanged.
+inline int32_t skew_rule() {
+    const int64_t k = knobs().skew;
+    if (k >= 0) return (int32_t)k;                     // 0: equal slices;  > 0: w0 | w1 << 10 | w2 << 20 (tests, A/B tools)
+    return 480 | (320 << 10) | (150 << 20);
+}
+
 // Which FK walk a launch of this model uses (fk_device.h FkWalk).  DH arms: the step table where the model has one, else
 // the FkProg through scalar loads; knob fkk = 0 / 1 / 2 forces a walk for tests (0: the LDS walks every other kind uses).
 void set_fk_walk(const dcx_model* m, ScoreArgs& a) {
@@ -603,6 +615,8 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
         a.s_super = (a.s_super + 1) & ~1;
         a.s_chunk = ((a.s_super + g.nw - 1) / g.nw + 1) & ~1;
     }
+    // 16-wave blocks: the slices of a block's four wave groups are not equal (score_kernel.h wave_slice; knob skew: 0 = equal, > 0 = packed shares)
+    a.s_skew = (g.nw == 16 && !qt) ? skew_rule() : 0;
     a.red_slots = g.red_slots;
     a.dof = m->fk.dof;
     a.d_fk = d_fk;
@@ -648,6 +662,7 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
     // 16-row blocks of the A planes.
     a.xm = (a.xf && mode == MODE_GRAD_ROW && m->aplanes_dev != nullptr && xm_applies(m->Dt, m->Cc, m->kf) && knobs().xm > 0) ? 1 : 0;
     if (a.xm) {
+        a.s_skew = 0;   // (slices on the 16-row blocks of the A planes)
         a.aplanes = m->aplanes_dev;
         a.s_super = (a.s_super + 15) / 16 * 16;
         a.s_chunk = ((a.s_super + g.nw - 1) / g.nw + 15) / 16 * 16;
@@ -741,7 +756,7 @@ int dcx_debug_set(const char* name, int64_t value) {
     const std::string n(name);
     std::atomic<int64_t>* dst = n == "ys" ? &k.ys : n == "nw" ? &k.nw : n == "min_rows" ? &k.min_rows
         : n == "split_finish_kernel" ? &k.split_finish_kernel : n == "inlaunch_tiles" ? &k.inlaunch_tiles
-        : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : n == "traj_fused" ? &k.traj_fused : n == "xf" ? &k.xf : n == "jac_one_sweep" ? &k.jac_one_sweep : n == "train_grid" ? &k.train_grid : n == "fkk" ? &k.fkk : n == "jt_waves" ? &k.jt_waves : n == "hess_ys" ? &k.hess_ys : n == "xm" ? &k.xm : n == "traj_ys" ? &k.traj_ys : n == "traj_across" ? &k.traj_across : n == "owner_poll" ? &k.owner_poll : n == "solve_threads" ? &k.solve_threads : n == "qt" ? &k.qt : n == "giveup_inject" ? &k.giveup_inject : nullptr;
+        : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : n == "traj_fused" ? &k.traj_fused : n == "xf" ? &k.xf : n == "jac_one_sweep" ? &k.jac_one_sweep : n == "train_grid" ? &k.train_grid : n == "fkk" ? &k.fkk : n == "jt_waves" ? &k.jt_waves : n == "hess_ys" ? &k.hess_ys : n == "xm" ? &k.xm : n == "traj_ys" ? &k.traj_ys : n == "traj_across" ? &k.traj_across : n == "owner_poll" ? &k.owner_poll : n == "solve_threads" ? &k.solve_threads : n == "qt" ? &k.qt : n == "giveup_inject" ? &k.giveup_inject : n == "skew" ? &k.skew : nullptr;
     if (!dst) return fail(DCX_ERR_INVALID, "unknown knob: " + n);
 #ifndef DCX_WITH_MATRIX_FORMS
     if ((dst == &k.mfma || dst == &k.xm) && value > 0)
@@ -1278,6 +1293,7 @@ int dcx_score_jac(const dcx_model* m, const float* q, int64_t B, float* score, f
         a.ys = 1;
         a.s_super = m->S_active;
         a.s_chunk = (m->S_active + nw - 1) / nw;
+        a.s_skew = (nw == 16) ? skew_rule() : 0;
         a.dof = m->fk.dof;
         a.d_fk = d_fk;
         a.frame_floats = m->frame_floats;
@@ -1446,6 +1462,7 @@ static int traj_run(const dcx_model* m, const dcx_traj_state* st, const dcx_traj
                 traj_p2 = true;
             }
             slice(ys);
+            a.sc.s_skew = (nw == 16) ? skew_rule() : 0;
             a.st = *st;
             a.opt = *opt;
             a.n_points = m->fk.n_points;

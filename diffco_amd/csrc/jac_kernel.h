@@ -150,8 +150,8 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void score
 #pragma unroll
         for (int k = 0; k < D / 2 + 1; ++k) gj[c][k] = v2f{0.0f, 0.0f};
     }
-    const int j0 = (wave * a.s_chunk < a.S) ? wave * a.s_chunk : a.S;
-    const int j1 = (j0 + a.s_chunk < a.S) ? j0 + a.s_chunk : a.S;
+    int j0, j1;
+    wave_slice(wave, (int)(blockDim.x >> 6), a.s_chunk, a.s_skew, 0, a.S, j0, j1);   // (the sweep kernel's slices: bit-identical to its one-hot sweeps)
     sweep_rows_jac<D, KF, CC>(a, x, j0, j1, sc, gj, gt);
     lane = fresh_lane();
 

@@ -104,6 +104,7 @@ struct ScoreArgs {
                               // weight * sum_c clamp(score_c - margin_c, 0) (optim.py:88-89 on a MultiDiffCo, scripts/active.py:65)
     float hinge_margin, hinge_weight;
     float hinge_margin_c[8];  // hinge == 2: the per-class margins (DCX_MAX_C)
+    int32_t s_skew;           // 16-wave blocks: per mille of s_chunk by which the slices of a block's wave GROUPS differ (wave_slice below)
     int32_t qt;               // 1: the quarter-tile form (score_kernel<..., QT>): 16 configurations per block, rows from LDS
     int32_t qt_off;           // ... float offset of the rows' copy inside the block's LDS
     int32_t qt_per;           // ... rows per slice (kQtSlices * nw slices; a slice starts four banks behind the one before)
@@ -123,6 +124,30 @@ struct RowLayout {
     static constexpr int AL = CC > 1 ? DCX_ROW_ALIGN_MULTI : 4;
     static constexpr int RS = (SS_OFF + 1 + AL - 1) / AL * AL;
 };
+
+// This wave's slice [j0, j1) of its block's supports [ybase, yend).  Equal slices of s_chunk rows - unless skew > 0 (16-wave blocks):
+// the SIMD's arbiter issues oldest-first, so the four waves a block has on a SIMD do not advance together - the stamps of one block
+// of the headline launch (tools/phase_timing.py) have waves 0-3 leave the sweep after 22 k cycles, 4-7 after 30 k, 8-11 after 41 k and
+// 12-15 after 51 k, the last group running nearly alone (and a lone wave uses a third of a SIMD's issue slots) while the first waits
+// at the barrier.  With skew the groups' slices are s_chunk + (3, 1, -1, -3) e rows, e = s_chunk * skew / 1000 (even), so that
+// the groups finish closer together.  The slices still tile [ybase, ybase + 16 s_chunk) in wave order: the fold's order of the sums
+// is unchanged, the sums themselves are those of the new slices.
+__device__ __forceinline__ void wave_slice(int wave, int nw, int s_chunk, int skew, int ybase, int yend, int& j0, int& j1) {
+    int start = wave * s_chunk, len = s_chunk;
+    if (skew > 0 && nw == 16) {
+        // skew = w0 | w1 << 10 | w2 << 20: the per-mille shares of the block's 16 s_chunk rows that wave groups 0, 1, 2 take (group 3:
+        // the rest); a group's four waves share its rows equally, lengths even
+        const int w0 = skew & 1023, w1 = (skew >> 10) & 1023, w2 = (skew >> 20) & 1023;
+        const int l0 = (s_chunk * w0 / 250) & ~1, l1 = (s_chunk * w1 / 250) & ~1, l2 = (s_chunk * w2 / 250) & ~1;
+        int l3 = 4 * s_chunk - l0 - l1 - l2;
+        l3 = l3 > 0 ? l3 : 0;
+        const int g = wave >> 2, q = wave & 3;
+        len = (g == 0) ? l0 : (g == 1) ? l1 : (g == 2) ? l2 : l3;
+        start = 4 * ((g > 0 ? l0 : 0) + (g > 1 ? l1 : 0) + (g > 2 ? l2 : 0)) + q * len;
+    }
+    j0 = (ybase + start < yend) ? ybase + start : yend;
+    j1 = (j0 + len < yend) ? j0 + len : yend;
+}
 
 // arrival counters of a split launch sit one per 128-byte line: 256 blocks bumping 64 counters inside one line serialise
 // at the memory-side atomic unit (~12 ns each; the count took 2.5 k cycles instead of ~0.7 k)
@@ -1840,12 +1865,12 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF, MF, XM, QT, XF)) v
     for (int k = 0; k < D; ++k) gx[k] = 0.0f;
     const int ybase = blockIdx.y * a.s_super;                               // this block's super-chunk
     const int yend = (ybase + a.s_super < a.S) ? (ybase + a.s_super) : a.S;
+    int j0, j1;
+    wave_slice(wave, nw, a.s_chunk, a.s_skew, ybase, yend, j0, j1);
 #ifdef DCX_EXP_SAME_SLICE   // timing experiment only (wrong results): every wave of a block sweeps the SAME rows (scalar-cache hits)
-    const int j0 = ybase;
-#else
-    const int j0 = (ybase + wave * a.s_chunk < yend) ? (ybase + wave * a.s_chunk) : yend;
+    j1 -= j0 - ybase;
+    j0 = ybase;
 #endif
-    const int j1 = (j0 + a.s_chunk < yend) ? (j0 + a.s_chunk) : yend;
 
     DCX_TSB(1);
     if constexpr (QT) {

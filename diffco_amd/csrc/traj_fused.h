@@ -397,11 +397,9 @@ __global__ __launch_bounds__(MAXT, (MAXT / 256 > 0 ? MAXT / 256 : 1)) void traj_
             if constexpr (CL) {  // ... of this workgroup's share [y * s_super, (y + 1) * s_super) (score_kernel's split slicing)
                 const int ybase = ycl * b.s_super;
                 const int yend = (ybase + b.s_super < b.sc.S) ? ybase + b.s_super : b.sc.S;
-                j0 = (ybase + wave * b.sc.s_chunk < yend) ? ybase + wave * b.sc.s_chunk : yend;
-                j1 = (j0 + b.sc.s_chunk < yend) ? j0 + b.sc.s_chunk : yend;
+                wave_slice(wave, nw, b.sc.s_chunk, b.sc.s_skew, ybase, yend, j0, j1);
             } else {
-            j0 = (wave * b.sc.s_chunk < b.sc.S) ? wave * b.sc.s_chunk : b.sc.S;
-            j1 = (j0 + b.sc.s_chunk < b.sc.S) ? j0 + b.sc.s_chunk : b.sc.S;
+                wave_slice(wave, nw, b.sc.s_chunk, b.sc.s_skew, 0, b.sc.S, j0, j1);
             }
             if constexpr (XF) {  // the expanded form works on centred data (score_kernel.h)
                 cfloat_ptr cen = (cfloat_ptr)(uintptr_t)b.sc.centre;

@@ -189,3 +189,16 @@ def test_profiled_kernel_names_are_kernels_of_this_library():
     for f in files:
         name = re.sub(r"\s+", "", json.load(open(f))["kernel"].split("  ")[0].split(" (")[0])
         assert name in have, f"{os.path.basename(f)} names {name}, which this libdcx.so does not contain: re-collect the counters"
+    # the matrix-core forms' counters (bench.py `roofline.mfma`, profiles/mfma_*.json) name kernels of the matrix-forms library, which
+    # build() makes beside the shipped one (round 3's file named kernels no library contained any more)
+    mlib = os.path.join(ROOT, "diffco_amd", "libdcx_matrix.so")
+    assert os.path.exists(mlib), "diffco_amd/libdcx_matrix.so is missing: __graft_entry__.build() makes it"
+    msyms = subprocess.run(["nm", "-C", "--defined-only", mlib], capture_output=True, text=True, check=True).stdout
+    mhave = {re.sub(r"\s+", "", m.group(1)) for m in re.finditer(r"\bvoid (dcx::\w+<[^>]*>)\(", msyms)}
+    mfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "mfma_*.json")))
+    assert mfiles
+    for f in mfiles:
+        for key, form in (json.load(open(f)).get("forms") or {}).items():
+            name = re.sub(r"\s+", "", re.sub(r"^void ", "", form["kernel"]).split("(")[0])
+            assert name in mhave, f"{os.path.basename(f)} [{key}] names {name}, which libdcx_matrix.so does not contain"
+            assert name not in have, f"{name} is a matrix-core form: it must not be in the shipped library"
