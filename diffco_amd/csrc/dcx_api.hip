@@ -267,7 +267,7 @@ int fk_device_copy(int device, const dcx_fk_desc& fk, FkProg** out) {
 struct Knobs {
     std::atomic<int64_t> ys{-1}, nw{-1}, min_rows{-1}, split_finish_kernel{-1}, inlaunch_tiles{-1}, jac_per_class{-1},
         mfma{-1}, traj_fused{-1}, xf{-1}, jac_one_sweep{-1}, train_grid{-1}, fkk{-1}, jt_waves{-1}, hess_ys{-1}, xm{-1},
-        traj_ys{-1}, traj_across{-1}, owner_poll{-1}, solve_threads{-1}, qt{-1}, giveup_inject{-1}, skew{-1};
+        traj_ys{-1}, traj_across{-1}, owner_poll{-1}, solve_threads{-1}, qt{-1}, giveup_inject{-1}, skew{-1}, skew8{-1};
     Knobs() {
         auto rd = [](const char* name, std::atomic<int64_t>& dst, bool flag) {
             if (const char* e = std::getenv(name)) dst = flag ? 1 : std::atoll(e);
@@ -293,6 +293,7 @@ struct Knobs {
         rd("DCX_SOLVE_THREADS", solve_threads, false);
         rd("DCX_QT", qt, false);
         rd("DCX_SKEW", skew, false);
+        rd("DCX_SKEW8", skew8, false);
 #ifndef DCX_WITH_MATRIX_FORMS
         if (mfma > 0) mfma = -1;   // (forms this build does not carry)
         if (xm > 0) xm = -1;
@@ -501,6 +502,13 @@ inline int32_t skew_rule() {
     return 480 | (320 << 10) | (150 << 20);
 }
 
+// the same for 8-wave blocks (two wave groups): minus the per-mille share of waves 0-3 (knob skew8: 0 = equal slices)
+inline int32_t skew8_rule() {
+    const int64_t k = knobs().skew8;
+    if (k >= 0) return -(int32_t)k;
+    return -600;   // (config #3's model at B = 65536: 99.7 -> 96.9 us, Panda's 21 features 79.8 -> 77.5: profiles/r06_wave_skew.txt)
+}
+
 // Which FK walk a launch of this model uses (fk_device.h FkWalk).  DH arms: the step table where the model has one, else
 // the FkProg through scalar loads; knob fkk = 0 / 1 / 2 forces a walk for tests (0: the LDS walks every other kind uses).
 void set_fk_walk(const dcx_model* m, ScoreArgs& a) {
@@ -616,7 +624,7 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
         a.s_chunk = ((a.s_super + g.nw - 1) / g.nw + 1) & ~1;
     }
     // 16-wave blocks: the slices of a block's four wave groups are not equal (score_kernel.h wave_slice; knob skew: 0 = equal, > 0 = packed shares)
-    a.s_skew = (g.nw == 16 && !qt) ? skew_rule() : 0;
+    a.s_skew = (g.nw == 16 && !qt) ? skew_rule() : (g.nw == 8 && !qt) ? skew8_rule() : 0;
     a.red_slots = g.red_slots;
     a.dof = m->fk.dof;
     a.d_fk = d_fk;
@@ -644,6 +652,19 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
         a.xf = 0;
         a.qt = 1;
         a.qt_per = qt_per;
+        // the wave groups' shares of the rows (skew_rule: a SIMD issues oldest-first, see score_kernel.h wave_slice); every group
+        // keeps 16 slices, their lengths differ - the same rows, the same LDS
+        for (int gq = 0; gq < 4; ++gq) a.qt_per_g[gq] = qt_per;
+        if (g.nw == 16 && skew_rule() > 0) {
+            const int32_t sk = skew_rule();
+            const int w3[3] = {sk & 1023, (sk >> 10) & 1023, (sk >> 20) & 1023};
+            int left = 4 * qt_per;
+            for (int gq = 0; gq < 3; ++gq) {
+                a.qt_per_g[gq] = std::min(left, (int)((int64_t)4 * qt_per * w3[gq] / 1000));
+                left -= a.qt_per_g[gq];
+            }
+            a.qt_per_g[3] = left;
+        }
         a.qt_off = (int32_t)((lds_plan(a.dof, d_fk, m->frame_floats, g.nw, acc, true).total + m->prog_floats + 3) & ~3);
         a.qt_scr = a.qt_off + QT_SLICES * g.nw * (qt_per * row_stride(m->Dt, m->Cc) + 4);
         // rows copied before the first barrier: ~45 % (the FK chain hides the rest behind its 2 k cycles; tried: the loads of that part
@@ -756,7 +777,7 @@ int dcx_debug_set(const char* name, int64_t value) {
     const std::string n(name);
     std::atomic<int64_t>* dst = n == "ys" ? &k.ys : n == "nw" ? &k.nw : n == "min_rows" ? &k.min_rows
         : n == "split_finish_kernel" ? &k.split_finish_kernel : n == "inlaunch_tiles" ? &k.inlaunch_tiles
-        : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : n == "traj_fused" ? &k.traj_fused : n == "xf" ? &k.xf : n == "jac_one_sweep" ? &k.jac_one_sweep : n == "train_grid" ? &k.train_grid : n == "fkk" ? &k.fkk : n == "jt_waves" ? &k.jt_waves : n == "hess_ys" ? &k.hess_ys : n == "xm" ? &k.xm : n == "traj_ys" ? &k.traj_ys : n == "traj_across" ? &k.traj_across : n == "owner_poll" ? &k.owner_poll : n == "solve_threads" ? &k.solve_threads : n == "qt" ? &k.qt : n == "giveup_inject" ? &k.giveup_inject : n == "skew" ? &k.skew : nullptr;
+        : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : n == "traj_fused" ? &k.traj_fused : n == "xf" ? &k.xf : n == "jac_one_sweep" ? &k.jac_one_sweep : n == "train_grid" ? &k.train_grid : n == "fkk" ? &k.fkk : n == "jt_waves" ? &k.jt_waves : n == "hess_ys" ? &k.hess_ys : n == "xm" ? &k.xm : n == "traj_ys" ? &k.traj_ys : n == "traj_across" ? &k.traj_across : n == "owner_poll" ? &k.owner_poll : n == "solve_threads" ? &k.solve_threads : n == "qt" ? &k.qt : n == "giveup_inject" ? &k.giveup_inject : n == "skew" ? &k.skew : n == "skew8" ? &k.skew8 : nullptr;
     if (!dst) return fail(DCX_ERR_INVALID, "unknown knob: " + n);
 #ifndef DCX_WITH_MATRIX_FORMS
     if ((dst == &k.mfma || dst == &k.xm) && value > 0)
@@ -1293,7 +1314,7 @@ int dcx_score_jac(const dcx_model* m, const float* q, int64_t B, float* score, f
         a.ys = 1;
         a.s_super = m->S_active;
         a.s_chunk = (m->S_active + nw - 1) / nw;
-        a.s_skew = (nw == 16) ? skew_rule() : 0;
+        a.s_skew = (nw == 16) ? skew_rule() : (nw == 8) ? skew8_rule() : 0;
         a.dof = m->fk.dof;
         a.d_fk = d_fk;
         a.frame_floats = m->frame_floats;
@@ -1462,7 +1483,7 @@ static int traj_run(const dcx_model* m, const dcx_traj_state* st, const dcx_traj
                 traj_p2 = true;
             }
             slice(ys);
-            a.sc.s_skew = (nw == 16) ? skew_rule() : 0;
+            a.sc.s_skew = (nw == 16) ? skew_rule() : (nw == 8) ? skew8_rule() : 0;
             a.st = *st;
             a.opt = *opt;
             a.n_points = m->fk.n_points;

@@ -108,6 +108,8 @@ struct ScoreArgs {
     int32_t qt;               // 1: the quarter-tile form (score_kernel<..., QT>): 16 configurations per block, rows from LDS
     int32_t qt_off;           // ... float offset of the rows' copy inside the block's LDS
     int32_t qt_per;           // ... rows per slice (kQtSlices * nw slices; a slice starts four banks behind the one before)
+    int32_t qt_per_g[4];      // ... per wave group (waves 4 g .. 4 g + 3: 16 slices): equal to qt_per, or skewed like wave_slice's shares
+                              //     (sum over the groups = (nw / 4) qt_per: the same rows, the same LDS)
     int32_t qt_scr;           // ... float offset of J^T's own scratch columns (phase R1 runs beside the sweep's tail)
     int32_t qt_front;         // ... rows copied into LDS before the first barrier (the rest during the FK chain)
 };
@@ -144,6 +146,13 @@ __device__ __forceinline__ void wave_slice(int wave, int nw, int s_chunk, int sk
         const int g = wave >> 2, q = wave & 3;
         len = (g == 0) ? l0 : (g == 1) ? l1 : (g == 2) ? l2 : l3;
         start = 4 * ((g > 0 ? l0 : 0) + (g > 1 ? l1 : 0) + (g > 2 ? l2 : 0)) + q * len;
+    } else if (skew < 0 && nw == 8) {
+        // 8-wave blocks (two wave groups): -skew = the per-mille share of the block's 8 s_chunk rows that waves 0-3 take
+        int l0 = (s_chunk * (-skew) / 500) & ~1;
+        l0 = l0 < 2 * s_chunk ? l0 : 2 * s_chunk;
+        const int g = wave >> 2, q = wave & 3;
+        len = g ? 2 * s_chunk - l0 : l0;
+        start = (g ? 4 * l0 : 0) + q * len;
     }
     j0 = (ybase + start < yend) ? ybase + start : yend;
     j1 = (j0 + len < yend) ? j0 + len : yend;
@@ -1767,14 +1776,21 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF, MF, XM, QT, XF)) v
             constexpr int RS4 = RowLayout<D, CC>::RS / 4;
             typedef float v4f_t __attribute__((ext_vector_type(4)));
             const v4f_t* src = reinterpret_cast<const v4f_t*>(a.rows);
-            const int per = a.qt_per, stride = per * RowLayout<D, CC>::RS + 4;
+            constexpr int RSQ = RowLayout<D, CC>::RS;
+            const int p0 = a.qt_per_g[0], p1 = a.qt_per_g[1], p2 = a.qt_per_g[2], p3 = a.qt_per_g[3];
+            const int r1 = 16 * p0, r2 = r1 + 16 * p1, r3 = r2 + 16 * p2;                  // first row of wave groups 1, 2, 3
+            const int b1 = 16 * (p0 * RSQ + 4), b2 = b1 + 16 * (p1 * RSQ + 4), b3 = b2 + 16 * (p2 * RSQ + 4);   // ... and their LDS offsets
             float* dst = smem + a.qt_off;
             for (int e = row0 * RS4 + (int)threadIdx.x - 64 * first_wave; e < row1 * RS4; e += (int)blockDim.x - 64 * first_wave) {
-                const int row = e / RS4, q4 = e - row * RS4;   // row = slice * per + jj: consecutive rows of the model
-                const int sl = row / per, jj = row - sl * per;
+                const int row = e / RS4, q4 = e - row * RS4;   // consecutive rows of the model: group, slice of the group, row of the slice
+                const int g = (row >= r3) ? 3 : (row >= r2) ? 2 : (row >= r1) ? 1 : 0;
+                const int per = (g == 3) ? p3 : (g == 2) ? p2 : (g == 1) ? p1 : p0;
+                const int rr = row - ((g == 3) ? r3 : (g == 2) ? r2 : (g == 1) ? r1 : 0);
+                const int base = (g == 3) ? b3 : (g == 2) ? b2 : (g == 1) ? b1 : 0;
+                const int sl = per > 0 ? rr / per : 0, jj = rr - sl * per;
                 v4f_t v = {0.0f, 0.0f, 0.0f, 0.0f};
                 if (row < a.S) v = src[(size_t)row * RS4 + q4];
-                *reinterpret_cast<v4f_t*>(dst + sl * stride + jj * RowLayout<D, CC>::RS + 4 * q4) = v;
+                if (per > 0 && sl < 16) *reinterpret_cast<v4f_t*>(dst + base + sl * (per * RSQ + 4) + jj * RSQ + 4 * q4) = v;
             }
         }
     };
@@ -1875,9 +1891,13 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF, MF, XM, QT, XF)) v
     DCX_TSB(1);
     if constexpr (QT) {
         // this lane's slice of the rows: four per wave
-        const int sl = wave * kQtSlices + (lane >> 4);
-        const float* slice = smem + a.qt_off + sl * (a.qt_per * RowLayout<D, CC>::RS + 4);
-        sweep_rows_lds<D, KF, GRAD>(a, x, slice, a.qt_per, sc[0], gx);
+        constexpr int RSQ = RowLayout<D, CC>::RS;
+        const int g = wave >> 2;
+        const int per = a.qt_per_g[g];
+        int base = 0;
+        for (int h = 0; h < g; ++h) base += 16 * (a.qt_per_g[h] * RSQ + 4);
+        const float* slice = smem + a.qt_off + base + ((wave & 3) * kQtSlices + (lane >> 4)) * (per * RSQ + 4);
+        sweep_rows_lds<D, KF, GRAD>(a, x, slice, per, sc[0], gx);
     } else if constexpr (MF) {
         // this wave's slice of the reduction scratch doubles as its transpose buffer (X is dead, the fold comes later)
         sweep_rows_mfma<D, KF, CC, MODE>(a, x, up, j0, j1, sc, gx, sRed + (size_t)wave * ACC * 64, lane);

@@ -167,7 +167,8 @@ int dcx_device_count(void);
  * instead of the split launch: 0 = never, 1 = wherever it is compiled and fits with >= 4 waves; rule = at most 16
  * configurations per CU and room for all 16 waves, unless another knob asks for a particular form of the launch).
  * "skew" (how a 16-wave block's rows are dealt to its four wave groups: 0 = equal slices, w0 | w1 << 10 | w2 << 20 = the per-mille
- * shares of groups 0 - 2, rule = 480 / 320 / 150 / 50: a SIMD issues oldest-first and a block's last waves would finish alone).
+ * shares of groups 0 - 2, rule = 480 / 320 / 150 / 50: a SIMD issues oldest-first and a block's last waves would finish alone; the tile of 16 configurations
+ * deals its row slices the same way), "skew8" (the same for 8-wave blocks: the per-mille share of waves 0 - 3, rule = 600, 0 = equal).
  * value < 0 restores the rule.  The initial values come from the DCX_YS / DCX_NW / DCX_XF / ... environment variables,
  * read once at library load; no launch calls getenv.   */
 int dcx_debug_set(const char* name, int64_t value);

@@ -660,7 +660,11 @@ def gen_optim_scipy(out, robots):
     dense = R.utils.dense_path(init, max_speed)
     with torch.no_grad():
         s_dense = dc64.poly_score(dense[1:-1]).reshape(-1)
-    margin = float(s_dense.quantile(0.4))   # ~60 % of the dense points violate the margin: an active constraint
+    # ~60 % of the dense points violate the margin: an active constraint.  The margin sits BETWEEN two scores (round 6: the 0.4
+    # quantile of 16 points is the 7th score itself - a dense point exactly on the hinge, whose side fp32 rounding decided)
+    srt = s_dense.sort().values
+    k40 = int(0.4 * (len(srt) - 1))
+    margin = float(0.5 * (srt[k40] + srt[k40 + 1]))
 
     def con(p, dist_est):  # optim.py:190-207 with return_tensor=True
         dense_p = R.utils.dense_path(p, max_speed)
