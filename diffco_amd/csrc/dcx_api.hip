@@ -496,10 +496,12 @@ unsigned long long* traj_exchange_rows(const dcx_model* m, hipStream_t st, size_
 // 22 k cycles and its last after 51 k, running nearly alone at the end (profiles/r06_wave_skew.txt): 48 / 32 / 15 / 5 % instead of
 // 25 % each - headline 85.4 -> 83.0 us, B = 16384 29.3 -> 25.8, config #3's shard 20.9 -> 19.7, config #5 29.3 -> 26.6 us per
 // iteration; chip-filling batches of many rounds and the five-class sweeps at B = 65536 are unchanged.
-inline int32_t skew_rule() {
+inline int32_t skew_rule(int Cc = 1) {
     const int64_t k = knobs().skew;
     if (k >= 0) return (int32_t)k;                     // 0: equal slices;  > 0: w0 | w1 << 10 | w2 << 20 (tests, A/B tools)
-    return 480 | (320 << 10) | (150 << 20);
+    // (a heavier pair body - several classes - leaves the young waves more: config #3's shard 20.7 us equal, 19.6 with the one-class
+    // shares, 19.1 with these)
+    return Cc > 1 ? (460 | (300 << 10) | (180 << 20)) : (480 | (320 << 10) | (150 << 20));
 }
 
 // the same for 8-wave blocks (two wave groups): minus the per-mille share of waves 0-3 (knob skew8: 0 = equal slices)
@@ -624,7 +626,9 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
         a.s_chunk = ((a.s_super + g.nw - 1) / g.nw + 1) & ~1;
     }
     // 16-wave blocks: the slices of a block's four wave groups are not equal (score_kernel.h wave_slice; knob skew: 0 = equal, > 0 = packed shares)
-    a.s_skew = (g.nw == 16 && !qt) ? skew_rule() : (g.nw == 8 && !qt) ? skew8_rule() : 0;
+    // (slices of fewer than ~24 rows stay equal unless a knob asks: a three-row slice is all pipeline prologue - config #5's 32-restart
+    // shard, 16 rows per wave, read 13.7 us skewed against 13.0)
+    a.s_skew = (g.nw == 16 && !qt && (a.s_chunk >= 24 || knobs().skew > 0)) ? skew_rule(m->Cc) : (g.nw == 8 && !qt && (a.s_chunk >= 24 || knobs().skew8 > 0)) ? skew8_rule() : 0;
     a.red_slots = g.red_slots;
     a.dof = m->fk.dof;
     a.d_fk = d_fk;
@@ -1314,7 +1318,7 @@ int dcx_score_jac(const dcx_model* m, const float* q, int64_t B, float* score, f
         a.ys = 1;
         a.s_super = m->S_active;
         a.s_chunk = (m->S_active + nw - 1) / nw;
-        a.s_skew = (nw == 16) ? skew_rule() : (nw == 8) ? skew8_rule() : 0;
+        a.s_skew = (nw == 16 && (a.s_chunk >= 24 || knobs().skew > 0)) ? skew_rule(m->Cc) : (nw == 8 && (a.s_chunk >= 24 || knobs().skew8 > 0)) ? skew8_rule() : 0;
         a.dof = m->fk.dof;
         a.d_fk = d_fk;
         a.frame_floats = m->frame_floats;
@@ -1462,6 +1466,8 @@ static int traj_run(const dcx_model* m, const dcx_traj_state* st, const dcx_traj
                     a.s_super = (a.s_super + 1) & ~1;
                     a.sc.s_chunk = ((a.s_super + nw - 1) / nw + 1) & ~1;
                 }
+                // (the wave groups' shares of a block's rows: run_score's rule, so that the loop of launches slices the same way)
+                a.sc.s_skew = (nw == 16 && (a.sc.s_chunk >= 24 || knobs().skew > 0)) ? skew_rule(m->Cc) : (nw == 8 && (a.sc.s_chunk >= 24 || knobs().skew8 > 0)) ? skew8_rule() : 0;
             };
             a.sc.dof = m->fk.dof;
             a.sc.d_fk = d_fk;
@@ -1483,7 +1489,6 @@ static int traj_run(const dcx_model* m, const dcx_traj_state* st, const dcx_traj
                 traj_p2 = true;
             }
             slice(ys);
-            a.sc.s_skew = (nw == 16) ? skew_rule() : (nw == 8) ? skew8_rule() : 0;
             a.st = *st;
             a.opt = *opt;
             a.n_points = m->fk.n_points;
