@@ -2114,6 +2114,17 @@ __global__ __launch_bounds__(MAXT, sweep_min_waves(D, CC, KF, MF, XM, QT, XF)) v
                 }
                 float* gq = smem + lp.q;
                 float* scr = (QT && r1_done) ? smem + b.qt_scr + lane : sRed + (size_t)ACC * 64 + lane;
+#if defined(DCX_ABLATE) && (DCX_ABLATE & 4)  // timing ablation only (wrong results): no J^T on the several-wave path either
+                if (wave != 0) return;
+                for (int i = 0; i < dof; ++i) gq[lane * dof + i] = sRed[(CC + (i % b.d_fk)) * 64 + lane] * scale;
+                if (true) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    float* gdst0 = b.grad + b0 * b.grad_stride;
+                    for (int i = lane; i < nb * dof; i += 64) gdst0[(int64_t)(i / dof) * b.grad_stride + (i % dof)] = gq[i];
+                    return;
+                }
+#endif
                 if (!r1_done) {  // unsplit launches (and blocks too small to run it beside the counter)
                     dh2_vjp_r1_sel(fw.dh, dhb, sF + lane, scr, wave);
                     __syncthreads();
