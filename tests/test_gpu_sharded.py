@@ -53,6 +53,11 @@ def _compute(rob, m1, m5, q, up, start, target, options, group):
     rec = fused_adam_traj_optimize(rob, m1, start, target, dict(options), group=group)
     out["solution"] = torch.tensor(rec["solution"])
     out["scalars"] = torch.tensor([rec["cost"], float(rec["cnt_check"]), float(rec["success"]), float(rec["trial"])], dtype=torch.float64)
+    # the same optimiser on the five-class model under per-class margins (round 6: dcx_traj_adam_run_mc, restarts sharded)
+    margins = m5.score_raw(q[:256]).median(dim=0).values.cpu()
+    rec5 = fused_adam_traj_optimize(rob, m5, start, target, dict(options, safety_margin=margins), group=group)
+    out["solution5"] = torch.tensor(rec5["solution"])
+    out["scalars5"] = torch.tensor([rec5["cost"], float(rec5["cnt_check"]), float(rec5["success"]), float(rec5["trial"])], dtype=torch.float64)
     return out
 
 
