@@ -647,6 +647,22 @@ def two_stream_us(loop, dev, n=200):
             "what": "independent headline launches alternating over two HIP streams against the same launches on one stream"}
 
 
+def score_only_us(w, dev, n=400):
+    """The same batch through dcx_score alone (DiffCo.score / is_collision: no gradient): microseconds per launch, events on the
+    launches' stream after the clock has settled.  A side measurement: the headline metric counts score + gradient."""
+    m, q = w["model"], w["q"]
+    for _ in range(1500):
+        m.score_raw(q)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        m.score_raw(q)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    us = e0.elapsed_time(e1) / n * 1e3
+    return {"us_per_launch": round(us, 2), "M_scores_per_s": round(w["B"] / us, 1), "launches": n}
+
+
 def cold_launch_us(loop, dev, n=20, idle_s=1.0, rounds=3):
     """microseconds per launch of the FIRST `n` launches after `idle_s` seconds of an idle GPU (HIP events on the launch stream),
     `rounds` times: the clocks have dropped, the first launches run below the settled rate (tools/clock_ramp.py,
@@ -1193,6 +1209,11 @@ def main():
             callers["headline_two_streams_us"] = two_stream_us(loop, dev)
         except Exception as exc:  # noqa: BLE001
             callers["headline_two_streams_us"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+        if not is_traj:
+            try:   # the batch's scores alone (dcx_score: the checker's score() / is_collision)
+                callers["headline_score_only"] = score_only_us(w, dev)
+            except Exception as exc:  # noqa: BLE001
+                callers["headline_score_only"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
         try:
             callers["fit_poly_solve"] = solve_times(dev)
         except Exception as exc:  # noqa: BLE001

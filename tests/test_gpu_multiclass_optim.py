@@ -211,7 +211,9 @@ def test_multiclass_loop_on_widths_and_kernels_without_a_persistent_form():
         torch.cuda.synchronize()
         col = torch.clamp(s0.double() - margin.double(), min=0).reshape(R, W * C_).sum(dim=1)
         assert relerr(bufs["stats"][:, 4].cpu().double().numpy(), col.cpu().numpy()) < 1e-5
-        assert torch.equal(bufs["col_score"].reshape(R * W, C_), s0)
+        # (the loop's score sweep is sliced like its gradient sweep - bit-identical to the persistent kernel where there is one -,
+        # dcx_score has its own slices: the same sums in another order)
+        assert relerr(bufs["col_score"].reshape(R * W, C_).cpu().numpy(), s0.cpu().numpy()) < 1e-6
 
 
 def test_multiclass_scipy_constraint_terms_against_the_reference_fixture():
