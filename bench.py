@@ -663,6 +663,42 @@ def score_only_us(w, dev, n=400):
     return {"us_per_launch": round(us, 2), "M_scores_per_s": round(w["B"] / us, 1), "launches": n}
 
 
+def hess_us(w, dev, n=100):
+    """dcx_score_hess on the same model (trust-constr's constraint Hessian, analytic second derivatives): microseconds
+    per call for a few batch sizes, events on the calls' stream; `lanes_form_us` = the same batch through the other form of the kernel
+    (one lane per (configuration, direction) sweeps the supports; the shipped rule takes the moments form from B = 1024)."""
+    from diffco_amd import _lib
+    lib = _lib.load()
+    m = w["model"]
+    out = {"unit": "us per call", "what": "gradient + Hessian [B, dof, dof] of the score, q and outputs on the GPU"}
+
+    def timed(q, up):
+        for _ in range(30):
+            m.score_hess_raw(q, up)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            m.score_hess_raw(q, up)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return round(e0.elapsed_time(e1) / n * 1e3, 2)
+
+    for B in (256, 1024, 8192, 65536):
+        if B > w["B"]:
+            continue
+        q = w["q"][:B].contiguous()
+        up = torch.ones((B, w["C"]), device=dev)
+        r = {"us": timed(q, up)}
+        if B >= 1024:
+            try:
+                _lib.check(lib.dcx_debug_set(b"hess_form", 0))
+                r["lanes_form_us"] = timed(q, up)
+            finally:
+                lib.dcx_debug_set(b"hess_form", -1)
+        out[f"B{B}"] = r
+    return out
+
+
 def cold_launch_us(loop, dev, n=20, idle_s=1.0, rounds=3):
     """microseconds per launch of the FIRST `n` launches after `idle_s` seconds of an idle GPU (HIP events on the launch stream),
     `rounds` times: the clocks have dropped, the first launches run below the settled rate (tools/clock_ramp.py,
@@ -1214,6 +1250,11 @@ def main():
                 callers["headline_score_only"] = score_only_us(w, dev)
             except Exception as exc:  # noqa: BLE001
                 callers["headline_score_only"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+        if not is_traj:
+            try:   # second derivatives of the same model (row f4)
+                callers["score_hess_us"] = hess_us(w, dev)
+            except Exception as exc:  # noqa: BLE001
+                callers["score_hess_us"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
         try:
             callers["fit_poly_solve"] = solve_times(dev)
         except Exception as exc:  # noqa: BLE001

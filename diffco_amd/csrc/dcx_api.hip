@@ -72,6 +72,14 @@ struct dcx_model {
         uint32_t epoch;
     };
     mutable std::vector<TrajExch> traj_exch;
+    // the sums of dcx_score_hess's moments form (hess_kernel.hip hess_moments_kernel): one buffer per stream, allocated at the
+    // first such call on it, sized for the largest chunk the launcher forms (kHessMomentRows rows of nacc x 64 floats)
+    struct HessMom {
+        hipStream_t stream;
+        float* ptr;
+        size_t bytes;
+    };
+    mutable std::vector<HessMom> hess_mom;
 };
 
 #ifdef DCX_TIMING
@@ -266,7 +274,7 @@ int fk_device_copy(int device, const dcx_fk_desc& fk, FkProg** out) {
 // path calls getenv.  -1 = "use the rule".
 struct Knobs {
     std::atomic<int64_t> ys{-1}, nw{-1}, min_rows{-1}, split_finish_kernel{-1}, inlaunch_tiles{-1}, jac_per_class{-1},
-        mfma{-1}, traj_fused{-1}, xf{-1}, jac_one_sweep{-1}, train_grid{-1}, fkk{-1}, jt_waves{-1}, hess_ys{-1}, xm{-1},
+        mfma{-1}, traj_fused{-1}, xf{-1}, jac_one_sweep{-1}, train_grid{-1}, fkk{-1}, jt_waves{-1}, hess_ys{-1}, hess_form{-1}, xm{-1},
         traj_ys{-1}, traj_across{-1}, owner_poll{-1}, solve_threads{-1}, qt{-1}, giveup_inject{-1}, skew{-1}, skew8{-1};
     Knobs() {
         auto rd = [](const char* name, std::atomic<int64_t>& dst, bool flag) {
@@ -286,6 +294,7 @@ struct Knobs {
         rd("DCX_FKK", fkk, false);
         rd("DCX_JT_WAVES", jt_waves, false);
         rd("DCX_HESS_YS", hess_ys, false);
+        rd("DCX_HESS_FORM", hess_form, false);
         rd("DCX_XM", xm, false);
         rd("DCX_TRAJ_YS", traj_ys, false);
         rd("DCX_TRAJ_ACROSS", traj_across, false);
@@ -489,6 +498,23 @@ unsigned long long* traj_exchange_rows(const dcx_model* m, hipStream_t st, size_
     hit->epoch += 1;
     *tag_base = hit->epoch << 8;   // tags tag_base + 1 .. + kTrajFusedMaxIters (< 256) belong to this launch
     return hit->ptr;
+}
+
+// This stream's buffer for the sums of dcx_score_hess's moments form; null when it cannot be provided now (the stream is being
+// captured at its first use, or the allocation failed): the caller then runs the form that needs none.
+float* hess_moment_rows(const dcx_model* m, hipStream_t st, size_t bytes) {
+    std::lock_guard<std::mutex> lock(m->mu);
+    for (auto& hm : m->hess_mom)
+        if (hm.stream == st) return hm.bytes >= bytes ? hm.ptr : nullptr;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
+    float* p = nullptr;
+    if (hipMalloc((void**)&p, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    m->hess_mom.push_back({st, p, bytes});
+    return p;
 }
 
 // The shares of a 16-wave block's rows its four wave groups (waves 0-3, 4-7, 8-11, 12-15: one wave per SIMD each) sweep, packed
@@ -788,7 +814,7 @@ int dcx_debug_set(const char* name, int64_t value) {
     const std::string n(name);
     std::atomic<int64_t>* dst = n == "ys" ? &k.ys : n == "nw" ? &k.nw : n == "min_rows" ? &k.min_rows
         : n == "split_finish_kernel" ? &k.split_finish_kernel : n == "inlaunch_tiles" ? &k.inlaunch_tiles
-        : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : n == "traj_fused" ? &k.traj_fused : n == "xf" ? &k.xf : n == "jac_one_sweep" ? &k.jac_one_sweep : n == "train_grid" ? &k.train_grid : n == "fkk" ? &k.fkk : n == "jt_waves" ? &k.jt_waves : n == "hess_ys" ? &k.hess_ys : n == "xm" ? &k.xm : n == "traj_ys" ? &k.traj_ys : n == "traj_across" ? &k.traj_across : n == "owner_poll" ? &k.owner_poll : n == "solve_threads" ? &k.solve_threads : n == "qt" ? &k.qt : n == "giveup_inject" ? &k.giveup_inject : n == "skew" ? &k.skew : n == "skew8" ? &k.skew8 : nullptr;
+        : n == "jac_per_class" ? &k.jac_per_class : n == "mfma" ? &k.mfma : n == "traj_fused" ? &k.traj_fused : n == "xf" ? &k.xf : n == "jac_one_sweep" ? &k.jac_one_sweep : n == "train_grid" ? &k.train_grid : n == "fkk" ? &k.fkk : n == "jt_waves" ? &k.jt_waves : n == "hess_ys" ? &k.hess_ys : n == "hess_form" ? &k.hess_form : n == "xm" ? &k.xm : n == "traj_ys" ? &k.traj_ys : n == "traj_across" ? &k.traj_across : n == "owner_poll" ? &k.owner_poll : n == "solve_threads" ? &k.solve_threads : n == "qt" ? &k.qt : n == "giveup_inject" ? &k.giveup_inject : n == "skew" ? &k.skew : n == "skew8" ? &k.skew8 : nullptr;
     if (!dst) return fail(DCX_ERR_INVALID, "unknown knob: " + n);
 #ifndef DCX_WITH_MATRIX_FORMS
     if ((dst == &k.mfma || dst == &k.xm) && value > 0)
@@ -1176,6 +1202,8 @@ void dcx_model_destroy(dcx_model* m) {
     if (m->giveup_host) (void)hipHostFree(m->giveup_host);
     for (auto& sc : m->scratch)
         if (sc.ptr) (void)hipFree(sc.ptr);
+    for (auto& hm : m->hess_mom)
+        if (hm.ptr) (void)hipFree(hm.ptr);
     for (auto& ex : m->traj_exch)
         if (ex.ptr) (void)hipFree(ex.ptr);
     delete m;
@@ -1277,6 +1305,7 @@ int dcx_score_hess(const dcx_model* m, const float* q, int64_t B, const float* u
     v.kp1 = m->kp1;
     v.n_cu = m->n_cu;
     v.ys_knob = (int32_t)knobs().hess_ys;
+    v.form_knob = (int32_t)knobs().hess_form;
     v.fk_dh = (m->fk.kind == DCX_FK_DH && knobs().fkk != 0) ? 1 : 0;
     uint32_t unused_tag = 0;
     if (float* sc = split_scratch(m, (hipStream_t)stream, 0, &unused_tag)) {  // small batches split the supports across blocks
@@ -1285,6 +1314,11 @@ int dcx_score_hess(const dcx_model* m, const float* q, int64_t B, const float* u
         v.counter_stride = kCounterStride;
         v.scratch = sc + kScratchHead / sizeof(float);
         v.scratch_bytes = (size_t)2 * m->n_cu * (m->Dt + m->Cc) * 64 * sizeof(float);
+    }
+    // the moments form's sums (batches it applies to: hess_kernel.hip launch_hess; knob hess_form 0 = never)
+    if (hess_moments_applies(v, B)) {
+        v.mom_bytes = hess_moments_bytes(m->Dt);
+        v.mom = hess_moment_rows(m, (hipStream_t)stream, v.mom_bytes);
     }
     const hipError_t e = launch_hess(v, q, B, upstream, grad, hess, (hipStream_t)stream);
     if (e == hipErrorInvalidValue) return fail(DCX_ERR_UNSUPPORTED, "dcx_score_hess: the transform's feature row does not fit the LDS in duals");

@@ -98,7 +98,19 @@ struct ModelView {
     int32_t n_counters = 0, counter_stride = 0, n_cu = 0;
     int32_t fk_dh = 0;      // the transform is a DH arm
     int32_t ys_knob = -1;   // developer knob hess_ys: blocks per tile (1 = never split)
+    int32_t form_knob = -1; // developer knob hess_form: 1 = the moments form wherever it is compiled, 0 = never
+    float* mom = nullptr;   // this stream's buffer for the moments form's sums (hess_moments_bytes), or null: the other form runs
+    size_t mom_bytes = 0;
 };
+// the moments form of the second-derivative kernel (hess_kernel.hip): widths it is compiled for, the batches it takes, its buffer
+constexpr int kHessMomentRows = 512;        // (tile, y) rows per chunk: 32768 configurations, or fewer tiles split over the supports
+constexpr int64_t kHessMomentsMinB = 1024;  // smaller batches are launch latency either way: one launch instead of two (measured equal at 1024)
+constexpr bool hess_moments_width(int D) { return D == 2 || D == 4 || D == 6 || D == 8 || D == 12 || D == 16; }
+constexpr int hess_moments_nacc(int D) { return D + 1 + (D / 2) * (D / 2 + 1) * 2; }
+inline size_t hess_moments_bytes(int D) { return (size_t)kHessMomentRows * hess_moments_nacc(D) * 64 * sizeof(float); }
+inline bool hess_moments_applies(const ModelView& m, int64_t B) {
+    return hess_moments_width(m.Dt) && (m.form_knob == 1 || (m.form_knob < 0 && B >= kHessMomentsMinB));
+}
 hipError_t launch_hess(const ModelView& m, const float* q, int64_t B, const float* upstream, float* grad, float* hess,
                        hipStream_t stream);
 

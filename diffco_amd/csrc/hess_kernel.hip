@@ -16,9 +16,14 @@
 // the float64 Hessian; this one is fp32 round-off, ~1e-6).
 //
 // This is a callers'-side kernel (hundreds to thousands of dense-path points per trust-constr iteration), written for
-// exactness and generality — any feature width, every kernel function and transform — not for the instruction-rate
-// roofline of the sweep: for D <= 32 x, dx and the sums sit in registers, beyond that in LDS (4 D ds operations per pair
-// and lane).
+// exactness and generality — any feature width, every kernel function and transform: for D <= 32 x, dx and the sums sit in
+// registers, beyond that in LDS (4 D ds operations per pair and lane).
+//
+// Round 6, the moments form (hess_moments_kernel below) for the narrow compiled widths (D <= 16) and B >= 1024: phase 2 does not
+// need the direction - dgX = (sum_j c_j) dx + (sum_j e'_j delta_j delta_j^T) dx - so one lane per CONFIGURATION sweeps the
+// supports for gX, sum c and the symmetric D x D matrix (81 VALU instructions per configuration and pair at D = 12 instead of
+// 7 x 46), and the (configuration, direction) lanes of this kernel read M dx from it: B = 8192 288 -> 77 us, B = 65536
+// 2010 -> 510 us on the headline model (profiles/r06_hess_moments.txt).
 #include "dcx_internal.h"
 
 #include <algorithm>
@@ -50,6 +55,12 @@ struct HessArgs {
     // in global memory at frames_g + b * frame_floats * 64 (same column layout, coalesced 512-byte columns)
     Dual* frames_g;
     int64_t lane0;            // first (configuration, direction) pair of this launch (chunked launches)
+    // the moments form (hess_moments_kernel below): the sweep's sums per CONFIGURATION, [tile][m_ys][m_nacc][64] floats; the
+    // (configuration, direction) lanes of score_hess_kernel read them instead of sweeping
+    float* mom;
+    int64_t mom_b0;           // first configuration the buffer holds
+    int32_t m_ys, m_nacc;
+    int32_t o_m;              // (floats) the block's configurations' folded sums: [configuration of the block][m_nacc]
     // LDS plan, in Dual elements (8 bytes)
     int32_t o_q, o_f, o_x, o_acc, o_fk_floats, prog_floats;
 };
@@ -231,6 +242,191 @@ __device__ __forceinline__ void sweep_hess_regs(const HessArgs& a, const Dual* s
     }
 }
 
+// ---- the moments form (round 6) ---------------------------------------------------------------------------------------------
+// The (configuration, direction) lanes above repeat the distance, the kernel function and g X for every one of the dof
+// directions: 46 VALU instructions per lane and pair at D = 12, 322 per configuration and pair.  But the tangent sum is linear
+// in dx:    dgX = (sum_j c_j) dx + (sum_j e'_j delta_j delta_j^T) dx,     e'_j = w_j h(d2_j),
+// so ONE lane per configuration can sweep the supports for gX [D], sum c [1] and the symmetric D x D matrix M [D (D + 1) / 2]
+// - 78 instructions per configuration and pair at D = 12 (6 differences, 6 + 3 distance, ~8 kernel function, 6 t = e' delta,
+// 42 packed M += t_k (delta_2p, delta_2p+1) on the pairs p >= k / 2, 6 gX, 1) - and the direction lanes take M dx from it.
+// Accumulators: D + 1 + (D / 2)(D / 2 + 1) 2 floats per lane (97 at D = 12, 171 at D = 16): two waves per SIMD.
+// Layout of a lane's sums: [0, D) gX, [D] sum c, then row k of M as the packed pairs p = k / 2 .. D / 2 - 1 (entry (k, 2 p) and
+// (k, 2 p + 1); for odd k the first one is the lower-triangle duplicate (k, k - 1), never read).
+// waves per block: three per SIMD where the sums leave room for it (153 VGPRs at D = 12), else two
+__host__ __device__ constexpr int hess_moments_waves(int D, int kft) { return (D <= 12 && kft != KF_GEN) ? 12 : 8; }
+
+template <int D>
+struct HessMom {
+    static constexpr int NP = D / 2, NM = NP * (NP + 1), NACC = D + 1 + 2 * NM;
+    static constexpr int CH = 24;   // accumulators per fold pass (12 waves x 24 x 256 B = 72 KB of LDS)
+    static __host__ __device__ constexpr int row_off(int k) {  // first packed pair of M's row k
+        int o = 0;
+        for (int i = 0; i < k; ++i) o += NP - i / 2;
+        return o;
+    }
+};
+
+// UPW: 0 = no upstream (the row's own weight, or its class sum), 1 / 8 = the caller's upstream over one / up to eight class weights
+template <int D, int KFT, int UPW>
+__global__ __launch_bounds__(64 * hess_moments_waves(D, KFT)) void hess_moments_kernel(const HessArgs a) {
+    using HM = HessMom<D>;
+    constexpr int NP = HM::NP, NM = HM::NM, NACC = HM::NACC, CH = HM::CH;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = blockDim.x >> 6;
+    const int dof = a.dof;
+    int64_t b = a.lane0 + (int64_t)blockIdx.x * 64 + lane;   // (lane0, n_lanes: configurations here)
+    if (b >= a.n_lanes) b = a.n_lanes - 1;                   // surplus lanes repeat the last configuration; nobody reads their sums
+    float* sQ = smem + a.o_q + lane * dof;
+    float* sF = smem + a.o_f + lane;
+    float* sX = smem + a.o_x + lane;
+    float* sR = smem + a.o_acc;
+    const fk_cptr fk = stage_fk_prog(a.fk, smem + a.o_fk_floats, threadIdx.x, blockDim.x);
+    if (wave == 0)
+        for (int k = 0; k < dof; ++k) sQ[k] = a.q[b * dof + k];
+    __syncthreads();
+    fk_forward_trig<float>(fk, sQ, sF, wave, nw);
+    __syncthreads();
+    if (wave == 0) {
+        if (a.fk_dh) fk_forward_chain_dh_k<float>((fk_kptr)(uintptr_t)a.fk, sX, sF);
+        else fk_forward_chain<float>(fk, sQ, sX, sF);
+        for (int k = a.d_fk; k < D; ++k) sX[k * 64] = 0.0f;
+    }
+    __syncthreads();
+    const int ybase = (int)blockIdx.y * a.s_super;
+    const int yend = (ybase + a.s_super < a.S) ? ybase + a.s_super : a.S;
+    const int j0 = (ybase + wave * a.s_chunk < yend) ? ybase + wave * a.s_chunk : yend;
+    const int j1 = (j0 + a.s_chunk < yend) ? j0 + a.s_chunk : yend;
+
+    v2f xv[NP], gx[NP], mm[NM];
+    float cs = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        xv[k] = v2f{sX[(2 * k) * 64], sX[(2 * k + 1) * 64]};
+        gx[k] = v2f{0.0f, 0.0f};
+    }
+#pragma unroll
+    for (int i = 0; i < NM; ++i) mm[i] = v2f{0.0f, 0.0f};
+    // the caller's upstream: this configuration's row, zero beyond the caller's classes; the weights it multiplies are read from
+    // loop-invariant offsets (a class the row does not have re-reads the first one: finite, times zero)
+    constexpr int CW = UPW > 0 ? UPW : 1;
+    float upv[CW];
+    int woff[CW];
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+        upv[c] = (UPW > 0 && c < a.c_out) ? a.upstream[b * a.c_out + c] : 0.0f;
+        woff[c] = UPW > 0 ? a.w_off + (c < a.C ? c : 0) : (a.C > 1 ? a.wsum_off : a.w_off);
+    }
+    cfloat_ptr rows = (cfloat_ptr)(uintptr_t)a.rows;
+    // one support row - D coordinates and its weight(s) - read one row ahead of its use into scalar registers
+    auto load_row = [&](float (&dst)[D + CW], int j) __attribute__((always_inline)) {
+        cfloat_ptr r = rows + (size_t)j * a.RS;
+#pragma unroll
+        for (int k = 0; k < D; ++k) dst[k] = r[k];
+#pragma unroll
+        for (int c = 0; c < CW; ++c) dst[D + c] = r[woff[c]];
+    };
+    // A pair in two stages - A: differences, distance, kernel function, coefficients (a dependent chain of ~25 instructions);
+    // B: the 54 independent accumulations - so that stage A of row j + 1 sits in the same scheduling region as stage B of row j
+    // and fills its latencies (two waves per SIMD do not hide them: 0.52 us per row and wave unpipelined)
+    struct StageA {
+        v2f dl[NP];
+        float cf, ef;
+    };
+    auto stage_a = [&](const float (&r)[D + CW], StageA& o, float on) __attribute__((always_inline)) {
+        v2f s2a = {0.0f, 0.0f}, s2b = {0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            o.dl[k] = xv[k] - v2f{r[2 * k], r[2 * k + 1]};
+            if (k & 1) s2b = __builtin_elementwise_fma(o.dl[k], o.dl[k], s2b);
+            else       s2a = __builtin_elementwise_fma(o.dl[k], o.dl[k], s2a);
+        }
+        if (NP > 1) s2a += s2b;
+        float w = r[D] * on;   // (on = 0: a row past the slice's end, loaded again and left out)
+        if constexpr (UPW > 0) {
+            w *= upv[0];
+#pragma unroll
+            for (int c = 1; c < CW; ++c) w = fmaf(upv[c] * on, r[D + c], w);
+        }
+        float g, h;
+        kernel_eval_h<KFT>(a, s2a.x + s2a.y, g, h);
+        o.cf = w * g;
+        o.ef = w * h;
+    };
+    auto stage_b = [&](const StageA& o) __attribute__((always_inline)) {
+        cs += o.cf;
+        const v2f c2 = {o.cf, o.cf}, e2 = {o.ef, o.ef};
+        v2f t[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            gx[k] = __builtin_elementwise_fma(c2, o.dl[k], gx[k]);
+            t[k] = e2 * o.dl[k];
+        }
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const float tk = (k & 1) ? t[k / 2].y : t[k / 2].x;
+            const v2f t2 = {tk, tk};
+#pragma unroll
+            for (int p = k / 2; p < NP; ++p) {
+                v2f& m = mm[HM::row_off(k) + p - k / 2];
+                m = __builtin_elementwise_fma(t2, o.dl[p], m);
+            }
+        }
+    };
+    if (j0 < j1) {
+        float ra[D + CW], rb[D + CW];
+        StageA sa, sb;
+        const int jl = j1 - 1;
+        load_row(ra, j0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        stage_a(ra, sa, 1.0f);
+        load_row(ra, j0 + 1 < j1 ? j0 + 1 : jl);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int j = j0; j < j1; j += 2) {
+            // here: sa = stage A of row j; ra holds row j + 1
+            load_row(rb, j + 2 < j1 ? j + 2 : jl);
+            __builtin_amdgcn_sched_barrier(0);
+            stage_a(ra, sb, j + 1 < j1 ? 1.0f : 0.0f);
+            stage_b(sa);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_sched_barrier(0);
+            load_row(ra, j + 3 < j1 ? j + 3 : jl);
+            __builtin_amdgcn_sched_barrier(0);
+            stage_a(rb, sa, j + 2 < j1 ? 1.0f : 0.0f);
+            stage_b(sb);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // ---- fold over the block's waves, CH sums per pass through the LDS: sum i of a pass belongs to wave i % nw, which adds the
+    //      waves' rows in wave order and writes the total to this (tile, y)'s row of the moments buffer (coalesced, 256 B per sum)
+    float* out = a.mom + (((size_t)blockIdx.x * a.m_ys + blockIdx.y) * NACC) * 64 + lane;
+    auto sum_at = [&](int i) __attribute__((always_inline)) -> float {   // (i is a compile-time constant after unrolling)
+        if (i < D) return (i & 1) ? gx[i / 2].y : gx[i / 2].x;
+        if (i == D) return cs;
+        const int m = i - D - 1;
+        return (m & 1) ? mm[m / 2].y : mm[m / 2].x;
+    };
+#pragma unroll
+    for (int c0 = 0; c0 < NACC; c0 += CH) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+            if (c0 + i < NACC) sR[((size_t)wave * CH + i) * 64 + lane] = sum_at(c0 + i);
+        __syncthreads();
+        for (int i = wave; i < CH && c0 + i < NACC; i += nw) {
+            float tot = sR[(size_t)i * 64 + lane];
+            for (int w = 1; w < nw; ++w) tot += sR[((size_t)w * CH + i) * 64 + lane];
+            out[(size_t)(c0 + i) * 64] = tot;
+        }
+        __syncthreads();
+    }
+}
+
 // SMALL: compiled widths <= 16 only, up to 16 waves per block (128 VGPRs); otherwise every width, up to 8 waves
 template <bool SMALL>
 __global__ __launch_bounds__(SMALL ? 1024 : 512) void score_hess_kernel(const HessArgs a) {
@@ -265,6 +461,77 @@ __global__ __launch_bounds__(SMALL ? 1024 : 512) void score_hess_kernel(const He
     for (int k = 0; k < a.D; ++k) sAcc[k * 64] = Dual(0.0f, 0.0f);
     __syncthreads();
 
+    if (a.mom) {
+        // ---- the moments form: this lane's configuration was swept by hess_moments_kernel; gX as it stands, the tangent sum
+        //      = (sum c) dx + M dx from the symmetric matrix's packed rows (layout: HessMom), the m_ys partial rows added in y order
+        // (a single-wave block.)  First the fold over y, spread over the lanes: the block's configurations (a configuration's
+        // directions may straddle two blocks: both fold it) x their sums are dealt out to the 64 lanes - all (at most 16) partial
+        // rows of a sum loaded together, added in y order - and left in the LDS for the configurations' lanes
+        const int nacc = a.m_nacc, mys = a.m_ys;
+        const int64_t g0 = a.lane0 + (int64_t)blockIdx.x * 64;
+        const int64_t b_first = g0 / dof;
+        const int64_t b_last = (g0 + 63 < a.n_lanes ? g0 + 63 : a.n_lanes - 1) / dof;
+        const int items = (int)(b_last - b_first + 1) * nacc;
+        float* sMb = smem + a.o_m;
+        auto fold_y = [&](auto ny) __attribute__((always_inline)) {
+            constexpr int NY = decltype(ny)::value;   // partial rows loaded together (>= m_ys)
+            for (int w = lane; w < items; w += 64) {
+                const int ci = w / nacc, i = w - ci * nacc;
+                const int64_t rel = b_first + ci - a.mom_b0;
+                const float* mp = a.mom + ((size_t)(rel >> 6) * mys * nacc) * 64 + (rel & 63);
+                float v[NY];
+#pragma unroll
+                for (int y = 0; y < NY; ++y) v[y] = mp[((size_t)(y < mys ? y : mys - 1) * nacc + i) * 64];
+                float t = v[0];
+#pragma unroll
+                for (int y = 1; y < NY; ++y) t += (y < mys) ? v[y] : 0.0f;
+                sMb[w] = t;
+            }
+        };
+        if (mys == 1) fold_y(std::integral_constant<int, 1>{});
+        else if (mys <= 4) fold_y(std::integral_constant<int, 4>{});
+        else fold_y(std::integral_constant<int, 16>{});
+        const float* sM = sMb + (size_t)(b - b_first) * nacc;
+        __syncthreads();
+        // gX as it stands; the tangent sum = (sum c) dx + M dx, in registers for the compiled widths
+        auto apply = [&](auto width) __attribute__((always_inline)) {
+            constexpr int W = decltype(width)::value;
+            float dx[W], ad[W];
+            const float csum = sM[W];
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                dx[k] = sX[k * 64].d;
+                ad[k] = csum * dx[k];
+            }
+            int idx = W + 1;
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+#pragma unroll
+                for (int p = k / 2; p < W / 2; ++p, idx += 2) {
+                    const int l0 = 2 * p, l1 = l0 + 1;
+                    if (l0 >= k) {
+                        const float m0 = sM[idx];
+                        ad[k] = fmaf(m0, dx[l0], ad[k]);
+                        if (l0 != k) ad[l0] = fmaf(m0, dx[k], ad[l0]);
+                    }
+                    const float m1 = sM[idx + 1];
+                    ad[k] = fmaf(m1, dx[l1], ad[k]);
+                    if (l1 != k) ad[l1] = fmaf(m1, dx[k], ad[l1]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < W; ++k) sAcc[k * 64] = Dual(sM[k], ad[k]);
+        };
+        switch (a.D) {
+            case 2: apply(std::integral_constant<int, 2>{}); break;
+            case 4: apply(std::integral_constant<int, 4>{}); break;
+            case 6: apply(std::integral_constant<int, 6>{}); break;
+            case 8: apply(std::integral_constant<int, 8>{}); break;
+            case 12: apply(std::integral_constant<int, 12>{}); break;
+            case 16: apply(std::integral_constant<int, 16>{}); break;
+            default: break;   // (the launcher forms the sums for these widths only)
+        }
+    } else {
     // ---- the sweep: this wave's slice of this block's supports ----
     const int ybase = (int)blockIdx.y * a.s_super;
     const int yend = (ybase + a.s_super < a.S) ? ybase + a.s_super : a.S;
@@ -290,6 +557,7 @@ __global__ __launch_bounds__(SMALL ? 1024 : 512) void score_hess_kernel(const He
     else if (a.kf == KF_RQ2) sweep(std::integral_constant<int, KF_RQ2>{});
     else sweep(std::integral_constant<int, KF_GEN>{});
 #undef DCX_HESS_CASE
+    }
     __syncthreads();
     // ---- every wave adds its share of the sums (accumulator k belongs to wave k % nw) over the waves' rows, in wave order;
     //      totals land in row 0.  In a split launch (ys > 1) they go straight out instead: the fused gradient kernel's
@@ -372,6 +640,104 @@ __global__ __launch_bounds__(SMALL ? 1024 : 512) void score_hess_kernel(const He
     }
 }
 
+// The moments form: per chunk of configurations one hess_moments_kernel launch (lanes = configurations, the supports split over
+// gridDim.y when the chunk's tiles do not fill the chip) and one score_hess_kernel launch of single-wave blocks (lanes =
+// (configuration, direction) pairs) that reads the sums.  The sums live in stream-ordered scratch.
+namespace {
+template <int D>
+hipError_t launch_moments_width(int kf, const dim3& grid, int nw, size_t lds, hipStream_t stream, const HessArgs& a) {
+    auto go = [&](auto kern) {
+        if (lds > 64 * 1024)
+            if (hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return e;
+        hipLaunchKernelGGL(kern, grid, dim3(64 * nw), lds, stream, a);
+        return hipGetLastError();
+    };
+    auto by_up = [&](auto kft) {
+        constexpr int KFT = decltype(kft)::value;
+        if (!a.upstream) return go(hess_moments_kernel<D, KFT, 0>);
+        if (a.c_out == 1) return go(hess_moments_kernel<D, KFT, 1>);
+        return go(hess_moments_kernel<D, KFT, 8>);
+    };
+    if (kf == KF_POLY1) return by_up(std::integral_constant<int, KF_POLY1>{});
+    if (kf == KF_RQ2) return by_up(std::integral_constant<int, KF_RQ2>{});
+    return by_up(std::integral_constant<int, KF_GEN>{});
+}
+}  // namespace
+
+static hipError_t launch_hess_moments(const ModelView& m, HessArgs a, int64_t B, hipStream_t stream, bool* not_applicable) {
+    *not_applicable = false;
+    const int nacc = hess_moments_nacc(m.Dt);
+    constexpr int CH = 24;
+    const int NW1 = hess_moments_waves(m.Dt, m.kf == KF_POLY1 || m.kf == KF_RQ2 ? m.kf : KF_GEN);
+    // first launch: LDS plan in floats - q rows, frames, x, the fold's pass, the staged FK program
+    HessArgs k1 = a;
+    k1.o_q = 0;
+    k1.o_f = k1.o_q + 64 * m.dof;
+    k1.o_x = k1.o_f + 64 * m.frame_floats;
+    k1.o_acc = k1.o_x + 64 * m.Dt;
+    k1.o_fk_floats = k1.o_acc + NW1 * CH * 64;
+    const size_t lds1 = sizeof(float) * ((size_t)k1.o_fk_floats + m.prog_floats + 4);
+    // second launch: single-wave blocks, LDS plan in duals as in launch_hess
+    HessArgs k2 = a;
+    k2.o_q = 0;
+    k2.o_f = k2.o_q + 64 * m.dof;
+    k2.o_x = k2.o_f + 64 * m.frame_floats;
+    k2.o_acc = k2.o_x + 64 * m.Dt;
+    k2.o_fk_floats = 2 * (k2.o_acc + 64 * m.Dt);
+    k2.ys = 1;
+    k2.s_super = m.S;
+    k2.s_chunk = m.S;
+    k2.o_m = k2.o_fk_floats + m.prog_floats + 4;
+    const size_t lds2 = sizeof(float) * ((size_t)k2.o_m + (size_t)(64 / m.dof + 2) * nacc);
+    if (lds1 > 150 * 1024 || lds2 > 150 * 1024) {
+        *not_applicable = true;
+        return hipSuccess;
+    }
+    if (lds2 > 64 * 1024)
+        if (hipError_t e = hipFuncSetAttribute((const void*)score_hess_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)) return e;
+    const int64_t chunk = std::min<int64_t>(B, (int64_t)kHessMomentRows * 64);   // 512 tiles: two rounds of blocks; 12.7 MB of sums at D = 12
+    const int64_t tiles = (chunk + 63) / 64;
+    int ys = (int)std::max<int64_t>(1, std::min<int64_t>(16, m.n_cu / tiles));
+    while (ys > 1 && (m.S + ys - 1) / ys < NW1 * 16) --ys;   // at least 16 rows per wave
+    if (m.ys_knob >= 1) ys = std::min(m.ys_knob, 16);
+    while (ys > 1 && tiles * ys > kHessMomentRows) --ys;
+    k1.s_super = std::max(1, (m.S + ys - 1) / ys);
+    ys = std::max(1, (m.S + k1.s_super - 1) / k1.s_super);
+    k1.ys = ys;
+    k1.s_chunk = (k1.s_super + NW1 - 1) / NW1;
+    k1.m_ys = k2.m_ys = ys;
+    k1.m_nacc = k2.m_nacc = nacc;
+    k1.n_lanes = B;   // (configurations)
+    float* mom = m.mom;
+    if ((size_t)tiles * ys * nacc * 64 * sizeof(float) > m.mom_bytes) {
+        *not_applicable = true;
+        return hipSuccess;
+    }
+    k1.mom = k2.mom = mom;
+    hipError_t rc = hipSuccess;
+    for (int64_t c0 = 0; c0 < B && rc == hipSuccess; c0 += chunk) {
+        const int64_t nc = std::min(chunk, B - c0);
+        k1.lane0 = c0;
+        const dim3 g1((unsigned)((nc + 63) / 64), (unsigned)ys);
+        switch (m.Dt) {
+            case 2: rc = launch_moments_width<2>(m.kf, g1, NW1, lds1, stream, k1); break;
+            case 4: rc = launch_moments_width<4>(m.kf, g1, NW1, lds1, stream, k1); break;
+            case 6: rc = launch_moments_width<6>(m.kf, g1, NW1, lds1, stream, k1); break;
+            case 8: rc = launch_moments_width<8>(m.kf, g1, NW1, lds1, stream, k1); break;
+            case 12: rc = launch_moments_width<12>(m.kf, g1, NW1, lds1, stream, k1); break;
+            case 16: rc = launch_moments_width<16>(m.kf, g1, NW1, lds1, stream, k1); break;
+            default: rc = hipErrorInvalidValue;
+        }
+        if (rc != hipSuccess) break;
+        k2.lane0 = c0 * m.dof;
+        k2.mom_b0 = c0;
+        const int64_t nblk = (nc * m.dof + 63) / 64;
+        hipLaunchKernelGGL(score_hess_kernel<true>, dim3((unsigned)nblk), dim3(64), lds2, stream, k2);
+        rc = hipGetLastError();
+    }
+    return rc;
+}
+
 hipError_t launch_hess(const ModelView& m, const float* q, int64_t B, const float* upstream, float* grad, float* hess,
                        hipStream_t stream) {
     HessArgs a{};
@@ -405,6 +771,12 @@ hipError_t launch_hess(const ModelView& m, const float* q, int64_t B, const floa
     if (fixed + m.Dt > budget) return hipErrorInvalidValue;
     const int64_t nblk = (a.n_lanes + 63) / 64;
     if (nblk > 0x7fffffffLL) return hipErrorInvalidValue;
+    // The moments form (hess_moments_kernel) for the narrow compiled widths: knob hess_form 1 = always, 0 = never, otherwise the rule
+    if (!paged && m.mom && hess_moments_applies(m, B)) {
+        bool na = false;
+        const hipError_t e = launch_hess_moments(m, a, B, stream, &na);
+        if (!na) return e;
+    }
     // Small batches (trust-constr's few hundred dense-path points): split the supports across blocks until the chip is
     // full - each (configuration, direction) tile is swept by ys blocks, the last to arrive folds (kernel above).
     const size_t part_row = (size_t)m.Dt * 64 * sizeof(Dual);

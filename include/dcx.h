@@ -160,7 +160,9 @@ int dcx_device_count(void);
  * across XCDs instead of onto one: a measurement), "owner_poll" (the split launch's hand-over: 0 = arrival counters, last
  * block to arrive finishes; 1 / rule = block y = 0 owns its tile and polls its peers' (value, tag) words - bit-identical;
  * the rule takes it when every block of the launch is resident at once), "hess_ys" (blocks per tile of dcx_score_hess; 1 =
- * never split the supports), "xm" (1 = the expanded form takes its distance GEMM from the matrix cores, bf16x3 split
+ * never split the supports), "hess_form" (dcx_score_hess: 0 = one lane per (configuration, direction) sweeps the supports, 1 = the
+ * moments form - one lane per configuration sweeps gradient, coefficient sum and the symmetric D x D matrix, the direction lanes
+ * read M dx - wherever it is compiled (D <= 16); rule = from B = 1024; same Hessian to fp32 round-off), "xm" (1 = the expanded form takes its distance GEMM from the matrix cores, bf16x3 split
  * operands, where compiled: one class, Polyharmonic(1), even D <= 16; agrees with the VALU form to ~1e-6, measured slower),
  * "solve_threads" (dcx_solve's workgroup size: 256 or 512; rule = 256 up to 736 unknowns; same pivots, same arithmetic),
  * "qt" (small batches of a one-class D = 12 / 24 model as tiles of 16 configurations that sweep all the rows from an LDS copy

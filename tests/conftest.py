@@ -18,7 +18,7 @@ def _built_oracle():
     oracle.build()
 
 
-_KNOBS = ("ys", "nw", "min_rows", "split_finish_kernel", "inlaunch_tiles", "jac_per_class", "mfma", "traj_fused", "xf", "jac_one_sweep", "train_grid", "fkk", "jt_waves", "hess_ys", "xm", "traj_ys", "traj_across", "owner_poll", "solve_threads", "qt", "giveup_inject", "skew", "skew8")
+_KNOBS = ("ys", "nw", "min_rows", "split_finish_kernel", "inlaunch_tiles", "jac_per_class", "mfma", "traj_fused", "xf", "jac_one_sweep", "train_grid", "fkk", "jt_waves", "hess_ys", "hess_form", "xm", "traj_ys", "traj_across", "owner_poll", "solve_threads", "qt", "giveup_inject", "skew", "skew8")
 
 
 @pytest.fixture

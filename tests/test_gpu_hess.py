@@ -4,7 +4,11 @@ with torch.autograd.functional.hessian through dist_est for trust-constr's const
 Pins: (a) tests/golden/hess_points.npz — the reference's own fp32 double backward and a float64 referee at 6
 configurations of 14 score fixtures (tools/make_golden.py gen_hess); (b) central differences of the float64 CPU
 oracle's analytic gradient (step 1e-5: ~1e-9 of the Hessian) at more configurations and on URDF trees.
-Metric max|a - ref| / max|ref|, as everywhere."""
+Metric max|a - ref| / max|ref|, as everywhere.
+
+Every case runs in both forms of the kernel (knob hess_form): 0 = one lane per (configuration, direction) sweeps the
+supports; 1 = the moments form (hess_moments_kernel: one lane per configuration sweeps gX, sum c and the symmetric D x D
+matrix, the direction lanes take M dx from it) wherever it is compiled - widths 2 .. 16; the rule picks it from B = 1024."""
 import numpy as np
 import pytest
 import torch
@@ -28,6 +32,12 @@ def ops():
     from diffco_amd import _lib, _ops
     _lib.require_gpu()
     return _ops
+
+
+@pytest.fixture(autouse=True, params=[0, 1], ids=["lanes", "moments"])
+def form(request, knob):
+    knob("hess_form", request.param)
+    return request.param
 
 
 def _model(ops, name, d):
@@ -164,3 +174,27 @@ def test_hessian_split_across_blocks_equals_the_unsplit_launch(ops, knob, name, 
         assert torch.equal(H1, H1b) and torch.equal(g1, g1b), ys
         scale = max(float(H0.abs().max()), 1e-30)
         assert float((H1 - H0).abs().max()) / scale < 3e-6 and relerr(_n(g1), _n(g0)) < 3e-6, ys
+
+
+@pytest.mark.parametrize("name,B", [("cfg2_baxter_poly1", 1024), ("cfg3_baxter_rq_c5", 3000), ("misc_planar3_poly2", 70000),
+                                    ("cfg1_planar2_rq", 40000)])
+def test_hessian_forms_agree_at_the_batches_the_rule_switches(ops, knob, name, B):
+    """the rule (knob -1) takes the moments form from B = 1024 where it is compiled; both forms and the rule agree to fp32
+    round-off at those batches - one and several chunks of 32768 configurations, ragged last tiles - and call to call the
+    result is identical (the sums are folded in a fixed order)"""
+    d = load(name)
+    m, desc, kspec = _model(ops, name, d)
+    rng = np.random.default_rng(B)
+    q = _t(np.repeat(d["q"], -(-B // len(d["q"])), axis=0)[:B] + 0.05 * rng.standard_normal((B, d["q"].shape[1])).astype(np.float32))
+    up = _t(rng.standard_normal((B, m.C)).astype(np.float32)) if m.C > 1 else None
+    knob("hess_form", 0)
+    g0, H0 = m.score_hess_raw(q, up)
+    knob("hess_form", 1)
+    g1, H1 = m.score_hess_raw(q, up)
+    knob("hess_form", -1)
+    g2, H2 = m.score_hess_raw(q, up)
+    assert torch.equal(H1, H2) and torch.equal(g1, g2)          # the rule's choice at these sizes
+    scale = max(float(H0.abs().max()), 1e-30)
+    assert float((H1 - H0).abs().max()) / scale < 5e-6 and relerr(_n(g1), _n(g0)) < 3e-6
+    _, g = m.score_grad_raw(q, up)
+    assert relerr(_n(g1), _n(g)) < 5e-6

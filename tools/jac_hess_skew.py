@@ -12,7 +12,7 @@ def t(fn, n=200, settle=600):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-for wl, B in (("cfg3", 65536), ("cfg3", 8192), ("cfg3", 1024), ("headline", 8192), ("headline", 50)):
+for wl, B in (("cfg3", 65536), ("cfg3", 8192), ("cfg3", 1024), ("cfg3", 256), ("headline", 65536), ("headline", 8192), ("headline", 1024), ("headline", 300), ("headline", 128), ("headline", 50)):
     w = bench.make_workload(wl, B, dev)
     m, q = w["model"], w["q"]
     up = torch.ones((B, w["C"]), device=dev)
