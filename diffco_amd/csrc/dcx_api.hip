@@ -525,13 +525,17 @@ float* hess_moment_rows(const dcx_model* m, hipStream_t st, size_t bytes) {
 // A sweep of scores alone (score_only: dcx_score - 11 VALU per pair and no gradient fold behind it) wants milder shares: with the
 // gradient sweeps' 48 / 32 / 15 / 5 % it is SLOWER than with equal slices (headline 57.5 us against 56.3, B = 16384 20.0 against 19.3,
 // config #3's model at B = 8192 15.9 against 13.7); 32 / 30 / 24 / 14 % reads 54.5, 17.1 and 13.1 us (profiles/r06_score_only_skew.txt).
-inline int32_t skew_rule(int Cc = 1, bool score_only = false) {
+// The persistent trajectory kernel of a several-class model slices ONCE for its score sweep and its gradient sweep (traj: it and the
+// loop of launches that must stay bit-identical to it): 34 / 30 / 24 / 12 % - config #5's loop on config #3's model 55.3 -> 51.0 us
+// per iteration where the indicators flip, 29.5 -> 24.6 in free space (score sweeps only), unchanged where it speculates.
+inline int32_t skew_rule(int Cc = 1, bool score_only = false, bool traj = false) {
     const int64_t k = knobs().skew;
     if (k >= 0) return (int32_t)k;                     // 0: equal slices;  > 0: w0 | w1 << 10 | w2 << 20 (tests, A/B tools)
+    if (traj && Cc > 1) return 340 | (300 << 10) | (240 << 20);
     if (score_only) return 320 | (300 << 10) | (240 << 20);
     // (a heavier pair body - several classes - leaves the young waves more: config #3's shard 20.7 us equal, 19.6 with the one-class
-    // shares, 19.1 with these)
-    return Cc > 1 ? (460 | (300 << 10) | (180 << 20)) : (480 | (320 << 10) | (150 << 20));
+    // shares, 19.4 with 46 / 30 / 18, 18.9 with these)
+    return Cc > 1 ? (420 | (300 << 10) | (200 << 20)) : (480 | (320 << 10) | (150 << 20));
 }
 
 // the same for 8-wave blocks (two wave groups): minus the per-mille share of waves 0-3 (knob skew8: 0 = equal slices)
@@ -559,7 +563,7 @@ struct Hinge {
     int on = 0;                 // 1: one class, applied to the gradient row;  2: several classes, `upstream` holds the scores (score_kernel.h)
     float margin = 0.f, weight = 0.f;
     float margin_c[DCX_MAX_C] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int grad_slices = 0;        // a MODE_SCORE sweep sliced like the gradient sweeps (the trajectory loop's launches: bit-identical to the persistent kernel)
+    int traj_slices = 0;        // the trajectory loop's launches: both sweeps sliced like the persistent kernel slices (bit-identical to it)
 };
 
 // nz > 1 (MODE_GRAD_UP): the nz classes' one-hot sweeps in ONE launch (gridDim.z), rows to grad + z * dof.  Returns
@@ -660,8 +664,8 @@ int run_score(const dcx_model* m, const float* q, int64_t B, const float* upstre
     // 16-wave blocks: the slices of a block's four wave groups are not equal (score_kernel.h wave_slice; knob skew: 0 = equal, > 0 = packed shares)
     // (slices of fewer than ~24 rows stay equal unless a knob asks: a three-row slice is all pipeline prologue - config #5's 32-restart
     // shard, 16 rows per wave, read 13.7 us skewed against 13.0)
-    const bool so = mode == MODE_SCORE && !hinge.grad_slices;   // (scores alone: their own shares, see skew_rule)
-    a.s_skew = (g.nw == 16 && !qt && (a.s_chunk >= 24 || knobs().skew > 0)) ? skew_rule(m->Cc, so) : (g.nw == 8 && !qt && (a.s_chunk >= 24 || knobs().skew8 > 0)) ? skew8_rule(so) : 0;
+    const bool so = mode == MODE_SCORE && !hinge.traj_slices;   // (scores alone: their own shares, see skew_rule)
+    a.s_skew = (g.nw == 16 && !qt && (a.s_chunk >= 24 || knobs().skew > 0)) ? skew_rule(m->Cc, so, hinge.traj_slices != 0) : (g.nw == 8 && !qt && (a.s_chunk >= 24 || knobs().skew8 > 0)) ? skew8_rule(so) : 0;
     a.red_slots = g.red_slots;
     a.dof = m->fk.dof;
     a.d_fk = d_fk;
@@ -1238,9 +1242,10 @@ int dcx_score_grad(const dcx_model* m, const float* q, int64_t B, const float* u
 // the collision term of the optimisers for any class count: one launch for one class; for several, the class scores first and
 // then the sweep whose upstream is weight * 1[score_c > margin_c] (score_kernel.h, ScoreArgs::hinge == 2)
 static int run_hinge(const dcx_model* m, const float* q, int64_t B, const float* margin /* host [C] */, float weight, float* score,
-                     float* grad, hipStream_t st, bool grad_slices = false) {
+                     float* grad, hipStream_t st, bool traj_slices = false) {
     Hinge h;
     h.weight = weight;
+    h.traj_slices = traj_slices ? 1 : 0;
     if (m->C == 1) {
         h.on = 1;
         h.margin = margin[0];
@@ -1248,8 +1253,8 @@ static int run_hinge(const dcx_model* m, const float* q, int64_t B, const float*
     }
     h.on = 2;
     for (int c = 0; c < m->C; ++c) h.margin_c[c] = margin[c];
-    Hinge hs;   // (the scores' sweep: its own slices, or - for the trajectory loop - the gradient sweep's)
-    hs.grad_slices = grad_slices ? 1 : 0;
+    Hinge hs;   // (the scores' sweep: its own slices, or - for the trajectory loop - the persistent kernel's)
+    hs.traj_slices = traj_slices ? 1 : 0;
     if (int rc = run_score(m, q, B, nullptr, score, nullptr, MODE_SCORE, -1, m->fk.dof, st, hs)) return rc;
     return run_score(m, q, B, score, nullptr, grad, MODE_GRAD_UP, -1, m->fk.dof, st, h);
 }
@@ -1510,7 +1515,7 @@ static int traj_run(const dcx_model* m, const dcx_traj_state* st, const dcx_traj
                     a.sc.s_chunk = ((a.s_super + nw - 1) / nw + 1) & ~1;
                 }
                 // (the wave groups' shares of a block's rows: run_score's rule, so that the loop of launches slices the same way)
-                a.sc.s_skew = (nw == 16 && (a.sc.s_chunk >= 24 || knobs().skew > 0)) ? skew_rule(m->Cc) : (nw == 8 && (a.sc.s_chunk >= 24 || knobs().skew8 > 0)) ? skew8_rule() : 0;
+                a.sc.s_skew = (nw == 16 && (a.sc.s_chunk >= 24 || knobs().skew > 0)) ? skew_rule(m->Cc, false, true) : (nw == 8 && (a.sc.s_chunk >= 24 || knobs().skew8 > 0)) ? skew8_rule() : 0;
             };
             a.sc.dof = m->fk.dof;
             a.sc.d_fk = d_fk;
@@ -1577,7 +1582,7 @@ static int traj_run(const dcx_model* m, const dcx_traj_state* st, const dcx_traj
     // and the fused step (traj_kernels.hip)
     for (int it = 0; it < n_iters; ++it) {
         int rc = run_hinge(m, st->path, B, margin, opt->w_collision, const_cast<float*>(st->col_score), const_cast<float*>(st->col_grad),
-                           (hipStream_t)stream, /*grad_slices=*/true);
+                           (hipStream_t)stream, /*traj_slices=*/true);
         if (rc) return rc;
         hipError_t e = launch_traj_adam_step(m->fk_dev, m->fk, *st, *opt, first_step + it, (hipStream_t)stream, m->C, margin);
         if (e != hipSuccess) return fail_hip(e, "trajectory step launch");

@@ -247,9 +247,10 @@ __device__ __forceinline__ void sweep_hess_regs(const HessArgs& a, const Dual* s
 // directions: 46 VALU instructions per lane and pair at D = 12, 322 per configuration and pair.  But the tangent sum is linear
 // in dx:    dgX = (sum_j c_j) dx + (sum_j e'_j delta_j delta_j^T) dx,     e'_j = w_j h(d2_j),
 // so ONE lane per configuration can sweep the supports for gX [D], sum c [1] and the symmetric D x D matrix M [D (D + 1) / 2]
-// - 78 instructions per configuration and pair at D = 12 (6 differences, 6 + 3 distance, ~8 kernel function, 6 t = e' delta,
+// - 81 instructions per configuration and pair at D = 12 (6 differences, 6 + 3 distance, ~8 kernel function, 6 t = e' delta,
 // 42 packed M += t_k (delta_2p, delta_2p+1) on the pairs p >= k / 2, 6 gX, 1) - and the direction lanes take M dx from it.
-// Accumulators: D + 1 + (D / 2)(D / 2 + 1) 2 floats per lane (97 at D = 12, 171 at D = 16): two waves per SIMD.
+// Accumulators: D + 1 + (D / 2)(D / 2 + 1) 2 floats per lane (97 at D = 12, 171 at D = 16): three waves per SIMD at
+// D <= 12 (153 VGPRs), two at D = 16.
 // Layout of a lane's sums: [0, D) gX, [D] sum c, then row k of M as the packed pairs p = k / 2 .. D / 2 - 1 (entry (k, 2 p) and
 // (k, 2 p + 1); for odd k the first one is the lower-triangle duplicate (k, k - 1), never read).
 // waves per block: three per SIMD where the sums leave room for it (153 VGPRs at D = 12), else two
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(64 * hess_moments_waves(D, KFT)) void hess_moments_
     };
     // A pair in two stages - A: differences, distance, kernel function, coefficients (a dependent chain of ~25 instructions);
     // B: the 54 independent accumulations - so that stage A of row j + 1 sits in the same scheduling region as stage B of row j
-    // and fills its latencies (two waves per SIMD do not hide them: 0.52 us per row and wave unpipelined)
+    // and fills its latencies (218.6 -> 206.1 us per 32768 configurations; profiles/r06_hess_moments.txt)
     struct StageA {
         v2f dl[NP];
         float cf, ef;
