@@ -198,3 +198,25 @@ def test_hessian_forms_agree_at_the_batches_the_rule_switches(ops, knob, name, B
     assert float((H1 - H0).abs().max()) / scale < 5e-6 and relerr(_n(g1), _n(g0)) < 3e-6
     _, g = m.score_grad_raw(q, up)
     assert relerr(_n(g1), _n(g)) < 5e-6
+
+
+def test_hessian_moments_form_on_two_streams(ops, knob):
+    """the moments form keeps its sums in a buffer per (model, stream): calls of one model enqueued on two streams at once - different
+    batches, interleaved - give what each gives alone"""
+    d = load("cfg2_baxter_poly1")
+    m, desc, kspec = _model(ops, "cfg2_baxter_poly1", d)
+    knob("hess_form", 1)
+    rng = np.random.default_rng(9)
+    qs = [_t(np.repeat(d["q"], -(-B // len(d["q"])), axis=0)[:B] + 0.05 * rng.standard_normal((B, 7)).astype(np.float32)) for B in (3000, 1700)]
+    alone = [m.score_hess_raw(q) for q in qs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [[], []]
+    for _ in range(20):
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                outs[i].append(m.score_hess_raw(qs[i]))
+    torch.cuda.synchronize()
+    for i in range(2):
+        for g, H in outs[i]:
+            assert torch.equal(H, alone[i][1]) and torch.equal(g, alone[i][0])
