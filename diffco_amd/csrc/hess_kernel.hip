@@ -27,6 +27,7 @@
 #include "dcx_internal.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace dcx {
 
@@ -45,6 +46,7 @@ struct HessArgs {
     int32_t fk_dh;          // 1: a DH arm - the chain and its reverse sweep read the FK program with scalar loads (fk_*_dh_k)
     float kp0, kp1;
     int32_t s_chunk;
+    int32_t m_skew;           // moments form, 12-wave blocks: per mille of the block's rows for wave groups 0 and 1 (w0 | w1 << 10; 0 = equal slices)
     // supports split across gridDim.y blocks per 64-lane tile (small batches): block y sweeps [y * s_super, (y + 1) * s_super),
     // leaves its partial sums in `part`, and the block that arrives last at the tile's counter adds them in y order and
     // runs the reverse sweep
@@ -297,8 +299,21 @@ __global__ __launch_bounds__(64 * hess_moments_waves(D, KFT)) void hess_moments_
     __syncthreads();
     const int ybase = (int)blockIdx.y * a.s_super;
     const int yend = (ybase + a.s_super < a.S) ? ybase + a.s_super : a.S;
-    const int j0 = (ybase + wave * a.s_chunk < yend) ? ybase + wave * a.s_chunk : yend;
-    const int j1 = (j0 + a.s_chunk < yend) ? j0 + a.s_chunk : yend;
+    // (a SIMD issues oldest-first - score_kernel.h wave_slice: the three wave groups of a 12-wave block take unequal shares of its rows)
+    int j0, j1;
+    if (a.m_skew > 0 && nw == 12) {
+        const int tot = 12 * a.s_chunk;
+        const int l0 = tot * (a.m_skew & 1023) / 4000, l1 = tot * ((a.m_skew >> 10) & 1023) / 4000;
+        const int l2 = 3 * a.s_chunk - l0 - l1;
+        const int g = wave >> 2, q = wave & 3;
+        const int len = g == 0 ? l0 : g == 1 ? l1 : (l2 > 0 ? l2 : 0);
+        const int start = 4 * (g == 0 ? 0 : g == 1 ? l0 : l0 + l1) + q * len;
+        j0 = (ybase + start < yend) ? ybase + start : yend;
+        j1 = (j0 + len < yend) ? j0 + len : yend;
+    } else {
+        j0 = (ybase + wave * a.s_chunk < yend) ? ybase + wave * a.s_chunk : yend;
+        j1 = (j0 + a.s_chunk < yend) ? j0 + a.s_chunk : yend;
+    }
 
     v2f xv[NP], gx[NP], mm[NM];
     float cs = 0.0f;
@@ -706,6 +721,11 @@ static hipError_t launch_hess_moments(const ModelView& m, HessArgs a, int64_t B,
     ys = std::max(1, (m.S + k1.s_super - 1) / k1.s_super);
     k1.ys = ys;
     k1.s_chunk = (k1.s_super + NW1 - 1) / NW1;
+    {
+        static const int skew_env = [] { const char* e = std::getenv("DCX_HESS_SKEW"); return e ? std::atoi(e) : -1; }();
+        // 44 / 33 / 23 %: 518 -> 505 us at B = 65536 (profiles/r06_hess_moments.txt; DCX_HESS_SKEW = w0 | w1 << 10 for A/B runs, 0 = equal)
+        k1.m_skew = (NW1 == 12 && k1.s_chunk >= 24) ? (skew_env >= 0 ? skew_env : (440 | (330 << 10))) : 0;
+    }
     k1.m_ys = k2.m_ys = ys;
     k1.m_nacc = k2.m_nacc = nacc;
     k1.n_lanes = B;   // (configurations)
