@@ -131,9 +131,9 @@ struct RowLayout {
 // the SIMD's arbiter issues oldest-first, so the four waves a block has on a SIMD do not advance together - the stamps of one block
 // of the headline launch (tools/phase_timing.py) have waves 0-3 leave the sweep after 22 k cycles, 4-7 after 30 k, 8-11 after 41 k and
 // 12-15 after 51 k, the last group running nearly alone (and a lone wave uses a third of a SIMD's issue slots) while the first waits
-// at the barrier.  With skew the groups' slices are s_chunk + (3, 1, -1, -3) e rows, e = s_chunk * skew / 1000 (even), so that
-// the groups finish closer together.  The slices still tile [ybase, ybase + 16 s_chunk) in wave order: the fold's order of the sums
-// is unchanged, the sums themselves are those of the new slices.
+// at the barrier.  With skew the groups take unequal shares of the block's rows (packed per mille, below; the rules: dcx_api.hip
+// skew_rule / skew8_rule), so that the groups finish closer together.  The slices still tile [ybase, ybase + 16 s_chunk) in wave
+// order: the fold's order of the sums is unchanged, the sums themselves are those of the new slices.
 __device__ __forceinline__ void wave_slice(int wave, int nw, int s_chunk, int skew, int ybase, int yend, int& j0, int& j1) {
     int start = wave * s_chunk, len = s_chunk;
     if (skew > 0 && nw == 16) {

@@ -1032,3 +1032,40 @@ def test_tile_of_16_configurations_on_raw_inputs(ops, knob, kspec):
     assert not torch.equal(g0, g1)
     assert relerr(_n(s1), so) < TOL and relerr(_n(g1), go) < TOL
     assert torch.isfinite(g1).all()
+
+
+@pytest.mark.parametrize("name", ["headline_baxter_poly1_s2000", "cfg3_baxter_rq_c5"])
+def test_wave_group_shares_tile_the_rows(ops, name, knob):
+    """the unequal slices of a block's wave groups (score_kernel.h wave_slice, knobs skew / skew8): whatever the shares - the rules',
+    one group taking everything, shares that overshoot the block's rows, a last group left with nothing - every support is swept
+    exactly once: scores, gradients and Jacobians agree with the equal slices to the order of the fp32 sums, in the unsplit and the
+    split launch, on 16- and 8-wave blocks"""
+    d = load(name)
+    m, _, _ = _model(ops, name, d)
+    rng = np.random.default_rng(3)
+    B = 700
+    q = _t(np.repeat(d["q"], -(-B // len(d["q"])), axis=0)[:B] + 0.05 * rng.standard_normal((B, d["q"].shape[1])).astype(np.float32))
+    up = _t(rng.standard_normal((B, m.C)).astype(np.float32)) if m.C > 1 else None
+
+    def pack(w0, w1, w2):
+        return w0 | (w1 << 10) | (w2 << 20)
+
+    def run():
+        s, g = m.score_grad_raw(q, up)
+        return _n(s), _n(g), _n(m.score_raw(q)), _n(m.score_jac_raw(q)[1])
+
+    for nw, ys in ((16, 1), (16, 3), (8, 1), (8, 2)):
+        knob("nw", nw)
+        knob("ys", ys)
+        knob("skew", 0)
+        knob("skew8", 0)
+        ref = run()
+        cases = [("skew", v) for v in (-1, pack(480, 320, 150), pack(1000, 0, 0), pack(10, 10, 10), pack(700, 700, 700), pack(333, 333, 334),
+                                       pack(0, 0, 1000), pack(1, 998, 1))] if nw == 16 else \
+                [("skew8", v) for v in (-1, 600, 1000, 10, 500, 999)]
+        for k, v in cases:
+            knob(k, v)
+            out = run()
+            for a, b in zip(out, ref):
+                assert a.shape == b.shape and relerr(a, b) < 3e-6, (nw, ys, k, v)
+            knob(k, 0)
