@@ -77,3 +77,51 @@ def test_fused_sweep_shapes(kind, D, C, ki):
     if B <= 700:
         _, jac = m.score_jac_raw(_t(q))
         assert relerr(_n(jac), rj) < 2e-5
+
+
+HESS_CASES = []
+for D in (2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 14, 15, 16):          # widths that land on the compiled 2 .. 16 (odd ones are padded)
+    HESS_CASES.append(("none", D, int(_rng.integers(1, 9)), int(_rng.integers(len(KERNELS)))))
+for D in (4, 8, 12, 16):
+    HESS_CASES.append(("planar", D, int(_rng.integers(1, 9)), int(_rng.integers(len(KERNELS)))))
+for D in (6, 9, 12, 15):
+    HESS_CASES.append(("se3", D, int(_rng.integers(1, 6)), int(_rng.integers(len(KERNELS)))))
+
+
+@pytest.mark.parametrize("kind,D,C,ki", HESS_CASES)
+def test_hessian_moments_form_shapes(kind, D, C, ki):
+    """shape fuzz of dcx_score_hess's moments form (hess_kernel.hip hess_moments_kernel) against the lanes form - which the reference's
+    double backward and the float64 oracle pin (tests/test_gpu_hess.py): every width the form is compiled for, class counts 1 .. 8
+    with and without an upstream, all kernel families (the generic ones through KF_GEN), supports that do not fill the block's
+    waves, ragged batches, forced splits of the supports"""
+    from diffco_amd import _lib, _ops
+    lib = _lib.load()
+    seed = zlib.crc32(repr(("hess", kind, D, C, ki)).encode())
+    rng = np.random.default_rng(seed)
+    desc, dof = _desc(kind, D, rng)
+    kern = KERNELS[ki]
+    S = int(rng.choice([5, 37, 150, 333, 1000]))
+    B = int(rng.choice([1, 63, 130, 700, 3000]))
+    sq = rng.uniform(-1.5, 1.5, (S, dof)).astype(np.float32)
+    q = _t(rng.uniform(-1.5, 1.5, (B, dof)).astype(np.float32))
+    W = rng.standard_normal((S, C)).astype(np.float32)
+    W[rng.random((S, C)) < 0.2] = 0.0
+    W[0, :] = 1.0   # (at least one active support)
+    sup = _ops.fkine(desc, _t(sq)).reshape(S, -1)
+    m = _ops.ScoreModel(desc, *kern, sup, _t(W))
+    ups = [None] + ([_t(rng.standard_normal((B, C)).astype(np.float32))] if C > 1 or rng.random() < 0.5 else [])
+    try:
+        for up in ups:
+            _lib.check(lib.dcx_debug_set(b"hess_form", 0))
+            g0, H0 = m.score_hess_raw(q, up)
+            for ys in (-1, 3):
+                _lib.check(lib.dcx_debug_set(b"hess_form", 1))
+                _lib.check(lib.dcx_debug_set(b"hess_ys", ys))
+                g1, H1 = m.score_hess_raw(q, up)
+                lib.dcx_debug_set(b"hess_ys", -1)
+                scale = max(float(H0.abs().max()), 1e-30)
+                assert float((H1 - H0).abs().max()) / scale < 1e-5, (kind, D, C, kern, S, B, ys, up is None)
+                assert relerr(_n(g1), _n(g0)) < 5e-6, (kind, D, C, kern, S, B, ys, up is None)
+    finally:
+        lib.dcx_debug_set(b"hess_form", -1)
+        lib.dcx_debug_set(b"hess_ys", -1)
