@@ -542,7 +542,7 @@ inline int32_t skew_rule(int Cc = 1, bool score_only = false, bool traj = false)
 inline int32_t skew8_rule(bool score_only = false) {
     const int64_t k = knobs().skew8;
     if (k >= 0) return -(int32_t)k;
-    if (score_only) return -540;   // (config #3's model at B = 65536, scores alone: 61.3 us equal, 65.5 with 60 %, 59.4 - 60.0 with 53 - 55 %)
+    if (score_only) return -540;   // (scores alone at B = 262144: headline 201 us equal, 199 with 54 %, 203 with 60 %; five classes 222 / 220 / 229)
     return -600;   // (config #3's model at B = 65536: 99.7 -> 96.9 us, Panda's 21 features 79.8 -> 77.5: profiles/r06_wave_skew.txt)
 }
 
